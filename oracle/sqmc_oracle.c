@@ -1,0 +1,902 @@
+/*
+ * sqmc_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ * See sqmc_oracle.h for scope, rules of use and pinning status.
+ * Plain C restatement of the reference algorithms; file:line citations are
+ * relative to /root/reference/src.  Written to be read next to the reference,
+ * not to be fast.  Compile with -ffp-contract=off (the reference Makefile's
+ * gfortran -O2 on x86-64 issues no fused multiply-adds).
+ */
+#include "sqmc_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+
+#define BIT(k) ((det_t)1 << (k))
+static inline int btest(det_t d, int k) { return (int)((d >> k) & 1u); }
+static inline int trailz(det_t d) { return __builtin_ctzll(d); }
+static inline int popcnt(det_t d) { return __builtin_popcountll(d); }
+
+/* ===================================================================== RNG */
+/* rannyu.f90:11-21 : seed copy, last limb forced odd */
+void orc_setrn(orc_rng *g, const int seed[4]) {
+  for (int i = 0; i < 4; i++) g->l[i] = seed[i];
+  g->l[3] = 2 * (g->l[3] / 2) + 1;
+}
+/* rannyu.f90:77-87 */
+void orc_savern(const orc_rng *g, int seed[4]) { for (int i = 0; i < 4; i++) seed[i] = g->l[i]; }
+/* rannyu.f90:54-74 : l <- l * 11^13 mod 2^48 on four 12-bit limbs; m = 502,1521,4071,2107 */
+double orc_rannyu(orc_rng *g) {
+  const int m1 = 502, m2 = 1521, m3 = 4071, m4 = 2107;
+  int l1 = g->l[0], l2 = g->l[1], l3 = g->l[2], l4 = g->l[3];
+  int i1 = l1 * m4 + l2 * m3 + l3 * m2 + l4 * m1;
+  int i2 = l2 * m4 + l3 * m3 + l4 * m2;
+  int i3 = l3 * m4 + l4 * m3;
+  int i4 = l4 * m4;
+  l4 = i4 % 4096; i3 += i4 / 4096;
+  l3 = i3 % 4096; i2 += i3 / 4096;
+  l2 = i2 % 4096;
+  l1 = (i1 + i2 / 4096) % 4096;
+  g->l[0] = l1; g->l[1] = l2; g->l[2] = l3; g->l[3] = l4;
+  const double t = 2.44140625e-4;
+  return t * ((double)l1 + t * ((double)l2 + t * ((double)l3 + t * ((double)l4))));
+}
+/* tools.f90:129-147 */
+int orc_random_int(orc_rng *g, int n) { return (int)((double)n * orc_rannyu(g)) + 1; }
+
+/* ============================================================== integrals */
+/* chemistry.f90:9106-9134 */
+int64_t orc_integral_index(const orc_chem *s, int i, int j, int k, int l) {
+  int64_t a = s->combine_2[i][j], b = s->combine_2[k][l];
+  return (a > b) ? (a * (a - 1)) / 2 + b : (b * (b - 1)) / 2 + a;
+}
+/* chemistry.f90:1234-1256 */
+double orc_integral_value(const orc_chem *s, int p, int q, int r, int t) {
+  return s->integrals[orc_integral_index(s, p, q, r, t)];
+}
+#define IV(p, q, r, t) orc_integral_value(s, (p), (q), (r), (t))
+
+/* chemistry.f90:7232-7343 (c1, cs, c2v, c2h, d2h; 'dih' is not restated) */
+static int init_point_group(orc_chem *s, const char *pg) {
+  static const int d2h[8][8] = {{1,2,3,4,5,6,7,8},{2,1,4,3,6,5,8,7},{3,4,1,2,7,8,5,6},{4,3,2,1,8,7,6,5},
+                                {5,6,7,8,1,2,3,4},{6,5,8,7,2,1,4,3},{7,8,5,6,3,4,1,2},{8,7,6,5,4,3,2,1}};
+  int n;
+  if (!strcmp(pg, "c1")) n = 1; else if (!strcmp(pg, "cs")) n = 2;
+  else if (!strcmp(pg, "c2v") || !strcmp(pg, "c2h")) n = 4; else if (!strcmp(pg, "d2h")) n = 8;
+  else return -1;
+  s->n_group = n;
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) s->prod[i + 1][j + 1] = d2h[i][j];
+  return 0;
+}
+
+/* tools.f90:1294-1340 */
+int orc_permutation_factor(det_t a, det_t b) {
+  det_t diff = (a > b) ? (a & (a - b)) : (b & (b - a));
+  return (popcnt(diff) & 1) ? -1 : 1;
+}
+static inline det_t maskr(int n) { return n >= 64 ? ~(det_t)0 : (BIT(n) - 1); }
+/* tools.f90:1345-1396 */
+void orc_permutation_factor2(det_t di, det_t dj, int *gamma, int *i1, int *i2, int *j1, int *j2) {
+  det_t d = di & ~dj;
+  *i1 = trailz(d); *i2 = trailz(d & ~BIT(*i1));
+  d = dj & ~di;
+  *j1 = trailz(d); *j2 = trailz(d & ~BIT(*j1));
+  d = di & dj & ((maskr(*i1) ^ maskr(*j1)) ^ (maskr(*i2) ^ maskr(*j2)));
+  *gamma = (popcnt(d) & 1) ? -1 : 1;
+}
+/* chemistry.f90:7162-7227 : 0/1/2 or -1 if more than a double apart */
+int orc_excitation_level(det_t iu, det_t id, det_t ju, det_t jd) {
+  int n = popcnt(iu & ~ju) + popcnt(id & ~jd);
+  return n > 2 ? -1 : n;
+}
+
+/* chemistry.f90:1382-1437 */
+static double one_body(const orc_chem *s, det_t up, det_t dn) {
+  double e = 0; int n1 = s->norb + 1;
+  for (det_t d = up; d; d &= d - 1) { int i = trailz(d) + 1; e = e + IV(i, i, n1, n1); }
+  if (dn == up) e = e * 2.0;
+  else for (det_t d = dn; d; d &= d - 1) { int i = trailz(d) + 1; e = e + IV(i, i, n1, n1); }
+  return e;
+}
+/* chemistry.f90:1609-1841, the non-incremental ("usual way") branch 1773-1838.  The
+ * reference also has a stateful incremental branch (1642-1772) whose round-off depends
+ * on call history; it is not restated (tolerance 1e-12 Ha on H_ii). */
+static double two_body(const orc_chem *s, det_t up, det_t dn) {
+  double ex = 0, di = 0; int n = s->norb;
+  for (int i = 1; i <= n; i++) if (btest(up, i - 1))
+    for (int j = i + 1; j <= n; j++) if (btest(up, j - 1)) ex = ex - IV(i, j, j, i);
+  if (dn == up) ex = ex * 2.0;
+  else if (dn != 0)
+    for (int i = 1; i <= n; i++) if (btest(dn, i - 1))
+      for (int j = i + 1; j <= n; j++) if (btest(dn, j - 1)) ex = ex - IV(i, j, j, i);
+  for (int i = 1; i <= n; i++) {
+    if (btest(up, i - 1)) {
+      for (int j = i + 1; j <= n; j++) if (btest(up, j - 1)) di = di + IV(i, i, j, j);
+      for (int j = 1; j <= n; j++) if (btest(dn, j - 1)) di = di + IV(i, i, j, j);
+    }
+    if (btest(dn, i - 1))
+      for (int j = i + 1; j <= n; j++) if (btest(dn, j - 1)) di = di + IV(i, i, j, j);
+  }
+  return ex + di;
+}
+/* chemistry.f90:1439-1478 */
+static double one_body_single(const orc_chem *s, det_t iu, det_t id, det_t ju, det_t jd) {
+  int n1 = s->norb + 1;
+  if (iu != ju) {
+    int ib = trailz(iu & ~ju), jb = trailz(ju & ~iu);
+    return orc_permutation_factor(iu, ju) * IV(ib + 1, jb + 1, n1, n1);
+  }
+  int ib = trailz(id & ~jd), jb = trailz(jd & ~id);
+  return orc_permutation_factor(id, jd) * IV(ib + 1, jb + 1, n1, n1);
+}
+/* chemistry.f90:1845-1930 */
+static double two_body_single(const orc_chem *s, det_t iu, det_t id, det_t ju, det_t jd) {
+  double e = 0;
+  det_t a = iu, b = id, aj = ju;           /* a = spin channel that changes */
+  if (iu == ju) { a = id; b = iu; aj = jd; }
+  int ib = trailz(a & ~aj) + 1, jb = trailz(aj & ~a) + 1;
+  for (det_t d = a; d; d &= d - 1) {
+    int i = trailz(d) + 1;
+    if (i != ib && i != jb) e = e - IV(ib, i, i, jb) + IV(ib, jb, i, i);
+  }
+  for (det_t d = b; d; d &= d - 1) { int i = trailz(d) + 1; e = e + IV(ib, jb, i, i); }
+  return orc_permutation_factor(a, aj) * e;
+}
+/* chemistry.f90:1934-2001 */
+static double two_body_double(const orc_chem *s, det_t iu, det_t id, det_t ju, det_t jd) {
+  int g, i1, i2, j1, j2;
+  if (iu == ju) {
+    orc_permutation_factor2(id, jd, &g, &i1, &i2, &j1, &j2);
+    return g * (IV(i1 + 1, j1 + 1, i2 + 1, j2 + 1) - IV(i1 + 1, j2 + 1, i2 + 1, j1 + 1));
+  } else if (id == jd) {
+    orc_permutation_factor2(iu, ju, &g, &i1, &i2, &j1, &j2);
+    return g * (IV(i1 + 1, j1 + 1, i2 + 1, j2 + 1) - IV(i1 + 1, j2 + 1, i2 + 1, j1 + 1));
+  }
+  i1 = trailz(iu & ~ju); j1 = trailz(ju & ~iu);
+  i2 = trailz(id & ~jd); j2 = trailz(jd & ~id);
+  return orc_permutation_factor(iu, ju) * orc_permutation_factor(id, jd) * IV(i1 + 1, j1 + 1, i2 + 1, j2 + 1);
+}
+/* chemistry.f90:1260-1320 */
+double orc_hamiltonian_chem(const orc_chem *s, det_t iu, det_t id, det_t ju, det_t jd, int level) {
+  if (level == 0) return one_body(s, iu, id) + two_body(s, iu, id) + s->nuclear;
+  if (level == 1) return one_body_single(s, iu, id, ju, jd) + two_body_single(s, iu, id, ju, jd);
+  if (level == 2) return two_body_double(s, iu, id, ju, jd);
+  return 0.0;
+}
+/* chemistry.f90:1323-1377 */
+double orc_hamiltonian_chem_time_sym(const orc_chem *s, det_t iu, det_t id, det_t ju, det_t jd) {
+  const double sqrt2 = sqrt(2.0), sqrt2inv = 1.0 / sqrt2;
+  double m1 = 0, m2 = 0, norm_ketinv = 1, norm_bra = 1; int check = 1, lev;
+  if (ju == jd) norm_ketinv = sqrt2inv;
+  if (iu == id) { norm_bra = sqrt2; check = 0; }
+  lev = (iu == ju && id == jd) ? 0 : orc_excitation_level(iu, id, ju, jd);
+  if (lev >= 0) m1 = orc_hamiltonian_chem(s, iu, id, ju, jd, lev);
+  if (check) {
+    if (ju != jd) {
+      lev = orc_excitation_level(id, iu, ju, jd);
+      if (lev >= 0) m2 = orc_hamiltonian_chem(s, id, iu, ju, jd, lev);
+    } else m2 = m1;
+  }
+  return (norm_bra * norm_ketinv) * (m1 + (s->z * m2));
+}
+/* semistoch.f90:2234-2302 (chem branch) */
+double orc_hamiltonian(const orc_chem *s, det_t iu, det_t id, det_t ju, det_t jd) {
+  if (s->time_sym) return orc_hamiltonian_chem_time_sym(s, iu, id, ju, jd);
+  int lev = orc_excitation_level(iu, id, ju, jd);
+  return lev < 0 ? 0.0 : orc_hamiltonian_chem(s, iu, id, ju, jd, lev);
+}
+
+/* chemistry.f90:10525-10560 */
+static int det_sym(const orc_chem *s, det_t up, det_t dn) {
+  int sym = 1;
+  for (det_t d = up; d; d &= d - 1) sym = s->prod[sym][s->orbsym[trailz(d) + 1]];
+  for (det_t d = dn; d; d &= d - 1) sym = s->prod[sym][s->orbsym[trailz(d) + 1]];
+  return sym;
+}
+
+/* chemistry.f90:6471-6815 : every symmetry-allowed single and double (element may be 0).
+ * Order: the det itself, up-up, dn-dn, up-dn doubles, up singles, dn singles.  With
+ * sym_filter>0 keep dets of that total symmetry instead of the pairwise symmetry test. */
+static int connected_all(const orc_chem *s, det_t up, det_t dn, det_t *cu, det_t *cd, double *el,
+                         int cap, int sym_filter) {
+  int fu[ORC_MAXORB], eu[ORC_MAXORB], fd[ORC_MAXORB], ed[ORC_MAXORB], nfu = 0, neu = 0, nfd = 0, ned = 0;
+  const int *os = s->orbsym; int n = 0, nc = s->n_core_orb;
+  for (int i = 0; i < s->norb; i++) {
+    if (btest(up, i)) fu[nfu++] = i; else eu[neu++] = i;
+    if (btest(dn, i)) fd[nfd++] = i; else ed[ned++] = i;
+  }
+#define PUSH(U, D, LEV) do { if (n < cap) { cu[n] = (U); cd[n] = (D); \
+    if (el) el[n] = s->time_sym ? orc_hamiltonian_chem_time_sym(s, up, dn, (U), (D)) \
+                                : orc_hamiltonian_chem(s, up, dn, (U), (D), (LEV)); } n++; } while (0)
+  PUSH(up, dn, 0);
+  for (int i = nc; i < nfu - 1; i++) for (int j = i + 1; j < nfu; j++)
+    for (int k = 0; k < neu - 1; k++) for (int l = k + 1; l < neu; l++) {
+      det_t t = (up & ~BIT(fu[i]) & ~BIT(fu[j])) | BIT(eu[k]) | BIT(eu[l]);
+      int keep = sym_filter ? det_sym(s, t, dn) == sym_filter
+                            : s->prod[os[fu[i] + 1]][os[fu[j] + 1]] == s->prod[os[eu[k] + 1]][os[eu[l] + 1]];
+      if (keep) PUSH(t, dn, 2);
+    }
+  for (int i = nc; i < nfd - 1; i++) for (int j = i + 1; j < nfd; j++)
+    for (int k = 0; k < ned - 1; k++) for (int l = k + 1; l < ned; l++) {
+      det_t t = (dn & ~BIT(fd[i]) & ~BIT(fd[j])) | BIT(ed[k]) | BIT(ed[l]);
+      int keep = sym_filter ? det_sym(s, up, t) == sym_filter
+                            : s->prod[os[fd[i] + 1]][os[fd[j] + 1]] == s->prod[os[ed[k] + 1]][os[ed[l] + 1]];
+      if (keep) PUSH(up, t, 2);
+    }
+  for (int i = nc; i < nfu; i++) for (int j = nc; j < nfd; j++)
+    for (int k = 0; k < neu; k++) for (int l = 0; l < ned; l++) {
+      det_t tu = (up & ~BIT(fu[i])) | BIT(eu[k]), td = (dn & ~BIT(fd[j])) | BIT(ed[l]);
+      int keep = sym_filter ? det_sym(s, tu, td) == sym_filter
+                            : s->prod[os[fu[i] + 1]][os[fd[j] + 1]] == s->prod[os[eu[k] + 1]][os[ed[l] + 1]];
+      if (keep) PUSH(tu, td, 2);
+    }
+  for (int i = nc; i < nfu; i++) for (int k = 0; k < neu; k++) {
+    det_t t = (up & ~BIT(fu[i])) | BIT(eu[k]);
+    int keep = sym_filter ? det_sym(s, t, dn) == sym_filter : os[fu[i] + 1] == os[eu[k] + 1];
+    if (keep) PUSH(t, dn, 1);
+  }
+  for (int i = nc; i < nfd; i++) for (int k = 0; k < ned; k++) {
+    det_t t = (dn & ~BIT(fd[i])) | BIT(ed[k]);
+    int keep = sym_filter ? det_sym(s, up, t) == sym_filter : os[fd[i] + 1] == os[ed[k] + 1];
+    if (keep) PUSH(up, t, 1);
+  }
+#undef PUSH
+  return n;
+}
+int orc_find_connected_dets_chem(const orc_chem *s, det_t up, det_t dn, det_t *cu, det_t *cd,
+                                 double *elems, int cap) {
+  return connected_all(s, up, dn, cu, cd, elems, cap, 0);
+}
+
+/* chemistry.f90:9378-9442 */
+static void compute_orbital_energies(const orc_chem *s, det_t hu, det_t hd, double *oe) {
+  int n = s->norb, n1 = n + 1;
+  for (int i = 1; i <= n; i++) {
+    double ex = 0, di = 0;
+    for (int j = 1; j <= n; j++) {
+      if (j != i && btest(hu, j - 1)) ex = ex - IV(i, j, j, i);
+      if (j != i && btest(hd, j - 1)) ex = ex - IV(i, j, j, i);
+    }
+    for (int j = 1; j <= n; j++) if (j != i && btest(hu, j - 1)) di = di + IV(i, i, j, j);
+    for (int j = 1; j <= n; j++) if (btest(hd, j - 1)) di = di + IV(i, i, j, j);
+    for (int j = 1; j <= n; j++) if (j != i && btest(hd, j - 1)) di = di + IV(i, i, j, j);
+    for (int j = 1; j <= n; j++) if (btest(hu, j - 1)) di = di + IV(i, i, j, j);
+    oe[i] = IV(i, i, n1, n1) + .5 * (ex + di);
+  }
+}
+
+/* chemistry.f90:538-869 (FCIDUMP branch), 8921-9022 sort_integrals, 10359-10522 auto HF */
+orc_chem *orc_chem_load(const char *path, int nelec, int nup, const char *pg, int time_sym, int z,
+                        int n_core_orb, int hf_mode, int hf_symmetry) {
+  FILE *f = fopen(path, "r");
+  if (!f) return NULL;
+  orc_chem *s = (orc_chem *)calloc(1, sizeof(orc_chem));
+  s->nelec = nelec; s->nup = nup; s->ndn = nelec - nup; s->time_sym = time_sym; s->z = z;
+  s->n_core_orb = n_core_orb;
+  if (init_point_group(s, pg)) { free(s); fclose(f); return NULL; }
+  /* header: NORB= and ORBSYM= up to the line holding &END or / */
+  char line[4096]; char hdr[16384] = "";
+  while (fgets(line, sizeof line, f)) {
+    strncat(hdr, line, sizeof hdr - strlen(hdr) - 1);
+    if (strstr(line, "&END") || strstr(line, "&end") || strchr(line, '/')) break;
+  }
+  char *p = strstr(hdr, "NORB=");
+  if (!p) { free(s); fclose(f); return NULL; }
+  s->norb = atoi(p + 5);
+  int n = s->norb, n1 = n + 1;
+  if (n > ORC_MAXORB) { free(s); fclose(f); return NULL; }
+  p = strstr(hdr, "ORBSYM=");
+  if (p) { p += 7; for (int i = 1; i <= n; i++) { s->orbsym[i] = (int)strtol(p, &p, 10); while (*p == ',' || isspace((unsigned char)*p)) p++; } }
+  else for (int i = 1; i <= n; i++) s->orbsym[i] = 1;
+  /* chemistry.f90:384-394 : identity-order combine_2 while reading */
+  for (int i = 1; i <= n1; i++) { s->orb_order[i] = i; s->orb_order_inv[i] = i; }
+  for (int i = 1; i <= n; i++) for (int j = 1; j <= n; j++)
+    s->combine_2[i][j] = (i > j) ? (i * (i - 1)) / 2 + j : (j * (j - 1)) / 2 + i;
+  s->combine_2[n1][n1] = (n1 * n) / 2 + n1;
+  s->n_int = orc_integral_index(s, n1, n1, n1, n1);
+  s->integrals = (double *)calloc((size_t)s->n_int + 1, sizeof(double));
+  double v; int a, b, c, d;
+  while (fscanf(f, "%lf %d %d %d %d", &v, &a, &b, &c, &d) == 5) {
+    if (a == 0) a = n1; if (b == 0) b = n1; if (c == 0) c = n1; if (d == 0) d = n1;
+    /* one-body entries come as (p,q,0,0): combine_2(p,q) then (n1,n1): fine; guard (p,n1) */
+    if (fabs(v) > 1e-9) s->integrals[orc_integral_index(s, a, b, c, d)] = v;
+  }
+  fclose(f);
+  s->nuclear = s->integrals[orc_integral_index(s, n1, n1, n1, n1)];
+  /* starting det: first orbitals (chemistry.f90:700-712) */
+  det_t hu = maskr(s->nup), hd = maskr(s->ndn);
+  if (hf_mode == 1) {   /* auto_assign_hci0_occs with a nonzero input det: CISD descent */
+    int cap = 200000; det_t *cu = malloc(cap * sizeof(det_t)), *cd = malloc(cap * sizeof(det_t));
+    det_t du = 0, dd = 0;
+    while (!(hu == du && hd == dd)) {
+      if (du != 0) { hu = du; hd = dd; }
+      int nc = connected_all(s, hu, hd, cu, cd, NULL, cap, hf_symmetry);
+      double best = 1e50;
+      for (int i = 0; i < nc; i++) {
+        if (det_sym(s, cu[i], cd[i]) != hf_symmetry) continue;
+        if (time_sym && z < 0 && cu[i] == cd[i]) continue;
+        double e = time_sym ? orc_hamiltonian_chem_time_sym(s, cu[i], cd[i], cu[i], cd[i])
+                            : orc_hamiltonian_chem(s, cu[i], cd[i], cu[i], cd[i], 0);
+        if (e < best) { best = e; du = cu[i]; dd = cd[i]; }
+      }
+    }
+    free(cu); free(cd);
+  }
+  /* sort_integrals */
+  double oe[ORC_MAXORB + 1], tmp[ORC_MAXORB + 1];
+  compute_orbital_energies(s, hu, hd, oe);
+  for (int i = 1; i <= n; i++) {
+    tmp[i] = oe[i];
+    if (btest(hu, i - 1)) tmp[i] = tmp[i] - 1.e9;
+    if (btest(hd, i - 1)) tmp[i] = tmp[i] - 1.e9;
+  }
+  for (int i = 1; i <= n; i++) {
+    double mn = tmp[1]; for (int j = 2; j <= n; j++) if (tmp[j] < mn) mn = tmp[j];
+    for (int j = 1; j <= n; j++) if (tmp[j] == mn) { s->orb_order[i] = j; s->orb_order_inv[j] = i; tmp[j] = 1.e99; break; }
+  }
+  int os_new[ORC_MAXORB + 1];
+  for (int i = 1; i <= n; i++) { os_new[i] = s->orbsym[s->orb_order[i]]; s->orbital_energies[i] = oe[s->orb_order[i]]; }
+  for (int i = 1; i <= n; i++) s->orbsym[i] = os_new[i];
+  det_t nu = 0, nd = 0;
+  for (det_t t = hu; t; t &= t - 1) nu |= BIT(s->orb_order_inv[trailz(t) + 1] - 1);
+  for (det_t t = hd; t; t &= t - 1) nd |= BIT(s->orb_order_inv[trailz(t) + 1] - 1);
+  if (time_sym && nd < nu) { det_t t = nu; nu = nd; nd = t; }
+  s->hf_up = nu; s->hf_dn = nd;
+  /* chemistry.f90:856-866 : combine_2 through orb_order */
+  for (int i = 1; i <= n; i++) { int aa = s->orb_order[i];
+    for (int j = 1; j <= n; j++) { int bb = s->orb_order[j];
+      s->combine_2[i][j] = (aa > bb) ? (aa * (aa - 1)) / 2 + bb : (bb * (bb - 1)) / 2 + aa; } }
+  /* setup_orb_by_symm chemistry.f90:2500-2504 */
+  for (int i = 1; i <= n; i++) { int sy = s->orbsym[i]; s->which_orb_by_sym[sy][++s->num_orb_by_sym[sy]] = i; }
+  return s;
+}
+void orc_chem_free(orc_chem *s) {
+  if (!s) return;
+  free(s->integrals); free(s->hb_r); free(s->hb_s); free(s->hb_absH); free(s->pq_ind); free(s->pq_count); free(s);
+}
+void orc_free(void *p) { free(p); }
+
+/* ============================================================ HCI tables */
+/* chemistry.f90:9137-9151 */
+static int64_t combine_2_indices(int i, int j) { return i > j ? ((int64_t)i * (i - 1)) / 2 + j : ((int64_t)j * (j - 1)) / 2 + i; }
+/* chemistry.f90:9615-9646 */
+static double dexc_no_ref(const orc_chem *s, int p, int q, int r, int t) {
+  int n = s->norb;
+  if (p == q || r == t || p == r || q == t || p == t || q == r) return 0.0;
+  if (p <= n && q <= n) return orc_hamiltonian_chem(s, BIT(p - 1) | BIT(q - 1), 0, BIT(r - 1) | BIT(t - 1), 0, 2);
+  if (p > n && q > n) return orc_hamiltonian_chem(s, 0, BIT(p - n - 1) | BIT(q - n - 1), 0, BIT(r - n - 1) | BIT(t - n - 1), 2);
+  return orc_hamiltonian_chem(s, BIT(p - 1), BIT(q - n - 1), BIT(r - 1), BIT(t - n - 1), 2);
+}
+typedef struct { int r, s; double a; int seq; } rsh;
+static int cmp_rsh(const void *x, const void *y) {   /* descending absH, stable */
+  const rsh *a = x, *b = y;
+  if (a->a > b->a) return -1; if (a->a < b->a) return 1; return a->seq - b->seq;
+}
+/* chemistry.f90:900-993 */
+void orc_chem_setup_hb(orc_chem *s) {
+  int n = s->norb;
+  s->n_pq = (int)combine_2_indices(n, 2 * n);
+  s->pq_ind = calloc(s->n_pq + 1, sizeof(int64_t)); s->pq_count = calloc(s->n_pq + 1, sizeof(int));
+  int64_t cap = 1 << 16, cnt = 0; rsh *all = malloc(cap * sizeof(rsh));
+  s->max_double = 0;
+  for (int pass = 0; pass < 2; pass++)
+    for (int p = 1; p <= n; p++) {
+      int sym_p = s->orbsym[p];
+      int q0 = pass ? n + p : p + 1, q1 = pass ? 2 * n : n;
+      for (int q = q0; q <= q1; q++) {
+        int sym_q = s->prod[sym_p][s->orbsym[pass ? q - n : q]];
+        int64_t e = combine_2_indices(p, q), first = cnt;
+        s->pq_ind[e] = cnt + 1; s->pq_count[e] = 0;
+        for (int r = 1; r <= n; r++) {
+          int sym_r = s->prod[sym_q][s->orbsym[r]];
+          for (int k = 1; k <= s->num_orb_by_sym[sym_r]; k++) {
+            int t = s->which_orb_by_sym[sym_r][k];
+            if (!pass && t < r) continue;
+            if (pass) t += n;
+            double h = fabs(dexc_no_ref(s, p, q, r, t));
+            if (h != 0.0) {
+              if (cnt == cap) { cap *= 2; all = realloc(all, cap * sizeof(rsh)); }
+              all[cnt].r = r; all[cnt].s = t; all[cnt].a = h; all[cnt].seq = (int)(cnt - first); cnt++;
+              s->pq_count[e]++;
+            }
+          }
+        }
+        if (s->pq_count[e] > 1) qsort(all + first, s->pq_count[e], sizeof(rsh), cmp_rsh);
+        if (s->pq_count[e] > 0 && all[first].a > s->max_double) s->max_double = all[first].a;
+      }
+    }
+  s->n_hb = cnt;
+  s->hb_r = malloc(cnt * sizeof(int)); s->hb_s = malloc(cnt * sizeof(int)); s->hb_absH = malloc(cnt * sizeof(double));
+  for (int64_t i = 0; i < cnt; i++) { s->hb_r[i] = all[i].r; s->hb_s[i] = all[i].s; s->hb_absH[i] = all[i].a; }
+  free(all);
+}
+
+/* chemistry.f90:6819-7159 with matrix_elements present, no active-space masks, no eps_big */
+int orc_find_important_connected_dets_chem(const orc_chem *s, det_t up, det_t dn, double eps,
+                                           det_t *cu, det_t *cd, double *el, int cap) {
+  const double sqrt2 = sqrt(2.0), sqrt2inv = 1.0 / sqrt2;
+  int n = s->norb, nc = 0, occ_u[ORC_MAXORB], occ_d[ORC_MAXORB], nu = 0, nd = 0;
+#define EMIT(U, D, M) do { if (nc < cap) { cu[nc] = (U); cd[nc] = (D); if (el) el[nc] = (M); } nc++; } while (0)
+  EMIT(up, dn, 0.0);
+  for (det_t t = up; t; t &= t - 1) occ_u[nu++] = trailz(t) + 1;
+  for (det_t t = dn; t; t &= t - 1) occ_d[nd++] = trailz(t) + 1;
+  for (int p = 1; p <= s->nelec; p++) {
+    int isup = p <= s->nup, pe = isup ? occ_u[p - 1] : occ_d[p - s->nup - 1];
+    for (int r = 1; r <= n; r++) {
+      if (btest(isup ? up : dn, r - 1)) continue;
+      if (s->orbsym[pe] != s->orbsym[r]) continue;
+      det_t nu_ = up, nd_ = dn;
+      if (isup) nu_ = (up & ~BIT(pe - 1)) | BIT(r - 1); else nd_ = (dn & ~BIT(pe - 1)) | BIT(r - 1);
+      if (s->time_sym) {
+        if (nu_ == nd_ && s->z < 0) continue;
+        if (up == nd_ && dn == nu_) continue;
+      }
+      double m = orc_hamiltonian_chem(s, up, dn, nu_, nd_, 1);
+      if (fabs(m) < eps) continue;
+      if (s->time_sym) {
+        if (up == dn && nu_ != nd_) m = sqrt2inv * m;
+        if (nu_ == nd_ && up != dn) m = sqrt2 * m;
+        if (nu_ > nd_) { det_t t = nu_; nu_ = nd_; nd_ = t; m = s->z * m; }
+      }
+      EMIT(nu_, nd_, m);
+    }
+  }
+  if (eps > s->max_double) return nc;
+  int pe1[ORC_MAXORB * ORC_MAXORB], pe2[ORC_MAXORB * ORC_MAXORB], np = 0;
+  for (int p = 0; p < nu; p++) for (int q = p + 1; q < nu; q++) { pe1[np] = occ_u[p]; pe2[np++] = occ_u[q]; }
+  for (int p = 0; p < nd; p++) for (int q = p + 1; q < nd; q++) { pe1[np] = occ_d[p] + n; pe2[np++] = occ_d[q] + n; }
+  for (int p = 0; p < nu; p++) for (int q = 0; q < nd; q++) { pe1[np] = occ_u[p]; pe2[np++] = occ_d[q] + n; }
+  for (int ip = 0; ip < np; ip++) {
+    int p = pe1[ip], q = pe2[ip], p2 = p, q2 = q;
+    int both_dn = (p > n && q > n), swapped = (p <= n && q > n && p > q - n);
+    if (both_dn) { p2 = p - n; q2 = q - n; }
+    if (swapped) { p2 = q - n; q2 = p + n; }
+    int64_t e = combine_2_indices(p2, q2);
+    for (int h = 0; h < s->pq_count[e]; h++) {
+      int64_t k = s->pq_ind[e] - 1 + h;
+      if (s->hb_absH[k] <= eps) break;
+      int r = s->hb_r[k], t = s->hb_s[k];
+      if (both_dn) { r += n; t += n; }
+      if (swapped) { int rt = t - n; t = r + n; r = rt; }
+      if (r <= n ? btest(up, r - 1) : btest(dn, r - n - 1)) continue;
+      if (t <= n ? btest(up, t - 1) : btest(dn, t - n - 1)) continue;
+      det_t nu_ = up, nd_ = dn;
+      if (p <= n) nu_ &= ~BIT(p - 1); else nd_ &= ~BIT(p - n - 1);
+      if (q <= n) nu_ &= ~BIT(q - 1); else nd_ &= ~BIT(q - n - 1);
+      if (r <= n) nu_ |= BIT(r - 1); else nd_ |= BIT(r - n - 1);
+      if (t <= n) nu_ |= BIT(t - 1); else nd_ |= BIT(t - n - 1);
+      if (s->time_sym) {
+        if (nu_ == nd_ && s->z < 0) continue;
+        if (up == nd_ && dn == nu_) continue;
+      }
+      double m = orc_hamiltonian_chem(s, up, dn, nu_, nd_, 2);
+      if (s->time_sym) {
+        if (up == dn && nu_ != nd_) m = sqrt2inv * m;
+        if (nu_ == nd_ && up != dn) m = sqrt2 * m;
+        if (nu_ > nd_) { det_t tt = nu_; nu_ = nd_; nd_ = tt; m = s->z * m; }
+      }
+      EMIT(nu_, nd_, m);
+    }
+  }
+#undef EMIT
+  return nc;
+}
+
+/* =================================================================== SpMV */
+/* more_tools.f90:3622-3670, general branch; 1-based indices as in the reference */
+void orc_spmv_sym_upper(int64_t n, const int64_t *row_counts, const int64_t *indices,
+                        const double *values, const double *x, double *y) {
+  for (int64_t i = 0; i < n; i++) y[i] = 0.0;
+  int64_t k = 0;
+  for (int64_t i = 0; i < n; i++)
+    for (int64_t j = 0; j < row_counts[i]; j++, k++) {
+      int64_t m = indices[k] - 1;
+      y[i] = y[i] + values[k] * x[m];
+      if (i != m) y[m] = y[m] + values[k] * x[i];
+    }
+}
+
+/* ================================================== sparse H among a list */
+static int64_t bsearch_det(const det_t *up, const det_t *dn, int64_t n, det_t u, det_t d) {
+  int64_t lo = 0, hi = n - 1;
+  while (lo <= hi) {
+    int64_t mid = (lo + hi) / 2;
+    if (up[mid] == u && dn[mid] == d) return mid;
+    if (up[mid] < u || (up[mid] == u && dn[mid] < d)) lo = mid + 1; else hi = mid - 1;
+  }
+  return -1;
+}
+/* Lower triangle, diagonal first in each row, then columns ascending.  The list must be
+ * sorted by (up,dn).  Connections are enumerated and looked up (pure function of the
+ * list; the reference's own builder, chemistry.f90:7639-8010, is a "next" row). */
+int64_t orc_build_sparse_ham(const orc_chem *s, int64_t n, const det_t *up, const det_t *dn,
+                             int64_t **row_counts, int64_t **indices, double **values) {
+  int64_t cap = n * 64 + 1024, nnz = 0;
+  int64_t *rc = calloc(n, sizeof(int64_t)), *idx = malloc(cap * sizeof(int64_t));
+  double *val = malloc(cap * sizeof(double));
+  int ccap = 400000; det_t *cu = malloc(ccap * sizeof(det_t)), *cd = malloc(ccap * sizeof(det_t));
+  int64_t *cols = malloc(ccap * sizeof(int64_t));
+  for (int64_t i = 0; i < n; i++) {
+    int nc = connected_all(s, up[i], dn[i], cu, cd, NULL, ccap, 0), m = 0;
+    for (int c = 1; c < nc; c++) {
+      det_t a = cu[c], b = cd[c];
+      if (s->time_sym && a > b) { det_t t = a; a = b; b = t; }
+      int64_t j = bsearch_det(up, dn, n, a, b);
+      if (j >= 0 && j < i) cols[m++] = j;
+    }
+    /* sort + unique columns */
+    for (int a = 1; a < m; a++) { int64_t v = cols[a]; int b = a - 1; while (b >= 0 && cols[b] > v) { cols[b + 1] = cols[b]; b--; } cols[b + 1] = v; }
+    if (nnz + m + 1 > cap) { cap = 2 * cap + m; idx = realloc(idx, cap * sizeof(int64_t)); val = realloc(val, cap * sizeof(double)); }
+    idx[nnz] = i + 1; val[nnz] = orc_hamiltonian(s, up[i], dn[i], up[i], dn[i]); nnz++; rc[i] = 1;
+    int64_t last = -1;
+    for (int a = 0; a < m; a++) {
+      if (cols[a] == last) continue; last = cols[a];
+      double h = orc_hamiltonian(s, up[i], dn[i], up[last], dn[last]);
+      if (h == 0.0) continue;
+      idx[nnz] = last + 1; val[nnz] = h; nnz++; rc[i]++;
+    }
+  }
+  free(cu); free(cd); free(cols);
+  *row_counts = rc; *indices = idx; *values = val;
+  return nnz;
+}
+
+/* ===================================================== uniform2 proposal */
+/* k-th (1-based) orbital of symmetry sym that is empty in det and != skip (1-based, 0=none).
+ * Equivalent to the reference's "bump excite_to past occupied orbitals" loops
+ * (chemistry.f90:4521-4530, 4594-4628) because both orbital lists are ascending. */
+static int kth_open_sym(const orc_chem *s, det_t det, int sym, int k, int skip) {
+  for (int a = 1; a <= s->num_orb_by_sym[sym]; a++) {
+    int o = s->which_orb_by_sym[sym][a];
+    if (btest(det, o - 1) || o == skip) continue;
+    if (--k == 0) return o;
+  }
+  return 0;
+}
+static int kth_open(const orc_chem *s, det_t det, int k) {   /* chemistry.f90:4566-4574 */
+  for (int o = 1; o <= s->norb; o++) { if (btest(det, o - 1)) continue; if (--k == 0) return o; }
+  return 0;
+}
+static int nocc_sym(const orc_chem *s, det_t det, int sym) {
+  int c = 0;
+  for (det_t t = det; t; t &= t - 1) if (s->orbsym[trailz(t) + 1] == sym) c++;
+  return c;
+}
+/* chemistry.f90:4237-5084, time_sym=.false., importance_sampling=0.  Returns det_j and
+ * weight_j = -tau*H_ij/proposal_prob (0 and det_j partly built if no valid move, exactly
+ * like the reference's early returns).  n_draws = rannyu calls consumed. */
+void orc_off_diagonal_move_chem(const orc_chem *s, orc_rng *g, double tau, det_t iu, det_t id,
+                                det_t *pju, det_t *pjd, double *weight_j, int *n_draws) {
+  int nup = s->nup, ndn = s->ndn, norb = s->norb, nc = s->n_core_orb, nelec = s->nelec, draws = 0;
+  int occ[2 * ORC_MAXORB], n_occ_up = 0, n_occ = 0;
+  for (det_t t = iu; t; t &= t - 1) occ[n_occ++] = trailz(t) + 1;
+  n_occ_up = n_occ;
+  for (det_t t = id; t; t &= t - 1) occ[n_occ++] = trailz(t) + 1;
+  det_t ju = iu, jd = id;
+  *weight_j = 0; *pju = ju; *pjd = jd;
+  int n_single = (nup - nc) * (norb - nup) + (ndn - nc) * (norb - ndn);
+  int n_double_up = (nup - nc) * (nup - nc - 1) * (norb - nup) * (norb - nup - 1) / 4;
+  int n_double_dn = (ndn - nc) * (ndn - nc - 1) * (norb - ndn) * (norb - ndn - 1) / 4;
+  int n_double_both = (nup - nc) * (norb - nup) * (ndn - nc) * (norb - ndn);
+  int n_double = n_double_up + n_double_dn + n_double_both, n_total = n_single + n_double;
+  int level, e1 = 0, e2 = 0, tot_spin = 0;
+  double prob = 1.0;
+#define RI(n) (draws++, orc_random_int(g, (n)))
+  if (RI(n_total) > n_single) {
+    level = 2; prob = n_double / (double)n_total;
+    e1 = RI(nelec - 2 * nc); e2 = RI(nelec - 2 * nc - 1);
+    if (e2 == e1) e2 = nelec - 2 * nc;
+    if (e1 > nup - nc) { tot_spin -= 1; e1 += 2 * nc; } else { tot_spin += 1; e1 += nc; }
+    if (e2 > nup - nc) { tot_spin -= 1; e2 += 2 * nc; } else { tot_spin += 1; e2 += nc; }
+  } else {
+    level = 1; prob = prob * n_single / (n_total * 1.0);
+    e1 = RI(nelec - 2 * nc);
+    if (e1 > nup - nc) { tot_spin = -1; e1 += 2 * nc; } else { tot_spin = 1; e1 += nc; }
+  }
+  { int t = e1 + e2; e1 = t - (e1 > e2 ? e1 : e2); e2 = t - e1; }   /* 4460-4462 */
+  int sym1 = 1, o;
+  if (level == 1) {
+    o = occ[e2 - 1];
+    if (e2 <= n_occ_up) ju &= ~BIT(o - 1); else jd &= ~BIT(o - 1);
+    sym1 = s->orbsym[o];
+  } else {
+    o = occ[e1 - 1];
+    if (e1 <= n_occ_up) ju &= ~BIT(o - 1); else jd &= ~BIT(o - 1);
+    sym1 = s->orbsym[o];
+    o = occ[e2 - 1];
+    if (e2 <= n_occ_up) ju &= ~BIT(o - 1); else jd &= ~BIT(o - 1);
+    sym1 = s->prod[sym1][s->orbsym[o]];
+  }
+  *pju = ju; *pjd = jd;
+  int i_open, to1, to2, sp1, sym2; double temp1;
+  if (level == 1) {
+    prob = prob / (nelec - 2 * nc);
+    det_t occdet = (tot_spin == 1) ? iu : id;
+    i_open = s->num_orb_by_sym[sym1] - nocc_sym(s, occdet, sym1);
+    if (i_open == 0) goto done;
+    to1 = RI(i_open); prob = prob / i_open;
+    o = kth_open_sym(s, occdet, sym1, to1, 0);
+    if (tot_spin == 1) ju |= BIT(o - 1); else jd |= BIT(o - 1);
+  } else {
+    prob = prob * 2.0 / (1.0 * (nelec - 2 * nc) * (nelec - 2 * nc - 1));
+    if (tot_spin == 2 || tot_spin == -2) {
+      det_t occdet = (tot_spin == 2) ? iu : id; int nsp = (tot_spin == 2) ? nup : ndn;
+      to1 = RI(norb - nsp); prob = prob / (norb - nsp);
+      sp1 = kth_open(s, occdet, to1);
+      if (tot_spin == 2) ju |= BIT(sp1 - 1); else jd |= BIT(sp1 - 1);
+      *pju = ju; *pjd = jd;
+      sym2 = s->prod[s->orbsym[sp1]][sym1];
+      int same = (sym2 == s->orbsym[sp1]);
+      i_open = s->num_orb_by_sym[sym2] - nocc_sym(s, occdet, sym2) - (same ? 1 : 0);
+      if (i_open == 0) goto done;
+      to2 = RI(i_open); temp1 = 1.0 / i_open;
+      o = kth_open_sym(s, occdet, sym2, to2, same ? sp1 : 0);
+      if (tot_spin == 2) ju |= BIT(o - 1); else jd |= BIT(o - 1);
+      int sy = s->prod[sym2][sym1];
+      i_open = s->num_orb_by_sym[sy] - nocc_sym(s, occdet, sy) - (same ? 1 : 0);
+      if (i_open == 0) prob = prob * temp1; else prob = prob * (temp1 + (1.0 / i_open));
+    } else {
+      prob = prob * 1.0 / (2 * norb - ndn - nup);
+      to1 = RI(2 * norb - nup - ndn);
+      det_t d1, d2; int first_up = (to1 <= norb - nup);
+      if (first_up) { d1 = iu; d2 = id; } else { d1 = id; d2 = iu; to1 -= (norb - nup); }
+      sp1 = kth_open(s, d1, to1);
+      if (first_up) ju |= BIT(sp1 - 1); else jd |= BIT(sp1 - 1);
+      *pju = ju; *pjd = jd;
+      sym2 = s->prod[sym1][s->orbsym[sp1]];
+      i_open = s->num_orb_by_sym[sym2] - nocc_sym(s, d2, sym2);
+      if (i_open == 0) goto done;
+      to2 = RI(i_open); temp1 = 1.0 / i_open;
+      o = kth_open_sym(s, d2, sym2, to2, 0);
+      if (first_up) jd |= BIT(o - 1); else ju |= BIT(o - 1);
+      int sy = s->prod[sym2][sym1];
+      i_open = s->num_orb_by_sym[sy] - nocc_sym(s, d1, sy);
+      if (i_open != 0) prob = prob * (temp1 + (1.0 / i_open)); else prob = prob * temp1;
+    }
+  }
+  *pju = ju; *pjd = jd;
+  { double me = orc_hamiltonian_chem(s, iu, id, ju, jd, level);
+    *weight_j = -tau * me / prob; }
+done:
+#undef RI
+  if (n_draws) *n_draws = draws;
+}
+
+/* ================================================================== walk */
+orc_walk *orc_walk_new(int64_t mwalk) {
+  orc_walk *w = calloc(1, sizeof(orc_walk));
+  w->mwalk = mwalk;
+  w->up = calloc(mwalk, sizeof(det_t)); w->dn = calloc(mwalk, sizeof(det_t));
+  w->wt = calloc(mwalk, sizeof(double));
+  w->imp_distance = malloc(mwalk); w->initiator = calloc(mwalk, 1);
+  w->matrix_elements = malloc(mwalk * sizeof(double));
+  w->e_num_walker = malloc(mwalk * sizeof(double)); w->e_den_walker = malloc(mwalk * sizeof(double));
+  for (int64_t i = 0; i < mwalk; i++) {            /* do_walk.f90:1133-1155 */
+    w->imp_distance[i] = 1; w->matrix_elements[i] = 1e51; w->e_num_walker[i] = 1e51; w->e_den_walker[i] = 1e51;
+  }
+  return w;
+}
+void orc_walk_free(orc_walk *w) {
+  if (!w) return;
+  free(w->up); free(w->dn); free(w->wt); free(w->imp_distance); free(w->initiator);
+  free(w->matrix_elements); free(w->e_num_walker); free(w->e_den_walker);
+  free(w->prj_counts); free(w->prj_indices); free(w->prj_values);
+  free(w->ct_up); free(w->ct_dn); free(w->ct_num); free(w->ct_den); free(w->sign_perm); free(w);
+}
+
+/* do_walk.f90:5169-5197 + 5411-5614 : stable sort on (up,dn), all 8 arrays permuted */
+static void msort_idx(const det_t *up, const det_t *dn, int64_t *a, int64_t *tmp, int64_t n) {
+  if (n < 2) return;
+  int64_t na = (n + 1) / 2, nb = n - na;
+  msort_idx(up, dn, a, tmp, na); msort_idx(up, dn, a + na, tmp, nb);
+  memcpy(tmp, a, na * sizeof(int64_t));
+  int64_t i = 0, j = na, k = 0;
+  while (i < na && j < n) {
+    int64_t x = tmp[i], y = a[j];
+    if (up[x] < up[y] || (up[x] == up[y] && dn[x] <= dn[y])) a[k++] = tmp[i++]; else a[k++] = a[j++];
+  }
+  while (i < na) a[k++] = tmp[i++];
+}
+void orc_merge_sort_walkers(orc_walk *w, int64_t n) {
+  int64_t *ord = malloc(n * sizeof(int64_t)), *tmp = malloc(((n + 1) / 2 + 1) * sizeof(int64_t));
+  for (int64_t i = 0; i < n; i++) ord[i] = i;
+  msort_idx(w->up, w->dn, ord, tmp, n);
+#define PERM(T, A) do { T *b = malloc(n * sizeof(T)); for (int64_t i = 0; i < n; i++) b[i] = (A)[ord[i]]; \
+                        memcpy((A), b, n * sizeof(T)); free(b); } while (0)
+  PERM(det_t, w->up); PERM(det_t, w->dn); PERM(double, w->wt); PERM(int8_t, w->imp_distance);
+  PERM(int8_t, w->initiator); PERM(double, w->matrix_elements); PERM(double, w->e_num_walker); PERM(double, w->e_den_walker);
+#undef PERM
+  free(ord); free(tmp);
+}
+
+static double ipow(int b, int e) { double r = 1; for (int i = 0; i < e; i++) r *= b; return r; }  /* integer ** integer */
+/* do_walk.f90:6838-6872 / the inlined copies at 5952-5972 and 5989-6038 */
+static int check_initiator(orc_walk *w, int64_t i, const orc_step_params *p, int *i_perm) {
+  double thr = p->r_initiator * ipow(w->imp_distance[i] - p->initiator_min_distance > 0 ? w->imp_distance[i] - p->initiator_min_distance : 0, p->initiator_power);
+  double aw = fabs(w->wt[i]); int d = w->imp_distance[i];
+  if (w->initiator[i] == 3 && p->r_initiator >= 0) {
+    int sg = w->sign_perm[(*i_perm)++];
+    if (w->wt[i] * sg < 1.0) w->wt[i] = sg;
+  } else if (w->initiator[i] == 2 && ((aw <= thr && d > 0) || ((aw <= p->r_initiator && !p->c_t_initiator) && d == -2))) {
+    w->initiator[i] = 1;
+  } else if (w->initiator[i] < 2 && ((aw > thr && d >= 0) || ((aw > p->r_initiator || p->c_t_initiator) && d == -2))) {
+    w->initiator[i] = (int8_t)(w->initiator[i] + 1);
+  }
+  return (((w->wt[i] == 0 && (w->initiator[i] != 3 || p->r_initiator < 0)) || w->initiator[i] == 0) && w->imp_distance[i] >= 1);
+}
+#define DMIN(a, b) ((a) < (b) ? (a) : (b))
+/* do_walk.f90:5866-6083 (chem: e_num/e_den merged too).  0-based restatement of the
+ * nshift scan; returns the new nwalk. */
+int64_t orc_merge_original_with_spawned2(orc_walk *w, int64_t nwalk, const orc_step_params *p) {
+  if (nwalk <= 0) return nwalk;
+  int64_t nshift = 0; int i_perm = 0;
+  for (int64_t iw = 1; iw < nwalk; iw++) {
+    int64_t t = iw - nshift - 1;                   /* previous kept slot */
+    if (w->up[iw] == w->up[t] && w->dn[iw] == w->dn[t]) {
+      nshift++;                                   /* now t == iw - nshift */
+      if (w->wt[iw] * w->wt[t] > 0) {
+        if (w->initiator[iw] > w->initiator[t]) w->initiator[t] = w->initiator[iw];
+        w->e_num_walker[t] = DMIN(w->e_num_walker[t], w->e_num_walker[iw]);
+        w->e_den_walker[t] = DMIN(w->e_den_walker[t], w->e_den_walker[iw]);
+      }
+      w->matrix_elements[t] = DMIN(w->matrix_elements[t], w->matrix_elements[iw]);
+      if (w->imp_distance[t] == -2) { if (w->imp_distance[iw] == 0) w->imp_distance[t] = 0; }
+      else if (w->imp_distance[iw] == -2) { if (w->imp_distance[t] != 0) w->imp_distance[t] = -2; }
+      else if (w->imp_distance[t] != 0 && w->imp_distance[t] != -2) {
+        int a = abs(w->imp_distance[iw]);
+        if (a < w->imp_distance[t]) w->imp_distance[t] = (int8_t)a;
+      }
+      if (!(w->wt[iw] * w->wt[t] > 0)) {
+        if (fabs(w->wt[t]) < fabs(w->wt[iw])) { if (w->initiator[t] != 3 || p->r_initiator == -1.0) w->initiator[t] = w->initiator[iw]; }
+        else if (fabs(w->wt[t]) == fabs(w->wt[iw])) { if (w->initiator[t] != 3 || p->r_initiator == -1.0) w->initiator[t] = 0; }
+      }
+      if (!(w->imp_distance[t] == 0 && w->imp_distance[iw] == -1)) w->wt[t] = w->wt[t] + w->wt[iw];
+    } else {
+      if (check_initiator(w, t, p, &i_perm)) nshift++;
+      int64_t u = iw - nshift;
+      w->up[u] = w->up[iw]; w->dn[u] = w->dn[iw]; w->wt[u] = w->wt[iw]; w->initiator[u] = w->initiator[iw];
+      w->e_num_walker[u] = w->e_num_walker[iw]; w->e_den_walker[u] = w->e_den_walker[iw];
+      w->imp_distance[u] = w->imp_distance[iw]; w->matrix_elements[u] = w->matrix_elements[iw];
+      if (w->imp_distance[iw] == -1) w->imp_distance[u] = 1;
+    }
+  }
+  int64_t last = nwalk - nshift - 1;
+  int discard = check_initiator(w, last, p, &i_perm);
+  /* 6032-6036 runs between the flag update and the discard test of the last det */
+  for (int64_t i = 0; i <= last; i++) if (w->imp_distance[i] == -1) w->imp_distance[i] = 1;
+  discard = (((w->wt[last] == 0 && (w->initiator[last] != 3 || p->r_initiator < 0)) || w->initiator[last] == 0) && w->imp_distance[last] >= 1);
+  if (discard) nshift++;
+  int64_t nn = nwalk - nshift;
+  for (int64_t i = nn; i < w->mwalk && i < nwalk; i++) { w->e_num_walker[i] = 1e51; w->e_den_walker[i] = 1e51; w->matrix_elements[i] = 1e51; }
+  return nn;
+}
+
+/* do_walk.f90:7196-7254 (hf_to_psit = false) */
+int64_t orc_reduce_my_walker(orc_walk *w, int64_t n, const orc_step_params *p) {
+  for (int64_t i = 0; i < n; i++)
+    if (w->imp_distance[i] >= 1 && fabs(w->wt[i]) < p->min_wt) {
+      if (orc_rannyu(&w->rng) < (fabs(w->wt[i]) / p->min_wt)) w->wt[i] = copysign(p->min_wt, w->wt[i]);
+      else w->wt[i] = 0.0;
+    }
+  int64_t nshift = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (w->wt[i] == 0.0 && w->imp_distance[i] >= 1) nshift++;
+    else if (nshift) {
+      int64_t u = i - nshift;
+      w->wt[u] = w->wt[i]; w->up[u] = w->up[i]; w->dn[u] = w->dn[i];
+      w->e_num_walker[u] = w->e_num_walker[i]; w->e_den_walker[u] = w->e_den_walker[i];
+      w->initiator[u] = w->initiator[i]; w->imp_distance[u] = w->imp_distance[i]; w->matrix_elements[u] = w->matrix_elements[i];
+    }
+  }
+  return n - nshift;
+}
+
+/* do_walk.f90:3538-3800, chem + uniform2 proposal, hf_to_psit=.false.  Returns status
+ * (0 ok, 1 nwalk>MWALK, 3 negative diagonal factor after equilibration). */
+static int move_uniform2(const orc_chem *s, orc_walk *w, const orc_step_params *p, int64_t iw, int64_t *attempts) {
+  int spawn, use_wt;
+  if (fabs(w->wt[iw]) < p->always_spawn_cutoff_wt) {
+    spawn = (orc_rannyu(&w->rng) < fabs(w->wt[iw] / p->always_spawn_cutoff_wt)); use_wt = 0; w->n_spawn_draws++;
+  } else { spawn = 1; use_wt = 1; }
+  if (spawn) {
+    long nchild; double wchild;
+    if (use_wt) { nchild = lround(fabs(w->wt[iw])); if (nchild < 1) nchild = 1; wchild = w->wt[iw] / nchild; }
+    else { nchild = 1; wchild = copysign(p->always_spawn_cutoff_wt, w->wt[iw]); }
+    for (long c = 1; c <= nchild; c++) {
+      det_t ju, jd; double wj; int nd;
+      orc_off_diagonal_move_chem(s, &w->rng, p->tau, w->up[iw], w->dn[iw], &ju, &jd, &wj, &nd);
+      w->n_spawn_draws += nd; (*attempts)++;
+      wj = wchild * wj;
+      if (wj != 0) {
+        int64_t k = w->nwalk++;
+        if (w->nwalk > w->mwalk) return 1;
+        w->up[k] = ju; w->dn[k] = jd; w->wt[k] = wj;
+        if (w->imp_distance[iw] == -2) w->imp_distance[k] = p->c_t_initiator ? 1 : 2;
+        else w->imp_distance[k] = (int8_t)((w->imp_distance[iw] < 126 ? w->imp_distance[iw] : 126) + 1);
+        if (p->semistochastic && w->imp_distance[iw] == 0) w->imp_distance[k] = -1;
+        w->initiator[k] = (w->initiator[iw] >= 2) ? 1 : 0;
+        if (p->c_t_initiator && w->imp_distance[iw] == -2) w->initiator[k] = 1;
+        if (p->semistochastic && w->imp_distance[iw] == 0) w->initiator[k] = 1;
+        w->e_num_walker[k] = 1e51; w->e_den_walker[k] = 1e51; w->matrix_elements[k] = 1e51;
+      }
+    }
+  }
+  if (!p->semistochastic || w->imp_distance[iw] >= 1) {
+    double hii;
+    if (w->matrix_elements[iw] > 1e50) {
+      hii = orc_hamiltonian(s, w->up[iw], w->dn[iw], w->up[iw], w->dn[iw]);
+      w->matrix_elements[iw] = hii;
+    } else hii = w->matrix_elements[iw];
+    double f = 1.0 + p->tau * (p->e_trial - hii);
+    if (f < 0) { if (p->reached_w_abs_gen > 1) return 3; f = 0; }
+    w->wt[iw] = w->wt[iw] * f;
+  }
+  return 0;
+}
+
+/* more_tools.f90:4041-4098 : walkers scanned from the last to the first; lookups only for
+ * walkers whose e_num is still the 1e51 sentinel.  The shrinking upper bound of the
+ * reference is an optimisation of the same search (both lists sorted). */
+static void search_list_and_update(orc_walk *w, int64_t n, double acc[7]) {
+  for (int64_t i = n - 1; i >= 0; i--) {
+    if (w->e_num_walker[i] > 1e50) {
+      int64_t j = bsearch_det(w->ct_up, w->ct_dn, w->n_ct, w->up[i], w->dn[i]);
+      if (j < 0) { w->e_num_walker[i] = 0; w->e_den_walker[i] = 0; }
+      else { w->e_num_walker[i] = w->ct_num[j]; w->e_den_walker[i] = w->ct_den[j]; }
+    }
+    double en = w->e_num_walker[i] * w->wt[i], ed = w->e_den_walker[i] * w->wt[i];
+    if (en != 0.0) {
+      if (fabs(ed) < 1e-22) ed = fabs(ed);
+      acc[1] += ed; acc[3] += ed * ed; acc[5] += fabs(ed);
+      acc[0] += en; acc[2] += en * en; acc[4] += en * copysign(1.0, ed); acc[6] += en * ed;
+    }
+  }
+}
+
+/* One MC step, do_walk.f90:2186-2790 for semistochastic chem, ncores=1, hf_to_psit=.false.,
+ * run_type 'none'.  Population control (2880-2901) stays with the caller. */
+int orc_walk_step(const orc_chem *s, orc_walk *w, const orc_step_params *p, double out[16]) {
+  int64_t n0 = w->nwalk, nimp = 0, attempts = 0;
+  int64_t *loc = NULL; double *impw = NULL, *dw = NULL;
+  w->n_spawn_draws = 0;
+  if (p->semistochastic) {                         /* 2188-2212 */
+    loc = malloc((w->n_imp + 1) * sizeof(int64_t)); impw = malloc((w->n_imp + 1) * sizeof(double)); dw = malloc((w->n_imp + 1) * sizeof(double));
+    for (int64_t i = 0; i < n0 && nimp < w->n_imp; i++) if (w->imp_distance[i] == 0) { loc[nimp] = i; impw[nimp] = w->wt[i]; nimp++; }
+    if (nimp != w->n_imp) { free(loc); free(impw); free(dw); return 5; }
+  }
+  for (int64_t i = 0; i < n0; i++) {               /* 2220-2231 */
+    int st = move_uniform2(s, w, p, i, &attempts);
+    if (st) { free(loc); free(impw); free(dw); return st; }
+  }
+  if (p->semistochastic) {                         /* 2255-2325 */
+    double *x = malloc((nimp + 1) * sizeof(double));
+    for (int64_t i = 0; i < nimp; i++) x[i] = w->wt[loc[i]];
+    orc_spmv_sym_upper(nimp, w->prj_counts, w->prj_indices, w->prj_values, x, dw);
+    for (int64_t i = 0; i < nimp; i++) dw[i] = dw[i] + p->e_trial * p->tau * impw[i];
+    for (int64_t i = 0; i < nimp; i++) w->wt[loc[i]] = w->wt[loc[i]] + dw[i];
+    free(x);
+  }
+  free(loc); free(impw); free(dw);
+  int64_t n = w->nwalk;
+  orc_merge_sort_walkers(w, n);                    /* 2335 */
+  double wabs_before = 0; for (int64_t i = 0; i < n; i++) wabs_before += fabs(w->wt[i]);
+  int64_t nbefore = n;
+  n = orc_merge_original_with_spawned2(w, n, p);   /* 2373 */
+  if (p->semistochastic) n = orc_reduce_my_walker(w, n, p);   /* 2473 */
+  w->nwalk = n;
+  for (int64_t i = 0; i < n; i++) w->wt[i] = w->wt[i] * p->reweight_factor_inv;   /* 2487 */
+  if (n == 0) return 4;
+  double w_gen = 0, w2 = 0, w_abs = 0, w_abs_imp = 0, w_perm = 0; int ip = 0;      /* 2573-2598 */
+  for (int64_t i = 0; i < n; i++) {
+    if (w->initiator[i] == 3) w_perm += w->wt[i] * w->sign_perm[ip++];
+    w_gen += w->wt[i]; w2 += w->wt[i] * w->wt[i]; w_abs += fabs(w->wt[i]);
+    if (w->imp_distance[i] == 0 || (w->imp_distance[i] == -2 && p->c_t_initiator)) w_abs_imp += fabs(w->wt[i]);
+  }
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  search_list_and_update(w, n, acc);               /* 2755-2759 */
+  out[0] = w_gen; out[1] = w_abs; out[2] = acc[1]; out[3] = acc[0]; out[4] = w_perm; out[5] = (double)n;
+  out[6] = w_abs_imp; out[7] = (double)nbefore; out[8] = w2; out[9] = acc[2]; out[10] = acc[3];
+  out[11] = acc[4]; out[12] = acc[5]; out[13] = acc[6]; out[14] = wabs_before; out[15] = (double)attempts;
+  return 0;
+}

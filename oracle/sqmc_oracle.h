@@ -1,0 +1,133 @@
+/*
+ * sqmc_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the sqmc reference algorithms on the walker hot
+ * path.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library, and only as the checker.
+ * Every function cites the reference file:line (relative to /root/reference/src)
+ * whose behaviour it restates.  Determinants are one 64-bit word per spin
+ * (norb <= 64); bit k <-> orbital k+1, as in the reference (types.f90:14-44).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - rannyu / random_int / permutation_factor / merge sort: checked against the
+ *     real reference objects compiled unmodified into oracle/_ref (tools.f90,
+ *     rannyu.f90).
+ *   - hamiltonian_chem + HCI generator + sym. matvec: checked against the HCI
+ *     energies and determinant counts the reference produced on
+ *     C2_v2z_curve/r1.24253.
+ *   - walker step (move/merge/reduce/estimators): the reference holds no fixture
+ *     for it ("parity unpinned" beyond the component pins above).
+ */
+#ifndef SQMC_ORACLE_H
+#define SQMC_ORACLE_H
+#include <stdint.h>
+
+typedef uint64_t det_t;
+
+/* ---- RNG: rannyu.f90:11-87, tools.f90:129-147 ---- */
+typedef struct { int l[4]; } orc_rng;
+void   orc_setrn(orc_rng *g, const int seed[4]);
+void   orc_savern(const orc_rng *g, int seed[4]);
+double orc_rannyu(orc_rng *g);
+int    orc_random_int(orc_rng *g, int n);
+
+/* ---- chemistry system: chemistry.f90:121-869 ---- */
+#define ORC_MAXORB 64
+#define ORC_MAXSYM 8
+typedef struct {
+  int norb, nelec, nup, ndn, n_core_orb;
+  int time_sym, z;
+  int n_group;                       /* point group order (d2h = 8)            */
+  int prod[ORC_MAXSYM + 1][ORC_MAXSYM + 1];       /* product_table, 1-based     */
+  int orbsym[ORC_MAXORB + 1];        /* orbital_symmetries after reordering     */
+  int orb_order[ORC_MAXORB + 2];     /* new index -> FCIDUMP label (1-based)    */
+  int orb_order_inv[ORC_MAXORB + 2];
+  int combine_2[ORC_MAXORB + 2][ORC_MAXORB + 2];  /* chemistry.f90:384-394,856  */
+  int64_t n_int;
+  double *integrals;                 /* 1-based packed array (index 0 unused)   */
+  double nuclear;                    /* nuclear_nuclear_energy                  */
+  double orbital_energies[ORC_MAXORB + 1];
+  det_t hf_up, hf_dn;
+  int num_orb_by_sym[ORC_MAXSYM + 1];
+  int which_orb_by_sym[ORC_MAXSYM + 1][ORC_MAXORB + 1];
+  /* HCI heat-bath double-excitation table: chemistry.f90:900-993 */
+  int64_t n_hb;
+  int *hb_r, *hb_s; double *hb_absH;
+  int64_t *pq_ind; int *pq_count; int n_pq;
+  double max_double;
+} orc_chem;
+
+/* hf_mode: 0 = first nup/ndn orbitals (walk decks), 1 = auto HF of symmetry
+ * hf_symmetry (HCI decks, chemistry.f90:10359-10454). */
+orc_chem *orc_chem_load(const char *fcidump, int nelec, int nup, const char *point_group,
+                        int time_sym, int z, int n_core_orb, int hf_mode, int hf_symmetry);
+void   orc_chem_free(orc_chem *s);
+void   orc_chem_setup_hb(orc_chem *s);
+int64_t orc_integral_index(const orc_chem *s, int i, int j, int k, int l);
+double orc_integral_value(const orc_chem *s, int p, int q, int r, int t);
+
+int    orc_permutation_factor(det_t a, det_t b);
+void   orc_permutation_factor2(det_t di, det_t dj, int *gamma, int *i1, int *i2, int *j1, int *j2);
+int    orc_excitation_level(det_t iu, det_t id, det_t ju, det_t jd);
+double orc_hamiltonian_chem(const orc_chem *s, det_t iu, det_t id, det_t ju, det_t jd, int level);
+double orc_hamiltonian_chem_time_sym(const orc_chem *s, det_t iu, det_t id, det_t ju, det_t jd);
+/* dispatcher semistoch.f90:2234: time_sym aware, any pair; returns 0 if not connected */
+double orc_hamiltonian(const orc_chem *s, det_t iu, det_t id, det_t ju, det_t jd);
+
+/* off_diagonal_move_chem, chemistry.f90:4237-5084 (time_sym = false branch) */
+void orc_off_diagonal_move_chem(const orc_chem *s, orc_rng *g, double tau, det_t iu, det_t id,
+                                det_t *ju, det_t *jd, double *weight_j, int *n_draws);
+
+/* connections */
+int orc_find_connected_dets_chem(const orc_chem *s, det_t up, det_t dn, det_t *cu, det_t *cd,
+                                 double *elems, int cap);
+int orc_find_important_connected_dets_chem(const orc_chem *s, det_t up, det_t dn, double eps,
+                                           det_t *cu, det_t *cd, double *elems, int cap);
+
+/* symmetric "upper triangular" CSR matvec, more_tools.f90:3622-3670 */
+void orc_spmv_sym_upper(int64_t n, const int64_t *row_counts, const int64_t *indices,
+                        const double *values, const double *x, double *y);
+
+/* sparse Hamiltonian among a sorted determinant list (lower triangle, diagonal first
+ * in each row); pure function of the list -- any construction algorithm gives the same
+ * matrix (reference: chemistry.f90:7639-8010). Returns nnz; arrays malloc'ed. */
+int64_t orc_build_sparse_ham(const orc_chem *s, int64_t n, const det_t *up, const det_t *dn,
+                             int64_t **row_counts, int64_t **indices, double **values);
+void orc_free(void *p);
+
+/* ---- walker state + one MC step: do_walk.f90:2171-2934 ---- */
+typedef struct {
+  int64_t nwalk, mwalk;
+  det_t *up, *dn;
+  double *wt;
+  int8_t *imp_distance, *initiator;
+  double *matrix_elements, *e_num_walker, *e_den_walker;
+  /* deterministic projector -tau*H, common_imp.f90:4-17 */
+  int64_t n_imp, nnz;
+  int64_t *prj_counts, *prj_indices; double *prj_values;
+  /* C(T): common_psi_t.f90:20-32 (sorted by up,dn) */
+  int64_t n_ct; det_t *ct_up, *ct_dn; double *ct_num, *ct_den;
+  /* permanent initiators (sorted order) do_walk.f90:1150 */
+  int n_perm; int8_t *sign_perm;
+  orc_rng rng;
+  int64_t n_spawn_draws;            /* RNG draws consumed in the last step      */
+} orc_walk;
+
+typedef struct {
+  double tau, e_trial, reweight_factor_inv, r_initiator, min_wt, always_spawn_cutoff_wt;
+  int initiator_power, initiator_min_distance, c_t_initiator, semistochastic, reached_w_abs_gen;
+} orc_step_params;
+
+/* out[16]: 0 w_gen 1 w_abs_gen 2 e_den_gen 3 e_num_gen 4 w_perm_initiator_gen 5 nwalk
+ *          6 w_abs_gen_imp 7 nwalk_before_merge 8 w2_gen 9 e_num2 10 e_den2 11 e_num_abs
+ *          12 e_den_abs 13 e_num_e_den 14 w_abs_before_merge 15 n_spawn_attempts */
+orc_walk *orc_walk_new(int64_t mwalk);
+void orc_walk_free(orc_walk *w);
+int  orc_walk_step(const orc_chem *s, orc_walk *w, const orc_step_params *p, double out[16]);
+
+/* pieces exposed for component tests */
+void orc_merge_sort_walkers(orc_walk *w, int64_t n);                       /* do_walk.f90:5169-5197 */
+int64_t orc_merge_original_with_spawned2(orc_walk *w, int64_t n, const orc_step_params *p); /* 5866-6083 */
+int64_t orc_reduce_my_walker(orc_walk *w, int64_t n, const orc_step_params *p);            /* 7196-7254 */
+
+#endif
