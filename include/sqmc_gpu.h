@@ -1,0 +1,170 @@
+/*
+ * sqmc_gpu.h -- C ABI of libsqmc_gpu.so: the MI355X (gfx950) implementation of sqmc's
+ * semistochastic walker step, deterministic-core matvec and HCI connection generation.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  A Fortran
+ * host binds it with iso_c_binding (sqmc_amd/fortran/sqmc_gpu_mod.f90; INTEGRATION.md shows
+ * the call sites to patch in the reference).  Each entry point cites the reference
+ * interface it replaces, file:line relative to the reference's src/.
+ *
+ * Conventions (identical to the reference):
+ *   - determinants: one 64-bit word per spin (n_det_words = 1, norb <= 64 this round); bit k
+ *     <-> orbital k+1; walkers sorted by (up, then dn) as unsigned integers.  The reference
+ *     splits its 128-bit dets into 2 x int64 on the wire (mpi_routines.f90:671-680); the
+ *     low word is what is passed here, the high word must be zero.
+ *   - CSR of the symmetric projector/Hamiltonian: "upper triangular" storage of
+ *     more_tools.f90:3622-3670 -- row_counts(n), 1-based int64 column indices, fp64 values;
+ *     every stored (i,m) with i != m is applied to both y(i) and y(m).
+ *   - weights fp64; initiator in {0,1,2,3}; imp_distance in {-2,-1,0,1..127} as int8.
+ *   - every function returns 0 on success; >0 are the reference's own stop conditions
+ *     (see SQMC_ERR_*), <0 are library/HIP failures (text via sqmc_gpu_last_error()).
+ *   - one context per process/GPU, driven by one host thread (the reference is
+ *     single-threaded per MPI rank).
+ */
+#ifndef SQMC_GPU_H
+#define SQMC_GPU_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sqmc_gpu_ctx sqmc_gpu_ctx;
+
+/* status codes > 0 mirror the reference's stop statements */
+#define SQMC_OK 0
+#define SQMC_ERR_MWALK 1          /* 'nwalk>MWALK'                    do_walk.f90:3684-3690 */
+#define SQMC_ERR_SPAWN_OVERFLOW 2 /* spawn buffer full                mpi_routines.f90:2494 */
+#define SQMC_ERR_NEG_DIAG 3       /* diagonal_factor<0 after equil.   do_walk.f90:3788     */
+#define SQMC_ERR_NO_WALKERS 4     /* 'my_nwalk=0'                     do_walk.f90:2489     */
+#define SQMC_ERR_IMP_BROKEN 5     /* 'locations of my imp broken'     do_walk.f90:2204     */
+#define SQMC_ERR_BAD_ARG -1
+#define SQMC_ERR_HIP -2
+#define SQMC_ERR_UNSUPPORTED -3
+
+/* RNG discipline.  REPLAY reproduces the reference's single rannyu stream draw for draw
+ * (rannyu.f90:54-74 consumed in walker order, do_walk.f90:3577-3583, chemistry.f90:4391-4439,
+ * do_walk.f90:7222-7230) and is meant for fixed-seed parity runs; COUNTER keys an
+ * independent 48-bit stream on (seed, step, stage, walker/child index) so that every
+ * stage is fully parallel.  Both give reals k/2^48 like rannyu. */
+#define SQMC_RNG_REPLAY 0
+#define SQMC_RNG_COUNTER 1
+
+/* Tables the reference builds in system_setup_chem / read_integrals / setup_orb_by_symm
+ * (chemistry.f90:299-537, 538-869, 2461-2527) and keeps in module chemistry. */
+typedef struct {
+  int32_t norb, nup, ndn, n_core_orb;
+  int32_t time_sym, z;              /* chemistry.f90:163-181 (walk kernels need time_sym=0) */
+  int32_t n_group;                  /* order of the abelian point group (<= 8)             */
+  const int32_t *product_table;     /* [9*9], 1-based: product_table(i,j) at [i*9+j]       */
+  const int32_t *orbital_symmetries;/* [norb+1], 1-based, after orbital reordering         */
+  const int32_t *combine_2;         /* [(norb+2)*(norb+2)], 1-based, chemistry.f90:856-866 */
+  int64_t n_integrals;              /* integral_index(norb+1,...,norb+1)                   */
+  const double *integrals;          /* [n_integrals+1], 1-based packed array               */
+  int32_t rng_mode;                 /* SQMC_RNG_*                                          */
+  int32_t irand_seed[4];            /* stream-2 seed of input line 1, do_walk.f90:231,646  */
+  int64_t mwalk;                    /* MWALK: capacity of the walker arrays                */
+} sqmc_chem_cfg;
+
+/* replaces: system_setup_chem + init_move table setup.  Copies everything to HBM. */
+int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out);
+int sqmc_gpu_finalize(sqmc_gpu_ctx *ctx);
+const char *sqmc_gpu_last_error(void);
+
+/* replaces: dtm_hb / pq_ind / pq_count built by setup_efficient_heatbath (chemistry.f90:900-993).
+ * hb_r/hb_s/hb_absH: n_hb records sorted by descending absH inside each (p,q) class;
+ * pq_ind (1-based start) / pq_count indexed by combine_2_indices(p,q) in [1, n_pq]. */
+int sqmc_gpu_set_hb_tables(sqmc_gpu_ctx *ctx, int64_t n_hb, const int32_t *hb_r, const int32_t *hb_s,
+                           const double *hb_absH, int32_t n_pq, const int64_t *pq_ind,
+                           const int32_t *pq_count, double max_double);
+
+/* replaces: minus_tau_H_indices / _nonzero_elements / _values (common_imp.f90:14-15) as
+ * consumed at do_walk.f90:2262; scale = the tau_ratio rescale of do_walk.f90:2179,2919. */
+int sqmc_gpu_set_projector(sqmc_gpu_ctx *ctx, int64_t n_imp, int64_t nnz, const int64_t *row_counts,
+                           const int64_t *indices, const double *values);
+int sqmc_gpu_scale_projector(sqmc_gpu_ctx *ctx, double ratio);
+
+/* replaces: psi_t_connected_dets_up/dn, psi_t_connected_e_loc_num/den (common_psi_t.f90:20-32),
+ * sorted by (up,dn), searched by binary_search_list_and_update (more_tools.f90:4041-4098). */
+int sqmc_gpu_set_ct_table(sqmc_gpu_ctx *ctx, int64_t n, const uint64_t *up, const uint64_t *dn,
+                          const double *e_num, const double *e_den);
+
+/* walker SoA of common_walk.f90:5-18.  perm_sign(i) = sign_permanent_initiator of walker i
+ * if initiator(i)==3 else 0 (the reference keeps the signs in sorted-walker order,
+ * do_walk.f90:1150,2593-2594; here the sign travels with its walker). */
+int sqmc_gpu_upload_walkers(sqmc_gpu_ctx *ctx, int64_t n, const uint64_t *up, const uint64_t *dn,
+                            const double *wt, const int8_t *imp_distance, const int8_t *initiator,
+                            const int8_t *perm_sign, const double *matrix_elements,
+                            const double *e_num, const double *e_den);
+int sqmc_gpu_num_walkers(sqmc_gpu_ctx *ctx, int64_t *n);
+int sqmc_gpu_download_walkers(sqmc_gpu_ctx *ctx, int64_t cap, int64_t *n, uint64_t *up, uint64_t *dn,
+                              double *wt, int8_t *imp_distance, int8_t *initiator,
+                              double *matrix_elements, double *e_num, double *e_den);
+
+/* by-value scalars of one MC step, do_walk.f90:2171-2934 */
+typedef struct {
+  double tau, e_trial, reweight_factor_inv, r_initiator, min_wt, always_spawn_cutoff_wt;
+  int32_t initiator_power, initiator_min_distance, c_t_initiator, semistochastic, reached_w_abs_gen;
+  int32_t reserved;
+} sqmc_step_params;
+
+/* out_stats[16]: 0 w_gen  1 w_abs_gen  2 e_den_gen  3 e_num_gen  4 w_perm_initiator_gen
+ *   5 nwalk  6 w_abs_gen_imp  (the 7 reduced values of do_walk.f90:2689-2725)
+ *   7 nwalk_before_merge  8 w2_gen  9 e_num2  10 e_den2  11 e_num_abs  12 e_den_abs
+ *   13 e_num_e_den (the my_*_cum increments, 2670-2679)  14 w_abs_before_merge
+ *   15 number of off-diagonal proposals made.
+ * replaces: the move loop, deterministic projection, sort, merge, reduce, reweight and
+ * estimator sums of do_walk.f90:2216-2487 and 2573-2790 (semistochastic chem, ncores=1). */
+int sqmc_gpu_step(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, double out_stats[16]);
+/* RNG state of the REPLAY stream (savern / setrn, rannyu.f90:11-21,77-87) */
+int sqmc_gpu_get_rng(sqmc_gpu_ctx *ctx, int32_t seed[4]);
+int sqmc_gpu_set_rng(sqmc_gpu_ctx *ctx, const int32_t seed[4]);
+
+/* replaces: fast_sparse_matrix_multiply_upper_triangular (more_tools.f90:3622-3670) as
+ * called from davidson_sparse (more_tools.f90:2115,2188).  prepare once per matrix
+ * (converts to int32 full CSR in HBM), apply per matvec.  x/y are host pointers unless
+ * on_device != 0. */
+typedef struct sqmc_spmv_plan sqmc_spmv_plan;
+int sqmc_gpu_spmv_prepare(int64_t n, const int64_t *row_counts, const int64_t *indices,
+                          const double *values, sqmc_spmv_plan **plan);
+int sqmc_gpu_spmv_apply(sqmc_spmv_plan *plan, const double *x, double *y, int on_device);
+int sqmc_gpu_spmv_free(sqmc_spmv_plan *plan);
+int sqmc_gpu_spmv_sym_upper(int64_t n, const int64_t *row_counts, const int64_t *indices,
+                            const double *values, const double *x, double *y);
+
+/* replaces: hamiltonian_chem / hamiltonian_chem_time_sym through the dispatcher
+ * semistoch.f90:2234-2302, for n (bra,ket) pairs; 0 where not connected. */
+int sqmc_gpu_hamiltonian_batch(sqmc_gpu_ctx *ctx, int64_t n, const uint64_t *iu, const uint64_t *id,
+                               const uint64_t *ju, const uint64_t *jd, double *h);
+
+/* test door onto the proposal kernel: off_diagonal_move_chem (chemistry.f90:4237-5084) for n
+ * parents, child k of the batch drawing from rannyu state seeds[4k..4k+3]; returns det_j,
+ * weight_j (= -tau*H/p) and the state after. */
+int sqmc_gpu_propose_batch(sqmc_gpu_ctx *ctx, int64_t n, double tau, const uint64_t *up,
+                           const uint64_t *dn, const int32_t *seeds, uint64_t *ju, uint64_t *jd,
+                           double *weight_j, int32_t *seeds_after);
+
+/* replaces: find_doubly_excited + find_important_connected_dets_chem + sort/dedup
+ * (semistoch.f90:1750-2131, chemistry.f90:6819-7159, tools.f90:577-660) as used by
+ * get_next_det_list (hci.f90:865) and generate_psi_t_connected_e_loc (semistoch.f90:27):
+ * for n_ref reference dets with coefficients coeffs, all connections with
+ * |H| >= eps/|c| (the reference det itself included), sorted by (up,dn), duplicates merged:
+ * e_mix_num = sum_j H_ij c_j, e_mix_den = c_i on the reference determinants, else 0
+ * (semistoch.f90:2039-2063).  diag_mode 0: the self slot carries H=0 (HCI, chemistry.f90:6896);
+ * 1: it carries H_ii (find_connected_dets_chem, chemistry.f90:6574-6576, for C(T)).
+ * out arrays are allocated by the library, release each with sqmc_gpu_free. */
+int sqmc_gpu_hci_connections(sqmc_gpu_ctx *ctx, int64_t n_ref, const uint64_t *ref_up,
+                             const uint64_t *ref_dn, const double *coeffs, double eps, int diag_mode,
+                             int64_t *out_n, uint64_t **out_up, uint64_t **out_dn,
+                             double **out_e_mix_num, double **out_e_mix_den);
+void sqmc_gpu_free(void *p);
+
+/* per-kernel timing of the last sqmc_gpu_step (HIP events on the library's stream):
+ * names[i] / ms[i] for i < *n (n <= 32); enabled by sqmc_gpu_set_timing(ctx,1). */
+int sqmc_gpu_set_timing(sqmc_gpu_ctx *ctx, int on);
+int sqmc_gpu_get_timing(sqmc_gpu_ctx *ctx, int32_t *n, const char **names, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -59,7 +59,7 @@ def lib():
 
 
 class Rng(C.Structure):
-    _fields_ = [("l", C.c_int * 4)]
+    _fields_ = [("l", C.c_int * 4), ("mode", C.c_int), ("pad", C.c_int), ("ctr", C.c_uint64), ("seed", C.c_uint64), ("step", C.c_uint64)]
 
 
 ORC_MAXORB, ORC_MAXSYM = 64, 8
@@ -282,3 +282,229 @@ def hci_variational(sysm, eps_var, eps_sched=(), n_states=1, max_iters=50, log=N
             break
         old_energy = energy.copy()
     return up, dn, wts, energy, hist
+
+
+# ------------------------------------------------------------------------------------
+# Walk setup + driver (oracle side).  Setup follows one iteration of
+# generate_space_iterate (semistoch.f90:145-560): connections of HF -> diagonalise ->
+# truncate by |coefficient| at a CSF boundary; C(T) as generate_psi_t_connected_e_loc
+# (semistoch.f90:27-133); initial population as do_walk.f90:1245-1366.
+# ------------------------------------------------------------------------------------
+def _truncate_at_csf(c_sorted, n_keep, eps=1e-10):
+    """semistoch.f90:331-345: cut where |c| changes, never inside a group of equal |c|."""
+    prev = 0.0
+    for i, v in enumerate(c_sorted):
+        if abs(abs(prev) - abs(v)) > eps:
+            prev = v
+            if i + 1 > n_keep:
+                return i
+    return len(c_sorted)
+
+
+class WalkSetup:
+    pass
+
+
+def setup_walk(sysm, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1):
+    """Returns Psi_T, C(T), deterministic space + projector (-tau*H), tau."""
+    s = WalkSetup()
+    cu, cd, _ = sysm.connected(sysm.hf_up, sysm.hf_dn, with_elems=False)
+    order = sort_dets(cu, cd)
+    up, dn = cu[order], cd[order]
+    counts, idx, val = sysm.build_sparse_ham(up, dn)
+    w, v = lowest_eigs(counts, idx, val, k=1)
+    c = v[:, 0]
+    if c[np.argmax(np.abs(c))] < 0:
+        c = -c
+    by = np.argsort(-np.abs(c), kind="stable")
+    up_s, dn_s, c_s = up[by], dn[by], c[by]
+    n_t = _truncate_at_csf(c_s, n_truncate_trial_wf)
+    n_i = _truncate_at_csf(c_s, size_deterministic)
+    norm = 1.0 / np.sqrt(np.dot(c_s[:n_t], c_s[:n_t]))
+    s.psi_up, s.psi_dn, s.psi_c = up_s[:n_t].copy(), dn_s[:n_t].copy(), c_s[:n_t] * norm
+    o = sort_dets(up_s[:n_i], dn_s[:n_i])
+    s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
+    lo, hi = sysm.diag_lowest_highest()
+    s.tau = tau_multiplier / (hi - lo)
+    s.e_var = float(w[0])
+    # projector: -tau * H on the deterministic space (do_walk.f90:954-962)
+    pc, pi, pv = sysm.build_sparse_ham(s.imp_up, s.imp_dn)
+    s.prj_counts, s.prj_indices, s.prj_values = pc, pi, -s.tau * pv
+    # C(T)
+    acc = {}
+    psi_index = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(s.psi_up, s.psi_dn))}
+    for j in range(n_t):
+        xu, xd, el = sysm.connected(int(s.psi_up[j]), int(s.psi_dn[j]), with_elems=True, cap=40000)
+        for a, b, h in zip(xu.tolist(), xd.tolist(), el.tolist()):
+            acc[(a, b)] = acc.get((a, b), 0.0) + h * s.psi_c[j]
+    keys = sorted(acc)
+    s.ct_up = np.array([k[0] for k in keys], np.uint64)
+    s.ct_dn = np.array([k[1] for k in keys], np.uint64)
+    s.ct_num = np.array([acc[k] for k in keys])
+    s.ct_den = np.array([s.psi_c[psi_index[k]] if k in psi_index else 0.0 for k in keys])
+    s.e_trial0 = float(np.dot(s.ct_num, s.ct_den) / np.dot(s.ct_den, s.ct_den))
+    return s
+
+
+def initial_walkers(s, w_abs_gen_begin, r_initiator=1.0, initiator_power=0):
+    """do_walk.f90:1245-1366 (hf_to_psit = false): deterministic-space dets with weight 0 plus
+    Psi_T dets with weight w_begin*c/sum|c|, duplicates combined (equal dets simply add here,
+    the det-space copy comes first and carries imp_distance 0).  Returns sorted SoA + signs."""
+    n_imp, n_t = len(s.imp_up), len(s.psi_up)
+    cmax, csum = np.max(np.abs(s.psi_c)), np.sum(np.abs(s.psi_c))
+    recs = {}
+    for a, b in zip(s.imp_up.tolist(), s.imp_dn.tolist()):
+        recs[(a, b)] = [0.0, 2, 0, 0]
+    scale = min(w_abs_gen_begin * cmax / csum, 1.0)
+    for a, b, c in zip(s.psi_up.tolist(), s.psi_dn.tolist(), s.psi_c.tolist()):
+        wt = (w_abs_gen_begin * c / csum) / scale
+        perm = abs(abs(c) - cmax) < 1e-3
+        r = recs.get((a, b))
+        if r is None:
+            recs[(a, b)] = [wt, 3 if perm else 2, 0 if perm else 1, int(np.sign(c)) if perm else 0]
+        else:
+            r[0] += wt
+            if perm:
+                r[1], r[3] = 3, int(np.sign(c))
+    keys = sorted(recs)
+    n = len(keys)
+    out = dict(
+        up=np.array([k[0] for k in keys], np.uint64), dn=np.array([k[1] for k in keys], np.uint64),
+        wt=np.array([recs[k][0] for k in keys]), initiator=np.array([recs[k][1] for k in keys], np.int8),
+        imp_distance=np.array([recs[k][2] for k in keys], np.int8), perm_sign=np.array([recs[k][3] for k in keys], np.int8),
+        matrix_elements=np.full(n, 1e51), e_num=np.full(n, 1e51), e_den=np.full(n, 1e51))
+    # check_initiator pass of the merge at do_walk.f90:1366 for non-permanent dets outside the core
+    for i in range(n):
+        d, ini, aw = int(out["imp_distance"][i]), int(out["initiator"][i]), abs(out["wt"][i])
+        thr = r_initiator * (max(0, d) ** initiator_power if not (d <= 0 and initiator_power == 0) else 1)
+        if ini == 2 and aw <= thr and d > 0:
+            out["initiator"][i] = 1
+    keep = ~((out["wt"] == 0) & (out["imp_distance"] >= 1))
+    for k in out:
+        out[k] = out[k][keep]
+    return out
+
+
+class OracleWalk:
+    """orc_walk handle fed from numpy arrays."""
+
+    def __init__(self, sysm, setup, walkers, mwalk, seed, rng_mode=0):
+        L = lib()
+        self.sysm, self.L = sysm, L
+        self.h = L.orc_walk_new(mwalk)
+        self.w = Walk.from_address(self.h)
+        self._keep = []
+        n = len(walkers["up"])
+        for name, key in (("up", "up"), ("dn", "dn"), ("wt", "wt"), ("imp_distance", "imp_distance"), ("initiator", "initiator"),
+                          ("matrix_elements", "matrix_elements"), ("e_num_walker", "e_num"), ("e_den_walker", "e_den")):
+            dst = getattr(self.w, name)
+            src = np.ascontiguousarray(walkers[key])
+            C.memmove(dst, src.ctypes.data, src.nbytes)
+        self.w.nwalk = n
+        signs = walkers["perm_sign"][walkers["initiator"] == 3].astype(np.int8)
+        self._set_ptr("sign_perm", signs if len(signs) else np.zeros(1, np.int8), C.c_int8)
+        self.w.n_perm = len(signs)
+        self.w.n_imp = len(setup.prj_counts)
+        self.w.nnz = len(setup.prj_values)
+        self._set_ptr("prj_counts", setup.prj_counts.astype(np.int64), C.c_int64)
+        self._set_ptr("prj_indices", setup.prj_indices.astype(np.int64), C.c_int64)
+        self._set_ptr("prj_values", setup.prj_values.astype(np.float64), C.c_double)
+        self.w.n_ct = len(setup.ct_up)
+        self._set_ptr("ct_up", setup.ct_up, C.c_uint64); self._set_ptr("ct_dn", setup.ct_dn, C.c_uint64)
+        self._set_ptr("ct_num", setup.ct_num, C.c_double); self._set_ptr("ct_den", setup.ct_den, C.c_double)
+        sd = (C.c_int * 4)(*seed)
+        L.orc_setrn(C.byref(self.w.rng), sd)
+        L.orc_rng_set_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orc_rng_set_mode(C.byref(self.w.rng), rng_mode)
+
+    def _set_ptr(self, name, arr, ctype):
+        # the C side free()s these in orc_walk_free: hand it malloc'ed copies
+        arr = np.ascontiguousarray(arr)
+        libc = C.CDLL(None)
+        libc.malloc.restype = C.c_void_p
+        p = libc.malloc(max(arr.nbytes, 8))
+        C.memmove(p, arr.ctypes.data, arr.nbytes)
+        setattr(self.w, name, C.cast(p, C.POINTER(ctype)))
+
+    def scale_projector(self, ratio):
+        v = np.ctypeslib.as_array(self.w.prj_values, shape=(self.w.nnz,))
+        v *= ratio
+
+    def step(self, params):
+        out = np.zeros(16)
+        p = StepParams(**params)
+        st = self.L.orc_walk_step(self.sysm.h, self.h, C.byref(p), _p(out))
+        return st, out
+
+    def walkers(self):
+        n = self.w.nwalk
+        g = lambda ptr, dt: np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+        return dict(up=g(self.w.up, None), dn=g(self.w.dn, None), wt=g(self.w.wt, None), imp_distance=g(self.w.imp_distance, None),
+                    initiator=g(self.w.initiator, None), matrix_elements=g(self.w.matrix_elements, None),
+                    e_num=g(self.w.e_num_walker, None), e_den=g(self.w.e_den_walker, None))
+
+    def rng_state(self):
+        return [self.w.rng.l[i] for i in range(4)]
+
+    def close(self):
+        if self.h:
+            self.L.orc_walk_free(self.h)
+            self.h = None
+
+
+class PopControl:
+    """Scalar logic around the step, do_walk.f90:2171-2184 (tau ramp) and 2880-2923
+    (e_est, e_trial, reweight factor); equilibration = first n_equil_steps steps."""
+
+    def __init__(self, tau, e_trial, w_target, r_initiator=1.0, initiator_rescale_power=1.0, pop_exp=10.0,
+                 rfi_max_multiplier=1.0, n_equil_steps=10**9):
+        self.tau_sav, self.tau, self.tau_prev = tau, tau, tau
+        self.e_trial, self.e_est = e_trial, e_trial
+        self.w_target, self.r_init_sav, self.r_init, self.irp = w_target, r_initiator, r_initiator, initiator_rescale_power
+        self.pop_exp = pop_exp
+        self.rfi, self.rfi_max = 1.0, 1.0 + rfi_max_multiplier * tau
+        self.reached = 0
+        self.n_equil, self.istep = n_equil_steps, 0
+        self.e_num_cum = self.e_den_cum = 0.0
+        self.w_abs_gen = None
+
+    def pre_step(self, w_abs_gen):
+        """returns tau_ratio to apply to the projector before the step (or 1.0)"""
+        ratio = 1.0
+        if self.reached == 0:
+            f = 1.0 + np.log(self.w_target / w_abs_gen)
+            self.tau = self.tau_sav * f
+            ratio = self.tau / self.tau_prev
+            self.r_init = self.r_init_sav * f ** self.irp
+        return ratio
+
+    def post_step(self, out):
+        """returns tau_ratio to apply to the projector after the step (or 1.0)"""
+        self.istep += 1
+        w_abs_gen, e_den_gen, e_num_gen = out[1], out[2], out[3]
+        self.e_num_cum += e_num_gen * np.sign(e_den_gen) if e_den_gen != 0 else 0.0
+        self.e_den_cum += abs(e_den_gen)
+        if self.e_den_cum != 0:
+            self.e_est = self.e_num_cum / self.e_den_cum
+        pw = min(1.0, self.tau * self.pop_exp)
+        if self.istep <= self.n_equil:
+            d = self.e_est - self.e_trial
+            self.e_trial = self.e_trial + np.sign(d) * min(abs(d), 1.0)
+            self.rfi = min(2.0, max(0.5, (self.w_target / w_abs_gen) ** pw))
+        else:
+            self.rfi = min(2.0, max(0.5, (1.0 / (1.0 + self.tau * (self.e_trial - self.e_est))) * (self.w_target / w_abs_gen) ** pw))
+        self.rfi = min(self.rfi, self.rfi_max)
+        ratio = 1.0
+        if self.reached == 0 and w_abs_gen >= self.w_target:
+            self.reached = 2
+            ratio = self.tau_sav / self.tau
+            self.tau = self.tau_sav
+            self.r_init = self.r_init_sav
+        self.tau_prev = self.tau
+        self.w_abs_gen = w_abs_gen
+        return ratio
+
+    def params(self, min_wt=0.5, cutoff=0.5, initiator_power=0, semistochastic=1):
+        return dict(tau=self.tau, e_trial=self.e_trial, reweight_factor_inv=self.rfi, r_initiator=self.r_init, min_wt=min_wt,
+                    always_spawn_cutoff_wt=cutoff, initiator_power=initiator_power, initiator_min_distance=0, c_t_initiator=0,
+                    semistochastic=semistochastic, reached_w_abs_gen=self.reached)

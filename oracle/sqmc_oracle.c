@@ -23,11 +23,24 @@ static inline int popcnt(det_t d) { return __builtin_popcountll(d); }
 void orc_setrn(orc_rng *g, const int seed[4]) {
   for (int i = 0; i < 4; i++) g->l[i] = seed[i];
   g->l[3] = 2 * (g->l[3] / 2) + 1;
+  g->seed = ((uint64_t)g->l[0] << 36) | ((uint64_t)g->l[1] << 24) | ((uint64_t)g->l[2] << 12) | (uint64_t)g->l[3];
+}
+static uint64_t mix64(uint64_t v) {
+  v ^= v >> 30; v *= 0xBF58476D1CE4E5B9ull; v ^= v >> 27; v *= 0x94D049BB133111EBull; v ^= v >> 31;
+  return v;
+}
+void orc_rng_set_mode(orc_rng *g, int mode) { g->mode = mode; g->step = 0; }
+void orc_rng_seek(orc_rng *g, int stage, uint64_t idx) {
+  if (g->mode == 1) g->ctr = mix64(mix64(g->seed ^ (g->step * 4ull + (uint64_t)stage)) + idx);
 }
 /* rannyu.f90:77-87 */
 void orc_savern(const orc_rng *g, int seed[4]) { for (int i = 0; i < 4; i++) seed[i] = g->l[i]; }
 /* rannyu.f90:54-74 : l <- l * 11^13 mod 2^48 on four 12-bit limbs; m = 502,1521,4071,2107 */
 double orc_rannyu(orc_rng *g) {
+  if (g->mode == 1) {
+    g->ctr += 0x9E3779B97F4A7C15ull;
+    return (double)(mix64(g->ctr) >> 16) * 3.552713678800500929355621337890625e-15;
+  }
   const int m1 = 502, m2 = 1521, m3 = 4071, m4 = 2107;
   int l1 = g->l[0], l2 = g->l[1], l3 = g->l[2], l4 = g->l[3];
   int i1 = l1 * m4 + l2 * m3 + l3 * m2 + l4 * m1;
@@ -776,6 +789,7 @@ int64_t orc_merge_original_with_spawned2(orc_walk *w, int64_t nwalk, const orc_s
 int64_t orc_reduce_my_walker(orc_walk *w, int64_t n, const orc_step_params *p) {
   for (int64_t i = 0; i < n; i++)
     if (w->imp_distance[i] >= 1 && fabs(w->wt[i]) < p->min_wt) {
+      orc_rng_seek(&w->rng, 2, (uint64_t)i);
       if (orc_rannyu(&w->rng) < (fabs(w->wt[i]) / p->min_wt)) w->wt[i] = copysign(p->min_wt, w->wt[i]);
       else w->wt[i] = 0.0;
     }
@@ -797,6 +811,7 @@ int64_t orc_reduce_my_walker(orc_walk *w, int64_t n, const orc_step_params *p) {
 static int move_uniform2(const orc_chem *s, orc_walk *w, const orc_step_params *p, int64_t iw, int64_t *attempts) {
   int spawn, use_wt;
   if (fabs(w->wt[iw]) < p->always_spawn_cutoff_wt) {
+    orc_rng_seek(&w->rng, 0, (uint64_t)iw);
     spawn = (orc_rannyu(&w->rng) < fabs(w->wt[iw] / p->always_spawn_cutoff_wt)); use_wt = 0; w->n_spawn_draws++;
   } else { spawn = 1; use_wt = 1; }
   if (spawn) {
@@ -805,6 +820,7 @@ static int move_uniform2(const orc_chem *s, orc_walk *w, const orc_step_params *
     else { nchild = 1; wchild = copysign(p->always_spawn_cutoff_wt, w->wt[iw]); }
     for (long c = 1; c <= nchild; c++) {
       det_t ju, jd; double wj; int nd;
+      orc_rng_seek(&w->rng, 1, (uint64_t)(*attempts));
       orc_off_diagonal_move_chem(s, &w->rng, p->tau, w->up[iw], w->dn[iw], &ju, &jd, &wj, &nd);
       w->n_spawn_draws += nd; (*attempts)++;
       wj = wchild * wj;
@@ -898,5 +914,6 @@ int orc_walk_step(const orc_chem *s, orc_walk *w, const orc_step_params *p, doub
   out[0] = w_gen; out[1] = w_abs; out[2] = acc[1]; out[3] = acc[0]; out[4] = w_perm; out[5] = (double)n;
   out[6] = w_abs_imp; out[7] = (double)nbefore; out[8] = w2; out[9] = acc[2]; out[10] = acc[3];
   out[11] = acc[4]; out[12] = acc[5]; out[13] = acc[6]; out[14] = wabs_before; out[15] = (double)attempts;
+  w->rng.step++;
   return 0;
 }

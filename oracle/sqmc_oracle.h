@@ -25,7 +25,12 @@
 typedef uint64_t det_t;
 
 /* ---- RNG: rannyu.f90:11-87, tools.f90:129-147 ---- */
-typedef struct { int l[4]; } orc_rng;
+/* mode 0: the reference's rannyu stream.  mode 1 ("counter"): an independent 48-bit
+ * splitmix64 stream per (seed, step, stage, entity) so that a parallel implementation can
+ * be checked draw for draw at any size; not in the reference (DESIGN.md "RNG"). */
+typedef struct { int l[4]; int mode; int pad; uint64_t ctr, seed, step; } orc_rng;
+void   orc_rng_set_mode(orc_rng *g, int mode);
+void   orc_rng_seek(orc_rng *g, int stage, uint64_t idx);
 void   orc_setrn(orc_rng *g, const int seed[4]);
 void   orc_savern(const orc_rng *g, int seed[4]);
 double orc_rannyu(orc_rng *g);

@@ -1,0 +1,236 @@
+"""ctypes binding of include/sqmc_gpu.h (the same entry points the Fortran iso_c_binding
+module sqmc_amd/fortran/sqmc_gpu_mod.f90 binds)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libsqmc_gpu.so")
+RNG_REPLAY, RNG_COUNTER = 0, 1
+_LIB = None
+
+EXPORTS = [
+    "sqmc_gpu_init_chem", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_projector",
+    "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
+    "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_spmv_prepare",
+    "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
+    "sqmc_gpu_propose_batch", "sqmc_gpu_hci_connections", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
+]
+
+
+class SqmcGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libsqmc_gpu status %d: %s" % (code, msg))
+        self.code = code
+
+
+def build_library(force=False):
+    """hipcc cross-compiles for gfx950 without a GPU present."""
+    src = [os.path.join(_HERE, "csrc", f) for f in ("sqmc_gpu.hip", "chem_device.h", "scan_sort.h")] + [os.path.join(_ROOT, "include", "sqmc_gpu.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in src):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value",
+           "-I" + os.path.join(_ROOT, "include"), src[0], "-o", LIB_PATH]
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class ChemCfg(C.Structure):
+    _fields_ = [("norb", C.c_int32), ("nup", C.c_int32), ("ndn", C.c_int32), ("n_core_orb", C.c_int32),
+                ("time_sym", C.c_int32), ("z", C.c_int32), ("n_group", C.c_int32),
+                ("product_table", C.c_void_p), ("orbital_symmetries", C.c_void_p), ("combine_2", C.c_void_p),
+                ("n_integrals", C.c_int64), ("integrals", C.c_void_p), ("rng_mode", C.c_int32),
+                ("irand_seed", C.c_int32 * 4), ("mwalk", C.c_int64)]
+
+
+class StepParams(C.Structure):
+    _fields_ = [("tau", C.c_double), ("e_trial", C.c_double), ("reweight_factor_inv", C.c_double), ("r_initiator", C.c_double),
+                ("min_wt", C.c_double), ("always_spawn_cutoff_wt", C.c_double), ("initiator_power", C.c_int32),
+                ("initiator_min_distance", C.c_int32), ("c_t_initiator", C.c_int32), ("semistochastic", C.c_int32),
+                ("reached_w_abs_gen", C.c_int32), ("reserved", C.c_int32)]
+
+
+def load_library():
+    """Loads the in-tree HIP library; raises if it is missing (no fallback path exists)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SqmcGpuError(-2, "sqmc_amd/libsqmc_gpu.so is not built: run __graft_entry__.build()")
+        L = C.CDLL(LIB_PATH)
+        L.sqmc_gpu_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            getattr(L, name)   # AttributeError if the ABI lost a symbol
+        L.sqmc_gpu_scale_projector.argtypes = [C.c_void_p, C.c_double]
+        L.sqmc_gpu_set_hb_tables.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double]
+        L.sqmc_gpu_set_projector.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sqmc_gpu_set_ct_table.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 4
+        L.sqmc_gpu_upload_walkers.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 9
+        L.sqmc_gpu_download_walkers.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 9
+        L.sqmc_gpu_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sqmc_gpu_hamiltonian_batch.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+        L.sqmc_gpu_propose_batch.argtypes = [C.c_void_p, C.c_int64, C.c_double] + [C.c_void_p] * 7
+        L.sqmc_gpu_hci_connections.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int] + [C.c_void_p] * 5
+        L.sqmc_gpu_spmv_prepare.argtypes = [C.c_int64] + [C.c_void_p] * 4
+        L.sqmc_gpu_spmv_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.sqmc_gpu_spmv_free.argtypes = [C.c_void_p]
+        L.sqmc_gpu_spmv_sym_upper.argtypes = [C.c_int64] + [C.c_void_p] * 5
+        L.sqmc_gpu_free.argtypes = [C.c_void_p]
+        L.sqmc_gpu_finalize.argtypes = [C.c_void_p]
+        L.sqmc_gpu_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.sqmc_gpu_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sqmc_gpu_get_rng.argtypes = [C.c_void_p, C.c_void_p]
+        L.sqmc_gpu_set_rng.argtypes = [C.c_void_p, C.c_void_p]
+        L.sqmc_gpu_num_walkers.argtypes = [C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _chk(code):
+    if code != 0:
+        raise SqmcGpuError(code, load_library().sqmc_gpu_last_error().decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class GpuChem:
+    """One sqmc_gpu_ctx: chemistry tables + (optionally) the walker arrays in HBM."""
+
+    def __init__(self, norb, nup, ndn, orbsym, product_table, combine_2, integrals, n_group=8, time_sym=False, z=1,
+                 n_core_orb=0, rng_mode=RNG_COUNTER, seed=(1346, 5634, 6635, 4361), mwalk=0):
+        L = load_library()
+        self.L = L
+        self._tabs = [np.ascontiguousarray(product_table, np.int32), np.ascontiguousarray(orbsym, np.int32),
+                      np.ascontiguousarray(combine_2, np.int32), _f64(integrals)]
+        cfg = ChemCfg()
+        cfg.norb, cfg.nup, cfg.ndn, cfg.n_core_orb = norb, nup, ndn, n_core_orb
+        cfg.time_sym, cfg.z, cfg.n_group = int(time_sym), z, n_group
+        cfg.product_table, cfg.orbital_symmetries, cfg.combine_2 = (t.ctypes.data for t in self._tabs[:3])
+        cfg.n_integrals, cfg.integrals = len(self._tabs[3]) - 1, self._tabs[3].ctypes.data
+        cfg.rng_mode, cfg.mwalk = rng_mode, mwalk
+        for i in range(4):
+            cfg.irand_seed[i] = seed[i]
+        h = C.c_void_p()
+        _chk(L.sqmc_gpu_init_chem(C.byref(cfg), C.byref(h)))
+        self.h, self.norb, self.mwalk = h, norb, mwalk
+
+    def close(self):
+        if self.h:
+            self.L.sqmc_gpu_finalize(self.h)
+            self.h = None
+
+    def set_hb_tables(self, hb_r, hb_s, hb_absH, pq_ind, pq_count, max_double):
+        r, s = np.ascontiguousarray(hb_r, np.int32), np.ascontiguousarray(hb_s, np.int32)
+        a, pi, pc = _f64(hb_absH), np.ascontiguousarray(pq_ind, np.int64), np.ascontiguousarray(pq_count, np.int32)
+        _chk(self.L.sqmc_gpu_set_hb_tables(self.h, len(r), _p(r), _p(s), _p(a), len(pi) - 1, _p(pi), _p(pc), float(max_double)))
+
+    def set_projector(self, counts, indices, values):
+        c, i, v = np.ascontiguousarray(counts, np.int64), np.ascontiguousarray(indices, np.int64), _f64(values)
+        _chk(self.L.sqmc_gpu_set_projector(self.h, len(c), len(v), _p(c), _p(i), _p(v)))
+
+    def scale_projector(self, ratio):
+        _chk(self.L.sqmc_gpu_scale_projector(self.h, float(ratio)))
+
+    def set_ct_table(self, up, dn, num, den):
+        u, d, n_, e = _u64(up), _u64(dn), _f64(num), _f64(den)
+        _chk(self.L.sqmc_gpu_set_ct_table(self.h, len(u), _p(u), _p(d), _p(n_), _p(e)))
+
+    def upload_walkers(self, w):
+        arrs = [_u64(w["up"]), _u64(w["dn"]), _f64(w["wt"]), np.ascontiguousarray(w["imp_distance"], np.int8),
+                np.ascontiguousarray(w["initiator"], np.int8), np.ascontiguousarray(w["perm_sign"], np.int8),
+                _f64(w["matrix_elements"]), _f64(w["e_num"]), _f64(w["e_den"])]
+        _chk(self.L.sqmc_gpu_upload_walkers(self.h, len(arrs[0]), *[_p(a) for a in arrs]))
+
+    def num_walkers(self):
+        n = C.c_int64()
+        _chk(self.L.sqmc_gpu_num_walkers(self.h, C.byref(n)))
+        return n.value
+
+    def download_walkers(self):
+        n = self.num_walkers()
+        out = dict(up=np.zeros(n, np.uint64), dn=np.zeros(n, np.uint64), wt=np.zeros(n), imp_distance=np.zeros(n, np.int8),
+                   initiator=np.zeros(n, np.int8), matrix_elements=np.zeros(n), e_num=np.zeros(n), e_den=np.zeros(n))
+        nn = C.c_int64()
+        _chk(self.L.sqmc_gpu_download_walkers(self.h, n, C.byref(nn), *[_p(out[k]) for k in
+                                              ("up", "dn", "wt", "imp_distance", "initiator", "matrix_elements", "e_num", "e_den")]))
+        return out
+
+    def step(self, params):
+        p = StepParams(**params)
+        out = np.zeros(16)
+        code = self.L.sqmc_gpu_step(self.h, C.byref(p), _p(out))
+        _chk(code)
+        return out
+
+    def rng_state(self):
+        s = (C.c_int32 * 4)()
+        _chk(self.L.sqmc_gpu_get_rng(self.h, s))
+        return list(s)
+
+    def set_timing(self, on=True):
+        _chk(self.L.sqmc_gpu_set_timing(self.h, int(on)))
+
+    def timing(self):
+        n = C.c_int32(); names = (C.c_char_p * 32)(); ms = (C.c_float * 32)()
+        _chk(self.L.sqmc_gpu_get_timing(self.h, C.byref(n), names, ms))
+        return [(names[i].decode(), ms[i]) for i in range(n.value)]
+
+    def hamiltonian_batch(self, iu, id_, ju, jd):
+        a, b, c, d = _u64(iu), _u64(id_), _u64(ju), _u64(jd)
+        h = np.zeros(len(a))
+        _chk(self.L.sqmc_gpu_hamiltonian_batch(self.h, len(a), _p(a), _p(b), _p(c), _p(d), _p(h)))
+        return h
+
+    def propose_batch(self, tau, up, dn, seeds):
+        u, d = _u64(up), _u64(dn)
+        s = np.ascontiguousarray(seeds, np.int32).reshape(-1)
+        n = len(u)
+        ju, jd, wj, sa = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n), np.zeros(4 * n, np.int32)
+        _chk(self.L.sqmc_gpu_propose_batch(self.h, n, float(tau), _p(u), _p(d), _p(s), _p(ju), _p(jd), _p(wj), _p(sa)))
+        return ju, jd, wj, sa.reshape(n, 4)
+
+    def hci_connections(self, ref_up, ref_dn, coeffs, eps, diag_mode=0):
+        u, d, c = _u64(ref_up), _u64(ref_dn), _f64(coeffs)
+        n = C.c_int64(); pu = C.c_void_p(); pd = C.c_void_p(); pn = C.c_void_p(); pe = C.c_void_p()
+        _chk(self.L.sqmc_gpu_hci_connections(self.h, len(u), _p(u), _p(d), _p(c), float(eps), int(diag_mode),
+                                             C.byref(n), C.byref(pu), C.byref(pd), C.byref(pn), C.byref(pe)))
+        k = n.value
+        def take(ptr, ct, dt):
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(max(k, 1),))[:k].astype(dt, copy=True)
+            self.L.sqmc_gpu_free(ptr)
+            return a
+        return take(pu, C.c_uint64, np.uint64), take(pd, C.c_uint64, np.uint64), take(pn, C.c_double, np.float64), take(pe, C.c_double, np.float64)
+
+
+class SpmvPlan:
+    """sqmc_gpu_spmv_prepare/apply: symmetric matvec of davidson_sparse (more_tools.f90:2115)."""
+
+    def __init__(self, counts, indices, values):
+        self.L = load_library()
+        c, i, v = np.ascontiguousarray(counts, np.int64), np.ascontiguousarray(indices, np.int64), _f64(values)
+        self.n = len(c)
+        h = C.c_void_p()
+        _chk(self.L.sqmc_gpu_spmv_prepare(self.n, _p(c), _p(i), _p(v), C.byref(h)))
+        self.h = h
+
+    def apply(self, x):
+        x = _f64(x); y = np.zeros(self.n)
+        _chk(self.L.sqmc_gpu_spmv_apply(self.h, _p(x), _p(y), 0))
+        return y
+
+    def close(self):
+        if self.h:
+            self.L.sqmc_gpu_spmv_free(self.h)
+            self.h = None

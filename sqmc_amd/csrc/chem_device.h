@@ -1,0 +1,285 @@
+// chem_device.h -- device-side chemistry: integral lookup, Slater-Condon matrix elements,
+// the 48-bit RNGs and the symmetry-aware uniform proposal.  gfx950 only.
+//
+// Arithmetic follows the reference operation by operation (no FMA contraction: the
+// library is compiled with -ffp-contract=off) so that spawn weights agree bit for bit
+// with a gfortran -O2 build of the reference:
+//   integral_index / integral_value   chemistry.f90:9106-9134, 1234-1256
+//   one_body, two_body ("usual way")  chemistry.f90:1382-1437, 1773-1838
+//   one/two_body_single, _double      chemistry.f90:1439-1478, 1845-2001
+//   permutation_factor(2)             tools.f90:1294-1396
+//   off_diagonal_move_chem            chemistry.f90:4237-5084 (time_sym = .false.)
+//   rannyu / random_int               rannyu.f90:54-74, tools.f90:129-147
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+
+#define SQ_MAXORB 64
+#define SQ_MAXSYM 8
+
+// Small tables every chemistry kernel stages into LDS (divergent per-lane lookups).
+struct ChemTab {
+  int norb, nup, ndn, ncore, nelec, time_sym, z, ngroup;
+  u64 orb_mask;                        // bits 0..norb-1
+  u64 sym_mask[SQ_MAXSYM + 1];         // orbitals of each irrep (which_orb_by_sym as a bitmask)
+  unsigned char prod[SQ_MAXSYM + 1][SQ_MAXSYM + 1];
+  unsigned char orbsym[SQ_MAXORB + 1]; // 1-based
+  unsigned short c2[SQ_MAXORB + 2][SQ_MAXORB + 2];   // combine_2, 1-based
+  double nuclear;
+};
+
+struct ChemDev {                        // pointers into HBM, passed by value
+  const ChemTab *tab;
+  const double *integrals;              // 1-based packed
+  // HCI heat-bath table (chemistry.f90:900-993)
+  const int *hb_r, *hb_s; const double *hb_absH; const long long *pq_ind; const int *pq_count;
+  double max_double;
+};
+
+__device__ __forceinline__ void stage_tab(ChemTab *dst, const ChemTab *src) {
+  const int n = (int)(sizeof(ChemTab) / sizeof(int));
+  const int *s = reinterpret_cast<const int *>(src);
+  int *d = reinterpret_cast<int *>(dst);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+  __syncthreads();
+}
+
+__device__ __forceinline__ int ctz64(u64 x) { return __builtin_ctzll(x); }
+__device__ __forceinline__ int popc64(u64 x) { return __popcll(x); }
+__device__ __forceinline__ u64 bit64(int k) { return 1ull << k; }
+__device__ __forceinline__ u64 maskr64(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
+// ----------------------------------------------------------------------------- RNG
+#define SQ_LCG_MULT 34522712143931ull          // 11^13 = 502*8^12 + 1521*8^8 + 4071*8^4 + 2107
+#define SQ_MASK48 0xFFFFFFFFFFFFull
+#define SQ_GOLDEN 0x9E3779B97F4A7C15ull
+struct Rng {
+  int mode;   // 0 = rannyu LCG state in x (48 bits); 1 = splitmix64 counter state in x
+  u64 x;
+};
+__host__ __device__ __forceinline__ u64 sq_mix64(u64 v) {
+  v ^= v >> 30; v *= 0xBF58476D1CE4E5B9ull; v ^= v >> 27; v *= 0x94D049BB133111EBull; v ^= v >> 31;
+  return v;
+}
+// stream key for the COUNTER discipline: (seed, step, stage, entity index)
+__host__ __device__ __forceinline__ u64 sq_counter_key(u64 seed, u64 step, int stage, u64 idx) {
+  return sq_mix64(sq_mix64(seed ^ (step * 4ull + (u64)stage)) + idx);
+}
+__device__ __forceinline__ double rng_draw(Rng &g) {
+  u64 k;
+  if (g.mode == 0) { g.x = (g.x * SQ_LCG_MULT) & SQ_MASK48; k = g.x; }
+  else { g.x += SQ_GOLDEN; k = sq_mix64(g.x) >> 16; }
+  return (double)k * 3.552713678800500929355621337890625e-15;   // 2^-48, exact
+}
+__device__ __forceinline__ int rng_int(Rng &g, int n) { return (int)((double)n * rng_draw(g)) + 1; }
+// LCG skip-ahead: state * M^k mod 2^48
+__host__ __device__ __forceinline__ u64 lcg_skip(u64 x, u64 k) {
+  u64 m = SQ_LCG_MULT;
+  while (k) { if (k & 1) x = (x * m) & SQ_MASK48; m = (m * m) & SQ_MASK48; k >>= 1; }
+  return x;
+}
+
+// ------------------------------------------------------------------------ integrals
+__device__ __forceinline__ int integral_index(const ChemTab &t, int i, int j, int k, int l) {
+  int a = t.c2[i][j], b = t.c2[k][l];
+  return (a > b) ? (a * (a - 1)) / 2 + b : (b * (b - 1)) / 2 + a;
+}
+#define IVAL(p, q, r, s) (ints[integral_index(t, (p), (q), (r), (s))])
+
+__device__ __forceinline__ int permutation_factor(u64 a, u64 b) {
+  u64 diff = (a > b) ? (a & (a - b)) : (b & (b - a));
+  return (popc64(diff) & 1) ? -1 : 1;
+}
+__device__ __forceinline__ void permutation_factor2(u64 di, u64 dj, int &gamma, int &i1, int &i2, int &j1, int &j2) {
+  u64 d = di & ~dj;
+  i1 = ctz64(d); i2 = ctz64(d & ~bit64(i1));
+  d = dj & ~di;
+  j1 = ctz64(d); j2 = ctz64(d & ~bit64(j1));
+  d = di & dj & ((maskr64(i1) ^ maskr64(j1)) ^ (maskr64(i2) ^ maskr64(j2)));
+  gamma = (popc64(d) & 1) ? -1 : 1;
+}
+__device__ __forceinline__ int excitation_level(u64 iu, u64 id, u64 ju, u64 jd) {
+  int n = popc64(iu & ~ju) + popc64(id & ~jd);
+  return n > 2 ? -1 : n;
+}
+
+__device__ inline double h_diag(const ChemTab &t, const double *__restrict__ ints, u64 up, u64 dn) {
+  const int n1 = t.norb + 1;
+  double e1 = 0.0;
+  for (u64 d = up; d; d &= d - 1) { int i = ctz64(d) + 1; e1 = e1 + IVAL(i, i, n1, n1); }
+  if (dn == up) e1 = e1 * 2.0;
+  else for (u64 d = dn; d; d &= d - 1) { int i = ctz64(d) + 1; e1 = e1 + IVAL(i, i, n1, n1); }
+  double ex = 0.0, di = 0.0;
+  for (u64 a = up; a; a &= a - 1) { int i = ctz64(a) + 1;
+    for (u64 b = a & (a - 1); b; b &= b - 1) { int j = ctz64(b) + 1; ex = ex - IVAL(i, j, j, i); } }
+  if (dn == up) ex = ex * 2.0;
+  else if (dn != 0)
+    for (u64 a = dn; a; a &= a - 1) { int i = ctz64(a) + 1;
+      for (u64 b = a & (a - 1); b; b &= b - 1) { int j = ctz64(b) + 1; ex = ex - IVAL(i, j, j, i); } }
+  // direct term: orbitals i ascending; for each, up-up (j>i), up-dn (all j), then dn-dn (j>i)
+  for (u64 occ = up | dn; occ; occ &= occ - 1) {
+    int i0 = ctz64(occ), i = i0 + 1;
+    if ((up >> i0) & 1) {
+      for (u64 b = up & ~maskr64(i); b; b &= b - 1) { int j = ctz64(b) + 1; di = di + IVAL(i, i, j, j); }
+      for (u64 b = dn; b; b &= b - 1) { int j = ctz64(b) + 1; di = di + IVAL(i, i, j, j); }
+    }
+    if ((dn >> i0) & 1)
+      for (u64 b = dn & ~maskr64(i); b; b &= b - 1) { int j = ctz64(b) + 1; di = di + IVAL(i, i, j, j); }
+  }
+  return e1 + (ex + di) + t.nuclear;
+}
+
+__device__ inline double h_single(const ChemTab &t, const double *__restrict__ ints, u64 iu, u64 id, u64 ju, u64 jd) {
+  const int n1 = t.norb + 1;
+  u64 a = iu, b = id, aj = ju;
+  if (iu == ju) { a = id; b = iu; aj = jd; }
+  int ib = ctz64(a & ~aj) + 1, jb = ctz64(aj & ~a) + 1;
+  int pf = permutation_factor(a, aj);
+  double one = pf * IVAL(ib, jb, n1, n1);
+  double e = 0.0;
+  for (u64 d = a; d; d &= d - 1) {
+    int i = ctz64(d) + 1;
+    if (i != ib && i != jb) e = e - IVAL(ib, i, i, jb) + IVAL(ib, jb, i, i);
+  }
+  for (u64 d = b; d; d &= d - 1) { int i = ctz64(d) + 1; e = e + IVAL(ib, jb, i, i); }
+  return one + pf * e;
+}
+
+__device__ inline double h_double(const ChemTab &t, const double *__restrict__ ints, u64 iu, u64 id, u64 ju, u64 jd) {
+  int g, i1, i2, j1, j2;
+  if (iu == ju) {
+    permutation_factor2(id, jd, g, i1, i2, j1, j2);
+    return g * (IVAL(i1 + 1, j1 + 1, i2 + 1, j2 + 1) - IVAL(i1 + 1, j2 + 1, i2 + 1, j1 + 1));
+  } else if (id == jd) {
+    permutation_factor2(iu, ju, g, i1, i2, j1, j2);
+    return g * (IVAL(i1 + 1, j1 + 1, i2 + 1, j2 + 1) - IVAL(i1 + 1, j2 + 1, i2 + 1, j1 + 1));
+  }
+  i1 = ctz64(iu & ~ju); j1 = ctz64(ju & ~iu);
+  i2 = ctz64(id & ~jd); j2 = ctz64(jd & ~id);
+  return permutation_factor(iu, ju) * permutation_factor(id, jd) * IVAL(i1 + 1, j1 + 1, i2 + 1, j2 + 1);
+}
+
+__device__ inline double h_level(const ChemTab &t, const double *__restrict__ ints, u64 iu, u64 id, u64 ju, u64 jd, int level) {
+  if (level == 0) return h_diag(t, ints, iu, id);
+  if (level == 1) return h_single(t, ints, iu, id, ju, jd);
+  if (level == 2) return h_double(t, ints, iu, id, ju, jd);
+  return 0.0;
+}
+// chemistry.f90:1323-1377
+__device__ inline double h_time_sym(const ChemTab &t, const double *__restrict__ ints, u64 iu, u64 id, u64 ju, u64 jd) {
+  const double sqrt2 = sqrt(2.0), sqrt2inv = 1.0 / sqrt2;
+  double m1 = 0.0, m2 = 0.0, norm_ketinv = 1.0, norm_bra = 1.0; bool check = true; int lev;
+  if (ju == jd) norm_ketinv = sqrt2inv;
+  if (iu == id) { norm_bra = sqrt2; check = false; }
+  lev = (iu == ju && id == jd) ? 0 : excitation_level(iu, id, ju, jd);
+  if (lev >= 0) m1 = h_level(t, ints, iu, id, ju, jd, lev);
+  if (check) {
+    if (ju != jd) {
+      lev = excitation_level(id, iu, ju, jd);
+      if (lev >= 0) m2 = h_level(t, ints, id, iu, ju, jd, lev);
+    } else m2 = m1;
+  }
+  return (norm_bra * norm_ketinv) * (m1 + (t.z * m2));
+}
+// dispatcher semistoch.f90:2234-2302
+__device__ inline double h_any(const ChemTab &t, const double *__restrict__ ints, u64 iu, u64 id, u64 ju, u64 jd) {
+  if (t.time_sym) return h_time_sym(t, ints, iu, id, ju, jd);
+  int lev = excitation_level(iu, id, ju, jd);
+  return lev < 0 ? 0.0 : h_level(t, ints, iu, id, ju, jd, lev);
+}
+
+// ------------------------------------------------------------------------- proposal
+__device__ __forceinline__ int kth_set(u64 bits, int k) {   // 1-based orbital of the k-th set bit
+  for (int i = 1; i < k; i++) bits &= bits - 1;
+  return ctz64(bits) + 1;
+}
+// One uniform symmetry-aware proposal from det_i.  Returns excitation level (1/2) with
+// det_j and the generation probability, or 0 when the reference returns with weight 0.
+// Consumes exactly the reference's random_int calls, in its order.
+__device__ inline int propose_uniform(const ChemTab &t, Rng &g, u64 iu, u64 id, u64 &ju, u64 &jd, double &prob) {
+  const int nup = t.nup, ndn = t.ndn, norb = t.norb, nc = t.ncore, nelec = t.nelec;
+  const int n_single = (nup - nc) * (norb - nup) + (ndn - nc) * (norb - ndn);
+  const int n_double_up = (nup - nc) * (nup - nc - 1) * (norb - nup) * (norb - nup - 1) / 4;
+  const int n_double_dn = (ndn - nc) * (ndn - nc - 1) * (norb - ndn) * (norb - ndn - 1) / 4;
+  const int n_double_both = (nup - nc) * (norb - nup) * (ndn - nc) * (norb - ndn);
+  const int n_double = n_double_up + n_double_dn + n_double_both, n_total = n_single + n_double;
+  int level, e1 = 0, e2 = 0, tot_spin = 0;
+  prob = 1.0;
+  ju = iu; jd = id;
+  if (rng_int(g, n_total) > n_single) {
+    level = 2; prob = n_double / (double)n_total;
+    e1 = rng_int(g, nelec - 2 * nc); e2 = rng_int(g, nelec - 2 * nc - 1);
+    if (e2 == e1) e2 = nelec - 2 * nc;
+    if (e1 > nup - nc) { tot_spin -= 1; e1 += 2 * nc; } else { tot_spin += 1; e1 += nc; }
+    if (e2 > nup - nc) { tot_spin -= 1; e2 += 2 * nc; } else { tot_spin += 1; e2 += nc; }
+  } else {
+    level = 1; prob = prob * n_single / (n_total * 1.0);
+    e1 = rng_int(g, nelec - 2 * nc);
+    if (e1 > nup - nc) { tot_spin = -1; e1 += 2 * nc; } else { tot_spin = 1; e1 += nc; }
+  }
+  { int s = e1 + e2; e1 = s - (e1 > e2 ? e1 : e2); e2 = s - e1; }
+  // electron index e (1-based over up electrons then dn electrons, each ascending) -> orbital
+  const int n_occ_up = popc64(iu);
+  int sym1, o;
+  {
+    o = (e2 <= n_occ_up) ? kth_set(iu, e2) : kth_set(id, e2 - n_occ_up);
+    if (e2 <= n_occ_up) ju &= ~bit64(o - 1); else jd &= ~bit64(o - 1);
+    sym1 = t.orbsym[o];
+    if (level == 2) {
+      int o1 = (e1 <= n_occ_up) ? kth_set(iu, e1) : kth_set(id, e1 - n_occ_up);
+      if (e1 <= n_occ_up) ju &= ~bit64(o1 - 1); else jd &= ~bit64(o1 - 1);
+      sym1 = t.prod[t.orbsym[o1]][sym1];
+    }
+  }
+  int i_open, sp1, sym2; double temp1;
+  if (level == 1) {
+    prob = prob / (nelec - 2 * nc);
+    const u64 occdet = (tot_spin == 1) ? iu : id;
+    const u64 open = t.sym_mask[sym1] & ~occdet;
+    i_open = popc64(open);
+    if (i_open == 0) return 0;
+    int to1 = rng_int(g, i_open); prob = prob / i_open;
+    o = kth_set(open, to1);
+    if (tot_spin == 1) ju |= bit64(o - 1); else jd |= bit64(o - 1);
+  } else {
+    prob = prob * 2.0 / (1.0 * (nelec - 2 * nc) * (nelec - 2 * nc - 1));
+    if (tot_spin == 2 || tot_spin == -2) {
+      const u64 occdet = (tot_spin == 2) ? iu : id; const int nsp = (tot_spin == 2) ? nup : ndn;
+      int to1 = rng_int(g, norb - nsp); prob = prob / (norb - nsp);
+      sp1 = kth_set(t.orb_mask & ~occdet, to1);
+      if (tot_spin == 2) ju |= bit64(sp1 - 1); else jd |= bit64(sp1 - 1);
+      sym2 = t.prod[t.orbsym[sp1]][sym1];
+      const bool same = (sym2 == t.orbsym[sp1]);
+      u64 open = t.sym_mask[sym2] & ~occdet; if (same) open &= ~bit64(sp1 - 1);
+      i_open = popc64(open);
+      if (i_open == 0) return 0;
+      int to2 = rng_int(g, i_open); temp1 = 1.0 / i_open;
+      o = kth_set(open, to2);
+      if (tot_spin == 2) ju |= bit64(o - 1); else jd |= bit64(o - 1);
+      const int sy = t.prod[sym2][sym1];
+      i_open = popc64(t.sym_mask[sy] & ~occdet) - (same ? 1 : 0);
+      if (i_open == 0) prob = prob * temp1; else prob = prob * (temp1 + (1.0 / i_open));
+    } else {
+      prob = prob * 1.0 / (2 * norb - ndn - nup);
+      int to1 = rng_int(g, 2 * norb - nup - ndn);
+      const bool first_up = (to1 <= norb - nup);
+      u64 d1, d2;
+      if (first_up) { d1 = iu; d2 = id; } else { d1 = id; d2 = iu; to1 -= (norb - nup); }
+      sp1 = kth_set(t.orb_mask & ~d1, to1);
+      if (first_up) ju |= bit64(sp1 - 1); else jd |= bit64(sp1 - 1);
+      sym2 = t.prod[sym1][t.orbsym[sp1]];
+      const u64 open = t.sym_mask[sym2] & ~d2;
+      i_open = popc64(open);
+      if (i_open == 0) return 0;
+      int to2 = rng_int(g, i_open); temp1 = 1.0 / i_open;
+      o = kth_set(open, to2);
+      if (first_up) jd |= bit64(o - 1); else ju |= bit64(o - 1);
+      const int sy = t.prod[sym2][sym1];
+      i_open = popc64(t.sym_mask[sy] & ~d1);
+      if (i_open != 0) prob = prob * (temp1 + (1.0 / i_open)); else prob = prob * temp1;
+    }
+  }
+  return level;
+}

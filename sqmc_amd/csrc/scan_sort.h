@@ -1,0 +1,185 @@
+// scan_sort.h -- device-wide exclusive scan (u64 lanes, used with packed 2x32-bit counters)
+// and a stable LSD radix sort of (u64 key, u32 value) pairs, written for 64-wide
+// wavefronts on gfx950.
+//
+// The sort replaces merge_sort2_up_dn (do_walk.f90:5411-5614): any stable sort on
+// (up, dn) yields the reference's order.  One wavefront owns one tile; inside a tile the
+// rank of a key among equal digits comes from 8 wave ballots (match-any) + popcount, so
+// the scatter is stable without any cross-wave hand-off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 8                       // elements per thread
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
+
+__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    u64 o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix,
+// total in *total (valid for all threads)
+__device__ __forceinline__ u64 block_excl_scan_u64(u64 v, u64 *total) {
+  __shared__ u64 wsum[SCAN_BLOCK / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  u64 inc = wave_incl_scan_u64(v, lane);
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  u64 off = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_BLOCK / 64; i++) { if (i < w) off += wsum[i]; tot += wsum[i]; }
+  __syncthreads();
+  *total = tot;
+  return off + inc - v;
+}
+
+// phase 1: per-tile sums
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_reduce_kernel(const u64 *__restrict__ in, u64 *__restrict__ tile_sums, long long n) {
+  long long base = (long long)blockIdx.x * SCAN_TILE;
+  u64 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    long long i = base + (long long)k * SCAN_BLOCK + threadIdx.x;
+    if (i < n) s += in[i];
+  }
+  u64 tot; block_excl_scan_u64(s, &tot);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+// phase 2: single block scans the tile sums in place (exclusive), writes grand total
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(u64 *__restrict__ tile_sums, int ntiles, u64 *__restrict__ total_out) {
+  u64 carry = 0;
+  for (int base = 0; base < ntiles; base += SCAN_BLOCK) {
+    int i = base + threadIdx.x;
+    u64 v = (i < ntiles) ? tile_sums[i] : 0, tot;
+    u64 ex = block_excl_scan_u64(v, &tot);
+    if (i < ntiles) tile_sums[i] = carry + ex;
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+// phase 3: per-tile exclusive scan + tile offset.  Thread-contiguous items keep order.
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, const u64 *__restrict__ tile_sums, long long n) {
+  long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+  u64 v[SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) { long long i = base + k; v[k] = (i < n) ? in[i] : 0; s += v[k]; }
+  u64 tot; u64 ex = block_excl_scan_u64(s, &tot) + tile_sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) { long long i = base + k; if (i < n) out[i] = ex; ex += v[k]; }
+}
+
+struct ScanWork { u64 *tile_sums; long long cap_tiles; };
+
+// exclusive scan of n u64 values; total (optional) is written on device
+static inline void device_excl_scan_u64(const u64 *in, u64 *out, long long n, u64 *total_out, ScanWork &w, hipStream_t st) {
+  if (n <= 0) { if (total_out) hipMemsetAsync(total_out, 0, sizeof(u64), st); return; }
+  int ntiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(ntiles), dim3(SCAN_BLOCK), 0, st, in, w.tile_sums, n);
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, w.tile_sums, ntiles, total_out);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(SCAN_BLOCK), 0, st, in, out, w.tile_sums, n);
+}
+
+// ------------------------------------------------------------------------ radix sort
+#define RS_BITS 8
+#define RS_RADIX 256
+#define RS_WAVE_ITEMS 32                    // rounds of 64 keys per wave
+#define RS_TILE (64 * RS_WAVE_ITEMS)        // 2048 keys per wavefront
+
+// histogram: hist[digit * ntiles + tile]
+__global__ void __launch_bounds__(64) rs_hist_kernel(const u64 *__restrict__ keys, u32 *__restrict__ hist, long long n, int ntiles, int shift) {
+  __shared__ u32 cnt[RS_RADIX];
+  const int lane = threadIdx.x;
+  for (int d = lane; d < RS_RADIX; d += 64) cnt[d] = 0;
+  __syncthreads();
+  long long base = (long long)blockIdx.x * RS_TILE;
+  for (int r = 0; r < RS_WAVE_ITEMS; r++) {
+    long long i = base + (long long)r * 64 + lane;
+    if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & (RS_RADIX - 1)], 1u);
+  }
+  __syncthreads();
+  for (int d = lane; d < RS_RADIX; d += 64) hist[(long long)d * ntiles + blockIdx.x] = cnt[d];
+}
+
+// one block per digit: in-place exclusive scan of that digit's row (ntiles entries) and the
+// row total; the scatter kernel turns the 256 row totals into digit bases itself.
+__global__ void __launch_bounds__(SCAN_BLOCK) rs_scan_kernel(u32 *__restrict__ hist, u32 *__restrict__ rowtot, int ntiles) {
+  u32 *row = hist + (long long)blockIdx.x * ntiles;
+  u64 carry = 0;
+  for (int base = 0; base < ntiles; base += SCAN_BLOCK * 4) {
+    int i0 = base + threadIdx.x * 4;
+    u32 v[4]; u64 s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = (i0 + k < ntiles) ? row[i0 + k] : 0; s += v[k]; }
+    u64 tot; u64 ex = carry + block_excl_scan_u64(s, &tot);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (i0 + k < ntiles) row[i0 + k] = (u32)ex; ex += v[k]; }
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rowtot[blockIdx.x] = (u32)carry;
+}
+
+__global__ void __launch_bounds__(64) rs_scatter_kernel(const u64 *__restrict__ kin, const u32 *__restrict__ vin,
+                                                        u64 *__restrict__ kout, u32 *__restrict__ vout,
+                                                        const u32 *__restrict__ hist, const u32 *__restrict__ rowtot,
+                                                        long long n, int ntiles, int shift) {
+  __shared__ u32 off[RS_RADIX];
+  const int lane = threadIdx.x;
+  {   // digit bases = exclusive scan of the 256 row totals (4 per lane + wave scan)
+    u32 t0 = rowtot[lane * 4], t1 = rowtot[lane * 4 + 1], t2 = rowtot[lane * 4 + 2], t3 = rowtot[lane * 4 + 3];
+    u64 inc = wave_incl_scan_u64((u64)t0 + t1 + t2 + t3, lane);
+    u32 ex = (u32)(inc - ((u64)t0 + t1 + t2 + t3));
+    off[lane * 4] = ex; off[lane * 4 + 1] = ex + t0; off[lane * 4 + 2] = ex + t0 + t1; off[lane * 4 + 3] = ex + t0 + t1 + t2;
+  }
+  __syncthreads();
+  for (int d = lane; d < RS_RADIX; d += 64) off[d] += hist[(long long)d * ntiles + blockIdx.x];
+  __syncthreads();
+  long long base = (long long)blockIdx.x * RS_TILE;
+  const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int r = 0; r < RS_WAVE_ITEMS; r++) {
+    long long i = base + (long long)r * 64 + lane;
+    bool valid = i < n;
+    u64 key = valid ? kin[i] : 0; u32 val = valid ? vin[i] : 0;
+    u32 dig = (u32)((key >> shift) & (RS_RADIX - 1));
+    u64 same = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < RS_BITS; b++) {
+      u64 m = __ballot((dig >> b) & 1);
+      same &= ((dig >> b) & 1) ? m : ~m;
+    }
+    u32 rank = (u32)__popcll(same & lt), cnt = (u32)__popcll(same);
+    u32 dst = 0;
+    if (valid) dst = off[dig] + rank;
+    __syncthreads();                     // all lanes have read off[] before leaders bump it
+    if (valid && rank == 0) off[dig] += cnt;
+    __syncthreads();
+    if (valid) { kout[dst] = key; vout[dst] = val; }
+  }
+}
+
+struct SortWork { u64 *k_alt; u32 *v_alt; u32 *hist; u32 *rowtot; long long cap; };
+
+// Sorts keys[0..n) (with values) on bits [0, nbits); result ends up in the returned buffers
+// (either the inputs or the alternates).  Stable.
+static inline void device_radix_sort(u64 *&keys, u32 *&vals, long long n, int nbits, SortWork &w, hipStream_t st) {
+  if (n <= 1) return;
+  int ntiles = (int)((n + RS_TILE - 1) / RS_TILE);
+  u64 *ka = keys, *kb = w.k_alt; u32 *va = vals, *vb = w.v_alt;
+  for (int shift = 0; shift < nbits; shift += RS_BITS) {
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(ntiles), dim3(64), 0, st, ka, w.hist, n, ntiles, shift);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(SCAN_BLOCK), 0, st, w.hist, w.rowtot, ntiles);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(ntiles), dim3(64), 0, st, ka, va, kb, vb, w.hist, w.rowtot, n, ntiles, shift);
+    u64 *tk = ka; ka = kb; kb = tk; u32 *tv = va; va = vb; vb = tv;
+  }
+  w.k_alt = kb; w.v_alt = vb; keys = ka; vals = va;
+}

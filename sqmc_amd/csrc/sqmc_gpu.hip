@@ -1,0 +1,989 @@
+// sqmc_gpu.hip -- libsqmc_gpu.so: HIP kernels (gfx950 / MI355X) + the C ABI of
+// include/sqmc_gpu.h for sqmc's semistochastic walker step.
+//
+// One MC step (do_walk.f90:2171-2934, semistochastic chem, ncores=1) runs as this
+// kernel pipeline on one HIP stream; all walker data stays in HBM as SoA arrays:
+//
+//   gate      per walker: low-weight spawn gate, nwalk_child, child weight   (3577-3589)
+//   scan      child offsets (device-wide exclusive scan)
+//   diag      per walker: death/clone factor 1+tau(E_T-H_ii), H_ii cached     (3743-3793)
+//   spawn     per CHILD (load-balanced): uniform proposal + H_ij -> appended  (3599-3731)
+//   project   deterministic core: gather, CSR matvec, scatter-add             (2255-2325)
+//   sort      stable LSD radix sort of (up,dn) keys                           (5169-5197)
+//   merge     one thread per determinant segment: annihilation + initiator    (5866-6083)
+//   round     stochastic rounding of small weights, compaction (2 scans)      (7196-7254)
+//   estimate  C(T) lookup, reweight, 13 block-reduced sums                    (2487-2790)
+//
+// Everything is HBM/latency bound integer + fp64 work: no MFMA anywhere.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <string>
+#include <algorithm>
+#include "../../include/sqmc_gpu.h"
+#include "chem_device.h"
+#include "scan_sort.h"
+
+#define TPB 256
+static thread_local std::string g_err;
+static int fail(int code, const std::string &m) { g_err = m; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(SQMC_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+static inline int nblk(long long n, int tpb = TPB) { return (int)((n + tpb - 1) / tpb); }
+
+// ------------------------------------------------------------------ walker SoA in HBM
+struct WalkArr {
+  u64 *up, *dn; double *wt; int8_t *impd, *init, *psign; double *me, *en, *ed;
+};
+static int alloc_walk(WalkArr &a, long long n) {
+  HIPCHK(hipMalloc(&a.up, n * 8)); HIPCHK(hipMalloc(&a.dn, n * 8)); HIPCHK(hipMalloc(&a.wt, n * 8));
+  HIPCHK(hipMalloc(&a.impd, n)); HIPCHK(hipMalloc(&a.init, n)); HIPCHK(hipMalloc(&a.psign, n));
+  HIPCHK(hipMalloc(&a.me, n * 8)); HIPCHK(hipMalloc(&a.en, n * 8)); HIPCHK(hipMalloc(&a.ed, n * 8));
+  return 0;
+}
+static void free_walk(WalkArr &a) {
+  hipFree(a.up); hipFree(a.dn); hipFree(a.wt); hipFree(a.impd); hipFree(a.init); hipFree(a.psign);
+  hipFree(a.me); hipFree(a.en); hipFree(a.ed);
+}
+
+struct StepP {       // device copy of sqmc_step_params + derived values
+  double tau, e_trial, rfi, r_init, min_wt, cutoff;
+  int ipow, imind, cti, semi, reached;
+};
+
+// device-side scalars of a step
+struct DevScalars {
+  u64 lcg;                 // REPLAY stream state (48 bits)
+  u64 n_children;          // total child proposals this step
+  u64 n_invalid;           // children that produced no walker (weight 0)
+  u64 tot1;                // packed scan total 1: lo = kept after merge, hi = rounding draws
+  u64 tot2;                // packed scan total 2: lo = final walkers, hi = det-space walkers
+  int err;                 // SQMC_ERR_* raised on device
+  int pad;
+  double stats[16];
+};
+
+#define NTIMERS 32
+struct sqmc_gpu_ctx {
+  hipStream_t st;
+  ChemTab htab; ChemTab *d_tab; double *d_ints; ChemDev dev;
+  int *d_hb_r, *d_hb_s; double *d_hb_absH; long long *d_pq_ind; int *d_pq_count;
+  long long mwalk, nwalk;
+  WalkArr w, m;                        // walkers (main + appended spawns), merge results
+  u64 *d_nchild; u64 *d_child_off; double *d_wchild; u64 *d_child_state;
+  u64 *d_keys, *d_keys_alt; u32 *d_vals, *d_vals_alt; u32 *d_hist, *d_rowtot;
+  u64 *d_flags, *d_pos, *d_flags2, *d_pos2; u64 *d_tile_sums; long long cap_tiles;
+  // projector (full CSR, rows in the reference's accumulation order)
+  long long n_imp, prj_nnz; int *d_prj_ptr, *d_prj_col; double *d_prj_val; int *d_loc_imp, *d_loc_imp_new; double *d_prj_x;
+  // C(T)
+  long long n_ct; u64 *d_ct_up, *d_ct_dn; double *d_ct_num, *d_ct_den;
+  int rng_mode; u64 seed64; u64 step_no;
+  DevScalars *d_sc; DevScalars *h_sc;   // h_sc pinned
+  double *d_partials; int n_partial_blocks;
+  int key_bits;
+  // timing
+  int timing; hipEvent_t ev[NTIMERS + 1]; const char *tname[NTIMERS]; int nt; float tms[NTIMERS];
+};
+
+// ===================================================================== step kernels
+__device__ __forceinline__ u64 pack_key(u64 up, u64 dn, int norb) { return (up << norb) | dn; }
+
+// gate + child count (COUNTER discipline).  do_walk.f90:3577-3589
+__global__ void __launch_bounds__(TPB) k_gate(const double *__restrict__ wt, u64 *__restrict__ nchild, double *__restrict__ wchild,
+                                              long long n, StepP p, u64 seed, u64 step) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  double w = wt[i]; bool spawn, use_wt;
+  if (fabs(w) < p.cutoff) {
+    Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 0, (u64)i);
+    spawn = rng_draw(g) < fabs(w / p.cutoff); use_wt = false;
+  } else { spawn = true; use_wt = true; }
+  long long nc = 0; double wc = 0.0;
+  if (spawn) {
+    if (use_wt) { nc = llround(fabs(w)); if (nc < 1) nc = 1; wc = w / (double)nc; }
+    else { nc = 1; wc = copysign(p.cutoff, w); }
+  }
+  nchild[i] = (u64)nc; wchild[i] = wc;
+}
+
+// REPLAY discipline: one lane walks the walkers in order, consuming the single rannyu
+// stream exactly as the reference does, and records where every child starts in it.
+__global__ void __launch_bounds__(64) k_replay_prepass(const ChemTab *__restrict__ gtab, const u64 *__restrict__ up, const u64 *__restrict__ dn,
+                                                       const double *__restrict__ wt, u64 *__restrict__ nchild, double *__restrict__ wchild,
+                                                       u64 *__restrict__ child_off, u64 *__restrict__ child_state, long long n,
+                                                       long long cap_children, StepP p, DevScalars *sc) {
+  __shared__ ChemTab t;
+  stage_tab(&t, gtab);
+  if (threadIdx.x != 0) return;
+  Rng g; g.mode = 0; g.x = sc->lcg;
+  u64 c = 0;
+  for (long long i = 0; i < n; i++) {
+    double w = wt[i]; bool spawn, use_wt;
+    if (fabs(w) < p.cutoff) { spawn = rng_draw(g) < fabs(w / p.cutoff); use_wt = false; }
+    else { spawn = true; use_wt = true; }
+    long long nc = 0; double wc = 0.0;
+    if (spawn) {
+      if (use_wt) { nc = llround(fabs(w)); if (nc < 1) nc = 1; wc = w / (double)nc; }
+      else { nc = 1; wc = copysign(p.cutoff, w); }
+    }
+    nchild[i] = (u64)nc; wchild[i] = wc; child_off[i] = c;
+    u64 iu = up[i], id = dn[i];
+    for (long long k = 0; k < nc; k++) {
+      if ((long long)c < cap_children) child_state[c] = g.x;
+      u64 ju, jd; double pr;
+      propose_uniform(t, g, iu, id, ju, jd, pr);
+      c++;
+    }
+  }
+  child_off[n] = c;
+  sc->n_children = c; sc->lcg = g.x;
+}
+
+// diagonal death/clone, do_walk.f90:3743-3793
+__global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, double *__restrict__ wt,
+                                              const int8_t *__restrict__ impd, double *__restrict__ me, long long n, StepP p, DevScalars *sc) {
+  __shared__ ChemTab t;
+  stage_tab(&t, dev.tab);
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  if (p.semi && impd[i] < 1) return;
+  double hii = me[i];
+  if (hii > 1e50) { hii = h_any(t, dev.integrals, up[i], dn[i], up[i], dn[i]); me[i] = hii; }
+  double f = 1.0 + p.tau * (p.e_trial - hii);
+  if (f < 0) { if (p.reached > 1) sc->err = SQMC_ERR_NEG_DIAG; f = 0; }
+  wt[i] = wt[i] * f;
+}
+
+// one thread per child proposal; parent found by binary search in the child offsets
+__global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
+                                               const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
+                                               long long n0, long long nchildren, StepP p, int mode, u64 seed, u64 step, DevScalars *sc) {
+  __shared__ ChemTab t;
+  stage_tab(&t, dev.tab);
+  long long c = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (c >= nchildren) return;
+  long long lo = 0, hi = n0;                  // largest i with child_off[i] <= c
+  while (hi - lo > 1) { long long mid = (lo + hi) >> 1; if (child_off[mid] <= (u64)c) lo = mid; else hi = mid; }
+  const long long ip = lo;
+  Rng g; g.mode = mode;
+  g.x = (mode == 0) ? child_state[c] : sq_counter_key(seed, step, 1, (u64)c);
+  const u64 iu = w.up[ip], id = w.dn[ip];
+  u64 ju, jd; double prob;
+  int level = propose_uniform(t, g, iu, id, ju, jd, prob);
+  double wj = 0.0;
+  if (level > 0) {
+    double mel = h_level(t, dev.integrals, iu, id, ju, jd, level);
+    wj = -p.tau * mel / prob;
+    wj = wchild[ip] * wj;
+  }
+  const long long k = n0 + c;
+  if (wj != 0.0) {
+    const int pd = w.impd[ip], pi = w.init[ip];
+    int d;
+    if (pd == -2) d = p.cti ? 1 : 2; else d = (pd < 126 ? pd : 126) + 1;
+    if (p.semi && pd == 0) d = -1;
+    int ini = (pi >= 2) ? 1 : 0;
+    if (p.cti && pd == -2) ini = 1;
+    if (p.semi && pd == 0) ini = 1;
+    w.up[k] = ju; w.dn[k] = jd; w.wt[k] = wj; w.impd[k] = (int8_t)d; w.init[k] = (int8_t)ini; w.psign[k] = 0;
+    w.me[k] = 1e51; w.en[k] = 1e51; w.ed[k] = 1e51;
+    keys[k] = pack_key(ju, jd, t.norb);
+  } else {
+    w.wt[k] = 0.0; keys[k] = ~0ull;           // sorts behind every real determinant
+    atomicAdd(&sc->n_invalid, 1ull);
+  }
+  vals[k] = (u32)k;
+}
+
+__global__ void __launch_bounds__(TPB) k_main_keys(const u64 *__restrict__ up, const u64 *__restrict__ dn, u64 *__restrict__ keys,
+                                                   u32 *__restrict__ vals, long long n, int norb) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) { keys[i] = pack_key(up[i], dn[i], norb); vals[i] = (u32)i; }
+}
+
+// deterministic projection: x = w(loc); y = A x (rows summed in the reference's order);
+// w(loc) += y + (E_T*tau)*x.   do_walk.f90:2262, 2290, 2321-2323
+__global__ void __launch_bounds__(TPB) k_prj_gather(const double *__restrict__ wt, const int *__restrict__ loc, double *__restrict__ x, long long n) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) x[i] = wt[loc[i]];
+}
+__global__ void __launch_bounds__(TPB) k_prj_apply(const int *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val,
+                                                   const double *__restrict__ x, const int *__restrict__ loc, double *__restrict__ wt,
+                                                   long long n, double e_trial, double tau) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  double y = 0.0;
+  for (int k = ptr[i]; k < ptr[i + 1]; k++) y = y + val[k] * x[col[k]];
+  y = y + e_trial * tau * x[i];
+  wt[loc[i]] = wt[loc[i]] + y;
+}
+__global__ void __launch_bounds__(TPB) k_scale(double *__restrict__ v, long long n, double r) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) v[i] = v[i] * r;
+}
+
+// integer ** integer of the reference (0**0 = 1)
+__device__ __forceinline__ double ipow_d(int b, int e) { double r = 1.0; for (int i = 0; i < e; i++) r *= (double)b; return r; }
+
+// Annihilation + initiator rules: one thread per run of equal determinants in the sorted
+// order.  Within a run the original walker comes first and spawns keep creation order
+// (stable sort), so the pairwise combination below is the reference's left-to-right scan.
+// do_walk.f90:5866-6083, check_initiator 6838-6872.
+__global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *__restrict__ skey, const u32 *__restrict__ perm,
+                                               u64 *__restrict__ flags, long long n_all, StepP p, const DevScalars *sc) {
+  long long j = (long long)blockIdx.x * TPB + threadIdx.x;
+  const long long n = n_all - (long long)sc->n_invalid;
+  if (j >= n_all) return;
+  if (j >= n) { flags[j] = 0; return; }
+  const u64 key = skey[j];
+  if (j > 0 && skey[j - 1] == key) { flags[j] = 0; return; }
+  u32 t = perm[j];
+  double wt = w.wt[t], me = w.me[t], en = w.en[t], ed = w.ed[t];
+  int ini = w.init[t], d = w.impd[t], ps = w.psign[t];
+  if (d == -1 && j > 0) d = 1;                 // 5985-5986 (the very first walker keeps -1 until the end)
+  long long jj = j + 1;
+  for (; jj < n && skey[jj] == key; jj++) {
+    const u32 s = perm[jj];
+    const double w2 = w.wt[s]; const int i2 = w.init[s], d2 = w.impd[s];
+    const bool same_sign = (w2 * wt > 0);
+    if (same_sign) {
+      if (i2 > ini) ini = i2;
+      en = fmin(en, w.en[s]); ed = fmin(ed, w.ed[s]);
+    }
+    me = fmin(me, w.me[s]);
+    if (d == -2) { if (d2 == 0) d = 0; }
+    else if (d2 == -2) { if (d != 0) d = -2; }
+    else if (d != 0 && d != -2) { int a = d2 < 0 ? -d2 : d2; if (a < d) d = a; }
+    if (!same_sign) {
+      if (fabs(wt) < fabs(w2)) { if (ini != 3 || p.r_init == -1.0) ini = i2; }
+      else if (fabs(wt) == fabs(w2)) { if (ini != 3 || p.r_init == -1.0) ini = 0; }
+    }
+    if (!(d == 0 && d2 == -1)) wt = wt + w2;
+  }
+  // check_initiator
+  {
+    const int dd = d - p.imind > 0 ? d - p.imind : 0;
+    const double thr = p.r_init * ipow_d(dd, p.ipow), aw = fabs(wt);
+    if (ini == 3 && p.r_init >= 0) { if (wt * ps < 1.0) wt = (double)ps; }
+    else if (ini == 2 && ((aw <= thr && d > 0) || ((aw <= p.r_init && !p.cti) && d == -2))) ini = 1;
+    else if (ini < 2 && ((aw > thr && d >= 0) || ((aw > p.r_init || p.cti) && d == -2))) ini = ini + 1;
+  }
+  int dtest = d;
+  if (d == -1) { if (jj >= n) dtest = 1; d = 1; }   // 6032-6036 then the last-det test at 6038
+  const bool discard = (((wt == 0.0 && (ini != 3 || p.r_init < 0)) || ini == 0) && dtest >= 1);
+  m.up[j] = w.up[t]; m.dn[j] = w.dn[t]; m.wt[j] = wt; m.impd[j] = (int8_t)d; m.init[j] = (int8_t)ini; m.psign[j] = (int8_t)ps;
+  m.me[j] = me; m.en[j] = en; m.ed[j] = ed;
+  u64 f = 0;
+  if (!discard) { f = 1ull; if (p.semi && d >= 1 && fabs(wt) < p.min_wt) f |= (1ull << 32); }
+  flags[j] = f;
+}
+
+// stochastic rounding of small weights (reduce_my_walker, do_walk.f90:7196-7254); RNG draws
+// are taken in merged-walker order: REPLAY = skip-ahead of the rannyu LCG by the rank of the
+// draw, COUNTER = stream keyed by the merged index.
+__global__ void __launch_bounds__(TPB) k_round(WalkArr m, const u64 *__restrict__ flags, const u64 *__restrict__ pos, u64 *__restrict__ flags2,
+                                               long long n_all, StepP p, int mode, u64 seed, u64 step, const DevScalars *sc) {
+  long long j = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (j >= n_all) return;
+  const u64 f = flags[j];
+  if (!(f & 1ull)) { flags2[j] = 0; return; }
+  double wt = m.wt[j];
+  if (f >> 32) {
+    const u64 ps = pos[j];
+    double r;
+    if (mode == 0) r = (double)lcg_skip(sc->lcg, (ps >> 32) + 1) * 3.552713678800500929355621337890625e-15;
+    else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, ps & 0xFFFFFFFFull); r = rng_draw(g); }
+    if (r < (fabs(wt) / p.min_wt)) wt = copysign(p.min_wt, wt); else wt = 0.0;
+    m.wt[j] = wt;
+  }
+  const int d = m.impd[j];
+  u64 f2 = 0;
+  if (!(p.semi && wt == 0.0 && d >= 1)) { f2 = 1ull; if (d == 0) f2 |= (1ull << 32); }
+  flags2[j] = f2;
+}
+
+__device__ __forceinline__ long long ct_search(const u64 *__restrict__ cu, const u64 *__restrict__ cd, long long n, u64 u, u64 d) {
+  long long lo = 0, hi = n - 1;
+  while (lo <= hi) {
+    long long mid = (lo + hi) >> 1; u64 a = cu[mid], b = cd[mid];
+    if (a == u && b == d) return mid;
+    if (a < u || (a == u && b < d)) lo = mid + 1; else hi = mid - 1;
+  }
+  return -1;
+}
+
+#define NSTAT 13
+// compaction into the walker arrays + reweight (2487) + estimator pieces (2573-2684 and
+// binary_search_list_and_update, more_tools.f90:4041-4098) + per-block partial sums
+__global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64 *__restrict__ flags2, const u64 *__restrict__ pos2,
+                                                 int *__restrict__ loc_imp, const u64 *__restrict__ cu, const u64 *__restrict__ cd,
+                                                 const double *__restrict__ cnum, const double *__restrict__ cden, long long n_ct,
+                                                 long long n_all, StepP p, double *__restrict__ partials) {
+  long long j = (long long)blockIdx.x * TPB + threadIdx.x;
+  double s[NSTAT];
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
+  if (j < n_all && (flags2[j] & 1ull)) {
+    const u64 ps = pos2[j]; const long long o = (long long)(ps & 0xFFFFFFFFull);
+    const u64 u = m.up[j], dd = m.dn[j];
+    const double wt = m.wt[j] * p.rfi;
+    const int d = m.impd[j], ini = m.init[j], psg = m.psign[j];
+    double en = m.en[j], ed = m.ed[j];
+    if (en > 1e50) {
+      long long q = ct_search(cu, cd, n_ct, u, dd);
+      if (q < 0) { en = 0.0; ed = 0.0; } else { en = cnum[q]; ed = cden[q]; }
+    }
+    w.up[o] = u; w.dn[o] = dd; w.wt[o] = wt; w.impd[o] = (int8_t)d; w.init[o] = (int8_t)ini; w.psign[o] = (int8_t)psg;
+    w.me[o] = m.me[j]; w.en[o] = en; w.ed[o] = ed;
+    if (d == 0) loc_imp[ps >> 32] = (int)o;
+    s[0] = wt; s[1] = fabs(wt); s[8] = wt * wt;
+    if (ini == 3) s[4] = wt * psg;
+    if (d == 0 || (d == -2 && p.cti)) s[6] = fabs(wt);
+    double e_num = en * wt, e_den = ed * wt;
+    if (e_num != 0.0) {
+      if (fabs(e_den) < 1e-22) e_den = fabs(e_den);
+      s[2] = e_den; s[3] = e_num; s[9] = e_num * e_num; s[10] = e_den * e_den;
+      s[11] = e_num * copysign(1.0, e_den); s[12] = fabs(e_den); s[5] = e_num * e_den;
+    }
+  }
+  // deterministic block reduction (wave shuffles, then 4 wave sums in LDS)
+  __shared__ double red[TPB / 64][NSTAT];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) {
+    double v = s[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) red[wv][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NSTAT) {
+    double v = 0.0;
+    for (int q = 0; q < TPB / 64; q++) v += red[q][threadIdx.x];
+    partials[(long long)blockIdx.x * NSTAT + threadIdx.x] = v;
+  }
+}
+
+// final: sum block partials in block order; publish stats; advance the REPLAY stream
+__global__ void __launch_bounds__(64) k_finish(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_blocks,
+                                               long long n_before, int mode, DevScalars *sc) {
+  __shared__ double tot[NSTAT];
+  if (threadIdx.x < NSTAT) {
+    double v = 0.0;
+    for (int b = 0; b < nblocks; b++) v += partials[(long long)b * NSTAT + threadIdx.x];
+    tot[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double *o = sc->stats;
+    o[0] = tot[0]; o[1] = tot[1]; o[2] = tot[2]; o[3] = tot[3]; o[4] = tot[4];
+    o[5] = (double)(sc->tot2 & 0xFFFFFFFFull); o[6] = tot[6];
+    o[7] = (double)(n_before - (long long)sc->n_invalid); o[8] = tot[8]; o[9] = tot[9]; o[10] = tot[10];
+    o[11] = tot[11]; o[12] = tot[12]; o[13] = tot[5]; o[15] = (double)sc->n_children;
+    { double wb = 0.0; for (int b = 0; b < 64; b++) wb += wabs_blocks[b]; o[14] = wb; }
+    if (mode == 0) sc->lcg = lcg_skip(sc->lcg, sc->tot1 >> 32);
+  }
+}
+// sum |w| over the sorted pre-merge list (my_w_abs_before_merge_cum, do_walk.f90:2347)
+__global__ void __launch_bounds__(TPB) k_wabs(const double *__restrict__ wt, long long n, double *__restrict__ out) {
+  __shared__ double red[TPB / 64];
+  double v = 0.0;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) v += fabs(wt[i]);
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ============================================================ batch / test door kernels
+__global__ void __launch_bounds__(TPB) k_ham_batch(ChemDev dev, const u64 *iu, const u64 *id, const u64 *ju, const u64 *jd, double *h, long long n) {
+  __shared__ ChemTab t;
+  stage_tab(&t, dev.tab);
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) h[i] = h_any(t, dev.integrals, iu[i], id[i], ju[i], jd[i]);
+}
+__global__ void __launch_bounds__(TPB) k_propose_batch(ChemDev dev, const u64 *up, const u64 *dn, const u64 *state_in, u64 *ju, u64 *jd,
+                                                       double *wj, u64 *state_out, long long n, double tau) {
+  __shared__ ChemTab t;
+  stage_tab(&t, dev.tab);
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  Rng g; g.mode = 0; g.x = state_in[i];
+  u64 a, b; double prob;
+  int level = propose_uniform(t, g, up[i], dn[i], a, b, prob);
+  double w = 0.0;
+  if (level > 0) w = -tau * h_level(t, dev.integrals, up[i], dn[i], a, b, level) / prob;
+  ju[i] = a; jd[i] = b; wj[i] = w; state_out[i] = g.x;
+}
+
+// ================================================================ HCI connections
+// find_important_connected_dets_chem, chemistry.f90:6819-7159: one thread per reference
+// determinant; pass 0 counts, pass 1 writes at the scanned offsets.  Emits (up, dn,
+// H_ij*c_j, e_mix_den) with the reference determinant itself in slot 0.
+__global__ void __launch_bounds__(TPB) k_hci_gen(ChemDev dev, const u64 *__restrict__ rup, const u64 *__restrict__ rdn, const double *__restrict__ coef,
+                                                 double eps_var, int diag_mode, long long n_ref, int pass, u64 *__restrict__ counts,
+                                                 const u64 *__restrict__ offs, u64 *__restrict__ ou, u64 *__restrict__ od,
+                                                 double *__restrict__ onum, double *__restrict__ oden) {
+  __shared__ ChemTab t;
+  stage_tab(&t, dev.tab);
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n_ref) return;
+  const double c = coef[i];
+  if (c == 0.0) { if (!pass) counts[i] = 0; return; }
+  const double eps = eps_var / fabs(c);
+  const u64 up = rup[i], dn = rdn[i];
+  const int n = t.norb;
+  const double sqrt2 = sqrt(2.0), sqrt2inv = 1.0 / sqrt2;
+  u64 cnt = 0; const u64 base = pass ? offs[i] : 0;
+#define EMIT(U, D, M, DEN) do { if (pass) { ou[base + cnt] = (U); od[base + cnt] = (D); onum[base + cnt] = (M) * c; oden[base + cnt] = (DEN); } cnt++; } while (0)
+  { double hd = diag_mode ? h_any(t, dev.integrals, up, dn, up, dn) : 0.0; EMIT(up, dn, hd, c); }
+  // singles
+  for (int sp = 0; sp < 2; sp++) {
+    const u64 occ = sp ? dn : up;
+    for (u64 e = occ; e; e &= e - 1) {
+      const int pe = ctz64(e) + 1;
+      for (u64 h = t.sym_mask[t.orbsym[pe]] & ~occ; h; h &= h - 1) {
+        const int r = ctz64(h) + 1;
+        u64 nu = up, nd = dn;
+        if (!sp) nu = (up & ~bit64(pe - 1)) | bit64(r - 1); else nd = (dn & ~bit64(pe - 1)) | bit64(r - 1);
+        if (t.time_sym) { if (nu == nd && t.z < 0) continue; if (up == nd && dn == nu) continue; }
+        double mel = h_single(t, dev.integrals, up, dn, nu, nd);
+        if (fabs(mel) < eps) continue;
+        if (t.time_sym) {
+          if (up == dn && nu != nd) mel = sqrt2inv * mel;
+          if (nu == nd && up != dn) mel = sqrt2 * mel;
+          if (nu > nd) { u64 x = nu; nu = nd; nd = x; mel = t.z * mel; }
+        }
+        EMIT(nu, nd, mel, 0.0);
+      }
+    }
+  }
+  if (!(eps > dev.max_double)) {
+    // occupied pairs: up-up, dn-dn, up-dn (chemistry.f90:7000-7021)
+    for (int cls = 0; cls < 3; cls++) {
+      const u64 A = (cls == 1) ? dn : up, B = (cls == 0) ? up : dn;
+      for (u64 ea = A; ea; ea &= ea - 1) {
+        const int pa = ctz64(ea) + 1;
+        for (u64 eb = (cls == 2) ? B : (ea & (ea - 1)); eb; eb &= eb - 1) {
+          const int qb = ctz64(eb) + 1;
+          int p = pa + (cls == 1 ? n : 0), q = qb + (cls == 0 ? 0 : n);
+          int p2 = p, q2 = q;
+          const bool both_dn = (cls == 1), swapped = (cls == 2 && p > q - n);
+          if (both_dn) { p2 = p - n; q2 = q - n; }
+          if (swapped) { p2 = q - n; q2 = p + n; }
+          const long long e = (p2 > q2) ? ((long long)p2 * (p2 - 1)) / 2 + q2 : ((long long)q2 * (q2 - 1)) / 2 + p2;
+          const long long k0 = dev.pq_ind[e] - 1; const int kc = dev.pq_count[e];
+          for (int hh = 0; hh < kc; hh++) {
+            if (dev.hb_absH[k0 + hh] <= eps) break;
+            int r = dev.hb_r[k0 + hh], s = dev.hb_s[k0 + hh];
+            if (both_dn) { r += n; s += n; }
+            if (swapped) { int rt = s - n; s = r + n; r = rt; }
+            if (r <= n ? ((up >> (r - 1)) & 1) : ((dn >> (r - n - 1)) & 1)) continue;
+            if (s <= n ? ((up >> (s - 1)) & 1) : ((dn >> (s - n - 1)) & 1)) continue;
+            u64 nu = up, nd = dn;
+            if (p <= n) nu &= ~bit64(p - 1); else nd &= ~bit64(p - n - 1);
+            if (q <= n) nu &= ~bit64(q - 1); else nd &= ~bit64(q - n - 1);
+            if (r <= n) nu |= bit64(r - 1); else nd |= bit64(r - n - 1);
+            if (s <= n) nu |= bit64(s - 1); else nd |= bit64(s - n - 1);
+            if (t.time_sym) { if (nu == nd && t.z < 0) continue; if (up == nd && dn == nu) continue; }
+            double mel = 0.0;
+            if (pass) {
+              mel = h_double(t, dev.integrals, up, dn, nu, nd);
+              if (t.time_sym) {
+                if (up == dn && nu != nd) mel = sqrt2inv * mel;
+                if (nu == nd && up != dn) mel = sqrt2 * mel;
+              }
+            }
+            if (t.time_sym && nu > nd) { u64 x = nu; nu = nd; nd = x; mel = t.z * mel; }
+            EMIT(nu, nd, mel, 0.0);
+          }
+        }
+      }
+    }
+  }
+#undef EMIT
+  if (!pass) counts[i] = cnt;
+}
+// dedup of the sorted connection list: sums e_mix_num / e_mix_den of equal determinants
+// left to right (merge_original_with_spawned3, tools.f90:577-660)
+__global__ void __launch_bounds__(TPB) k_hci_heads(const u64 *__restrict__ skey, u64 *__restrict__ flags, long long n) {
+  long long j = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (j < n) flags[j] = (j == 0 || skey[j] != skey[j - 1]) ? 1ull : 0ull;
+}
+__global__ void __launch_bounds__(TPB) k_hci_dedup(const u64 *__restrict__ skey, const u32 *__restrict__ perm, const u64 *__restrict__ flags,
+                                                   const u64 *__restrict__ pos, const u64 *__restrict__ iu, const u64 *__restrict__ id,
+                                                   const double *__restrict__ inum, const double *__restrict__ iden,
+                                                   u64 *__restrict__ ou, u64 *__restrict__ od, double *__restrict__ onum, double *__restrict__ oden, long long n) {
+  long long j = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (j >= n || !flags[j]) return;
+  const u64 key = skey[j]; u32 t = perm[j];
+  double a = inum[t], b = iden[t];
+  for (long long jj = j + 1; jj < n && skey[jj] == key; jj++) { a = a + inum[perm[jj]]; b = b + iden[perm[jj]]; }
+  const u64 o = pos[j];
+  ou[o] = iu[t]; od[o] = id[t]; onum[o] = a; oden[o] = b;
+}
+__global__ void __launch_bounds__(TPB) k_keys2(const u64 *__restrict__ up, const u64 *__restrict__ dn, u64 *__restrict__ keys, u32 *__restrict__ vals, long long n, int norb) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) { keys[i] = pack_key(up[i], dn[i], norb); vals[i] = (u32)i; }
+}
+
+// ============================================================================ SpMV
+// Symmetric matrix kept as FULL CSR (int32 columns) so that every row is owned by one
+// wavefront and no atomics are needed: 12 B per stored entry + 8 B gathered x.
+struct sqmc_spmv_plan { long long n, nnz_full; int *d_ptr, *d_col; double *d_val, *d_x, *d_y; hipStream_t st; };
+#define SPMV_ROWS_PER_BLOCK 4
+__global__ void __launch_bounds__(64 * SPMV_ROWS_PER_BLOCK) k_spmv_wave(const int *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val,
+                                                                        const double *__restrict__ x, double *__restrict__ y, long long n) {
+  const long long row = (long long)blockIdx.x * SPMV_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const int b = ptr[row], e = ptr[row + 1];
+  double s = 0.0;
+  for (int k = b + lane; k < e; k += 64) s += val[k] * x[col[k]];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) y[row] = s;
+}
+
+static void expand_full_csr(long long n, const int64_t *rc, const int64_t *idx, const double *val,
+                            std::vector<int> &ptr, std::vector<int> &col, std::vector<double> &v) {
+  std::vector<long long> cnt(n + 1, 0);
+  long long k = 0;
+  for (long long i = 0; i < n; i++) for (long long j = 0; j < rc[i]; j++, k++) { long long m = idx[k] - 1; cnt[i]++; if (m != i) cnt[m]++; }
+  ptr.assign(n + 1, 0);
+  for (long long i = 0; i < n; i++) ptr[i + 1] = ptr[i] + (int)cnt[i];
+  col.resize(ptr[n]); v.resize(ptr[n]);
+  std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+  k = 0;
+  for (long long i = 0; i < n; i++) for (long long j = 0; j < rc[i]; j++, k++) {   // k ascending == reference accumulation order
+    long long m = idx[k] - 1;
+    col[fill[i]] = (int)m; v[fill[i]++] = val[k];
+    if (m != i) { col[fill[m]] = (int)i; v[fill[m]++] = val[k]; }
+  }
+}
+
+// ================================================================================ ABI
+extern "C" {
+
+const char *sqmc_gpu_last_error(void) { return g_err.c_str(); }
+void sqmc_gpu_free(void *p) { free(p); }
+
+int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out) {
+  if (!cfg || !out) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  if (cfg->norb < 1 || cfg->norb > SQ_MAXORB) return fail(SQMC_ERR_UNSUPPORTED, "norb must be in 1..64 (one 64-bit word per spin)");
+  if (cfg->n_group < 1 || cfg->n_group > SQ_MAXSYM) return fail(SQMC_ERR_UNSUPPORTED, "point group order must be <= 8");
+  if (2 * cfg->norb > 64) return fail(SQMC_ERR_UNSUPPORTED, "2*norb > 64: two-word sort keys are a later round");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SQMC_ERR_HIP, "no HIP device: libsqmc_gpu has no CPU fallback");
+  sqmc_gpu_ctx *c = new sqmc_gpu_ctx();
+  memset((void *)c, 0, sizeof(*c));
+  HIPCHK(hipStreamCreate(&c->st));
+  ChemTab &t = c->htab;
+  t.norb = cfg->norb; t.nup = cfg->nup; t.ndn = cfg->ndn; t.ncore = cfg->n_core_orb; t.nelec = cfg->nup + cfg->ndn;
+  t.time_sym = cfg->time_sym; t.z = cfg->z; t.ngroup = cfg->n_group;
+  t.orb_mask = (cfg->norb >= 64) ? ~0ull : ((1ull << cfg->norb) - 1ull);
+  for (int i = 1; i <= cfg->n_group; i++) for (int j = 1; j <= cfg->n_group; j++) t.prod[i][j] = (unsigned char)cfg->product_table[i * 9 + j];
+  for (int i = 1; i <= cfg->norb; i++) {
+    int s = cfg->orbital_symmetries[i];
+    if (s < 1 || s > cfg->n_group) { delete c; return fail(SQMC_ERR_BAD_ARG, "orbital symmetry out of range"); }
+    t.orbsym[i] = (unsigned char)s; t.sym_mask[s] |= 1ull << (i - 1);
+  }
+  const int n2 = cfg->norb + 2;
+  for (int i = 1; i <= cfg->norb + 1; i++) for (int j = 1; j <= cfg->norb + 1; j++) t.c2[i][j] = (unsigned short)cfg->combine_2[i * n2 + j];
+  {
+    int a = t.c2[cfg->norb + 1][cfg->norb + 1]; long long ix = ((long long)a * (a - 1)) / 2 + a;
+    if (ix > cfg->n_integrals) { delete c; return fail(SQMC_ERR_BAD_ARG, "integral table shorter than integral_index(norb+1,...)"); }
+    t.nuclear = cfg->integrals[ix];
+  }
+  HIPCHK(hipMalloc(&c->d_tab, sizeof(ChemTab)));
+  HIPCHK(hipMemcpy(c->d_tab, &t, sizeof(ChemTab), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&c->d_ints, (cfg->n_integrals + 1) * sizeof(double)));
+  HIPCHK(hipMemcpy(c->d_ints, cfg->integrals, (cfg->n_integrals + 1) * sizeof(double), hipMemcpyHostToDevice));
+  c->dev.tab = c->d_tab; c->dev.integrals = c->d_ints; c->dev.max_double = 0.0;
+  c->key_bits = 2 * cfg->norb;
+  c->rng_mode = cfg->rng_mode;
+  u64 s48 = ((u64)cfg->irand_seed[0] << 36) | ((u64)cfg->irand_seed[1] << 24) | ((u64)cfg->irand_seed[2] << 12) | (u64)(2 * (cfg->irand_seed[3] / 2) + 1);
+  c->seed64 = s48; c->step_no = 0;
+  c->mwalk = cfg->mwalk > 0 ? cfg->mwalk : 0;
+  HIPCHK(hipMalloc(&c->d_sc, sizeof(DevScalars)));
+  HIPCHK(hipMemset(c->d_sc, 0, sizeof(DevScalars)));
+  HIPCHK(hipHostMalloc(&c->h_sc, sizeof(DevScalars)));
+  memset(c->h_sc, 0, sizeof(DevScalars));
+  c->h_sc->lcg = s48;
+  HIPCHK(hipMemcpy(&c->d_sc->lcg, &s48, 8, hipMemcpyHostToDevice));
+  if (c->mwalk > 0) {
+    const long long M = c->mwalk;
+    if (M >= (1ll << 31)) { delete c; return fail(SQMC_ERR_UNSUPPORTED, "MWALK must be < 2^31"); }
+    if (alloc_walk(c->w, M) || alloc_walk(c->m, M)) return SQMC_ERR_HIP;
+    HIPCHK(hipMalloc(&c->d_nchild, (M + 1) * 8)); HIPCHK(hipMalloc(&c->d_child_off, (M + 1) * 8));
+    HIPCHK(hipMalloc(&c->d_wchild, M * 8)); HIPCHK(hipMalloc(&c->d_child_state, M * 8));
+    HIPCHK(hipMalloc(&c->d_keys, M * 8)); HIPCHK(hipMalloc(&c->d_keys_alt, M * 8));
+    HIPCHK(hipMalloc(&c->d_vals, M * 4)); HIPCHK(hipMalloc(&c->d_vals_alt, M * 4));
+    long long ntiles = (M + RS_TILE - 1) / RS_TILE;
+    HIPCHK(hipMalloc(&c->d_hist, ntiles * RS_RADIX * 4)); HIPCHK(hipMalloc(&c->d_rowtot, RS_RADIX * 4));
+    HIPCHK(hipMalloc(&c->d_flags, M * 8)); HIPCHK(hipMalloc(&c->d_pos, M * 8));
+    HIPCHK(hipMalloc(&c->d_flags2, M * 8)); HIPCHK(hipMalloc(&c->d_pos2, M * 8));
+    c->cap_tiles = (M + SCAN_TILE - 1) / SCAN_TILE + 1;
+    HIPCHK(hipMalloc(&c->d_tile_sums, c->cap_tiles * 8));
+    c->n_partial_blocks = nblk(M);
+    HIPCHK(hipMalloc(&c->d_partials, ((long long)c->n_partial_blocks * NSTAT + 64) * 8));
+  }
+  for (int i = 0; i <= NTIMERS; i++) HIPCHK(hipEventCreate(&c->ev[i]));
+  *out = c;
+  return SQMC_OK;
+}
+
+int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
+  if (!c) return SQMC_OK;
+  hipStreamSynchronize(c->st);
+  if (c->mwalk > 0) {
+    free_walk(c->w); free_walk(c->m);
+    hipFree(c->d_nchild); hipFree(c->d_child_off); hipFree(c->d_wchild); hipFree(c->d_child_state);
+    hipFree(c->d_keys); hipFree(c->d_keys_alt); hipFree(c->d_vals); hipFree(c->d_vals_alt); hipFree(c->d_hist); hipFree(c->d_rowtot);
+    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_tile_sums); hipFree(c->d_partials);
+  }
+  hipFree(c->d_tab); hipFree(c->d_ints); hipFree(c->d_hb_r); hipFree(c->d_hb_s); hipFree(c->d_hb_absH); hipFree(c->d_pq_ind); hipFree(c->d_pq_count);
+  hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x);
+  hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den);
+  hipFree(c->d_sc); hipHostFree(c->h_sc);
+  for (int i = 0; i <= NTIMERS; i++) hipEventDestroy(c->ev[i]);
+  hipStreamDestroy(c->st);
+  delete c;
+  return SQMC_OK;
+}
+
+int sqmc_gpu_set_hb_tables(sqmc_gpu_ctx *c, int64_t n_hb, const int32_t *r, const int32_t *s, const double *a, int32_t n_pq,
+                           const int64_t *pq_ind, const int32_t *pq_count, double max_double) {
+  if (!c) return fail(SQMC_ERR_BAD_ARG, "null ctx");
+  HIPCHK(hipMalloc(&c->d_hb_r, (n_hb + 1) * 4)); HIPCHK(hipMalloc(&c->d_hb_s, (n_hb + 1) * 4)); HIPCHK(hipMalloc(&c->d_hb_absH, (n_hb + 1) * 8));
+  HIPCHK(hipMalloc(&c->d_pq_ind, (n_pq + 1) * 8)); HIPCHK(hipMalloc(&c->d_pq_count, (n_pq + 1) * 4));
+  HIPCHK(hipMemcpy(c->d_hb_r, r, n_hb * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->d_hb_s, s, n_hb * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_hb_absH, a, n_hb * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_pq_ind, pq_ind, (n_pq + 1) * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->d_pq_count, pq_count, (n_pq + 1) * 4, hipMemcpyHostToDevice));
+  c->dev.hb_r = c->d_hb_r; c->dev.hb_s = c->d_hb_s; c->dev.hb_absH = c->d_hb_absH; c->dev.pq_ind = c->d_pq_ind; c->dev.pq_count = c->d_pq_count;
+  c->dev.max_double = max_double;
+  return SQMC_OK;
+}
+
+int sqmc_gpu_set_projector(sqmc_gpu_ctx *c, int64_t n_imp, int64_t nnz, const int64_t *rc, const int64_t *idx, const double *val) {
+  if (!c) return fail(SQMC_ERR_BAD_ARG, "null ctx");
+  long long chk = 0; for (long long i = 0; i < n_imp; i++) chk += rc[i];
+  if (chk != nnz) return fail(SQMC_ERR_BAD_ARG, "sum(row_counts) != nnz");
+  for (long long k = 0; k < nnz; k++) if (idx[k] < 1 || idx[k] > n_imp) return fail(SQMC_ERR_BAD_ARG, "column index out of range");
+  std::vector<int> ptr, col; std::vector<double> v;
+  expand_full_csr(n_imp, rc, idx, val, ptr, col, v);
+  hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x);
+  c->n_imp = n_imp; c->prj_nnz = (long long)col.size();
+  HIPCHK(hipMalloc(&c->d_prj_ptr, (n_imp + 1) * 4)); HIPCHK(hipMalloc(&c->d_prj_col, (col.size() + 1) * 4)); HIPCHK(hipMalloc(&c->d_prj_val, (v.size() + 1) * 8));
+  HIPCHK(hipMalloc(&c->d_loc_imp, (n_imp + 1) * 4)); HIPCHK(hipMalloc(&c->d_prj_x, (n_imp + 1) * 8));
+  HIPCHK(hipMemcpy(c->d_prj_ptr, ptr.data(), (n_imp + 1) * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_prj_col, col.data(), col.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_prj_val, v.data(), v.size() * 8, hipMemcpyHostToDevice));
+  return SQMC_OK;
+}
+int sqmc_gpu_scale_projector(sqmc_gpu_ctx *c, double ratio) {
+  if (!c || !c->d_prj_val) return fail(SQMC_ERR_BAD_ARG, "no projector");
+  hipLaunchKernelGGL(k_scale, dim3(nblk(c->prj_nnz)), dim3(TPB), 0, c->st, c->d_prj_val, c->prj_nnz, ratio);
+  HIPCHK(hipGetLastError());
+  return SQMC_OK;
+}
+
+int sqmc_gpu_set_ct_table(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, const uint64_t *dn, const double *num, const double *den) {
+  if (!c) return fail(SQMC_ERR_BAD_ARG, "null ctx");
+  for (long long i = 1; i < n; i++)
+    if (!(up[i - 1] < up[i] || (up[i - 1] == up[i] && dn[i - 1] < dn[i]))) return fail(SQMC_ERR_BAD_ARG, "C(T) list must be strictly sorted by (up,dn)");
+  hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den);
+  c->n_ct = n;
+  HIPCHK(hipMalloc(&c->d_ct_up, (n + 1) * 8)); HIPCHK(hipMalloc(&c->d_ct_dn, (n + 1) * 8)); HIPCHK(hipMalloc(&c->d_ct_num, (n + 1) * 8)); HIPCHK(hipMalloc(&c->d_ct_den, (n + 1) * 8));
+  HIPCHK(hipMemcpy(c->d_ct_up, up, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->d_ct_dn, dn, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_ct_num, num, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->d_ct_den, den, n * 8, hipMemcpyHostToDevice));
+  return SQMC_OK;
+}
+
+int sqmc_gpu_upload_walkers(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, const uint64_t *dn, const double *wt, const int8_t *impd,
+                            const int8_t *init, const int8_t *psign, const double *me, const double *en, const double *ed) {
+  if (!c || c->mwalk <= 0) return fail(SQMC_ERR_BAD_ARG, "context has no walker arrays (mwalk=0)");
+  if (n > c->mwalk) return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
+  const u64 lim = c->htab.orb_mask;
+  for (long long i = 0; i < n; i++) {
+    if ((up[i] & ~lim) || (dn[i] & ~lim)) return fail(SQMC_ERR_BAD_ARG, "determinant has bits beyond norb");
+    if (i && !(up[i - 1] < up[i] || (up[i - 1] == up[i] && dn[i - 1] < dn[i]))) return fail(SQMC_ERR_BAD_ARG, "walkers must be sorted by (up,dn) and unique");
+  }
+  HIPCHK(hipMemcpy(c->w.up, up, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.dn, dn, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->w.wt, wt, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.impd, impd, n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->w.init, init, n, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.psign, psign, n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->w.me, me, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.en, en, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->w.ed, ed, n * 8, hipMemcpyHostToDevice));
+  c->nwalk = n;
+  if (c->n_imp > 0) {        // my_locations_of_imp_dets, do_walk.f90:2188-2212
+    std::vector<int> loc; loc.reserve(c->n_imp);
+    for (long long i = 0; i < n; i++) if (impd[i] == 0) loc.push_back((int)i);
+    if ((long long)loc.size() != c->n_imp) return fail(SQMC_ERR_IMP_BROKEN, "number of imp_distance==0 walkers != n_imp");
+    HIPCHK(hipMemcpy(c->d_loc_imp, loc.data(), loc.size() * 4, hipMemcpyHostToDevice));
+  }
+  return SQMC_OK;
+}
+int sqmc_gpu_num_walkers(sqmc_gpu_ctx *c, int64_t *n) { if (!c || !n) return SQMC_ERR_BAD_ARG; *n = c->nwalk; return SQMC_OK; }
+int sqmc_gpu_download_walkers(sqmc_gpu_ctx *c, int64_t cap, int64_t *n, uint64_t *up, uint64_t *dn, double *wt, int8_t *impd, int8_t *init,
+                              double *me, double *en, double *ed) {
+  if (!c || !n) return fail(SQMC_ERR_BAD_ARG, "null");
+  HIPCHK(hipStreamSynchronize(c->st));
+  *n = c->nwalk;
+  if (cap < c->nwalk) return fail(SQMC_ERR_BAD_ARG, "download buffer too small");
+  const long long k = c->nwalk;
+  if (up) HIPCHK(hipMemcpy(up, c->w.up, k * 8, hipMemcpyDeviceToHost));
+  if (dn) HIPCHK(hipMemcpy(dn, c->w.dn, k * 8, hipMemcpyDeviceToHost));
+  if (wt) HIPCHK(hipMemcpy(wt, c->w.wt, k * 8, hipMemcpyDeviceToHost));
+  if (impd) HIPCHK(hipMemcpy(impd, c->w.impd, k, hipMemcpyDeviceToHost));
+  if (init) HIPCHK(hipMemcpy(init, c->w.init, k, hipMemcpyDeviceToHost));
+  if (me) HIPCHK(hipMemcpy(me, c->w.me, k * 8, hipMemcpyDeviceToHost));
+  if (en) HIPCHK(hipMemcpy(en, c->w.en, k * 8, hipMemcpyDeviceToHost));
+  if (ed) HIPCHK(hipMemcpy(ed, c->w.ed, k * 8, hipMemcpyDeviceToHost));
+  return SQMC_OK;
+}
+
+int sqmc_gpu_get_rng(sqmc_gpu_ctx *c, int32_t seed[4]) {
+  if (!c) return SQMC_ERR_BAD_ARG;
+  u64 x; HIPCHK(hipStreamSynchronize(c->st)); HIPCHK(hipMemcpy(&x, &c->d_sc->lcg, 8, hipMemcpyDeviceToHost));
+  seed[0] = (int)((x >> 36) & 4095); seed[1] = (int)((x >> 24) & 4095); seed[2] = (int)((x >> 12) & 4095); seed[3] = (int)(x & 4095);
+  return SQMC_OK;
+}
+int sqmc_gpu_set_rng(sqmc_gpu_ctx *c, const int32_t seed[4]) {
+  if (!c) return SQMC_ERR_BAD_ARG;
+  u64 x = ((u64)seed[0] << 36) | ((u64)seed[1] << 24) | ((u64)seed[2] << 12) | (u64)(2 * (seed[3] / 2) + 1);
+  HIPCHK(hipStreamSynchronize(c->st)); HIPCHK(hipMemcpy(&c->d_sc->lcg, &x, 8, hipMemcpyHostToDevice));
+  c->seed64 = x;
+  return SQMC_OK;
+}
+
+int sqmc_gpu_set_timing(sqmc_gpu_ctx *c, int on) { if (!c) return SQMC_ERR_BAD_ARG; c->timing = on; return SQMC_OK; }
+int sqmc_gpu_get_timing(sqmc_gpu_ctx *c, int32_t *n, const char **names, float *ms) {
+  if (!c) return SQMC_ERR_BAD_ARG;
+  *n = c->nt;
+  for (int i = 0; i < c->nt; i++) { names[i] = c->tname[i]; ms[i] = c->tms[i]; }
+  return SQMC_OK;
+}
+#define TMARK(NAME) do { if (c->timing && c->nt < NTIMERS) { c->tname[c->nt] = NAME; hipEventRecord(c->ev[++c->nt], st); } } while (0)
+
+int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
+  if (!c || !sp || !out) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  if (c->mwalk <= 0 || c->nwalk <= 0) return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0");
+  if (c->htab.time_sym) return fail(SQMC_ERR_UNSUPPORTED, "walk kernels implement time_sym=.false. only this round");
+  if (sp->semistochastic && (c->n_imp <= 0 || !c->d_prj_ptr)) return fail(SQMC_ERR_BAD_ARG, "semistochastic step without projector");
+  if (!c->d_ct_up) return fail(SQMC_ERR_BAD_ARG, "C(T) table not set");
+  if (!sp->semistochastic) return fail(SQMC_ERR_UNSUPPORTED, "join_walker2 (non-semistochastic walk) is not implemented this round");
+  hipStream_t st = c->st;
+  StepP p; p.tau = sp->tau; p.e_trial = sp->e_trial; p.rfi = sp->reweight_factor_inv; p.r_init = sp->r_initiator; p.min_wt = sp->min_wt;
+  p.cutoff = sp->always_spawn_cutoff_wt; p.ipow = sp->initiator_power; p.imind = sp->initiator_min_distance; p.cti = sp->c_t_initiator;
+  p.semi = sp->semistochastic; p.reached = sp->reached_w_abs_gen;
+  const long long n0 = c->nwalk, M = c->mwalk;
+  const int mode = c->rng_mode; const u64 seed = c->seed64, step = c->step_no;
+  ScanWork sw; sw.tile_sums = c->d_tile_sums; sw.cap_tiles = c->cap_tiles;
+  c->nt = 0;
+  if (c->timing) hipEventRecord(c->ev[0], st);
+  HIPCHK(hipMemsetAsync(&c->d_sc->n_children, 0, 4 * sizeof(u64) + 2 * sizeof(int), st));
+  // ---- gate / child offsets
+  if (mode == SQMC_RNG_REPLAY) {
+    hipLaunchKernelGGL(k_replay_prepass, dim3(1), dim3(64), 0, st, c->d_tab, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_child_off,
+                       c->d_child_state, n0, M - n0, p, c->d_sc);
+  } else {
+    hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->w.wt, c->d_nchild, c->d_wchild, n0, p, seed, step);
+    device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw, st);
+  }
+  TMARK("gate+scan");
+  hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.impd, c->w.me, n0, p, c->d_sc);
+  TMARK("diag");
+  HIPCHK(hipMemcpyAsync(&c->h_sc->n_children, &c->d_sc->n_children, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const long long nch = (long long)c->h_sc->n_children;
+  if (n0 + nch > M) return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
+  const long long nall = n0 + nch;
+  // ---- spawn
+  if (nch > 0)
+    hipLaunchKernelGGL(k_spawn, dim3(nblk(nch)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                       n0, nch, p, mode, seed, step, c->d_sc);
+  hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0, c->htab.norb);
+  TMARK("spawn");
+  // ---- deterministic projection
+  if (p.semi) {
+    hipLaunchKernelGGL(k_prj_gather, dim3(nblk(c->n_imp)), dim3(TPB), 0, st, c->w.wt, c->d_loc_imp, c->d_prj_x, c->n_imp);
+    hipLaunchKernelGGL(k_prj_apply, dim3(nblk(c->n_imp)), dim3(TPB), 0, st, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, c->d_prj_x, c->d_loc_imp, c->w.wt,
+                       c->n_imp, p.e_trial, p.tau);
+  }
+  TMARK("project");
+  // ---- sort
+  SortWork so; so.k_alt = c->d_keys_alt; so.v_alt = c->d_vals_alt; so.hist = c->d_hist; so.rowtot = c->d_rowtot; so.cap = M;
+  u64 *skey = c->d_keys; u32 *perm = c->d_vals;
+  device_radix_sort(skey, perm, nall, c->key_bits, so, st);
+  if (skey != c->d_keys) { c->d_keys_alt = c->d_keys; c->d_vals_alt = c->d_vals; c->d_keys = skey; c->d_vals = perm; }
+  TMARK("sort");
+  // ---- |w| before merge
+  hipLaunchKernelGGL(k_wabs, dim3(64), dim3(TPB), 0, st, c->w.wt, nall, c->d_partials);
+  // ---- merge, round, compact
+  hipLaunchKernelGGL(k_merge, dim3(nblk(nall)), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, nall, p, c->d_sc);
+  device_excl_scan_u64(c->d_flags, c->d_pos, nall, &c->d_sc->tot1, sw, st);
+  TMARK("merge");
+  hipLaunchKernelGGL(k_round, dim3(nblk(nall)), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, c->d_flags2, nall, p, mode, seed, step, c->d_sc);
+  device_excl_scan_u64(c->d_flags2, c->d_pos2, nall, &c->d_sc->tot2, sw, st);
+  TMARK("round");
+  const int nb = nblk(nall);
+  hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, st, c->m, c->w, c->d_flags2, c->d_pos2, c->d_loc_imp, c->d_ct_up, c->d_ct_dn, c->d_ct_num, c->d_ct_den,
+                     c->n_ct, nall, p, c->d_partials + 64);
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, c->d_partials + 64, nb, c->d_partials, nall, mode, c->d_sc);
+  TMARK("estimate");
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (c->timing) for (int i = 0; i < c->nt; i++) hipEventElapsedTime(&c->tms[i], c->ev[i], c->ev[i + 1]);
+  c->step_no++;
+  if (c->h_sc->err) return fail(c->h_sc->err, "diagonal_factor<0 after target population has been reached");
+  const long long nfinal = (long long)(c->h_sc->tot2 & 0xFFFFFFFFull), nimp = (long long)(c->h_sc->tot2 >> 32);
+  c->nwalk = nfinal;
+  for (int i = 0; i < 16; i++) out[i] = c->h_sc->stats[i];
+  if (nfinal == 0) return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0");
+  if (p.semi && nimp != c->n_imp) return fail(SQMC_ERR_IMP_BROKEN, "locations of my imp broken");
+  return SQMC_OK;
+}
+
+// ---------------------------------------------------------------- batch doors
+int sqmc_gpu_hamiltonian_batch(sqmc_gpu_ctx *c, int64_t n, const uint64_t *iu, const uint64_t *id, const uint64_t *ju, const uint64_t *jd, double *h) {
+  if (!c) return fail(SQMC_ERR_BAD_ARG, "null ctx");
+  if (n <= 0) return SQMC_OK;
+  u64 *d[4]; double *dh;
+  const uint64_t *src[4] = {iu, id, ju, jd};
+  for (int k = 0; k < 4; k++) { HIPCHK(hipMalloc(&d[k], n * 8)); HIPCHK(hipMemcpy(d[k], src[k], n * 8, hipMemcpyHostToDevice)); }
+  HIPCHK(hipMalloc(&dh, n * 8));
+  hipLaunchKernelGGL(k_ham_batch, dim3(nblk(n)), dim3(TPB), 0, c->st, c->dev, d[0], d[1], d[2], d[3], dh, (long long)n);
+  HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->st));
+  HIPCHK(hipMemcpy(h, dh, n * 8, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 4; k++) hipFree(d[k]);
+  hipFree(dh);
+  return SQMC_OK;
+}
+
+int sqmc_gpu_propose_batch(sqmc_gpu_ctx *c, int64_t n, double tau, const uint64_t *up, const uint64_t *dn, const int32_t *seeds,
+                           uint64_t *ju, uint64_t *jd, double *wj, int32_t *seeds_after) {
+  if (!c) return fail(SQMC_ERR_BAD_ARG, "null ctx");
+  if (c->htab.time_sym) return fail(SQMC_ERR_UNSUPPORTED, "proposal kernel implements time_sym=.false. only");
+  if (n <= 0) return SQMC_OK;
+  std::vector<u64> s(n);
+  for (long long i = 0; i < n; i++) s[i] = ((u64)seeds[4 * i] << 36) | ((u64)seeds[4 * i + 1] << 24) | ((u64)seeds[4 * i + 2] << 12) | (u64)seeds[4 * i + 3];
+  u64 *du, *dd, *ds, *dju, *djd, *dso; double *dw;
+  HIPCHK(hipMalloc(&du, n * 8)); HIPCHK(hipMalloc(&dd, n * 8)); HIPCHK(hipMalloc(&ds, n * 8)); HIPCHK(hipMalloc(&dju, n * 8));
+  HIPCHK(hipMalloc(&djd, n * 8)); HIPCHK(hipMalloc(&dso, n * 8)); HIPCHK(hipMalloc(&dw, n * 8));
+  HIPCHK(hipMemcpy(du, up, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dd, dn, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ds, s.data(), n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_propose_batch, dim3(nblk(n)), dim3(TPB), 0, c->st, c->dev, du, dd, ds, dju, djd, dw, dso, (long long)n, tau);
+  HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->st));
+  HIPCHK(hipMemcpy(ju, dju, n * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(jd, djd, n * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(wj, dw, n * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(s.data(), dso, n * 8, hipMemcpyDeviceToHost));
+  for (long long i = 0; i < n; i++) { u64 x = s[i]; seeds_after[4 * i] = (int)((x >> 36) & 4095); seeds_after[4 * i + 1] = (int)((x >> 24) & 4095);
+    seeds_after[4 * i + 2] = (int)((x >> 12) & 4095); seeds_after[4 * i + 3] = (int)(x & 4095); }
+  hipFree(du); hipFree(dd); hipFree(ds); hipFree(dju); hipFree(djd); hipFree(dso); hipFree(dw);
+  return SQMC_OK;
+}
+
+int sqmc_gpu_hci_connections(sqmc_gpu_ctx *c, int64_t n_ref, const uint64_t *ref_up, const uint64_t *ref_dn, const double *coeffs, double eps,
+                             int diag_mode, int64_t *out_n, uint64_t **out_up, uint64_t **out_dn, double **out_num, double **out_den) {
+  if (!c || !out_n) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  if (!c->dev.hb_r) return fail(SQMC_ERR_BAD_ARG, "heat-bath tables not set (sqmc_gpu_set_hb_tables)");
+  *out_n = 0;
+  if (n_ref <= 0) return SQMC_OK;
+  hipStream_t st = c->st;
+  u64 *dru, *drd, *dcnt, *doff, *dtot, *dts; double *dco;
+  HIPCHK(hipMalloc(&dru, n_ref * 8)); HIPCHK(hipMalloc(&drd, n_ref * 8)); HIPCHK(hipMalloc(&dco, n_ref * 8));
+  HIPCHK(hipMalloc(&dcnt, n_ref * 8)); HIPCHK(hipMalloc(&doff, n_ref * 8)); HIPCHK(hipMalloc(&dtot, 8));
+  long long tiles = (n_ref + SCAN_TILE - 1) / SCAN_TILE + 1;
+  HIPCHK(hipMalloc(&dts, tiles * 8));
+  HIPCHK(hipMemcpy(dru, ref_up, n_ref * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(drd, ref_dn, n_ref * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dco, coeffs, n_ref * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_hci_gen, dim3(nblk(n_ref)), dim3(TPB), 0, st, c->dev, dru, drd, dco, eps, diag_mode, (long long)n_ref, 0, dcnt, doff,
+                     (u64 *)nullptr, (u64 *)nullptr, (double *)nullptr, (double *)nullptr);
+  ScanWork sw; sw.tile_sums = dts; sw.cap_tiles = tiles;
+  device_excl_scan_u64(dcnt, doff, n_ref, dtot, sw, st);
+  u64 total = 0;
+  HIPCHK(hipMemcpyAsync(&total, dtot, 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+  if (total >= (1ull << 31)) return fail(SQMC_ERR_UNSUPPORTED, "more than 2^31 connections in one call: batch the reference list");
+  const long long T = (long long)total;
+  u64 *du, *dd, *keys, *kalt, *flags, *pos, *ou, *od, *dts2, *dtot2; u32 *vals, *valt, *hist, *rowtot; double *dnum, *dden, *onum, *oden;
+  HIPCHK(hipMalloc(&du, T * 8)); HIPCHK(hipMalloc(&dd, T * 8)); HIPCHK(hipMalloc(&dnum, T * 8)); HIPCHK(hipMalloc(&dden, T * 8));
+  hipLaunchKernelGGL(k_hci_gen, dim3(nblk(n_ref)), dim3(TPB), 0, st, c->dev, dru, drd, dco, eps, diag_mode, (long long)n_ref, 1, dcnt, doff, du, dd, dnum, dden);
+  HIPCHK(hipMalloc(&keys, T * 8)); HIPCHK(hipMalloc(&kalt, T * 8)); HIPCHK(hipMalloc(&vals, T * 4)); HIPCHK(hipMalloc(&valt, T * 4));
+  long long ntiles = (T + RS_TILE - 1) / RS_TILE;
+  HIPCHK(hipMalloc(&hist, ntiles * RS_RADIX * 4)); HIPCHK(hipMalloc(&rowtot, RS_RADIX * 4));
+  hipLaunchKernelGGL(k_keys2, dim3(nblk(T)), dim3(TPB), 0, st, du, dd, keys, vals, T, c->htab.norb);
+  SortWork so; so.k_alt = kalt; so.v_alt = valt; so.hist = hist; so.rowtot = rowtot; so.cap = T;
+  u64 *skey = keys; u32 *perm = vals;
+  device_radix_sort(skey, perm, T, c->key_bits, so, st);
+  HIPCHK(hipMalloc(&flags, T * 8)); HIPCHK(hipMalloc(&pos, T * 8));
+  long long tiles2 = (T + SCAN_TILE - 1) / SCAN_TILE + 1;
+  HIPCHK(hipMalloc(&dts2, tiles2 * 8)); HIPCHK(hipMalloc(&dtot2, 8));
+  hipLaunchKernelGGL(k_hci_heads, dim3(nblk(T)), dim3(TPB), 0, st, skey, flags, T);
+  ScanWork sw2; sw2.tile_sums = dts2; sw2.cap_tiles = tiles2;
+  device_excl_scan_u64(flags, pos, T, dtot2, sw2, st);
+  u64 nuniq = 0;
+  HIPCHK(hipMemcpyAsync(&nuniq, dtot2, 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+  const long long U = (long long)nuniq;
+  HIPCHK(hipMalloc(&ou, U * 8)); HIPCHK(hipMalloc(&od, U * 8)); HIPCHK(hipMalloc(&onum, U * 8)); HIPCHK(hipMalloc(&oden, U * 8));
+  hipLaunchKernelGGL(k_hci_dedup, dim3(nblk(T)), dim3(TPB), 0, st, skey, perm, flags, pos, du, dd, dnum, dden, ou, od, onum, oden, T);
+  HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(st));
+  *out_n = U;
+  uint64_t *hu = (uint64_t *)malloc(U * 8 + 8), *hd = (uint64_t *)malloc(U * 8 + 8);
+  double *hn = (double *)malloc(U * 8 + 8), *hden = (double *)malloc(U * 8 + 8);
+  HIPCHK(hipMemcpy(hu, ou, U * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hd, od, U * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hn, onum, U * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hden, oden, U * 8, hipMemcpyDeviceToHost));
+  if (out_up) *out_up = hu; else free(hu);
+  if (out_dn) *out_dn = hd; else free(hd);
+  if (out_num) *out_num = hn; else free(hn);
+  if (out_den) *out_den = hden; else free(hden);
+  void *fr[] = {dru, drd, dco, dcnt, doff, dtot, dts, du, dd, dnum, dden, keys, kalt, vals, valt, hist, rowtot, flags, pos, dts2, dtot2, ou, od, onum, oden};
+  for (void *q : fr) hipFree(q);
+  return SQMC_OK;
+}
+
+// ----------------------------------------------------------------------- SpMV
+int sqmc_gpu_spmv_prepare(int64_t n, const int64_t *rc, const int64_t *idx, const double *val, sqmc_spmv_plan **plan) {
+  if (!rc || !idx || !val || !plan || n <= 0) return fail(SQMC_ERR_BAD_ARG, "bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SQMC_ERR_HIP, "no HIP device: libsqmc_gpu has no CPU fallback");
+  long long nnz = 0; for (long long i = 0; i < n; i++) nnz += rc[i];
+  for (long long k = 0; k < nnz; k++) if (idx[k] < 1 || idx[k] > n) return fail(SQMC_ERR_BAD_ARG, "column index out of range");
+  if (2 * nnz >= (1ll << 31)) return fail(SQMC_ERR_UNSUPPORTED, "more than 2^31 expanded nonzeros");
+  std::vector<int> ptr, col; std::vector<double> v;
+  expand_full_csr(n, rc, idx, val, ptr, col, v);
+  sqmc_spmv_plan *p = new sqmc_spmv_plan(); p->n = n; p->nnz_full = (long long)col.size();
+  HIPCHK(hipStreamCreate(&p->st));
+  HIPCHK(hipMalloc(&p->d_ptr, (n + 1) * 4)); HIPCHK(hipMalloc(&p->d_col, (col.size() + 1) * 4)); HIPCHK(hipMalloc(&p->d_val, (v.size() + 1) * 8));
+  HIPCHK(hipMalloc(&p->d_x, n * 8)); HIPCHK(hipMalloc(&p->d_y, n * 8));
+  HIPCHK(hipMemcpy(p->d_ptr, ptr.data(), (n + 1) * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(p->d_col, col.data(), col.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(p->d_val, v.data(), v.size() * 8, hipMemcpyHostToDevice));
+  *plan = p;
+  return SQMC_OK;
+}
+int sqmc_gpu_spmv_apply(sqmc_spmv_plan *p, const double *x, double *y, int on_device) {
+  if (!p || !x || !y) return fail(SQMC_ERR_BAD_ARG, "null");
+  const double *dx = x; double *dy = y;
+  if (!on_device) { HIPCHK(hipMemcpyAsync(p->d_x, x, p->n * 8, hipMemcpyHostToDevice, p->st)); dx = p->d_x; dy = p->d_y; }
+  hipLaunchKernelGGL(k_spmv_wave, dim3((unsigned)((p->n + SPMV_ROWS_PER_BLOCK - 1) / SPMV_ROWS_PER_BLOCK)), dim3(64 * SPMV_ROWS_PER_BLOCK), 0, p->st,
+                     p->d_ptr, p->d_col, p->d_val, dx, dy, p->n);
+  HIPCHK(hipGetLastError());
+  if (!on_device) { HIPCHK(hipMemcpyAsync(y, p->d_y, p->n * 8, hipMemcpyDeviceToHost, p->st)); }
+  HIPCHK(hipStreamSynchronize(p->st));
+  return SQMC_OK;
+}
+int sqmc_gpu_spmv_free(sqmc_spmv_plan *p) {
+  if (!p) return SQMC_OK;
+  hipFree(p->d_ptr); hipFree(p->d_col); hipFree(p->d_val); hipFree(p->d_x); hipFree(p->d_y); hipStreamDestroy(p->st); delete p;
+  return SQMC_OK;
+}
+int sqmc_gpu_spmv_sym_upper(int64_t n, const int64_t *rc, const int64_t *idx, const double *val, const double *x, double *y) {
+  sqmc_spmv_plan *p = nullptr;
+  int r = sqmc_gpu_spmv_prepare(n, rc, idx, val, &p);
+  if (r) return r;
+  r = sqmc_gpu_spmv_apply(p, x, y, 0);
+  sqmc_gpu_spmv_free(p);
+  return r;
+}
+
+}  // extern "C"

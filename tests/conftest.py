@@ -1,0 +1,44 @@
+import os
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+FCIDUMP = os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long CPU validation, excluded from the default CPU run")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def c2_walk(oracle):
+    """C2 cc-pVDZ r=1.24253, walk deck conventions (time_sym=f, HF = first 4 orbitals)."""
+    return oracle.ChemSystem(FCIDUMP, 8, 4, "d2h", time_sym=False, hf_mode=0)
+
+
+@pytest.fixture(scope="session")
+def c2_hci(oracle):
+    """Same molecule with the shipped HCI deck conventions (time_sym=t, z=1, hf_symmetry=1)."""
+    return oracle.ChemSystem(FCIDUMP, 8, 4, "d2h", time_sym=True, z=1, hf_mode=1, hf_symmetry=1)
+
+
+@pytest.fixture(scope="session")
+def c2_setup(oracle, c2_walk):
+    return oracle.setup_walk(c2_walk, 100, 1000, 0.1)
+
+
+def gpu_ctx_from_oracle(sysm, **kw):
+    """Hands the oracle's tables to the HIP library exactly as a Fortran host would."""
+    import sqmc_amd
+    return sqmc_amd.GpuChem(sysm.norb, sysm.nup, sysm.ndn, sysm.orbsym(), sysm.prod().reshape(-1), sysm.combine_2().reshape(-1),
+                            sysm.integrals(), n_group=sysm.s.n_group, time_sym=bool(sysm.s.time_sym), z=sysm.s.z, **kw)

@@ -1,0 +1,211 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical
+inputs.  Integer/bit results must be identical; fp64 results are compared bit for bit where
+the GPU keeps the reference's operation order (matrix elements, spawn weights, deterministic
+projection) and to 1e-12 relative where it uses tree reductions (estimator sums)."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from conftest import gpu_ctx_from_oracle
+
+pytestmark = pytest.mark.gpu
+SEED = [1346, 5634, 6635, 4361]
+
+
+def _random_dets(rng, norb, nel, n):
+    out = np.zeros(n, np.uint64)
+    for i in range(n):
+        occ = rng.choice(norb, nel, replace=False)
+        out[i] = np.uint64(sum(1 << int(o) for o in occ))
+    return out
+
+
+def _excite(rng, det, norb, k):
+    occ = [o for o in range(norb) if (int(det) >> o) & 1]
+    emp = [o for o in range(norb) if not (int(det) >> o) & 1]
+    a = rng.choice(occ, k, replace=False); b = rng.choice(emp, k, replace=False)
+    d = int(det)
+    for x in a: d &= ~(1 << int(x))
+    for x in b: d |= (1 << int(x))
+    return np.uint64(d)
+
+
+@pytest.mark.parametrize("which", ["walk", "hci"])
+def test_hamiltonian_batch_bit_exact(oracle, c2_walk, c2_hci, which):
+    sysm = c2_walk if which == "walk" else c2_hci
+    g = gpu_ctx_from_oracle(sysm)
+    rng = np.random.default_rng(7)
+    n = 4000
+    iu, id_ = _random_dets(rng, 26, 4, n), _random_dets(rng, 26, 4, n)
+    ju, jd = iu.copy(), id_.copy()
+    for i in range(n):
+        m = i % 6
+        if m == 1: ju[i] = _excite(rng, iu[i], 26, 1)
+        elif m == 2: jd[i] = _excite(rng, id_[i], 26, 1)
+        elif m == 3: ju[i] = _excite(rng, iu[i], 26, 2)
+        elif m == 4: ju[i] = _excite(rng, iu[i], 26, 1); jd[i] = _excite(rng, id_[i], 26, 1)
+        elif m == 5: jd[i] = _excite(rng, id_[i], 26, 2)
+    if which == "hci":   # time-reversal representatives, incl. up == dn
+        for i in range(0, n, 7): id_[i] = iu[i]
+        sw = iu > id_; iu[sw], id_[sw] = id_[sw], iu[sw]
+        sw = ju > jd; ju[sw], jd[sw] = jd[sw], ju[sw]
+    h_gpu = g.hamiltonian_batch(iu, id_, ju, jd)
+    h_cpu = np.array([sysm.ham(int(a), int(b), int(c), int(d)) for a, b, c, d in zip(iu, id_, ju, jd)])
+    g.close()
+    assert np.count_nonzero(h_cpu) > n // 3
+    assert np.array_equal(h_gpu, h_cpu)          # bit for bit
+
+
+def test_proposal_kernel_bit_exact(oracle, c2_walk):
+    """10^4 off_diagonal_move_chem calls from fixed rannyu states: det_j, weight_j and the RNG
+    state after the call are identical to the oracle's."""
+    L = oracle.lib()
+    g = gpu_ctx_from_oracle(c2_walk)
+    rng = np.random.default_rng(11)
+    n = 10000
+    up, dn = _random_dets(rng, 26, 4, n), _random_dets(rng, 26, 4, n)
+    seeds = rng.integers(0, 4096, size=(n, 4)).astype(np.int32)
+    seeds[:, 3] |= 1
+    tau = 0.0053
+    ju, jd, wj, sa = g.propose_batch(tau, up, dn, seeds)
+    g.close()
+    r = oracle.Rng()
+    a, b, w, nd = C.c_uint64(), C.c_uint64(), C.c_double(), C.c_int()
+    nz = 0
+    for i in range(n):
+        L.orc_setrn(C.byref(r), (C.c_int * 4)(*seeds[i]))
+        L.orc_off_diagonal_move_chem(c2_walk.h, C.byref(r), tau, int(up[i]), int(dn[i]), C.byref(a), C.byref(b), C.byref(w), C.byref(nd))
+        assert w.value == wj[i], (i, w.value, wj[i])
+        if w.value != 0.0:
+            nz += 1
+            assert (a.value, b.value) == (int(ju[i]), int(jd[i]))
+        assert [r.l[k] for k in range(4)] == list(sa[i])
+    assert nz > n // 2
+
+
+def test_spmv_matches_oracle(oracle, c2_setup):
+    import sqmc_amd
+    s = c2_setup
+    x = np.random.default_rng(3).standard_normal(len(s.prj_counts))
+    y_cpu = oracle.spmv_sym_upper(s.prj_counts, s.prj_indices, s.prj_values, x)
+    plan = sqmc_amd.SpmvPlan(s.prj_counts, s.prj_indices, s.prj_values)
+    y_gpu = plan.apply(x)
+    plan.close()
+    assert np.allclose(y_gpu, y_cpu, rtol=1e-12, atol=1e-14)
+    # linearity (size-independent property)
+    plan = sqmc_amd.SpmvPlan(s.prj_counts, s.prj_indices, s.prj_values)
+    x2 = np.random.default_rng(4).standard_normal(len(x))
+    assert np.allclose(plan.apply(2 * x - 3 * x2), 2 * plan.apply(x) - 3 * plan.apply(x2), rtol=1e-11, atol=1e-13)
+    plan.close()
+
+
+@pytest.mark.parametrize("which,eps", [("hci", 2e-4), ("hci", 5e-3), ("walk", 1e-3)])
+def test_hci_connections_match_oracle(oracle, c2_walk, c2_hci, which, eps):
+    sysm = c2_walk if which == "walk" else c2_hci
+    g = gpu_ctx_from_oracle(sysm)
+    r, s_, a, pi, pc = sysm.hb_tables()
+    g.set_hb_tables(r, s_, a, pi, pc, sysm.s.max_double)
+    # reference list: HF + some of its strongest connections, with mixed-size coefficients
+    cu, cd, el = sysm.important_connected(sysm.hf_up, sysm.hf_dn, 1e-2)
+    keys = sorted(set(zip(cu.tolist(), cd.tolist())))[:40]
+    ref_up = np.array([k[0] for k in keys], np.uint64); ref_dn = np.array([k[1] for k in keys], np.uint64)
+    coef = np.linspace(1.0, 0.02, len(keys)) * np.where(np.arange(len(keys)) % 3 == 0, -1, 1)
+    gu, gd, gnum, gden = g.hci_connections(ref_up, ref_dn, coef, eps)
+    g.close()
+    acc, den = {}, {}
+    for u, d, c in zip(ref_up.tolist(), ref_dn.tolist(), coef.tolist()):
+        xu, xd, xe = sysm.important_connected(u, d, eps / abs(c))
+        for k, (p, q, h) in enumerate(zip(xu.tolist(), xd.tolist(), xe.tolist())):
+            acc[(p, q)] = acc.get((p, q), 0.0) + h * c
+            den[(p, q)] = den.get((p, q), 0.0) + (c if k == 0 else 0.0)
+    ks = sorted(acc)
+    assert len(ks) == len(gu)
+    assert [k[0] for k in ks] == gu.tolist() and [k[1] for k in ks] == gd.tolist()    # sorted, unique, identical set
+    assert np.allclose(gnum, [acc[k] for k in ks], rtol=1e-12, atol=1e-15)
+    assert np.allclose(gden, [den[k] for k in ks], rtol=0, atol=0)
+
+
+def _run_pair(oracle, sysm, setup, rng_mode, nsteps, w_begin, w_target, mwalk=400000, n_equil=10**9):
+    g = gpu_ctx_from_oracle(sysm, rng_mode=rng_mode, seed=SEED, mwalk=mwalk)
+    g.set_projector(setup.prj_counts, setup.prj_indices, setup.prj_values)
+    g.set_ct_table(setup.ct_up, setup.ct_dn, setup.ct_num, setup.ct_den)
+    wk = oracle.initial_walkers(setup, w_begin)
+    g.upload_walkers(wk)
+    ow = oracle.OracleWalk(sysm, setup, wk, mwalk, SEED, rng_mode=rng_mode)
+    pc = oracle.PopControl(setup.tau, -75.72, w_target, n_equil_steps=n_equil)
+    w_abs = np.abs(wk["wt"]).sum()
+    for it in range(nsteps):
+        r = pc.pre_step(w_abs)
+        if r != 1.0:
+            ow.scale_projector(r); g.scale_projector(r)
+        prm = pc.params()
+        st, out_c = ow.step(prm)
+        assert st == 0
+        out_g = g.step(prm)
+        # integer bookkeeping identical; sums to tree-reduction tolerance
+        for k in (5, 7, 15):
+            assert out_g[k] == out_c[k], (it, k, out_g[k], out_c[k])
+        assert np.allclose(out_g, out_c, rtol=1e-11, atol=1e-11), (it, out_g, out_c)
+        r = pc.post_step(out_c)
+        if r != 1.0:
+            ow.scale_projector(r); g.scale_projector(r)
+        w_abs = out_c[1]
+    wg, wc = g.download_walkers(), ow.walkers()
+    rng_g, rng_c = g.rng_state(), ow.rng_state()
+    g.close(); ow.close()
+    return wg, wc, rng_g, rng_c, out_g, out_c
+
+
+def test_walk_replay_trajectory_bit_exact(oracle, c2_walk, c2_setup):
+    """60 steps with the reference's single rannyu stream: after the last step the walker list
+    (dets, weights, initiator, imp_distance, cached H_ii / e_loc) and the RNG state are
+    identical to the oracle's."""
+    wg, wc, rng_g, rng_c, og, oc = _run_pair(oracle, c2_walk, c2_setup, 0, 60, 10, 2000)
+    assert rng_g == rng_c
+    for k in ("up", "dn", "imp_distance", "initiator"):
+        assert np.array_equal(wg[k], wc[k]), k
+    assert np.array_equal(wg["wt"], wc["wt"])
+    assert np.array_equal(wg["matrix_elements"], wc["matrix_elements"])
+    assert len(wg["up"]) > 1200
+
+
+def test_walk_counter_trajectory_bit_exact(oracle, c2_walk, c2_setup):
+    """Production RNG discipline at a larger population (grown for 150 steps)."""
+    wg, wc, _, _, og, oc = _run_pair(oracle, c2_walk, c2_setup, 1, 150, 50, 20000)
+    for k in ("up", "dn", "imp_distance", "initiator"):
+        assert np.array_equal(wg[k], wc[k]), k
+    assert np.array_equal(wg["wt"], wc["wt"])
+    assert len(wg["up"]) > 3000
+
+
+def test_walk_invariants_large(oracle, c2_walk, c2_setup):
+    """Size-independent properties at a population the oracle is not run at: walkers stay
+    sorted and unique, det-space walkers are all present, weights of stochastic walkers are
+    never below min_wt, sums reported by the step equal sums recomputed from the download."""
+    g = gpu_ctx_from_oracle(c2_walk, rng_mode=1, seed=SEED, mwalk=3_000_000)
+    s = c2_setup
+    g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
+    g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
+    wk = oracle.initial_walkers(s, 1000)
+    g.upload_walkers(wk)
+    pc = oracle.PopControl(s.tau, -75.72, 200000, n_equil_steps=10**9)
+    w_abs = np.abs(wk["wt"]).sum()
+    for it in range(120):
+        r = pc.pre_step(w_abs)
+        if r != 1.0: g.scale_projector(r)
+        out = g.step(pc.params())
+        r = pc.post_step(out)
+        if r != 1.0: g.scale_projector(r)
+        w_abs = out[1]
+    w = g.download_walkers()
+    g.close()
+    key = (w["up"].astype(object) << 26) | w["dn"].astype(object)
+    assert all(key[i] < key[i + 1] for i in range(len(key) - 1))
+    assert (w["imp_distance"] == 0).sum() == len(s.prj_counts)
+    sto = w["imp_distance"] >= 1
+    assert np.all(np.abs(w["wt"][sto]) >= 0.5 * pc.rfi * (1 - 1e-12))
+    assert len(w["up"]) == int(out[5])
+    assert np.isclose(np.abs(w["wt"]).sum(), out[1], rtol=1e-12)
+    assert np.isclose(w["wt"].sum(), out[0], rtol=1e-10, atol=1e-8)
+    assert np.isclose((w["e_num"] * w["wt"]).sum(), out[3], rtol=1e-10)
+    assert -75.9 < out[3] / out[2] < -75.5
