@@ -23,7 +23,9 @@ static inline int popcnt(det_t d) { return __builtin_popcountll(d); }
 void orc_setrn(orc_rng *g, const int seed[4]) {
   for (int i = 0; i < 4; i++) g->l[i] = seed[i];
   g->l[3] = 2 * (g->l[3] / 2) + 1;
-  g->seed = ((uint64_t)g->l[0] << 36) | ((uint64_t)g->l[1] << 24) | ((uint64_t)g->l[2] << 12) | (uint64_t)g->l[3];
+  /* 48-bit value of the state; limbs read with '(4i4)' may exceed 12 bits, rannyu's limb
+   * products treat them as coefficients of 2^12 powers, hence the sum */
+  g->seed = ((((uint64_t)g->l[0] << 36) + ((uint64_t)g->l[1] << 24) + ((uint64_t)g->l[2] << 12) + (uint64_t)g->l[3])) & 0xFFFFFFFFFFFFull;
 }
 static uint64_t mix64(uint64_t v) {
   v ^= v >> 30; v *= 0xBF58476D1CE4E5B9ull; v ^= v >> 27; v *= 0x94D049BB133111EBull; v ^= v >> 31;

@@ -603,7 +603,9 @@ int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out) {
   c->dev.tab = c->d_tab; c->dev.integrals = c->d_ints; c->dev.max_double = 0.0;
   c->key_bits = 2 * cfg->norb;
   c->rng_mode = cfg->rng_mode;
-  u64 s48 = ((u64)cfg->irand_seed[0] << 36) | ((u64)cfg->irand_seed[1] << 24) | ((u64)cfg->irand_seed[2] << 12) | (u64)(2 * (cfg->irand_seed[3] / 2) + 1);
+  // limbs of the input seed may exceed 12 bits ('(4i4,x,4i4)' reads 4 decimal digits each):
+  // rannyu's limb products treat them as coefficients of powers of 2^12, so the state is the SUM
+  u64 s48 = (((u64)cfg->irand_seed[0] << 36) + ((u64)cfg->irand_seed[1] << 24) + ((u64)cfg->irand_seed[2] << 12) + (u64)(2 * (cfg->irand_seed[3] / 2) + 1)) & SQ_MASK48;
   c->seed64 = s48; c->step_no = 0;
   c->mwalk = cfg->mwalk > 0 ? cfg->mwalk : 0;
   HIPCHK(hipMalloc(&c->d_sc, sizeof(DevScalars)));
@@ -751,7 +753,7 @@ int sqmc_gpu_get_rng(sqmc_gpu_ctx *c, int32_t seed[4]) {
 }
 int sqmc_gpu_set_rng(sqmc_gpu_ctx *c, const int32_t seed[4]) {
   if (!c) return SQMC_ERR_BAD_ARG;
-  u64 x = ((u64)seed[0] << 36) | ((u64)seed[1] << 24) | ((u64)seed[2] << 12) | (u64)(2 * (seed[3] / 2) + 1);
+  u64 x = (((u64)seed[0] << 36) + ((u64)seed[1] << 24) + ((u64)seed[2] << 12) + (u64)(2 * (seed[3] / 2) + 1)) & SQ_MASK48;
   HIPCHK(hipStreamSynchronize(c->st)); HIPCHK(hipMemcpy(&c->d_sc->lcg, &x, 8, hipMemcpyHostToDevice));
   c->seed64 = x;
   return SQMC_OK;
@@ -868,7 +870,7 @@ int sqmc_gpu_propose_batch(sqmc_gpu_ctx *c, int64_t n, double tau, const uint64_
   if (c->htab.time_sym) return fail(SQMC_ERR_UNSUPPORTED, "proposal kernel implements time_sym=.false. only");
   if (n <= 0) return SQMC_OK;
   std::vector<u64> s(n);
-  for (long long i = 0; i < n; i++) s[i] = ((u64)seeds[4 * i] << 36) | ((u64)seeds[4 * i + 1] << 24) | ((u64)seeds[4 * i + 2] << 12) | (u64)seeds[4 * i + 3];
+  for (long long i = 0; i < n; i++) s[i] = (((u64)seeds[4 * i] << 36) + ((u64)seeds[4 * i + 1] << 24) + ((u64)seeds[4 * i + 2] << 12) + (u64)seeds[4 * i + 3]) & SQ_MASK48;
   u64 *du, *dd, *ds, *dju, *djd, *dso; double *dw;
   HIPCHK(hipMalloc(&du, n * 8)); HIPCHK(hipMalloc(&dd, n * 8)); HIPCHK(hipMalloc(&ds, n * 8)); HIPCHK(hipMalloc(&dju, n * 8));
   HIPCHK(hipMalloc(&djd, n * 8)); HIPCHK(hipMalloc(&dso, n * 8)); HIPCHK(hipMalloc(&dw, n * 8));
