@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py -- walker-steps/s of the semistochastic walk on C2 cc-pVDZ (BASELINE.json
+configs[1]: r=1.24253 A, w_abs_gen_target=10^5, uniform2 proposal, size_deterministic=1000).
+
+A "step" is one full MC step (spawn, death, deterministic projection, sort, annihilation,
+rounding, estimators) over the whole walker population resident in HBM; metric =
+sum over timed steps of occupied determinants after the merge (the nwalk column of the
+reference's walkalize file, do_walk.f90:2930) / wall time.
+
+N>1 (round 1): every rank propagates its own population of the same target size with a
+rank-offset seed (as the reference offsets seed 2 by the rank, do_walk.f90:234) and the
+per-step estimator sums are all-reduced over RCCL like do_walk.f90:2778; cross-rank
+annihilation is not sharded yet ("replicas", DESIGN.md section Multi-GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+FCIDUMP = os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP")
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--target", type=float, default=1e5, help="w_abs_gen_target")
+    ap.add_argument("--equil", type=int, default=400, help="untimed equilibration steps before warmup")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    import numpy as np
+    import torch
+    import sqmc_amd
+    from sqmc_amd import host as H
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    sqmc_amd.set_device(local)
+
+    hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+    seed = (1346, 5634, 6635, (4361 + 2 * rank) % 10000)
+    walk = H.GpuWalk(hst, args.target, seed=seed)
+    red = torch.zeros(8, dtype=torch.float64, device="cuda") if world > 1 else None
+
+    def one_step():
+        out = walk.step()
+        if world > 1:                      # the 7 reduced sums of do_walk.f90:2689-2725
+            red[:7] = torch.from_numpy(out[:7].copy()).cuda()
+            dist.all_reduce(red)
+        return out
+
+    for _ in range(args.equil):
+        one_step()
+    for _ in range(args.warmup):
+        one_step()
+    walk.g.set_timing(True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    nwalk_sum = spawn_sum = 0.0
+    stage_ms = {}
+    e_num = e_den = 0.0
+    for _ in range(args.steps):
+        out = one_step()
+        nwalk_sum += out[5]; spawn_sum += out[15]
+        e_num += out[3] * np.sign(out[2]); e_den += abs(out[2])
+        for name, ms in walk.g.timing():
+            stage_ms[name] = stage_ms.get(name, 0.0) + ms
+    fence()
+    dt = time.perf_counter() - t0
+    tot = torch.tensor([nwalk_sum, spawn_sum, dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot)
+        dt = float(mx[2])
+    nwalk_all, spawn_all = float(tot[0]), float(tot[1])
+
+    if rank == 0:
+        value = nwalk_all / dt
+        # dominant kernel stage of the step, timed live with HIP events on the library's stream
+        dom = max(stage_ms, key=stage_ms.get)
+        n_avg, s_avg = nwalk_sum / args.steps, spawn_sum / args.steps
+        alg_bytes = {"sort": 24.0 * 3 * (n_avg + s_avg), "spawn": 84.0 * s_avg, "merge": 68.0 * (n_avg + s_avg),
+                     "estimate": 68.0 * n_avg, "project": 20.0 * 2 * len(walk.setup.prj_values), "gate+scan": 24.0 * n_avg,
+                     "diag": 34.0 * n_avg, "round": 24.0 * (n_avg + s_avg)}
+        ach = alg_bytes.get(dom, 0.0) / (stage_ms[dom] / args.steps * 1e-3) / 1e9
+        line = {
+            "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2 cc-pVDZ r=1.24253 (8e,26o, D2h) semistochastic walk, uniform2 proposal, w_abs_gen_target=%g, "
+                                   "size_deterministic=1000, Psi_T 100 dets, min_wt 0.5, r_initiator 1, tau_multiplier 0.1" % args.target,
+                       "occupied_dets_per_step": n_avg, "spawns_per_step": s_avg, "spawns_per_s": spawn_all / dt,
+                       "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": "replicas x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "ms_per_launch": stage_ms[dom] / args.steps,
+                         "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()}},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(walk, hst, n_avg)
+        print(json.dumps(line), flush=True)
+    walk.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(walk, hst, n_avg, budget_s=15.0):
+    """The oracle (single-thread C restatement of the reference step) on this box's host
+    cores, started from the SAME equilibrated population, for a bounded number of steps."""
+    import numpy as np
+    from oracle import oracle as O
+    O.build()
+    sysm = O.ChemSystem(FCIDUMP, 8, 4, "d2h", time_sym=False, hf_mode=0)
+    w = walk.g.download_walkers()
+    # permanent-initiator signs travel with the walkers on the GPU; the HF det is the only one here
+    w["perm_sign"] = np.where(w["initiator"] == 3, 1, 0).astype(np.int8)
+    s = walk.setup
+    ow = O.OracleWalk(sysm, s, w, walk.g.mwalk, [1346, 5634, 6635, 4361], rng_mode=1)
+    ow.scale_projector(walk.pc.tau / s.tau)
+    prm = walk.pc.params(min_wt=walk.min_wt)
+    t0, n, nw = time.perf_counter(), 0, 0.0
+    while time.perf_counter() - t0 < budget_s and n < 200:
+        st, out = ow.step(prm)
+        if st != 0:
+            break
+        nw += out[5]; n += 1
+    dt = time.perf_counter() - t0
+    ow.close()
+    return {"value": nw / dt, "unit": "walker-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d oracle steps (%.1f s) continuing the GPU run's equilibrated population of %.0f determinants" % (n, dt, n_avg)}
+
+
+if __name__ == "__main__":
+    main()

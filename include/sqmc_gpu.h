@@ -66,6 +66,10 @@ typedef struct {
   int64_t mwalk;                    /* MWALK: capacity of the walker arrays                */
 } sqmc_chem_cfg;
 
+/* one process per GPU: select the device of this rank before creating a context (the
+ * reference's cluster_init, mpi_routines.f90:766, has no device notion). */
+int sqmc_gpu_set_device(int device);
+
 /* replaces: system_setup_chem + init_move table setup.  Copies everything to HBM. */
 int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out);
 int sqmc_gpu_finalize(sqmc_gpu_ctx *ctx);
@@ -136,6 +140,20 @@ int sqmc_gpu_spmv_sym_upper(int64_t n, const int64_t *row_counts, const int64_t 
  * semistoch.f90:2234-2302, for n (bra,ket) pairs; 0 where not connected. */
 int sqmc_gpu_hamiltonian_batch(sqmc_gpu_ctx *ctx, int64_t n, const uint64_t *iu, const uint64_t *id,
                                const uint64_t *ju, const uint64_t *jd, double *h);
+
+/* replaces: hamiltonian_chem (chemistry.f90:1260-1320) with the excitation level found from
+ * the pair (no time-reversal symmetrisation even when time_sym is set); used to build
+ * dtm_hb exactly as double_excitation_matrix_element_no_ref does (chemistry.f90:9615-9646). */
+int sqmc_gpu_hamiltonian_chem_batch(sqmc_gpu_ctx *ctx, int64_t n, const uint64_t *iu, const uint64_t *id,
+                                    const uint64_t *ju, const uint64_t *jd, double *h);
+
+/* replaces: generate_sparse_ham_chem_upper_triangular (chemistry.f90:7639-8010) for a list
+ * sorted by (up,dn): the symmetric Hamiltonian in the "upper triangular" storage above
+ * (each row: its diagonal first, then columns j < i ascending; zero elements dropped).
+ * Output arrays are allocated by the library; release each with sqmc_gpu_free. */
+int sqmc_gpu_build_sparse_ham(sqmc_gpu_ctx *ctx, int64_t n, const uint64_t *up, const uint64_t *dn,
+                              int64_t *out_nnz, int64_t **out_row_counts, int64_t **out_indices,
+                              double **out_values);
 
 /* test door onto the proposal kernel: off_diagonal_move_chem (chemistry.f90:4237-5084) for n
  * parents, child k of the batch drawing from rannyu state seeds[4k..4k+3]; returns det_j,

@@ -305,22 +305,32 @@ class WalkSetup:
     pass
 
 
-def setup_walk(sysm, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1):
-    """Returns Psi_T, C(T), deterministic space + projector (-tau*H), tau."""
+def setup_walk(sysm, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1, coeffs="eig"):
+    """Returns Psi_T, C(T), deterministic space + projector (-tau*H), tau.
+    coeffs="eig": lowest eigenvector of H in {HF + connections} (the reference's scheme);
+    coeffs="pt1": first-order perturbation coefficients H_i0/(H_00-H_ii), which involve no
+    eigensolver/BLAS and are therefore bit-reproducible on any machine (golden fixtures)."""
+    import math
     s = WalkSetup()
-    cu, cd, _ = sysm.connected(sysm.hf_up, sysm.hf_dn, with_elems=False)
+    cu, cd, el = sysm.connected(sysm.hf_up, sysm.hf_dn, with_elems=(coeffs == "pt1"))
     order = sort_dets(cu, cd)
     up, dn = cu[order], cd[order]
-    counts, idx, val = sysm.build_sparse_ham(up, dn)
-    w, v = lowest_eigs(counts, idx, val, k=1)
-    c = v[:, 0]
-    if c[np.argmax(np.abs(c))] < 0:
-        c = -c
+    if coeffs == "pt1":
+        h00 = sysm.ham(sysm.hf_up, sysm.hf_dn, sysm.hf_up, sysm.hf_dn)
+        c = np.array([1.0 if (int(a), int(b)) == (sysm.hf_up, sysm.hf_dn) else h / (h00 - sysm.ham(int(a), int(b), int(a), int(b)))
+                      for a, b, h in zip(up, dn, el[order])])
+        w = np.array([h00])
+    else:
+        counts, idx, val = sysm.build_sparse_ham(up, dn)
+        w, v = lowest_eigs(counts, idx, val, k=1)
+        c = v[:, 0]
+        if c[np.argmax(np.abs(c))] < 0:
+            c = -c
     by = np.argsort(-np.abs(c), kind="stable")
     up_s, dn_s, c_s = up[by], dn[by], c[by]
     n_t = _truncate_at_csf(c_s, n_truncate_trial_wf)
     n_i = _truncate_at_csf(c_s, size_deterministic)
-    norm = 1.0 / np.sqrt(np.dot(c_s[:n_t], c_s[:n_t]))
+    norm = 1.0 / math.sqrt(math.fsum(float(x) * float(x) for x in c_s[:n_t]))
     s.psi_up, s.psi_dn, s.psi_c = up_s[:n_t].copy(), dn_s[:n_t].copy(), c_s[:n_t] * norm
     o = sort_dets(up_s[:n_i], dn_s[:n_i])
     s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
@@ -342,7 +352,7 @@ def setup_walk(sysm, n_truncate_trial_wf=100, size_deterministic=1000, tau_multi
     s.ct_dn = np.array([k[1] for k in keys], np.uint64)
     s.ct_num = np.array([acc[k] for k in keys])
     s.ct_den = np.array([s.psi_c[psi_index[k]] if k in psi_index else 0.0 for k in keys])
-    s.e_trial0 = float(np.dot(s.ct_num, s.ct_den) / np.dot(s.ct_den, s.ct_den))
+    s.e_trial0 = float(math.fsum(a * b for a, b in zip(s.ct_num, s.ct_den)) / math.fsum(b * b for b in s.ct_den))
     return s
 
 

@@ -6,4 +6,4 @@ The Python in this package is host-side plumbing only (ctypes door, input tables
 scalar population-control logic of the reference's walk loop).  There is no CPU fallback:
 every compute entry point fails loudly when the HIP library or a GPU is missing.
 """
-from ._lib import load_library, build_library, GpuChem, SpmvPlan, SqmcGpuError, RNG_REPLAY, RNG_COUNTER  # noqa: F401
+from ._lib import set_device, load_library, build_library, GpuChem, SpmvPlan, SqmcGpuError, RNG_REPLAY, RNG_COUNTER  # noqa: F401

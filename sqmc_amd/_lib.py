@@ -12,11 +12,11 @@ RNG_REPLAY, RNG_COUNTER = 0, 1
 _LIB = None
 
 EXPORTS = [
-    "sqmc_gpu_init_chem", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_projector",
+    "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_projector",
     "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
     "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_spmv_prepare",
     "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
-    "sqmc_gpu_propose_batch", "sqmc_gpu_hci_connections", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
+    "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
 ]
 
 
@@ -71,6 +71,8 @@ def load_library():
         L.sqmc_gpu_download_walkers.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 9
         L.sqmc_gpu_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.sqmc_gpu_hamiltonian_batch.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+        L.sqmc_gpu_hamiltonian_chem_batch.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+        L.sqmc_gpu_build_sparse_ham.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 6
         L.sqmc_gpu_propose_batch.argtypes = [C.c_void_p, C.c_int64, C.c_double] + [C.c_void_p] * 7
         L.sqmc_gpu_hci_connections.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int] + [C.c_void_p] * 5
         L.sqmc_gpu_spmv_prepare.argtypes = [C.c_int64] + [C.c_void_p] * 4
@@ -86,6 +88,12 @@ def load_library():
         L.sqmc_gpu_num_walkers.argtypes = [C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
+
+
+def set_device(index):
+    L = load_library()
+    L.sqmc_gpu_set_device.argtypes = [C.c_int]
+    _chk(L.sqmc_gpu_set_device(int(index)))
 
 
 def _chk(code):
@@ -192,6 +200,25 @@ class GpuChem:
         h = np.zeros(len(a))
         _chk(self.L.sqmc_gpu_hamiltonian_batch(self.h, len(a), _p(a), _p(b), _p(c), _p(d), _p(h)))
         return h
+
+    def hamiltonian_chem_batch(self, iu, id_, ju, jd):
+        a, b, c, d = _u64(iu), _u64(id_), _u64(ju), _u64(jd)
+        h = np.zeros(len(a))
+        _chk(self.L.sqmc_gpu_hamiltonian_chem_batch(self.h, len(a), _p(a), _p(b), _p(c), _p(d), _p(h)))
+        return h
+
+    def build_sparse_ham(self, up, dn):
+        u, d = _u64(up), _u64(dn)
+        n = len(u)
+        nnz = C.c_int64(); prc = C.c_void_p(); pix = C.c_void_p(); pvl = C.c_void_p()
+        _chk(self.L.sqmc_gpu_build_sparse_ham(self.h, n, _p(u), _p(d), C.byref(nnz), C.byref(prc), C.byref(pix), C.byref(pvl)))
+        k = nnz.value
+        rc = np.ctypeslib.as_array(C.cast(prc, C.POINTER(C.c_int64)), shape=(n,)).copy()
+        ix = np.ctypeslib.as_array(C.cast(pix, C.POINTER(C.c_int64)), shape=(k,)).copy()
+        vl = np.ctypeslib.as_array(C.cast(pvl, C.POINTER(C.c_double)), shape=(k,)).copy()
+        for q in (prc, pix, pvl):
+            self.L.sqmc_gpu_free(q)
+        return rc, ix, vl
 
     def propose_batch(self, tau, up, dn, seeds):
         u, d = _u64(up), _u64(dn)

@@ -90,13 +90,14 @@ static inline void device_excl_scan_u64(const u64 *in, u64 *out, long long n, u6
 }
 
 // ------------------------------------------------------------------------ radix sort
-#define RS_BITS 8
-#define RS_RADIX 256
+#define RS_MAX_RADIX 1024                   // 10-bit digits at most
 #define RS_WAVE_ITEMS 32                    // rounds of 64 keys per wave
 #define RS_TILE (64 * RS_WAVE_ITEMS)        // 2048 keys per wavefront
 
 // histogram: hist[digit * ntiles + tile]
+template <int BITS>
 __global__ void __launch_bounds__(64) rs_hist_kernel(const u64 *__restrict__ keys, u32 *__restrict__ hist, long long n, int ntiles, int shift) {
+  constexpr int RS_RADIX = 1 << BITS;
   __shared__ u32 cnt[RS_RADIX];
   const int lane = threadIdx.x;
   for (int d = lane; d < RS_RADIX; d += 64) cnt[d] = 0;
@@ -129,17 +130,21 @@ __global__ void __launch_bounds__(SCAN_BLOCK) rs_scan_kernel(u32 *__restrict__ h
   if (threadIdx.x == 0) rowtot[blockIdx.x] = (u32)carry;
 }
 
+template <int BITS>
 __global__ void __launch_bounds__(64) rs_scatter_kernel(const u64 *__restrict__ kin, const u32 *__restrict__ vin,
                                                         u64 *__restrict__ kout, u32 *__restrict__ vout,
                                                         const u32 *__restrict__ hist, const u32 *__restrict__ rowtot,
                                                         long long n, int ntiles, int shift) {
+  constexpr int RS_RADIX = 1 << BITS, RS_BITS = BITS, PER = RS_RADIX / 64;
   __shared__ u32 off[RS_RADIX];
   const int lane = threadIdx.x;
-  {   // digit bases = exclusive scan of the 256 row totals (4 per lane + wave scan)
-    u32 t0 = rowtot[lane * 4], t1 = rowtot[lane * 4 + 1], t2 = rowtot[lane * 4 + 2], t3 = rowtot[lane * 4 + 3];
-    u64 inc = wave_incl_scan_u64((u64)t0 + t1 + t2 + t3, lane);
-    u32 ex = (u32)(inc - ((u64)t0 + t1 + t2 + t3));
-    off[lane * 4] = ex; off[lane * 4 + 1] = ex + t0; off[lane * 4 + 2] = ex + t0 + t1; off[lane * 4 + 3] = ex + t0 + t1 + t2;
+  {   // digit bases = exclusive scan of the row totals (PER per lane + wave scan)
+    u32 t[PER]; u64 sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; q++) { t[q] = rowtot[lane * PER + q]; sum += t[q]; }
+    u32 ex = (u32)(wave_incl_scan_u64(sum, lane) - sum);
+#pragma unroll
+    for (int q = 0; q < PER; q++) { off[lane * PER + q] = ex; ex += t[q]; }
   }
   __syncthreads();
   for (int d = lane; d < RS_RADIX; d += 64) off[d] += hist[(long long)d * ntiles + blockIdx.x];
@@ -171,14 +176,24 @@ struct SortWork { u64 *k_alt; u32 *v_alt; u32 *hist; u32 *rowtot; long long cap;
 
 // Sorts keys[0..n) (with values) on bits [0, nbits); result ends up in the returned buffers
 // (either the inputs or the alternates).  Stable.
+template <int BITS>
+static inline void radix_pass(u64 *ka, u32 *va, u64 *kb, u32 *vb, long long n, int ntiles, int shift, SortWork &w, hipStream_t st) {
+  hipLaunchKernelGGL(rs_hist_kernel<BITS>, dim3(ntiles), dim3(64), 0, st, ka, w.hist, n, ntiles, shift);
+  hipLaunchKernelGGL(rs_scan_kernel, dim3(1 << BITS), dim3(SCAN_BLOCK), 0, st, w.hist, w.rowtot, ntiles);
+  hipLaunchKernelGGL(rs_scatter_kernel<BITS>, dim3(ntiles), dim3(64), 0, st, ka, va, kb, vb, w.hist, w.rowtot, n, ntiles, shift);
+}
+// digit width: the fewest passes of at most 10 bits, then the narrowest digit that still
+// covers the key in that many passes (28-bit C2 keys: 3 passes of 10 bits)
 static inline void device_radix_sort(u64 *&keys, u32 *&vals, long long n, int nbits, SortWork &w, hipStream_t st) {
   if (n <= 1) return;
   int ntiles = (int)((n + RS_TILE - 1) / RS_TILE);
   u64 *ka = keys, *kb = w.k_alt; u32 *va = vals, *vb = w.v_alt;
-  for (int shift = 0; shift < nbits; shift += RS_BITS) {
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(ntiles), dim3(64), 0, st, ka, w.hist, n, ntiles, shift);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(SCAN_BLOCK), 0, st, w.hist, w.rowtot, ntiles);
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(ntiles), dim3(64), 0, st, ka, va, kb, vb, w.hist, w.rowtot, n, ntiles, shift);
+  const int npass = (nbits + 9) / 10;
+  int bits = (nbits + npass - 1) / npass; if (bits < 8) bits = 8;
+  for (int pss = 0, shift = 0; pss < npass; pss++, shift += bits) {
+    if (bits == 8) radix_pass<8>(ka, va, kb, vb, n, ntiles, shift, w, st);
+    else if (bits == 9) radix_pass<9>(ka, va, kb, vb, n, ntiles, shift, w, st);
+    else radix_pass<10>(ka, va, kb, vb, n, ntiles, shift, w, st);
     u64 *tk = ka; ka = kb; kb = tk; u32 *tv = va; va = vb; vb = tv;
   }
   w.k_alt = kb; w.v_alt = vb; keys = ka; vals = va;

@@ -83,13 +83,12 @@ struct sqmc_gpu_ctx {
   int rng_mode; u64 seed64; u64 step_no;
   DevScalars *d_sc; DevScalars *h_sc;   // h_sc pinned
   double *d_partials; int n_partial_blocks;
-  int key_bits;
+  int key_bits; u64 invalid_key; u64 *d_binom;
   // timing
   int timing; hipEvent_t ev[NTIMERS + 1]; const char *tname[NTIMERS]; int nt; float tms[NTIMERS];
 };
 
 // ===================================================================== step kernels
-__device__ __forceinline__ u64 pack_key(u64 up, u64 dn, int norb) { return (up << norb) | dn; }
 
 // gate + child count (COUNTER discipline).  do_walk.f90:3577-3589
 __global__ void __launch_bounds__(TPB) k_gate(const double *__restrict__ wt, u64 *__restrict__ nchild, double *__restrict__ wchild,
@@ -160,7 +159,7 @@ __global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict
 // one thread per child proposal; parent found by binary search in the child offsets
 __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
                                                const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
-                                               long long n0, long long nchildren, StepP p, int mode, u64 seed, u64 step, DevScalars *sc) {
+                                               long long n0, long long nchildren, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, DevScalars *sc) {
   __shared__ ChemTab t;
   stage_tab(&t, dev.tab);
   long long c = (long long)blockIdx.x * TPB + threadIdx.x;
@@ -190,18 +189,18 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
     if (p.semi && pd == 0) ini = 1;
     w.up[k] = ju; w.dn[k] = jd; w.wt[k] = wj; w.impd[k] = (int8_t)d; w.init[k] = (int8_t)ini; w.psign[k] = 0;
     w.me[k] = 1e51; w.en[k] = 1e51; w.ed[k] = 1e51;
-    keys[k] = pack_key(ju, jd, t.norb);
+    keys[k] = det_key(dev, ju, jd);
   } else {
-    w.wt[k] = 0.0; keys[k] = ~0ull;           // sorts behind every real determinant
+    w.wt[k] = 0.0; keys[k] = invalid_key;     // sorts behind every real determinant
     atomicAdd(&sc->n_invalid, 1ull);
   }
   vals[k] = (u32)k;
 }
 
-__global__ void __launch_bounds__(TPB) k_main_keys(const u64 *__restrict__ up, const u64 *__restrict__ dn, u64 *__restrict__ keys,
-                                                   u32 *__restrict__ vals, long long n, int norb) {
+__global__ void __launch_bounds__(TPB) k_main_keys(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, u64 *__restrict__ keys,
+                                                   u32 *__restrict__ vals, long long n) {
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
-  if (i < n) { keys[i] = pack_key(up[i], dn[i], norb); vals[i] = (u32)i; }
+  if (i < n) { keys[i] = det_key(dev, up[i], dn[i]); vals[i] = (u32)i; }
 }
 
 // deterministic projection: x = w(loc); y = A x (rows summed in the reference's order);
@@ -210,15 +209,27 @@ __global__ void __launch_bounds__(TPB) k_prj_gather(const double *__restrict__ w
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i < n) x[i] = wt[loc[i]];
 }
+// one wavefront per row: the 64 products of a chunk are formed in parallel (coalesced loads),
+// then added in storage order through lane broadcasts, so y is bit-identical to the
+// reference's sequential accumulation.
 __global__ void __launch_bounds__(TPB) k_prj_apply(const int *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val,
                                                    const double *__restrict__ x, const int *__restrict__ loc, double *__restrict__ wt,
                                                    long long n, double e_trial, double tau) {
-  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  const long long i = (long long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= n) return;
+  const int b = ptr[i], e = ptr[i + 1];
   double y = 0.0;
-  for (int k = ptr[i]; k < ptr[i + 1]; k++) y = y + val[k] * x[col[k]];
-  y = y + e_trial * tau * x[i];
-  wt[loc[i]] = wt[loc[i]] + y;
+  for (int base = b; base < e; base += 64) {
+    const int k = base + lane;
+    const double pr = (k < e) ? val[k] * x[col[k]] : 0.0;
+    const int cnt = (e - base < 64) ? (e - base) : 64;
+    for (int l = 0; l < cnt; l++) y = y + __shfl(pr, l, 64);
+  }
+  if (lane == 0) {
+    y = y + e_trial * tau * x[i];
+    wt[loc[i]] = wt[loc[i]] + y;
+  }
 }
 __global__ void __launch_bounds__(TPB) k_scale(double *__restrict__ v, long long n, double r) {
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
@@ -366,23 +377,29 @@ __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64
   }
 }
 
-// final: sum block partials in block order; publish stats; advance the REPLAY stream
-__global__ void __launch_bounds__(64) k_finish(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_blocks,
-                                               long long n_before, int mode, DevScalars *sc) {
-  __shared__ double tot[NSTAT];
-  if (threadIdx.x < NSTAT) {
+// final: sum block partials (fixed strided order + fixed tree: run-to-run reproducible);
+// publish stats; advance the REPLAY stream
+__global__ void __launch_bounds__(TPB) k_finish(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_blocks,
+                                                long long n_before, int mode, DevScalars *sc) {
+  __shared__ double red[TPB / 64][NSTAT + 1];
+  __shared__ double tot[NSTAT + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int k = 0; k <= NSTAT; k++) {
     double v = 0.0;
-    for (int b = 0; b < nblocks; b++) v += partials[(long long)b * NSTAT + threadIdx.x];
-    tot[threadIdx.x] = v;
+    if (k < NSTAT) { for (int b = threadIdx.x; b < nblocks; b += TPB) v += partials[(long long)b * NSTAT + k]; }
+    else if (threadIdx.x < 64) v = wabs_blocks[threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) red[wv][k] = v;
   }
+  __syncthreads();
+  if (threadIdx.x <= NSTAT) { double v = 0.0; for (int q = 0; q < TPB / 64; q++) v += red[q][threadIdx.x]; tot[threadIdx.x] = v; }
   __syncthreads();
   if (threadIdx.x == 0) {
     double *o = sc->stats;
     o[0] = tot[0]; o[1] = tot[1]; o[2] = tot[2]; o[3] = tot[3]; o[4] = tot[4];
     o[5] = (double)(sc->tot2 & 0xFFFFFFFFull); o[6] = tot[6];
     o[7] = (double)(n_before - (long long)sc->n_invalid); o[8] = tot[8]; o[9] = tot[9]; o[10] = tot[10];
-    o[11] = tot[11]; o[12] = tot[12]; o[13] = tot[5]; o[15] = (double)sc->n_children;
-    { double wb = 0.0; for (int b = 0; b < 64; b++) wb += wabs_blocks[b]; o[14] = wb; }
+    o[11] = tot[11]; o[12] = tot[12]; o[13] = tot[5]; o[14] = tot[NSTAT]; o[15] = (double)sc->n_children;
     if (mode == 0) sc->lcg = lcg_skip(sc->lcg, sc->tot1 >> 32);
   }
 }
@@ -404,6 +421,55 @@ __global__ void __launch_bounds__(TPB) k_ham_batch(ChemDev dev, const u64 *iu, c
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i < n) h[i] = h_any(t, dev.integrals, iu[i], id[i], ju[i], jd[i]);
 }
+__global__ void __launch_bounds__(TPB) k_ham_chem_batch(ChemDev dev, const u64 *iu, const u64 *id, const u64 *ju, const u64 *jd, double *h, long long n) {
+  __shared__ ChemTab t;
+  stage_tab(&t, dev.tab);
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  int lev = excitation_level(iu[i], id[i], ju[i], jd[i]);
+  h[i] = lev < 0 ? 0.0 : h_level(t, dev.integrals, iu[i], id[i], ju[i], jd[i], lev);
+}
+
+// Sparse Hamiltonian among a sorted determinant list by brute force over all pairs: a
+// popcount filter (<= 2 orbital differences, also against the time-reversed partner when
+// time_sym) in front of the Slater-Condon evaluation.  One thread per row, column
+// determinants staged through LDS in tiles.  pass 0 counts, pass 1 fills at the scanned
+// offsets; each row holds its diagonal first, then columns j < i ascending.
+// replaces: generate_sparse_ham_chem_upper_triangular (chemistry.f90:7639-8010)
+__global__ void __launch_bounds__(TPB) k_build_ham(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, long long n, int pass,
+                                                   u64 *__restrict__ counts, const u64 *__restrict__ offs, long long *__restrict__ idx, double *__restrict__ val) {
+  __shared__ ChemTab t;
+  __shared__ u64 su[TPB], sd[TPB];
+  stage_tab(&t, dev.tab);
+  const long long r0 = (long long)blockIdx.x * TPB, i = r0 + threadIdx.x;
+  const bool live = i < n;
+  const u64 ui = live ? up[i] : 0, di = live ? dn[i] : 0;
+  u64 cnt = 0; const u64 base = (pass && live) ? offs[i] : 0;
+  if (live) {
+    if (pass) { idx[base] = i + 1; val[base] = h_any(t, dev.integrals, ui, di, ui, di); }
+    cnt = 1;
+  }
+  const long long jend = (r0 + TPB < n) ? r0 + TPB : n;
+  for (long long j0 = 0; j0 < jend; j0 += TPB) {
+    __syncthreads();
+    { long long j = j0 + threadIdx.x; su[threadIdx.x] = (j < n) ? up[j] : 0; sd[threadIdx.x] = (j < n) ? dn[j] : 0; }
+    __syncthreads();
+    if (!live) continue;
+    const int lim = (int)((i - j0 < TPB) ? (i - j0) : TPB);      // only j < i
+    for (int q = 0; q < lim; q++) {
+      const u64 uj = su[q], dj = sd[q];
+      bool cand = (popc64(ui ^ uj) + popc64(di ^ dj)) <= 4;
+      if (!cand && t.time_sym) cand = (popc64(ui ^ dj) + popc64(di ^ uj)) <= 4;
+      if (!cand) continue;
+      const double h = h_any(t, dev.integrals, ui, di, uj, dj);
+      if (h == 0.0) continue;
+      if (pass) { idx[base + cnt] = j0 + q + 1; val[base + cnt] = h; }
+      cnt++;
+    }
+  }
+  if (!pass && live) counts[i] = cnt;
+}
+
 __global__ void __launch_bounds__(TPB) k_propose_batch(ChemDev dev, const u64 *up, const u64 *dn, const u64 *state_in, u64 *ju, u64 *jd,
                                                        double *wj, u64 *state_out, long long n, double tau) {
   __shared__ ChemTab t;
@@ -524,10 +590,7 @@ __global__ void __launch_bounds__(TPB) k_hci_dedup(const u64 *__restrict__ skey,
   const u64 o = pos[j];
   ou[o] = iu[t]; od[o] = id[t]; onum[o] = a; oden[o] = b;
 }
-__global__ void __launch_bounds__(TPB) k_keys2(const u64 *__restrict__ up, const u64 *__restrict__ dn, u64 *__restrict__ keys, u32 *__restrict__ vals, long long n, int norb) {
-  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
-  if (i < n) { keys[i] = pack_key(up[i], dn[i], norb); vals[i] = (u32)i; }
-}
+
 
 // ============================================================================ SpMV
 // Symmetric matrix kept as FULL CSR (int32 columns) so that every row is owned by one
@@ -567,13 +630,19 @@ static void expand_full_csr(long long n, const int64_t *rc, const int64_t *idx, 
 extern "C" {
 
 const char *sqmc_gpu_last_error(void) { return g_err.c_str(); }
+int sqmc_gpu_set_device(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SQMC_ERR_HIP, "no HIP device: libsqmc_gpu has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(SQMC_ERR_BAD_ARG, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  return SQMC_OK;
+}
 void sqmc_gpu_free(void *p) { free(p); }
 
 int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out) {
   if (!cfg || !out) return fail(SQMC_ERR_BAD_ARG, "null argument");
   if (cfg->norb < 1 || cfg->norb > SQ_MAXORB) return fail(SQMC_ERR_UNSUPPORTED, "norb must be in 1..64 (one 64-bit word per spin)");
   if (cfg->n_group < 1 || cfg->n_group > SQ_MAXSYM) return fail(SQMC_ERR_UNSUPPORTED, "point group order must be <= 8");
-  if (2 * cfg->norb > 64) return fail(SQMC_ERR_UNSUPPORTED, "2*norb > 64: two-word sort keys are a later round");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SQMC_ERR_HIP, "no HIP device: libsqmc_gpu has no CPU fallback");
   sqmc_gpu_ctx *c = new sqmc_gpu_ctx();
@@ -601,7 +670,19 @@ int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out) {
   HIPCHK(hipMalloc(&c->d_ints, (cfg->n_integrals + 1) * sizeof(double)));
   HIPCHK(hipMemcpy(c->d_ints, cfg->integrals, (cfg->n_integrals + 1) * sizeof(double), hipMemcpyHostToDevice));
   c->dev.tab = c->d_tab; c->dev.integrals = c->d_ints; c->dev.max_double = 0.0;
-  c->key_bits = 2 * cfg->norb;
+  {   // binomial table + width of the colex sort key
+    std::vector<u64> bn(64 * SQ_BINOM_STRIDE, 0);
+    for (int a = 0; a < 64; a++) { bn[a * SQ_BINOM_STRIDE] = 1; for (int b = 1; b <= 32 && b <= a; b++) bn[a * SQ_BINOM_STRIDE + b] = (b == a) ? 1 : bn[(a - 1) * SQ_BINOM_STRIDE + b - 1] + bn[(a - 1) * SQ_BINOM_STRIDE + b]; }
+    auto choose = [&](int n_, int k_) -> long double { long double r = 1; for (int q = 1; q <= k_; q++) r = r * (n_ - k_ + q) / q; return r; };
+    long double tot = choose(cfg->norb, cfg->nup) * choose(cfg->norb, cfg->ndn);
+    if (tot >= 9.0e18L) { delete c; return fail(SQMC_ERR_UNSUPPORTED, "determinant space needs more than 63 key bits"); }
+    u64 nd = (u64)(choose(cfg->norb, cfg->ndn) + 0.5L), total = (u64)(tot + 0.5L);
+    int bits = 1; while (bits < 63 && ((1ull << bits) - 1ull) < total) bits++;
+    c->key_bits = bits; c->invalid_key = (1ull << bits) - 1ull;
+    HIPCHK(hipMalloc(&c->d_binom, bn.size() * 8));
+    HIPCHK(hipMemcpy(c->d_binom, bn.data(), bn.size() * 8, hipMemcpyHostToDevice));
+    c->dev.binom = c->d_binom; c->dev.n_dn_strings = nd;
+  }
   c->rng_mode = cfg->rng_mode;
   // limbs of the input seed may exceed 12 bits ('(4i4,x,4i4)' reads 4 decimal digits each):
   // rannyu's limb products treat them as coefficients of powers of 2^12, so the state is the SUM
@@ -623,7 +704,7 @@ int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out) {
     HIPCHK(hipMalloc(&c->d_keys, M * 8)); HIPCHK(hipMalloc(&c->d_keys_alt, M * 8));
     HIPCHK(hipMalloc(&c->d_vals, M * 4)); HIPCHK(hipMalloc(&c->d_vals_alt, M * 4));
     long long ntiles = (M + RS_TILE - 1) / RS_TILE;
-    HIPCHK(hipMalloc(&c->d_hist, ntiles * RS_RADIX * 4)); HIPCHK(hipMalloc(&c->d_rowtot, RS_RADIX * 4));
+    HIPCHK(hipMalloc(&c->d_hist, ntiles * RS_MAX_RADIX * 4)); HIPCHK(hipMalloc(&c->d_rowtot, RS_MAX_RADIX * 4));
     HIPCHK(hipMalloc(&c->d_flags, M * 8)); HIPCHK(hipMalloc(&c->d_pos, M * 8));
     HIPCHK(hipMalloc(&c->d_flags2, M * 8)); HIPCHK(hipMalloc(&c->d_pos2, M * 8));
     c->cap_tiles = (M + SCAN_TILE - 1) / SCAN_TILE + 1;
@@ -645,6 +726,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
     hipFree(c->d_keys); hipFree(c->d_keys_alt); hipFree(c->d_vals); hipFree(c->d_vals_alt); hipFree(c->d_hist); hipFree(c->d_rowtot);
     hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_tile_sums); hipFree(c->d_partials);
   }
+  hipFree(c->d_binom);
   hipFree(c->d_tab); hipFree(c->d_ints); hipFree(c->d_hb_r); hipFree(c->d_hb_s); hipFree(c->d_hb_absH); hipFree(c->d_pq_ind); hipFree(c->d_pq_count);
   hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x);
   hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den);
@@ -804,13 +886,13 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   // ---- spawn
   if (nch > 0)
     hipLaunchKernelGGL(k_spawn, dim3(nblk(nch)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                       n0, nch, p, mode, seed, step, c->d_sc);
-  hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0, c->htab.norb);
+                       n0, nch, p, mode, seed, step, c->invalid_key, c->d_sc);
+  hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0);
   TMARK("spawn");
   // ---- deterministic projection
   if (p.semi) {
     hipLaunchKernelGGL(k_prj_gather, dim3(nblk(c->n_imp)), dim3(TPB), 0, st, c->w.wt, c->d_loc_imp, c->d_prj_x, c->n_imp);
-    hipLaunchKernelGGL(k_prj_apply, dim3(nblk(c->n_imp)), dim3(TPB), 0, st, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, c->d_prj_x, c->d_loc_imp, c->w.wt,
+    hipLaunchKernelGGL(k_prj_apply, dim3(nblk(c->n_imp, TPB / 64)), dim3(TPB), 0, st, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, c->d_prj_x, c->d_loc_imp, c->w.wt,
                        c->n_imp, p.e_trial, p.tau);
   }
   TMARK("project");
@@ -832,7 +914,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   const int nb = nblk(nall);
   hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, st, c->m, c->w, c->d_flags2, c->d_pos2, c->d_loc_imp, c->d_ct_up, c->d_ct_dn, c->d_ct_num, c->d_ct_den,
                      c->n_ct, nall, p, c->d_partials + 64);
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, c->d_partials + 64, nb, c->d_partials, nall, mode, c->d_sc);
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials + 64, nb, c->d_partials, nall, mode, c->d_sc);
   TMARK("estimate");
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
@@ -861,6 +943,50 @@ int sqmc_gpu_hamiltonian_batch(sqmc_gpu_ctx *c, int64_t n, const uint64_t *iu, c
   HIPCHK(hipMemcpy(h, dh, n * 8, hipMemcpyDeviceToHost));
   for (int k = 0; k < 4; k++) hipFree(d[k]);
   hipFree(dh);
+  return SQMC_OK;
+}
+
+int sqmc_gpu_hamiltonian_chem_batch(sqmc_gpu_ctx *c, int64_t n, const uint64_t *iu, const uint64_t *id, const uint64_t *ju, const uint64_t *jd, double *h) {
+  if (!c) return fail(SQMC_ERR_BAD_ARG, "null ctx");
+  if (n <= 0) return SQMC_OK;
+  u64 *d[4]; double *dh;
+  const uint64_t *src[4] = {iu, id, ju, jd};
+  for (int k = 0; k < 4; k++) { HIPCHK(hipMalloc(&d[k], n * 8)); HIPCHK(hipMemcpy(d[k], src[k], n * 8, hipMemcpyHostToDevice)); }
+  HIPCHK(hipMalloc(&dh, n * 8));
+  hipLaunchKernelGGL(k_ham_chem_batch, dim3(nblk(n)), dim3(TPB), 0, c->st, c->dev, d[0], d[1], d[2], d[3], dh, (long long)n);
+  HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->st));
+  HIPCHK(hipMemcpy(h, dh, n * 8, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 4; k++) hipFree(d[k]);
+  hipFree(dh);
+  return SQMC_OK;
+}
+
+int sqmc_gpu_build_sparse_ham(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, const uint64_t *dn, int64_t *out_nnz,
+                              int64_t **out_row_counts, int64_t **out_indices, double **out_values) {
+  if (!c || !out_nnz || !out_row_counts || !out_indices || !out_values || n <= 0) return fail(SQMC_ERR_BAD_ARG, "bad argument");
+  for (long long i = 1; i < n; i++)
+    if (!(up[i - 1] < up[i] || (up[i - 1] == up[i] && dn[i - 1] < dn[i]))) return fail(SQMC_ERR_BAD_ARG, "determinant list must be strictly sorted by (up,dn)");
+  hipStream_t st = c->st;
+  u64 *du, *dd, *dcnt, *doff, *dtot, *dts;
+  HIPCHK(hipMalloc(&du, n * 8)); HIPCHK(hipMalloc(&dd, n * 8)); HIPCHK(hipMalloc(&dcnt, n * 8)); HIPCHK(hipMalloc(&doff, n * 8)); HIPCHK(hipMalloc(&dtot, 8));
+  long long tiles = (n + SCAN_TILE - 1) / SCAN_TILE + 1;
+  HIPCHK(hipMalloc(&dts, tiles * 8));
+  HIPCHK(hipMemcpy(du, up, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dd, dn, n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_build_ham, dim3(nblk(n)), dim3(TPB), 0, st, c->dev, du, dd, (long long)n, 0, dcnt, doff, (long long *)nullptr, (double *)nullptr);
+  ScanWork sw; sw.tile_sums = dts; sw.cap_tiles = tiles;
+  device_excl_scan_u64(dcnt, doff, n, dtot, sw, st);
+  u64 total = 0;
+  HIPCHK(hipMemcpyAsync(&total, dtot, 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+  long long *didx; double *dval;
+  HIPCHK(hipMalloc(&didx, (total + 1) * 8)); HIPCHK(hipMalloc(&dval, (total + 1) * 8));
+  hipLaunchKernelGGL(k_build_ham, dim3(nblk(n)), dim3(TPB), 0, st, c->dev, du, dd, (long long)n, 1, dcnt, doff, didx, dval);
+  HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(st));
+  int64_t *rc = (int64_t *)malloc(n * 8), *ix = (int64_t *)malloc((total + 1) * 8); double *vl = (double *)malloc((total + 1) * 8);
+  HIPCHK(hipMemcpy(rc, dcnt, n * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(ix, didx, total * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(vl, dval, total * 8, hipMemcpyDeviceToHost));
+  *out_nnz = (int64_t)total; *out_row_counts = rc; *out_indices = ix; *out_values = vl;
+  void *fr[] = {du, dd, dcnt, doff, dtot, dts, didx, dval};
+  for (void *q : fr) hipFree(q);
   return SQMC_OK;
 }
 
@@ -913,8 +1039,8 @@ int sqmc_gpu_hci_connections(sqmc_gpu_ctx *c, int64_t n_ref, const uint64_t *ref
   hipLaunchKernelGGL(k_hci_gen, dim3(nblk(n_ref)), dim3(TPB), 0, st, c->dev, dru, drd, dco, eps, diag_mode, (long long)n_ref, 1, dcnt, doff, du, dd, dnum, dden);
   HIPCHK(hipMalloc(&keys, T * 8)); HIPCHK(hipMalloc(&kalt, T * 8)); HIPCHK(hipMalloc(&vals, T * 4)); HIPCHK(hipMalloc(&valt, T * 4));
   long long ntiles = (T + RS_TILE - 1) / RS_TILE;
-  HIPCHK(hipMalloc(&hist, ntiles * RS_RADIX * 4)); HIPCHK(hipMalloc(&rowtot, RS_RADIX * 4));
-  hipLaunchKernelGGL(k_keys2, dim3(nblk(T)), dim3(TPB), 0, st, du, dd, keys, vals, T, c->htab.norb);
+  HIPCHK(hipMalloc(&hist, ntiles * RS_MAX_RADIX * 4)); HIPCHK(hipMalloc(&rowtot, RS_MAX_RADIX * 4));
+  hipLaunchKernelGGL(k_main_keys, dim3(nblk(T)), dim3(TPB), 0, st, c->dev, du, dd, keys, vals, T);
   SortWork so; so.k_alt = kalt; so.v_alt = valt; so.hist = hist; so.rowtot = rowtot; so.cap = T;
   u64 *skey = keys; u32 *perm = vals;
   device_radix_sort(skey, perm, T, c->key_bits, so, st);

@@ -1,0 +1,168 @@
+!> sqmc_gpu_mod -- iso_c_binding view of include/sqmc_gpu.h for a Fortran host such as the
+!> reference's do_walk.f90 / more_tools.f90 / hci.f90.  Every interface names the C entry point
+!> it binds; INTEGRATION.md lists the reference call sites each one replaces.
+!> Determinants cross the boundary as integer(c_int64_t) (the low word of the reference's
+!> 128-bit ik, exactly as conv_128_to_64 does for MPI, mpi_routines.f90:671-680).
+module sqmc_gpu_mod
+  use iso_c_binding
+  implicit none
+  private
+  public :: sqmc_chem_cfg, sqmc_step_params
+  public :: sqmc_gpu_set_device, sqmc_gpu_init_chem, sqmc_gpu_finalize, sqmc_gpu_last_error, sqmc_gpu_set_hb_tables
+  public :: sqmc_gpu_set_projector, sqmc_gpu_scale_projector, sqmc_gpu_set_ct_table, sqmc_gpu_upload_walkers
+  public :: sqmc_gpu_num_walkers, sqmc_gpu_download_walkers, sqmc_gpu_step, sqmc_gpu_get_rng, sqmc_gpu_set_rng
+  public :: sqmc_gpu_spmv_prepare, sqmc_gpu_spmv_apply, sqmc_gpu_spmv_free, sqmc_gpu_spmv_sym_upper
+  public :: sqmc_gpu_hamiltonian_batch, sqmc_gpu_hamiltonian_chem_batch, sqmc_gpu_build_sparse_ham, sqmc_gpu_propose_batch
+  public :: sqmc_gpu_hci_connections, sqmc_gpu_free, sqmc_gpu_set_timing, sqmc_gpu_get_timing
+  public :: sqmc_gpu_check
+
+  integer(c_int), parameter, public :: SQMC_RNG_REPLAY = 0, SQMC_RNG_COUNTER = 1
+
+  type, bind(C) :: sqmc_chem_cfg
+    integer(c_int32_t) :: norb, nup, ndn, n_core_orb
+    integer(c_int32_t) :: time_sym, z
+    integer(c_int32_t) :: n_group
+    type(c_ptr) :: product_table       ! int32 (0:8,0:8) stored [i*9+j]
+    type(c_ptr) :: orbital_symmetries  ! int32 (0:norb)
+    type(c_ptr) :: combine_2           ! int32 (0:norb+1,0:norb+1) stored [i*(norb+2)+j]
+    integer(c_int64_t) :: n_integrals
+    type(c_ptr) :: integrals           ! real(c_double) (0:n_integrals)
+    integer(c_int32_t) :: rng_mode
+    integer(c_int32_t) :: irand_seed(4)
+    integer(c_int64_t) :: mwalk
+  end type
+
+  type, bind(C) :: sqmc_step_params
+    real(c_double) :: tau, e_trial, reweight_factor_inv, r_initiator, min_wt, always_spawn_cutoff_wt
+    integer(c_int32_t) :: initiator_power, initiator_min_distance, c_t_initiator, semistochastic, reached_w_abs_gen
+    integer(c_int32_t) :: reserved
+  end type
+
+  interface
+    integer(c_int) function sqmc_gpu_set_device(device) bind(C, name='sqmc_gpu_set_device')
+      import; integer(c_int), value :: device
+    end function
+    integer(c_int) function sqmc_gpu_init_chem(cfg, ctx) bind(C, name='sqmc_gpu_init_chem')
+      import; type(sqmc_chem_cfg), intent(in) :: cfg; type(c_ptr), intent(out) :: ctx
+    end function
+    integer(c_int) function sqmc_gpu_finalize(ctx) bind(C, name='sqmc_gpu_finalize')
+      import; type(c_ptr), value :: ctx
+    end function
+    type(c_ptr) function sqmc_gpu_last_error() bind(C, name='sqmc_gpu_last_error')
+      import
+    end function
+    integer(c_int) function sqmc_gpu_set_hb_tables(ctx, n_hb, hb_r, hb_s, hb_absH, n_pq, pq_ind, pq_count, max_double) &
+        bind(C, name='sqmc_gpu_set_hb_tables')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n_hb; integer(c_int32_t), intent(in) :: hb_r(*), hb_s(*)
+      real(c_double), intent(in) :: hb_absH(*); integer(c_int32_t), value :: n_pq; integer(c_int64_t), intent(in) :: pq_ind(*)
+      integer(c_int32_t), intent(in) :: pq_count(*); real(c_double), value :: max_double
+    end function
+    integer(c_int) function sqmc_gpu_set_projector(ctx, n_imp, nnz, row_counts, indices, values) bind(C, name='sqmc_gpu_set_projector')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n_imp, nnz
+      integer(c_int64_t), intent(in) :: row_counts(*), indices(*); real(c_double), intent(in) :: values(*)
+    end function
+    integer(c_int) function sqmc_gpu_scale_projector(ctx, ratio) bind(C, name='sqmc_gpu_scale_projector')
+      import; type(c_ptr), value :: ctx; real(c_double), value :: ratio
+    end function
+    integer(c_int) function sqmc_gpu_set_ct_table(ctx, n, up, dn, e_num, e_den) bind(C, name='sqmc_gpu_set_ct_table')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n; integer(c_int64_t), intent(in) :: up(*), dn(*)
+      real(c_double), intent(in) :: e_num(*), e_den(*)
+    end function
+    integer(c_int) function sqmc_gpu_upload_walkers(ctx, n, up, dn, wt, imp_distance, initiator, perm_sign, matrix_elements, e_num, e_den) &
+        bind(C, name='sqmc_gpu_upload_walkers')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n; integer(c_int64_t), intent(in) :: up(*), dn(*)
+      real(c_double), intent(in) :: wt(*), matrix_elements(*), e_num(*), e_den(*)
+      integer(c_int8_t), intent(in) :: imp_distance(*), initiator(*), perm_sign(*)
+    end function
+    integer(c_int) function sqmc_gpu_num_walkers(ctx, n) bind(C, name='sqmc_gpu_num_walkers')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), intent(out) :: n
+    end function
+    integer(c_int) function sqmc_gpu_download_walkers(ctx, cap, n, up, dn, wt, imp_distance, initiator, matrix_elements, e_num, e_den) &
+        bind(C, name='sqmc_gpu_download_walkers')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: cap; integer(c_int64_t), intent(out) :: n
+      integer(c_int64_t), intent(out) :: up(*), dn(*); real(c_double), intent(out) :: wt(*), matrix_elements(*), e_num(*), e_den(*)
+      integer(c_int8_t), intent(out) :: imp_distance(*), initiator(*)
+    end function
+    integer(c_int) function sqmc_gpu_step(ctx, p, out_stats) bind(C, name='sqmc_gpu_step')
+      import; type(c_ptr), value :: ctx; type(sqmc_step_params), intent(in) :: p; real(c_double), intent(out) :: out_stats(16)
+    end function
+    integer(c_int) function sqmc_gpu_get_rng(ctx, seed) bind(C, name='sqmc_gpu_get_rng')
+      import; type(c_ptr), value :: ctx; integer(c_int32_t), intent(out) :: seed(4)
+    end function
+    integer(c_int) function sqmc_gpu_set_rng(ctx, seed) bind(C, name='sqmc_gpu_set_rng')
+      import; type(c_ptr), value :: ctx; integer(c_int32_t), intent(in) :: seed(4)
+    end function
+    integer(c_int) function sqmc_gpu_spmv_prepare(n, row_counts, indices, values, plan) bind(C, name='sqmc_gpu_spmv_prepare')
+      import; integer(c_int64_t), value :: n; integer(c_int64_t), intent(in) :: row_counts(*), indices(*)
+      real(c_double), intent(in) :: values(*); type(c_ptr), intent(out) :: plan
+    end function
+    integer(c_int) function sqmc_gpu_spmv_apply(plan, x, y, on_device) bind(C, name='sqmc_gpu_spmv_apply')
+      import; type(c_ptr), value :: plan; real(c_double), intent(in) :: x(*); real(c_double), intent(out) :: y(*); integer(c_int), value :: on_device
+    end function
+    integer(c_int) function sqmc_gpu_spmv_free(plan) bind(C, name='sqmc_gpu_spmv_free')
+      import; type(c_ptr), value :: plan
+    end function
+    integer(c_int) function sqmc_gpu_spmv_sym_upper(n, row_counts, indices, values, x, y) bind(C, name='sqmc_gpu_spmv_sym_upper')
+      import; integer(c_int64_t), value :: n; integer(c_int64_t), intent(in) :: row_counts(*), indices(*)
+      real(c_double), intent(in) :: values(*), x(*); real(c_double), intent(out) :: y(*)
+    end function
+    integer(c_int) function sqmc_gpu_hamiltonian_batch(ctx, n, iu, id, ju, jd, h) bind(C, name='sqmc_gpu_hamiltonian_batch')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n; integer(c_int64_t), intent(in) :: iu(*), id(*), ju(*), jd(*)
+      real(c_double), intent(out) :: h(*)
+    end function
+    integer(c_int) function sqmc_gpu_hamiltonian_chem_batch(ctx, n, iu, id, ju, jd, h) bind(C, name='sqmc_gpu_hamiltonian_chem_batch')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n; integer(c_int64_t), intent(in) :: iu(*), id(*), ju(*), jd(*)
+      real(c_double), intent(out) :: h(*)
+    end function
+    integer(c_int) function sqmc_gpu_build_sparse_ham(ctx, n, up, dn, nnz, row_counts, indices, values) bind(C, name='sqmc_gpu_build_sparse_ham')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n; integer(c_int64_t), intent(in) :: up(*), dn(*)
+      integer(c_int64_t), intent(out) :: nnz; type(c_ptr), intent(out) :: row_counts, indices, values
+    end function
+    integer(c_int) function sqmc_gpu_propose_batch(ctx, n, tau, up, dn, seeds, ju, jd, weight_j, seeds_after) bind(C, name='sqmc_gpu_propose_batch')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n; real(c_double), value :: tau
+      integer(c_int64_t), intent(in) :: up(*), dn(*); integer(c_int32_t), intent(in) :: seeds(*)
+      integer(c_int64_t), intent(out) :: ju(*), jd(*); real(c_double), intent(out) :: weight_j(*); integer(c_int32_t), intent(out) :: seeds_after(*)
+    end function
+    integer(c_int) function sqmc_gpu_hci_connections(ctx, n_ref, ref_up, ref_dn, coeffs, eps, diag_mode, out_n, out_up, out_dn, out_num, out_den) &
+        bind(C, name='sqmc_gpu_hci_connections')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n_ref; integer(c_int64_t), intent(in) :: ref_up(*), ref_dn(*)
+      real(c_double), intent(in) :: coeffs(*); real(c_double), value :: eps; integer(c_int), value :: diag_mode
+      integer(c_int64_t), intent(out) :: out_n; type(c_ptr), intent(out) :: out_up, out_dn, out_num, out_den
+    end function
+    subroutine sqmc_gpu_free(p) bind(C, name='sqmc_gpu_free')
+      import; type(c_ptr), value :: p
+    end subroutine
+    integer(c_int) function sqmc_gpu_set_timing(ctx, on) bind(C, name='sqmc_gpu_set_timing')
+      import; type(c_ptr), value :: ctx; integer(c_int), value :: on
+    end function
+    integer(c_int) function sqmc_gpu_get_timing(ctx, n, names, ms) bind(C, name='sqmc_gpu_get_timing')
+      import; type(c_ptr), value :: ctx; integer(c_int32_t), intent(out) :: n; type(c_ptr), intent(out) :: names(*); real(c_float), intent(out) :: ms(*)
+    end function
+  end interface
+
+contains
+
+  !> Turns a non-zero status into the reference's way of failing: print the text and stop
+  !> (the reference stops with these very texts: 'nwalk>MWALK' do_walk.f90:3690, 'my_nwalk=0' :2492, ...).
+  subroutine sqmc_gpu_check(status, where)
+    integer(c_int), intent(in) :: status
+    character(len=*), intent(in) :: where
+    character(kind=c_char), pointer :: msg(:)
+    type(c_ptr) :: p
+    integer :: i
+    if (status == 0) return
+    p = sqmc_gpu_last_error()
+    write(6, '(a,a,a,i4)', advance='no') 'sqmc_gpu: ', where, ' failed with status', status
+    if (c_associated(p)) then
+      call c_f_pointer(p, msg, [512])
+      write(6, '(a)', advance='no') ': '
+      do i = 1, 512
+        if (msg(i) == c_null_char) exit
+        write(6, '(a)', advance='no') msg(i)
+      enddo
+    endif
+    write(6, *)
+    stop 'sqmc_gpu call failed'
+  end subroutine
+
+end module sqmc_gpu_mod

@@ -1,0 +1,398 @@
+"""Host side of the hot path: the run-once input handling the reference does on the CPU
+(FCIDUMP, orbital reordering, heat-bath table, trial wave function, deterministic space)
+and the scalar population-control logic of the walk loop.  Everything that touches more
+than a few thousand numbers goes through the HIP library; nothing here is a fallback.
+
+Mirrors (file:line relative to the reference's src/):
+  read_integrals / sort_integrals        chemistry.f90:538-869, 8921-9022
+  compute_orbital_energies               chemistry.f90:9378-9442
+  setup_efficient_heatbath (hci part)    chemistry.f90:900-993
+  generate_space_iterate (one iteration) semistoch.f90:145-560
+  generate_psi_t_connected_e_loc         semistoch.f90:27-133
+  initial population                     do_walk.f90:1245-1366
+  tau ramp, e_trial, reweight factor     do_walk.f90:2171-2184, 2880-2923
+  davidson_sparse                        more_tools.f90:2018-2244
+"""
+import numpy as np
+
+from ._lib import GpuChem, SpmvPlan, RNG_COUNTER
+
+_D2H = np.array([[1, 2, 3, 4, 5, 6, 7, 8], [2, 1, 4, 3, 6, 5, 8, 7], [3, 4, 1, 2, 7, 8, 5, 6], [4, 3, 2, 1, 8, 7, 6, 5],
+                 [5, 6, 7, 8, 1, 2, 3, 4], [6, 5, 8, 7, 2, 1, 4, 3], [7, 8, 5, 6, 3, 4, 1, 2], [8, 7, 6, 5, 4, 3, 2, 1]])
+_GROUP_ORDER = {"c1": 1, "cs": 2, "c2v": 4, "c2h": 4, "d2h": 8}
+
+
+def read_fcidump(path):
+    """Header (NORB, ORBSYM) + the (value, p, q, r, s) records."""
+    hdr, rows = "", []
+    with open(path) as f:
+        for line in f:
+            hdr += line
+            if "&END" in line.upper() or "/" in line:
+                break
+        data = np.loadtxt(f, ndmin=2)
+    import re
+    norb = int(re.search(r"NORB\s*=\s*(\d+)", hdr).group(1))
+    m = re.search(r"ORBSYM\s*=\s*([\d,\s]+)", hdr)
+    orbsym = [int(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip()][:norb] if m else [1] * norb
+    return norb, orbsym, data[:, 0].copy(), data[:, 1:5].astype(np.int64)
+
+
+def _dets_to_bits(det):
+    return [k for k in range(64) if (int(det) >> k) & 1]
+
+
+class ChemHost:
+    """Tables of module chemistry for one FCIDUMP, in the reference's conventions."""
+
+    def __init__(self, fcidump, nelec, nup, point_group="d2h", time_sym=False, z=1, n_core_orb=0):
+        self.norb, orbsym, vals, idx = read_fcidump(fcidump)
+        n, n1 = self.norb, self.norb + 1
+        self.nelec, self.nup, self.ndn = nelec, nup, nelec - nup
+        self.time_sym, self.z, self.n_core_orb = bool(time_sym), z, n_core_orb
+        self.n_group = _GROUP_ORDER[point_group]
+        self.prod = np.zeros((9, 9), np.int32)
+        self.prod[1:self.n_group + 1, 1:self.n_group + 1] = _D2H[:self.n_group, :self.n_group]
+        # identity-order combine_2 while reading (chemistry.f90:384-394)
+        c2 = np.zeros((n + 2, n + 2), np.int32)
+        i, j = np.meshgrid(np.arange(1, n1), np.arange(1, n1), indexing="ij")
+        hi, lo = np.maximum(i, j), np.minimum(i, j)
+        c2[1:n1, 1:n1] = (hi * (hi - 1)) // 2 + lo
+        c2[n1, n1] = (n1 * n) // 2 + n1
+        self._c2_id = c2
+        self.n_int = self._index(c2, n1, n1, n1, n1)
+        ints = np.zeros(self.n_int + 1)
+        p = idx.copy(); p[p == 0] = n1
+        keep = np.abs(vals) > 1e-9
+        ii = self._index(c2, p[:, 0], p[:, 1], p[:, 2], p[:, 3])
+        for k in np.nonzero(keep)[0]:          # later records overwrite earlier ones, as in the reference
+            ints[ii[k]] = vals[k]
+        self.integrals = ints
+        self.orbsym_file = np.array([0] + list(orbsym), np.int32)
+        # starting determinant: first orbitals (chemistry.f90:700-712)
+        hf_up, hf_dn = (1 << self.nup) - 1, (1 << self.ndn) - 1
+        self._finish(hf_up, hf_dn)
+
+    @staticmethod
+    def _index(c2, i, j, k, l):
+        a, b = c2[i, j].astype(np.int64) if hasattr(i, "__len__") else int(c2[i, j]), c2[k, l].astype(np.int64) if hasattr(k, "__len__") else int(c2[k, l])
+        hi, lo = np.maximum(a, b), np.minimum(a, b)
+        return (hi * (hi - 1)) // 2 + lo
+
+    def _iv(self, c2, p, q, r, s):
+        return self.integrals[self._index(c2, p, q, r, s)]
+
+    def _orbital_energies(self, hf_up, hf_dn):
+        n, n1, c2 = self.norb, self.norb + 1, self._c2_id
+        oe = np.zeros(n + 1)
+        for i in range(1, n + 1):
+            ex = di = 0.0
+            for j in range(1, n + 1):
+                if j != i and (hf_up >> (j - 1)) & 1: ex = ex - self._iv(c2, i, j, j, i)
+                if j != i and (hf_dn >> (j - 1)) & 1: ex = ex - self._iv(c2, i, j, j, i)
+            for j in range(1, n + 1):
+                if j != i and (hf_up >> (j - 1)) & 1: di = di + self._iv(c2, i, i, j, j)
+            for j in range(1, n + 1):
+                if (hf_dn >> (j - 1)) & 1: di = di + self._iv(c2, i, i, j, j)
+            for j in range(1, n + 1):
+                if j != i and (hf_dn >> (j - 1)) & 1: di = di + self._iv(c2, i, i, j, j)
+            for j in range(1, n + 1):
+                if (hf_up >> (j - 1)) & 1: di = di + self._iv(c2, i, i, j, j)
+            oe[i] = self._iv(c2, i, i, n1, n1) + .5 * (ex + di)
+        return oe
+
+    def _finish(self, hf_up, hf_dn):
+        """sort_integrals: orbital order by (occupied first, then orbital energy)."""
+        n, n1 = self.norb, self.norb + 1
+        oe = self._orbital_energies(hf_up, hf_dn)
+        tmp = oe.copy()
+        for i in range(1, n + 1):
+            if (hf_up >> (i - 1)) & 1: tmp[i] -= 1e9
+            if (hf_dn >> (i - 1)) & 1: tmp[i] -= 1e9
+        order, inv = np.zeros(n + 2, np.int32), np.zeros(n + 2, np.int32)
+        for i in range(1, n + 1):
+            j = 1 + int(np.argmin(tmp[1:]))
+            order[i], inv[j], tmp[j] = j, i, 1e99
+        order[n1] = inv[n1] = n1
+        self.orb_order, self.orb_order_inv = order, inv
+        self.orbsym = np.zeros(n + 1, np.int32); self.orbsym[1:] = self.orbsym_file[order[1:n1]]
+        self.orbital_energies = np.zeros(n + 1); self.orbital_energies[1:] = oe[order[1:n1]]
+        nu = sum(1 << (int(inv[k + 1]) - 1) for k in _dets_to_bits(hf_up))
+        nd = sum(1 << (int(inv[k + 1]) - 1) for k in _dets_to_bits(hf_dn))
+        if self.time_sym and nd < nu:
+            nu, nd = nd, nu
+        self.hf_up, self.hf_dn = nu, nd
+        a = order[1:n1][:, None].astype(np.int64); b = order[1:n1][None, :].astype(np.int64)
+        hi, lo = np.maximum(a, b), np.minimum(a, b)
+        c2 = np.zeros((n + 2, n + 2), np.int32)
+        c2[1:n1, 1:n1] = (hi * (hi - 1)) // 2 + lo
+        c2[n1, n1] = (n1 * n) // 2 + n1
+        self.combine_2 = c2
+
+    def gpu(self, **kw):
+        return GpuChem(self.norb, self.nup, self.ndn, self.orbsym, self.prod.reshape(-1), self.combine_2.reshape(-1), self.integrals,
+                       n_group=self.n_group, time_sym=self.time_sym, z=self.z, n_core_orb=self.n_core_orb, **kw)
+
+    def diag_lowest_highest(self, g):
+        nc, n = self.n_core_orb, self.norb
+        mk = lambda k: (1 << k) - 1
+        mu = mk(n) - mk(n + nc - self.nup) + mk(nc)
+        md = mk(n) - mk(n + nc - self.ndn) + mk(nc)
+        lo = g.hamiltonian_batch([self.hf_up], [self.hf_dn], [self.hf_up], [self.hf_dn])[0]
+        hi = g.hamiltonian_chem_batch([mu], [md], [mu], [md])[0]
+        return float(lo), float(hi)
+
+    def hb_tables(self, g):
+        """dtm_hb: for every electron-pair class (p,q) the (r,s,|H|) list, |H| descending.
+        Matrix elements come from the GPU (hamiltonian_chem on two-electron determinants,
+        like double_excitation_matrix_element_no_ref)."""
+        n = self.norb
+        c2i = lambda i, j: (max(i, j) * (max(i, j) - 1)) // 2 + min(i, j)
+        n_pq = c2i(n, 2 * n)
+        by_sym = {sy: [int(o) for o in np.nonzero(self.orbsym[1:] == sy)[0] + 1] for sy in range(1, self.n_group + 1)}
+        classes, cand_cls, cand_r, cand_s, dets = [], [], [], [], []
+        for opposite in (0, 1):
+            for p in range(1, n + 1):
+                for q in (range(n + p, 2 * n + 1) if opposite else range(p + 1, n + 1)):
+                    sym_q = self.prod[self.orbsym[p], self.orbsym[q - n if opposite else q]]
+                    ci = len(classes); classes.append(c2i(p, q))
+                    for r in range(1, n + 1):
+                        for s_ in by_sym[int(self.prod[sym_q, self.orbsym[r]])]:
+                            if not opposite and s_ < r:
+                                continue
+                            ss = s_ + n if opposite else s_
+                            if len({p, q, r, ss}) < 4:
+                                continue
+                            cand_cls.append(ci); cand_r.append(r); cand_s.append(ss)
+                            if opposite:
+                                dets.append((1 << (p - 1), 1 << (q - n - 1), 1 << (r - 1), 1 << (ss - n - 1)))
+                            else:
+                                dets.append(((1 << (p - 1)) | (1 << (q - 1)), 0, (1 << (r - 1)) | (1 << (s_ - 1)), 0))
+        D = np.array(dets, np.uint64)
+        h = np.abs(g.hamiltonian_chem_batch(D[:, 0], D[:, 1], D[:, 2], D[:, 3]))
+        cls, rr, ss = np.array(cand_cls), np.array(cand_r, np.int32), np.array(cand_s, np.int32)
+        nz = h != 0.0
+        cls, rr, ss, h = cls[nz], rr[nz], ss[nz], h[nz]
+        order = np.lexsort((np.arange(len(h)), -h, cls))       # class, |H| descending, generation order on ties
+        cls, rr, ss, h = cls[order], rr[order], ss[order], h[order]
+        per = np.bincount(cls, minlength=len(classes))
+        start = np.concatenate(([0], np.cumsum(per)))
+        pq_ind, pq_count = np.zeros(n_pq + 1, np.int64), np.zeros(n_pq + 1, np.int32)
+        for ci, e in enumerate(classes):
+            pq_ind[e], pq_count[e] = start[ci] + 1, per[ci]
+        self.hb = (rr, ss, h, pq_ind, pq_count, float(h.max()))
+        return self.hb
+
+
+# ----------------------------------------------------------------------------- Davidson
+def davidson_lowest(plan, diag, k=1, v0=None, tol=1e-10, max_iter=200, max_space=40):
+    """Lowest k eigenpairs with the GPU matvec (davidson_sparse, more_tools.f90:2018-2244:
+    diagonal preconditioner, small Krylov matrix diagonalised on the host)."""
+    n = len(diag)
+    if v0 is None:
+        v0 = np.zeros((n, k))
+        for j, i in enumerate(np.argsort(diag)[:k]):
+            v0[i, j] = 1.0
+    V = np.linalg.qr(v0.reshape(n, -1))[0]
+    AV = np.stack([plan.apply(V[:, j]) for j in range(V.shape[1])], axis=1)
+    for it in range(max_iter):
+        G = V.T @ AV
+        w, y = np.linalg.eigh((G + G.T) / 2)
+        w, y = w[:k], y[:, :k]
+        X, AX = V @ y, AV @ y
+        R = AX - X * w
+        res = np.linalg.norm(R, axis=0)
+        if np.all(res < tol):
+            return w, X
+        if V.shape[1] + k > max_space:
+            V, AV = np.linalg.qr(X)[0], None
+            AV = np.stack([plan.apply(V[:, j]) for j in range(V.shape[1])], axis=1)
+            continue
+        new = []
+        for j in range(k):
+            if res[j] < tol:
+                continue
+            d = diag - w[j]
+            d[np.abs(d) < 1e-8] = 1e-8
+            t = R[:, j] / d
+            t -= V @ (V.T @ t); t -= V @ (V.T @ t)
+            nt = np.linalg.norm(t)
+            if nt > 1e-12:
+                new.append(t / nt)
+        if not new:
+            return w, X
+        Vn = np.stack(new, axis=1)
+        Vn = np.linalg.qr(Vn - V @ (V.T @ Vn))[0]
+        AV = np.concatenate((AV, np.stack([plan.apply(Vn[:, j]) for j in range(Vn.shape[1])], axis=1)), axis=1)
+        V = np.concatenate((V, Vn), axis=1)
+    return w, X
+
+
+def sort_dets(up, dn):
+    return np.lexsort((dn, up))
+
+
+def lowest_state(g, up, dn, k=1, v0=None):
+    """Sparse H on the GPU (all-pairs builder) + Davidson with the GPU matvec."""
+    counts, idx, val = g.build_sparse_ham(up, dn)
+    starts = np.concatenate(([0], np.cumsum(counts)))[:-1]
+    diag = val[starts]
+    plan = SpmvPlan(counts, idx, val)
+    try:
+        w, X = davidson_lowest(plan, diag, k=k, v0=v0)
+    finally:
+        plan.close()
+    return w, X, (counts, idx, val)
+
+
+def _truncate_at_csf(c_sorted, n_keep, eps=1e-10):
+    prev = 0.0
+    for i, v in enumerate(c_sorted):
+        if abs(abs(prev) - abs(v)) > eps:
+            prev = v
+            if i + 1 > n_keep:
+                return i
+    return len(c_sorted)
+
+
+class WalkSetup:
+    pass
+
+
+def setup_walk(host, g, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1):
+    """Psi_T, C(T) and the deterministic space from one connect-diagonalise-truncate pass."""
+    s = WalkSetup()
+    tiny = 1e-300
+    up, dn, _, _ = g.hci_connections([host.hf_up], [host.hf_dn], [1.0], tiny)     # sorted, unique
+    w, X, _ = lowest_state(g, up, dn)
+    c = X[:, 0]
+    if c[np.argmax(np.abs(c))] < 0:
+        c = -c
+    by = np.argsort(-np.abs(c), kind="stable")
+    up_s, dn_s, c_s = up[by], dn[by], c[by]
+    n_t, n_i = _truncate_at_csf(c_s, n_truncate_trial_wf), _truncate_at_csf(c_s, size_deterministic)
+    s.psi_up, s.psi_dn = up_s[:n_t].copy(), dn_s[:n_t].copy()
+    s.psi_c = c_s[:n_t] / np.sqrt(np.dot(c_s[:n_t], c_s[:n_t]))
+    o = sort_dets(up_s[:n_i], dn_s[:n_i])
+    s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
+    lo, hi = host.diag_lowest_highest(g)
+    s.tau, s.e_var = tau_multiplier / (hi - lo), float(w[0])
+    pc, pi, pv = g.build_sparse_ham(s.imp_up, s.imp_dn)
+    s.prj_counts, s.prj_indices, s.prj_values = pc, pi, -s.tau * pv
+    s.ct_up, s.ct_dn, s.ct_num, s.ct_den = g.hci_connections(s.psi_up, s.psi_dn, s.psi_c, tiny, diag_mode=1)
+    s.e_trial0 = float(np.dot(s.ct_num, s.ct_den) / np.dot(s.ct_den, s.ct_den))
+    return s
+
+
+def initial_walkers(s, w_abs_gen_begin, r_initiator=1.0, initiator_power=0):
+    """do_walk.f90:1245-1366: deterministic-space dets (weight 0, initiator 2, imp_distance 0)
+    + Psi_T dets (weight w_begin*c/sum|c|, permanent initiators where |c| ~ max|c|), equal
+    determinants combined, sorted by (up,dn)."""
+    cmax, csum = np.max(np.abs(s.psi_c)), np.sum(np.abs(s.psi_c))
+    recs = {(int(a), int(b)): [0.0, 2, 0, 0] for a, b in zip(s.imp_up, s.imp_dn)}
+    scale = min(w_abs_gen_begin * cmax / csum, 1.0)
+    for a, b, c in zip(s.psi_up.tolist(), s.psi_dn.tolist(), s.psi_c.tolist()):
+        wt, perm = (w_abs_gen_begin * c / csum) / scale, abs(abs(c) - cmax) < 1e-3
+        r = recs.get((a, b))
+        if r is None:
+            recs[(a, b)] = [wt, 3 if perm else 2, 0 if perm else 1, int(np.sign(c)) if perm else 0]
+        else:
+            r[0] += wt
+            if perm:
+                r[1], r[3] = 3, int(np.sign(c))
+    keys = sorted(recs)
+    n = len(keys)
+    out = dict(up=np.array([k[0] for k in keys], np.uint64), dn=np.array([k[1] for k in keys], np.uint64),
+               wt=np.array([recs[k][0] for k in keys]), initiator=np.array([recs[k][1] for k in keys], np.int8),
+               imp_distance=np.array([recs[k][2] for k in keys], np.int8), perm_sign=np.array([recs[k][3] for k in keys], np.int8),
+               matrix_elements=np.full(n, 1e51), e_num=np.full(n, 1e51), e_den=np.full(n, 1e51))
+    d, ini, aw = out["imp_distance"].astype(int), out["initiator"], np.abs(out["wt"])
+    thr = r_initiator * np.where(initiator_power == 0, 1.0, np.maximum(d, 0).astype(float) ** initiator_power)
+    ini[(ini == 2) & (aw <= thr) & (d > 0)] = 1
+    keep = ~((out["wt"] == 0) & (out["imp_distance"] >= 1))
+    return {k: v[keep] for k, v in out.items()}
+
+
+class PopControl:
+    """Scalars around sqmc_gpu_step: tau/r_initiator ramp until the target population is first
+    reached (do_walk.f90:2175-2184, 2913-2923), e_est / e_trial / reweight_factor_inv
+    (2880-2901).  The first n_equil_steps steps count as equilibration."""
+
+    def __init__(self, tau, e_trial, w_target, r_initiator=1.0, initiator_rescale_power=1.0, pop_exp=10.0, rfi_max_multiplier=1.0,
+                 n_equil_steps=10**9):
+        self.tau_sav = self.tau = self.tau_prev = tau
+        self.e_trial = self.e_est = e_trial
+        self.w_target, self.r_init_sav, self.r_init, self.irp, self.pop_exp = w_target, r_initiator, r_initiator, initiator_rescale_power, pop_exp
+        self.rfi, self.rfi_max, self.reached = 1.0, 1.0 + rfi_max_multiplier * tau, 0
+        self.n_equil, self.istep, self.e_num_cum, self.e_den_cum, self.w_abs_gen = n_equil_steps, 0, 0.0, 0.0, None
+
+    def pre_step(self, w_abs_gen):
+        if self.reached != 0:
+            return 1.0
+        f = 1.0 + np.log(self.w_target / w_abs_gen)
+        self.tau = self.tau_sav * f
+        self.r_init = self.r_init_sav * f ** self.irp
+        return self.tau / self.tau_prev
+
+    def post_step(self, out):
+        self.istep += 1
+        w_abs_gen, e_den_gen, e_num_gen = out[1], out[2], out[3]
+        self.e_num_cum += e_num_gen * np.sign(e_den_gen) if e_den_gen != 0 else 0.0
+        self.e_den_cum += abs(e_den_gen)
+        if self.e_den_cum != 0:
+            self.e_est = self.e_num_cum / self.e_den_cum
+        pw = min(1.0, self.tau * self.pop_exp)
+        if self.istep <= self.n_equil:
+            d = self.e_est - self.e_trial
+            self.e_trial = self.e_trial + np.sign(d) * min(abs(d), 1.0)
+            self.rfi = min(2.0, max(0.5, (self.w_target / w_abs_gen) ** pw))
+        else:
+            self.rfi = min(2.0, max(0.5, (1.0 / (1.0 + self.tau * (self.e_trial - self.e_est))) * (self.w_target / w_abs_gen) ** pw))
+        self.rfi = min(self.rfi, self.rfi_max)
+        ratio = 1.0
+        if self.reached == 0 and w_abs_gen >= self.w_target:
+            self.reached, ratio = 2, self.tau_sav / self.tau
+            self.tau, self.r_init = self.tau_sav, self.r_init_sav
+        self.tau_prev, self.w_abs_gen = self.tau, w_abs_gen
+        return ratio
+
+    def params(self, min_wt=0.5, cutoff=0.5, initiator_power=0, semistochastic=1):
+        return dict(tau=self.tau, e_trial=self.e_trial, reweight_factor_inv=self.rfi, r_initiator=self.r_init, min_wt=min_wt,
+                    always_spawn_cutoff_wt=cutoff, initiator_power=initiator_power, initiator_min_distance=0, c_t_initiator=0,
+                    semistochastic=semistochastic, reached_w_abs_gen=self.reached)
+
+
+class GpuWalk:
+    """A C2-style semistochastic walk resident on one GPU."""
+
+    def __init__(self, host, w_target, w_begin=None, mwalk=None, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1,
+                 e_trial=None, seed=(1346, 5634, 6635, 4361), rng_mode=RNG_COUNTER, min_wt=0.5):
+        self.host = host
+        w_begin = w_begin if w_begin is not None else w_target
+        mwalk = mwalk or int(max(4 * (w_target / min_wt + size_deterministic), 200000))
+        self.g = host.gpu(rng_mode=rng_mode, seed=seed, mwalk=mwalk)
+        host.hb_tables(self.g)
+        self.g.set_hb_tables(*host.hb)
+        self.setup = s = setup_walk(host, self.g, n_truncate_trial_wf, size_deterministic, tau_multiplier)
+        self.g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
+        self.g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
+        wk = initial_walkers(s, w_begin)
+        self.g.upload_walkers(wk)
+        self.pc = PopControl(s.tau, e_trial if e_trial is not None else s.e_trial0, w_target)
+        self.w_abs = float(np.abs(wk["wt"]).sum())
+        self.min_wt = min_wt
+        self.last = None
+
+    def step(self):
+        r = self.pc.pre_step(self.w_abs)
+        if r != 1.0:
+            self.g.scale_projector(r)
+        out = self.g.step(self.pc.params(min_wt=self.min_wt))
+        r = self.pc.post_step(out)
+        if r != 1.0:
+            self.g.scale_projector(r)
+        self.w_abs, self.last = out[1], out
+        return out
+
+    def close(self):
+        self.g.close()

@@ -209,3 +209,89 @@ def test_walk_invariants_large(oracle, c2_walk, c2_setup):
     assert np.isclose(w["wt"].sum(), out[0], rtol=1e-10, atol=1e-8)
     assert np.isclose((w["e_num"] * w["wt"]).sum(), out[3], rtol=1e-10)
     assert -75.9 < out[3] / out[2] < -75.5
+
+
+def test_gpu_reproduces_golden_walk_fixture(oracle, c2_walk):
+    """The committed five-step fixture (tests/golden/walk_c2_5steps.json), REPLAY stream."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "walk_c2_5steps.json")))
+    setup = oracle.setup_walk(c2_walk, 100, 1000, 0.1, coeffs="pt1")
+    g = gpu_ctx_from_oracle(c2_walk, rng_mode=0, seed=gold["seed"], mwalk=200000)
+    g.set_projector(setup.prj_counts, setup.prj_indices, setup.prj_values)
+    g.set_ct_table(setup.ct_up, setup.ct_dn, setup.ct_num, setup.ct_den)
+    wk = oracle.initial_walkers(setup, gold["w_abs_gen_begin"])
+    g.upload_walkers(wk)
+    pc = oracle.PopControl(setup.tau, gold["e_trial"], gold["w_target"])
+    w_abs = float(np.abs(wk["wt"]).sum())
+    for k in range(5):
+        r = pc.pre_step(w_abs)
+        if r != 1.0: g.scale_projector(r)
+        out = g.step(pc.params())
+        ref = np.array([float.fromhex(x) for x in gold["steps"][k]])
+        assert out[5] == ref[5] and out[7] == ref[7] and out[15] == ref[15]
+        assert np.allclose(out, ref, rtol=1e-11, atol=1e-11)
+        r = pc.post_step(ref)
+        if r != 1.0: g.scale_projector(r)
+        w_abs = ref[1]
+    w = g.download_walkers()
+    assert g.rng_state() == gold["rng_after"]
+    assert int(np.bitwise_xor.reduce(w["up"] * np.uint64(0x9E3779B97F4A7C15) + w["dn"])) == gold["det_checksum"]
+    g.close()
+
+
+def test_host_tables_and_sparse_ham_match_oracle(oracle, c2_walk, c2_setup):
+    """The product's own input handling (sqmc_amd/host.py) builds the same tables as the
+    oracle; the GPU all-pairs Hamiltonian builder returns the oracle's matrix bit for bit."""
+    from conftest import FCIDUMP
+    from sqmc_amd import host as H
+    h = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+    assert (h.hf_up, h.hf_dn) == (c2_walk.hf_up, c2_walk.hf_dn)
+    assert np.array_equal(h.integrals, c2_walk.integrals()) and np.array_equal(h.combine_2, c2_walk.combine_2())
+    assert np.array_equal(h.orbsym, c2_walk.orbsym())
+    g = h.gpu()
+    hb = h.hb_tables(g)
+    r, s_, a, pi, pc = c2_walk.hb_tables()
+    assert np.array_equal(hb[0], r) and np.array_equal(hb[1], s_) and np.array_equal(hb[2], a)
+    assert np.array_equal(hb[3], pi) and np.array_equal(hb[4], pc) and hb[5] == c2_walk.s.max_double
+    rc, ix, vl = g.build_sparse_ham(c2_setup.imp_up, c2_setup.imp_dn)
+    oc, oi, ov = c2_walk.build_sparse_ham(c2_setup.imp_up, c2_setup.imp_dn)
+    assert np.array_equal(rc, oc) and np.array_equal(ix, oi) and np.array_equal(vl, ov)
+    g.set_hb_tables(*hb)
+    ws = H.setup_walk(h, g)
+    assert len(ws.psi_up) == len(c2_setup.psi_up) and len(ws.imp_up) == len(c2_setup.imp_up)
+    assert abs(ws.e_var - c2_setup.e_var) < 1e-9 and abs(ws.tau - c2_setup.tau) < 1e-15
+    # C(T) from the GPU generator holds every determinant with a non-zero numerator of the oracle's
+    oct_ = {(int(a_), int(b_)): (n_, d_) for a_, b_, n_, d_ in zip(c2_setup.ct_up, c2_setup.ct_dn, c2_setup.ct_num, c2_setup.ct_den)}
+    for a_, b_, n_, d_ in zip(ws.ct_up[::37], ws.ct_dn[::37], ws.ct_num[::37], ws.ct_den[::37]):
+        on, od = oct_[(int(a_), int(b_))]
+        assert abs(on - n_) < 1e-9 and abs(od - d_) < 1e-9
+    g.close()
+
+
+def test_hci_time_sym_hamiltonian_builder(oracle, c2_hci):
+    """time-reversal-symmetrised matrix (the HCI deck's conventions) from the GPU builder."""
+    g = gpu_ctx_from_oracle(c2_hci)
+    cu, cd, _ = c2_hci.important_connected(c2_hci.hf_up, c2_hci.hf_dn, 2e-3)
+    keys = sorted(set(zip(cu.tolist(), cd.tolist())))
+    up = np.array([k[0] for k in keys], np.uint64); dn = np.array([k[1] for k in keys], np.uint64)
+    rc, ix, vl = g.build_sparse_ham(up, dn)
+    oc, oi, ov = c2_hci.build_sparse_ham(up, dn)
+    g.close()
+    assert np.array_equal(rc, oc) and np.array_equal(ix, oi) and np.array_equal(vl, ov)
+    w, _ = oracle.lowest_eigs(rc, ix, vl, k=1)
+    assert abs(w[0] - (-75.654492433)) < 5e-9       # HCI iteration 1 energy of the reference-pinned oracle run
+
+
+def test_fortran_host_example():
+    """The Fortran iso_c_binding host (sqmc_amd/fortran/example_spmv.f90) runs against the library."""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(__file__)), "sqmc_amd", "fortran", "example_spmv")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran example not built")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "fortran host: OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
