@@ -91,8 +91,8 @@ static inline void device_excl_scan_u64(const u64 *in, u64 *out, long long n, u6
 
 // ------------------------------------------------------------------------ radix sort
 #define RS_MAX_RADIX 1024                   // 10-bit digits at most
-#define RS_WAVE_ITEMS 32                    // rounds of 64 keys per wave
-#define RS_TILE (64 * RS_WAVE_ITEMS)        // 2048 keys per wavefront
+#define RS_WAVE_ITEMS 16                    // rounds of 64 keys per wave
+#define RS_TILE (64 * RS_WAVE_ITEMS)        // 1024 keys per wavefront
 
 // histogram: hist[digit * ntiles + tile]
 template <int BITS>
@@ -103,9 +103,16 @@ __global__ void __launch_bounds__(64) rs_hist_kernel(const u64 *__restrict__ key
   for (int d = lane; d < RS_RADIX; d += 64) cnt[d] = 0;
   __syncthreads();
   long long base = (long long)blockIdx.x * RS_TILE;
+  u64 kreg[RS_WAVE_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RS_WAVE_ITEMS; r++) {          // all loads of the tile in flight at once
+    long long i = base + (long long)r * 64 + lane;
+    kreg[r] = (i < n) ? keys[i] : ~0ull;
+  }
+#pragma unroll
   for (int r = 0; r < RS_WAVE_ITEMS; r++) {
     long long i = base + (long long)r * 64 + lane;
-    if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & (RS_RADIX - 1)], 1u);
+    if (i < n) atomicAdd(&cnt[(kreg[r] >> shift) & (RS_RADIX - 1)], 1u);
   }
   __syncthreads();
   for (int d = lane; d < RS_RADIX; d += 64) hist[(long long)d * ntiles + blockIdx.x] = cnt[d];
@@ -151,10 +158,17 @@ __global__ void __launch_bounds__(64) rs_scatter_kernel(const u64 *__restrict__ 
   __syncthreads();
   long long base = (long long)blockIdx.x * RS_TILE;
   const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  u64 kreg[RS_WAVE_ITEMS]; u32 vreg[RS_WAVE_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RS_WAVE_ITEMS; r++) {          // the whole tile goes to registers first
+    long long i = base + (long long)r * 64 + lane;
+    kreg[r] = (i < n) ? kin[i] : 0; vreg[r] = (i < n) ? vin[i] : 0;
+  }
+#pragma unroll
   for (int r = 0; r < RS_WAVE_ITEMS; r++) {
     long long i = base + (long long)r * 64 + lane;
     bool valid = i < n;
-    u64 key = valid ? kin[i] : 0; u32 val = valid ? vin[i] : 0;
+    u64 key = kreg[r]; u32 val = vreg[r];
     u32 dig = (u32)((key >> shift) & (RS_RADIX - 1));
     u64 same = __ballot(valid);
 #pragma unroll

@@ -209,22 +209,31 @@ __global__ void __launch_bounds__(TPB) k_prj_gather(const double *__restrict__ w
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i < n) x[i] = wt[loc[i]];
 }
-// one wavefront per row: the 64 products of a chunk are formed in parallel (coalesced loads),
-// then added in storage order through lane broadcasts, so y is bit-identical to the
-// reference's sequential accumulation.
+// one wavefront per row: the 64 products of a chunk are formed in parallel (coalesced loads)
+// and parked in LDS, then added in storage order (LDS broadcast reads, only the fp64 adds
+// are on the dependent chain), so y is bit-identical to the reference's sequential
+// accumulation even for the HF row that touches the whole deterministic space.
 __global__ void __launch_bounds__(TPB) k_prj_apply(const int *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val,
                                                    const double *__restrict__ x, const int *__restrict__ loc, double *__restrict__ wt,
                                                    long long n, double e_trial, double tau) {
-  const long long i = (long long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+  __shared__ double sprod[TPB / 64][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * (TPB / 64) + wv;
   if (i >= n) return;
   const int b = ptr[i], e = ptr[i + 1];
   double y = 0.0;
   for (int base = b; base < e; base += 64) {
     const int k = base + lane;
-    const double pr = (k < e) ? val[k] * x[col[k]] : 0.0;
+    sprod[wv][lane] = (k < e) ? val[k] * x[col[k]] : 0.0;
+    __builtin_amdgcn_wave_barrier();
     const int cnt = (e - base < 64) ? (e - base) : 64;
-    for (int l = 0; l < cnt; l++) y = y + __shfl(pr, l, 64);
+    if (cnt == 64) {
+#pragma unroll
+      for (int l = 0; l < 64; l++) y = y + sprod[wv][l];
+    } else {
+      for (int l = 0; l < cnt; l++) y = y + sprod[wv][l];
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   if (lane == 0) {
     y = y + e_trial * tau * x[i];
@@ -333,11 +342,11 @@ __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64
                                                  int *__restrict__ loc_imp, const u64 *__restrict__ cu, const u64 *__restrict__ cd,
                                                  const double *__restrict__ cnum, const double *__restrict__ cden, long long n_ct,
                                                  long long n_all, StepP p, double *__restrict__ partials) {
-  long long j = (long long)blockIdx.x * TPB + threadIdx.x;
   double s[NSTAT];
 #pragma unroll
   for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
-  if (j < n_all && (flags2[j] & 1ull)) {
+  for (long long j = (long long)blockIdx.x * TPB + threadIdx.x; j < n_all; j += (long long)gridDim.x * TPB) {
+    if (!(flags2[j] & 1ull)) continue;
     const u64 ps = pos2[j]; const long long o = (long long)(ps & 0xFFFFFFFFull);
     const u64 u = m.up[j], dd = m.dn[j];
     const double wt = m.wt[j] * p.rfi;
@@ -350,14 +359,14 @@ __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64
     w.up[o] = u; w.dn[o] = dd; w.wt[o] = wt; w.impd[o] = (int8_t)d; w.init[o] = (int8_t)ini; w.psign[o] = (int8_t)psg;
     w.me[o] = m.me[j]; w.en[o] = en; w.ed[o] = ed;
     if (d == 0) loc_imp[ps >> 32] = (int)o;
-    s[0] = wt; s[1] = fabs(wt); s[8] = wt * wt;
-    if (ini == 3) s[4] = wt * psg;
-    if (d == 0 || (d == -2 && p.cti)) s[6] = fabs(wt);
+    s[0] += wt; s[1] += fabs(wt); s[8] += wt * wt;
+    if (ini == 3) s[4] += wt * psg;
+    if (d == 0 || (d == -2 && p.cti)) s[6] += fabs(wt);
     double e_num = en * wt, e_den = ed * wt;
     if (e_num != 0.0) {
       if (fabs(e_den) < 1e-22) e_den = fabs(e_den);
-      s[2] = e_den; s[3] = e_num; s[9] = e_num * e_num; s[10] = e_den * e_den;
-      s[11] = e_num * copysign(1.0, e_den); s[12] = fabs(e_den); s[5] = e_num * e_den;
+      s[2] += e_den; s[3] += e_num; s[9] += e_num * e_num; s[10] += e_den * e_den;
+      s[11] += e_num * copysign(1.0, e_den); s[12] += fabs(e_den); s[5] += e_num * e_den;
     }
   }
   // deterministic block reduction (wave shuffles, then 4 wave sums in LDS)
@@ -911,7 +920,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   hipLaunchKernelGGL(k_round, dim3(nblk(nall)), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, c->d_flags2, nall, p, mode, seed, step, c->d_sc);
   device_excl_scan_u64(c->d_flags2, c->d_pos2, nall, &c->d_sc->tot2, sw, st);
   TMARK("round");
-  const int nb = nblk(nall);
+  const int nb = std::min(nblk(nall), 512);
   hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, st, c->m, c->w, c->d_flags2, c->d_pos2, c->d_loc_imp, c->d_ct_up, c->d_ct_dn, c->d_ct_num, c->d_ct_den,
                      c->n_ct, nall, p, c->d_partials + 64);
   hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials + 64, nb, c->d_partials, nall, mode, c->d_sc);
