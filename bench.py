@@ -22,6 +22,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 FCIDUMP = os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# HBM bytes per k_spawn launch from the PMC passes in profiles/ (FETCH_SIZE doubled as the guide
+# prescribes for gfx950, + WRITE_SIZE, KiB -> bytes); None until measured for the current kernel.
+TRAFFIC_K_SPAWN = None
 
 
 def main():
@@ -47,15 +50,13 @@ def main():
     sqmc_amd.set_device(local)
 
     hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
-    seed = (1346, 5634, 6635, (4361 + 2 * rank) % 10000)
-    walk = H.GpuWalk(hst, args.target, seed=seed)
-    red = torch.zeros(8, dtype=torch.float64, device="cuda") if world > 1 else None
+    walk = H.GpuWalk(hst, args.target, seed=H.rank_seed((1346, 5634, 6635, 4361), rank))
+    dev = torch.device("cuda", local)
 
     def one_step():
         out = walk.step()
-        if world > 1:                      # the 7 reduced sums of do_walk.f90:2689-2725
-            red[:7] = torch.from_numpy(out[:7].copy()).cuda()
-            dist.all_reduce(red)
+        if world > 1:                      # the 7 reduced sums of do_walk.f90:2689-2725 (global estimators)
+            H.allreduce_step_sums(out, device=dev)
         return out
 
     for _ in range(args.equil):
@@ -92,13 +93,13 @@ def main():
 
     if rank == 0:
         value = nwalk_all / dt
-        # dominant kernel stage of the step, timed live with HIP events on the library's stream
-        dom = max(stage_ms, key=stage_ms.get)
+        # dominant single kernel of the step: k_spawn (one launch per step; the "spawn" timer is the
+        # pair of HIP events recorded on the library's stream right around that launch).
+        # Algorithmic bytes per launch = 84 B per child proposal x children.
         n_avg, s_avg = nwalk_sum / args.steps, spawn_sum / args.steps
-        alg_bytes = {"sort": 24.0 * 3 * (n_avg + s_avg), "spawn": 84.0 * s_avg, "merge": 68.0 * (n_avg + s_avg),
-                     "estimate": 68.0 * n_avg, "project": 20.0 * 2 * len(walk.setup.prj_values), "gate+scan": 24.0 * n_avg,
-                     "diag": 34.0 * n_avg, "round": 24.0 * (n_avg + s_avg)}
-        ach = alg_bytes.get(dom, 0.0) / (stage_ms[dom] / args.steps * 1e-3) / 1e9
+        dom, dom_ms = "k_spawn", stage_ms["spawn"] / args.steps
+        ach = 84.0 * s_avg / (dom_ms * 1e-3) / 1e9
+        step_bytes = 68.0 * n_avg + 84.0 * s_avg
         line = {
             "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -108,7 +109,9 @@ def main():
                        "occupied_dets_per_step": n_avg, "spawns_per_step": s_avg, "spawns_per_s": spawn_all / dt,
                        "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "ms_per_launch": stage_ms[dom] / args.steps,
+                         "traffic": TRAFFIC_K_SPAWN, "ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": 84.0 * s_avg,
+                         "whole_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
+                                        "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
                          "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()}},
         }
         if not args.no_cpu_baseline:

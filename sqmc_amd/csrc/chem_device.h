@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 
 typedef unsigned long long u64;
 
@@ -26,8 +27,9 @@ struct ChemTab {
   u64 sym_mask[SQ_MAXSYM + 1];         // orbitals of each irrep (which_orb_by_sym as a bitmask)
   unsigned char prod[SQ_MAXSYM + 1][SQ_MAXSYM + 1];
   unsigned char orbsym[SQ_MAXORB + 1]; // 1-based
-  unsigned short c2[SQ_MAXORB + 2][SQ_MAXORB + 2];   // combine_2, 1-based
   double nuclear;
+  int c2_stride, c2_pad;               // combine_2 is stored packed: c2[i*c2_stride + j], 1-based
+  unsigned short c2[(SQ_MAXORB + 2) * (SQ_MAXORB + 2)];   // only the first c2_stride^2 entries are used/staged
 };
 
 #define SQ_BINOM_STRIDE 33
@@ -42,7 +44,9 @@ struct ChemDev {                        // pointers into HBM, passed by value
 };
 
 __device__ __forceinline__ void stage_tab(ChemTab *dst, const ChemTab *src) {
-  const int n = (int)(sizeof(ChemTab) / sizeof(int));
+  // header + the used part of combine_2 only (norb=26: 2.3 KB instead of 9.4 KB per block)
+  const int used = src->c2_stride * src->c2_stride;
+  const int n = (int)((offsetof(ChemTab, c2) + (size_t)used * sizeof(unsigned short) + sizeof(int) - 1) / sizeof(int));
   const int *s = reinterpret_cast<const int *>(src);
   int *d = reinterpret_cast<int *>(dst);
   for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
@@ -100,7 +104,7 @@ __host__ __device__ __forceinline__ u64 lcg_skip(u64 x, u64 k) {
 
 // ------------------------------------------------------------------------ integrals
 __device__ __forceinline__ int integral_index(const ChemTab &t, int i, int j, int k, int l) {
-  int a = t.c2[i][j], b = t.c2[k][l];
+  int a = t.c2[i * t.c2_stride + j], b = t.c2[k * t.c2_stride + l];
   return (a > b) ? (a * (a - 1)) / 2 + b : (b * (b - 1)) / 2 + a;
 }
 #define IVAL(p, q, r, s) (ints[integral_index(t, (p), (q), (r), (s))])

@@ -396,3 +396,30 @@ class GpuWalk:
 
     def close(self):
         self.g.close()
+
+
+# ------------------------------------------------------------------------ multi-rank glue
+def rank_seed(seed, rank):
+    """Seed 2 of input line 1 is offset by the rank (do_walk.f90:234: irand_seed(:,2)+rank);
+    rannyu forces the last limb odd, so ranks step by 2 to stay distinct."""
+    s = list(seed)
+    s[3] = (s[3] + 2 * rank) % 10000
+    return tuple(s)
+
+
+def allreduce_step_sums(out, device=None):
+    """The MPI_Allreduce of do_walk.f90:2778 on the 7 per-step sums (w_gen, w_abs_gen,
+    e_den_gen, e_num_gen, w_perm_initiator_gen, nwalk, w_abs_gen_imp): torch.distributed SUM
+    (RCCL when the group backend is nccl, gloo on CPU).  Returns the reduced copy; entries
+    7..15 stay rank-local.  No-op without an initialised process group."""
+    import torch
+    import torch.distributed as dist
+    res = np.array(out, dtype=np.float64, copy=True)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return res
+    t = torch.from_numpy(res[:7].copy())
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    res[:7] = t.cpu().numpy()
+    return res
