@@ -53,17 +53,10 @@ def main():
     walk = H.GpuWalk(hst, args.target, seed=H.rank_seed((1346, 5634, 6635, 4361), rank))
     dev = torch.device("cuda", local)
 
-    def one_step():
-        out = walk.step()
-        if world > 1:                      # the 7 reduced sums of do_walk.f90:2689-2725 (global estimators)
-            H.allreduce_step_sums(out, device=dev)
-        return out
-
-    for _ in range(args.equil):
-        one_step()
-    for _ in range(args.warmup):
-        one_step()
-    walk.g.set_timing(True)
+    # equilibration + warmup (untimed), then EXACTLY --steps timed steps inside sqmc_gpu_run
+    walk.run(args.equil, keep_stats=False)
+    walk.run(args.warmup, keep_stats=False)
+    walk.g.set_timing(1)           # HIP events around the k_spawn launch only, accumulated over the timed steps
 
     def fence():
         torch.cuda.synchronize()
@@ -73,17 +66,15 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    nwalk_sum = spawn_sum = 0.0
-    stage_ms = {}
-    e_num = e_den = 0.0
-    for _ in range(args.steps):
-        out = one_step()
-        nwalk_sum += out[5]; spawn_sum += out[15]
-        e_num += out[3] * np.sign(out[2]); e_den += abs(out[2])
-        for name, ms in walk.g.timing():
-            stage_ms[name] = stage_ms.get(name, 0.0) + ms
+    stats, totals = walk.run(args.steps, keep_stats=True)
     fence()
     dt = time.perf_counter() - t0
+    nwalk_sum, spawn_sum = float(totals[5]), float(totals[15])
+    e_num, e_den = float((stats[:, 3] * np.sign(stats[:, 2])).sum()), float(np.abs(stats[:, 2]).sum())
+    spawn_ms = dict(walk.g.timing())["spawn"]          # mean ms per k_spawn launch over the K timed steps
+    walk.g.set_timing(2)                                # informational stage breakdown from an untimed tail
+    walk.run(20, keep_stats=False)
+    stage_ms = dict(walk.g.timing())
     tot = torch.tensor([nwalk_sum, spawn_sum, dt], dtype=torch.float64, device="cuda")
     if world > 1:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -97,7 +88,7 @@ def main():
         # pair of HIP events recorded on the library's stream right around that launch).
         # Algorithmic bytes per launch = 84 B per child proposal x children.
         n_avg, s_avg = nwalk_sum / args.steps, spawn_sum / args.steps
-        dom, dom_ms = "k_spawn", stage_ms["spawn"] / args.steps
+        dom, dom_ms = "k_spawn", spawn_ms
         ach = 84.0 * s_avg / (dom_ms * 1e-3) / 1e9
         step_bytes = 68.0 * n_avg + 84.0 * s_avg
         line = {
@@ -112,7 +103,7 @@ def main():
                          "traffic": TRAFFIC_K_SPAWN, "ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": 84.0 * s_avg,
                          "whole_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
                                         "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
-                         "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()}},
+                         "stage_ms_per_step": stage_ms},
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(walk, hst, n_avg)

@@ -120,6 +120,30 @@ typedef struct {
  * replaces: the move loop, deterministic projection, sort, merge, reduce, reweight and
  * estimator sums of do_walk.f90:2216-2487 and 2573-2790 (semistochastic chem, ncores=1). */
 int sqmc_gpu_step(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, double out_stats[16]);
+/* Population control around the step, as the reference's walk loop does it on the host:
+ * tau / r_initiator ramp until w_abs_gen_target is first reached (do_walk.f90:2175-2184,
+ * 2913-2923, with the projector rescaled by tau_ratio), e_est from the cumulated sums,
+ * e_trial and reweight_factor_inv (do_walk.f90:2880-2901).  The first n_equil steps count as
+ * equilibration (iblkk <= ntimes_nblk_eq*nblk_eq in the reference). */
+typedef struct {
+  double tau_sav, tau, tau_prev;          /* input tau; current (ramped) tau; tau of the previous step */
+  double e_trial, e_est;
+  double w_abs_gen_target, w_abs_gen;     /* target; w_abs_gen of the last step (set to the initial sum|w| before the first) */
+  double r_initiator_sav, r_initiator, initiator_rescale_power;
+  double population_control_exponent;
+  double reweight_factor_inv, reweight_factor_inv_max;
+  double e_num_cum, e_den_cum;            /* sums of e_num_gen*sign(e_den_gen), |e_den_gen| */
+  double min_wt, always_spawn_cutoff_wt;
+  int32_t reached_w_abs_gen, initiator_power, initiator_min_distance, c_t_initiator, semistochastic, reserved;
+  int64_t istep, n_equil;
+} sqmc_popctl;
+
+/* replaces: the body of "do istep=1,nstep" (do_walk.f90:2171-2934) for nsteps consecutive steps
+ * without returning to the caller in between: sqmc_gpu_step + the scalar updates above.
+ * stats (may be NULL) receives the 16 per-step values of every step (nsteps*16 doubles);
+ * totals[16] their sums over the nsteps steps.  pc is updated in place. */
+int sqmc_gpu_run(sqmc_gpu_ctx *ctx, sqmc_popctl *pc, int64_t nsteps, double *stats, double totals[16]);
+
 /* RNG state of the REPLAY stream (savern / setrn, rannyu.f90:11-21,77-87) */
 int sqmc_gpu_get_rng(sqmc_gpu_ctx *ctx, int32_t seed[4]);
 int sqmc_gpu_set_rng(sqmc_gpu_ctx *ctx, const int32_t seed[4]);
@@ -177,9 +201,10 @@ int sqmc_gpu_hci_connections(sqmc_gpu_ctx *ctx, int64_t n_ref, const uint64_t *r
                              double **out_e_mix_num, double **out_e_mix_den);
 void sqmc_gpu_free(void *p);
 
-/* per-kernel timing of the last sqmc_gpu_step (HIP events on the library's stream):
- * names[i] / ms[i] for i < *n (n <= 32); enabled by sqmc_gpu_set_timing(ctx,1). */
-int sqmc_gpu_set_timing(sqmc_gpu_ctx *ctx, int on);
+/* HIP-event timing on the library's streams.  level 0 off; 1 = only the k_spawn launch
+ * (one pair of events per step); 2 = every stage of the step.  get_timing returns the mean
+ * milliseconds per step of each timer over the steps run since set_timing (n <= 32). */
+int sqmc_gpu_set_timing(sqmc_gpu_ctx *ctx, int level);
 int sqmc_gpu_get_timing(sqmc_gpu_ctx *ctx, int32_t *n, const char **names, float *ms);
 
 #ifdef __cplusplus

@@ -14,7 +14,7 @@ _LIB = None
 EXPORTS = [
     "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_projector",
     "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
-    "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_spmv_prepare",
+    "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_spmv_prepare",
     "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
     "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
 ]
@@ -53,6 +53,16 @@ class StepParams(C.Structure):
                 ("reached_w_abs_gen", C.c_int32), ("reserved", C.c_int32)]
 
 
+class PopCtl(C.Structure):
+    _fields_ = [("tau_sav", C.c_double), ("tau", C.c_double), ("tau_prev", C.c_double), ("e_trial", C.c_double), ("e_est", C.c_double),
+                ("w_abs_gen_target", C.c_double), ("w_abs_gen", C.c_double), ("r_initiator_sav", C.c_double), ("r_initiator", C.c_double),
+                ("initiator_rescale_power", C.c_double), ("population_control_exponent", C.c_double), ("reweight_factor_inv", C.c_double),
+                ("reweight_factor_inv_max", C.c_double), ("e_num_cum", C.c_double), ("e_den_cum", C.c_double), ("min_wt", C.c_double),
+                ("always_spawn_cutoff_wt", C.c_double), ("reached_w_abs_gen", C.c_int32), ("initiator_power", C.c_int32),
+                ("initiator_min_distance", C.c_int32), ("c_t_initiator", C.c_int32), ("semistochastic", C.c_int32), ("reserved", C.c_int32),
+                ("istep", C.c_int64), ("n_equil", C.c_int64)]
+
+
 def load_library():
     """Loads the in-tree HIP library; raises if it is missing (no fallback path exists)."""
     global _LIB
@@ -70,6 +80,7 @@ def load_library():
         L.sqmc_gpu_upload_walkers.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 9
         L.sqmc_gpu_download_walkers.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 9
         L.sqmc_gpu_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sqmc_gpu_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.sqmc_gpu_hamiltonian_batch.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
         L.sqmc_gpu_hamiltonian_chem_batch.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
         L.sqmc_gpu_build_sparse_ham.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 6
@@ -182,13 +193,20 @@ class GpuChem:
         _chk(code)
         return out
 
+    def run(self, pc, nsteps, keep_stats=True):
+        """sqmc_gpu_run: nsteps steps with the population control done inside the library."""
+        stats = np.zeros((nsteps, 16)) if keep_stats else None
+        totals = np.zeros(16)
+        _chk(self.L.sqmc_gpu_run(self.h, C.byref(pc), int(nsteps), _p(stats) if keep_stats else None, _p(totals)))
+        return stats, totals
+
     def rng_state(self):
         s = (C.c_int32 * 4)()
         _chk(self.L.sqmc_gpu_get_rng(self.h, s))
         return list(s)
 
-    def set_timing(self, on=True):
-        _chk(self.L.sqmc_gpu_set_timing(self.h, int(on)))
+    def set_timing(self, level=2):
+        _chk(self.L.sqmc_gpu_set_timing(self.h, int(level)))
 
     def timing(self):
         n = C.c_int32(); names = (C.c_char_p * 32)(); ms = (C.c_float * 32)()

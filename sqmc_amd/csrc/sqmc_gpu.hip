@@ -36,16 +36,24 @@ static inline int nblk(long long n, int tpb = TPB) { return (int)((n + tpb - 1) 
 
 // ------------------------------------------------------------------ walker SoA in HBM
 struct WalkArr {
-  u64 *up, *dn; double *wt; int8_t *impd, *init, *psign; double *me, *en, *ed;
+  u64 *up, *dn; double *wt; u32 *flg; double *me, *en, *ed;
 };
+// imp_distance / initiator / perm_sign packed in one word: a gather through the sort
+// permutation costs one access instead of three
+__host__ __device__ __forceinline__ u32 pack_flg(int impd, int init, int psign) {
+  return (u32)(impd & 0xFF) | ((u32)(init & 0xFF) << 8) | ((u32)(psign & 0xFF) << 16);
+}
+__host__ __device__ __forceinline__ int flg_impd(u32 f) { return (int)(int8_t)(f & 0xFF); }
+__host__ __device__ __forceinline__ int flg_init(u32 f) { return (int)(int8_t)((f >> 8) & 0xFF); }
+__host__ __device__ __forceinline__ int flg_psign(u32 f) { return (int)(int8_t)((f >> 16) & 0xFF); }
 static int alloc_walk(WalkArr &a, long long n) {
   HIPCHK(hipMalloc(&a.up, n * 8)); HIPCHK(hipMalloc(&a.dn, n * 8)); HIPCHK(hipMalloc(&a.wt, n * 8));
-  HIPCHK(hipMalloc(&a.impd, n)); HIPCHK(hipMalloc(&a.init, n)); HIPCHK(hipMalloc(&a.psign, n));
+  HIPCHK(hipMalloc(&a.flg, n * 4));
   HIPCHK(hipMalloc(&a.me, n * 8)); HIPCHK(hipMalloc(&a.en, n * 8)); HIPCHK(hipMalloc(&a.ed, n * 8));
   return 0;
 }
 static void free_walk(WalkArr &a) {
-  hipFree(a.up); hipFree(a.dn); hipFree(a.wt); hipFree(a.impd); hipFree(a.init); hipFree(a.psign);
+  hipFree(a.up); hipFree(a.dn); hipFree(a.wt); hipFree(a.flg);
   hipFree(a.me); hipFree(a.en); hipFree(a.ed);
 }
 
@@ -85,7 +93,9 @@ struct sqmc_gpu_ctx {
   double *d_partials; int n_partial_blocks;
   int key_bits; u64 invalid_key; u64 *d_binom;
   // timing
-  int timing; hipEvent_t ev[NTIMERS + 1]; const char *tname[NTIMERS]; int nt; float tms[NTIMERS];
+  int timing; hipEvent_t ev0[NTIMERS], ev1[NTIMERS]; const char *tname[NTIMERS]; int nt; float tms[NTIMERS];
+  double tsum[NTIMERS]; long long tsteps;         // accumulated over the steps since sqmc_gpu_set_timing
+  hipStream_t st2; hipEvent_t e_fork, e_join;    // second stream: death + deterministic projection beside spawn + sort
 };
 
 // ===================================================================== step kernels
@@ -143,12 +153,12 @@ __global__ void __launch_bounds__(64) k_replay_prepass(const ChemTab *__restrict
 
 // diagonal death/clone, do_walk.f90:3743-3793
 __global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, double *__restrict__ wt,
-                                              const int8_t *__restrict__ impd, double *__restrict__ me, long long n, StepP p, DevScalars *sc) {
+                                              const u32 *__restrict__ flg, double *__restrict__ me, long long n, StepP p, DevScalars *sc) {
   __shared__ ChemTab t;
   stage_tab(&t, dev.tab);
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
-  if (p.semi && impd[i] < 1) return;
+  if (p.semi && flg_impd(flg[i]) < 1) return;
   double hii = me[i];
   if (hii > 1e50) { hii = h_any(t, dev.integrals, up[i], dn[i], up[i], dn[i]); me[i] = hii; }
   double f = 1.0 + p.tau * (p.e_trial - hii);
@@ -180,15 +190,16 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   }
   const long long k = n0 + c;
   if (wj != 0.0) {
-    const int pd = w.impd[ip], pi = w.init[ip];
+    const u32 pf = w.flg[ip]; const int pd = flg_impd(pf), pi = flg_init(pf);
     int d;
     if (pd == -2) d = p.cti ? 1 : 2; else d = (pd < 126 ? pd : 126) + 1;
     if (p.semi && pd == 0) d = -1;
     int ini = (pi >= 2) ? 1 : 0;
     if (p.cti && pd == -2) ini = 1;
     if (p.semi && pd == 0) ini = 1;
-    w.up[k] = ju; w.dn[k] = jd; w.wt[k] = wj; w.impd[k] = (int8_t)d; w.init[k] = (int8_t)ini; w.psign[k] = 0;
-    w.me[k] = 1e51; w.en[k] = 1e51; w.ed[k] = 1e51;
+    // matrix_elements / e_num / e_den of a spawn are the 1e51 sentinel (do_walk.f90:3728-3730):
+    // not stored, k_merge supplies them for every slot >= n0
+    w.up[k] = ju; w.dn[k] = jd; w.wt[k] = wj; w.flg[k] = pack_flg(d, ini, 0);
     keys[k] = det_key(dev, ju, jd);
   } else {
     w.wt[k] = 0.0; keys[k] = invalid_key;     // sorts behind every real determinant; counted by k_wabs
@@ -252,7 +263,7 @@ __device__ __forceinline__ double ipow_d(int b, int e) { double r = 1.0; for (in
 // (stable sort), so the pairwise combination below is the reference's left-to-right scan.
 // do_walk.f90:5866-6083, check_initiator 6838-6872.
 __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *__restrict__ skey, const u32 *__restrict__ perm,
-                                               u64 *__restrict__ flags, long long n_all, StepP p, u64 invalid_key) {
+                                               u64 *__restrict__ flags, long long n0, long long n_all, StepP p, u64 invalid_key) {
   long long j = (long long)blockIdx.x * TPB + threadIdx.x;
   const long long n = n_all;
   if (j >= n_all) return;
@@ -260,19 +271,19 @@ __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *
   if (key == invalid_key) { flags[j] = 0; return; }     // children that produced no walker sort last
   if (j > 0 && skey[j - 1] == key) { flags[j] = 0; return; }
   u32 t = perm[j];
-  double wt = w.wt[t], me = w.me[t], en = w.en[t], ed = w.ed[t];
-  int ini = w.init[t], d = w.impd[t], ps = w.psign[t];
+  const bool t_spawn = (long long)t >= n0;
+  double wt = w.wt[t], me = t_spawn ? 1e51 : w.me[t], en = t_spawn ? 1e51 : w.en[t], ed = t_spawn ? 1e51 : w.ed[t];
+  const u32 ft = w.flg[t];
+  int ini = flg_init(ft), d = flg_impd(ft), ps = flg_psign(ft);
   if (d == -1 && j > 0) d = 1;                 // 5985-5986 (the very first walker keeps -1 until the end)
   long long jj = j + 1;
   for (; jj < n && skey[jj] == key; jj++) {
     const u32 s = perm[jj];
-    const double w2 = w.wt[s]; const int i2 = w.init[s], d2 = w.impd[s];
+    const double w2 = w.wt[s]; const u32 fs = w.flg[s]; const int i2 = flg_init(fs), d2 = flg_impd(fs);
     const bool same_sign = (w2 * wt > 0);
-    if (same_sign) {
-      if (i2 > ini) ini = i2;
-      en = fmin(en, w.en[s]); ed = fmin(ed, w.ed[s]);
-    }
-    me = fmin(me, w.me[s]);
+    // every later walker of a run is a spawn (walkers are unique): its cached values are the
+    // 1e51 sentinel, so the reference's min() merges leave me / en / ed unchanged
+    if (same_sign) { if (i2 > ini) ini = i2; }
     if (d == -2) { if (d2 == 0) d = 0; }
     else if (d2 == -2) { if (d != 0) d = -2; }
     else if (d != 0 && d != -2) { int a = d2 < 0 ? -d2 : d2; if (a < d) d = a; }
@@ -293,7 +304,7 @@ __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *
   int dtest = d;
   if (d == -1) { if (jj >= n || skey[jj] == invalid_key) dtest = 1; d = 1; }   // 6032-6036 then the last-det test at 6038
   const bool discard = (((wt == 0.0 && (ini != 3 || p.r_init < 0)) || ini == 0) && dtest >= 1);
-  m.up[j] = w.up[t]; m.dn[j] = w.dn[t]; m.wt[j] = wt; m.impd[j] = (int8_t)d; m.init[j] = (int8_t)ini; m.psign[j] = (int8_t)ps;
+  m.up[j] = w.up[t]; m.dn[j] = w.dn[t]; m.wt[j] = wt; m.flg[j] = pack_flg(d, ini, ps);
   m.me[j] = me; m.en[j] = en; m.ed[j] = ed;
   u64 f = 0;
   if (!discard) { f = 1ull; if (p.semi && d >= 1 && fabs(wt) < p.min_wt) f |= (1ull << 32); }
@@ -318,7 +329,7 @@ __global__ void __launch_bounds__(TPB) k_round(WalkArr m, const u64 *__restrict_
     if (r < (fabs(wt) / p.min_wt)) wt = copysign(p.min_wt, wt); else wt = 0.0;
     m.wt[j] = wt;
   }
-  const int d = m.impd[j];
+  const int d = flg_impd(m.flg[j]);
   u64 f2 = 0;
   if (!(p.semi && wt == 0.0 && d >= 1)) { f2 = 1ull; if (d == 0) f2 |= (1ull << 32); }
   flags2[j] = f2;
@@ -349,13 +360,13 @@ __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64
     const u64 ps = pos2[j]; const long long o = (long long)(ps & 0xFFFFFFFFull);
     const u64 u = m.up[j], dd = m.dn[j];
     const double wt = m.wt[j] * p.rfi;
-    const int d = m.impd[j], ini = m.init[j], psg = m.psign[j];
+    const u32 fj = m.flg[j]; const int d = flg_impd(fj), ini = flg_init(fj), psg = flg_psign(fj);
     double en = m.en[j], ed = m.ed[j];
     if (en > 1e50) {
       long long q = ct_search(cu, cd, n_ct, u, dd);
       if (q < 0) { en = 0.0; ed = 0.0; } else { en = cnum[q]; ed = cden[q]; }
     }
-    w.up[o] = u; w.dn[o] = dd; w.wt[o] = wt; w.impd[o] = (int8_t)d; w.init[o] = (int8_t)ini; w.psign[o] = (int8_t)psg;
+    w.up[o] = u; w.dn[o] = dd; w.wt[o] = wt; w.flg[o] = fj;
     w.me[o] = m.me[j]; w.en[o] = en; w.ed[o] = ed;
     if (d == 0) loc_imp[ps >> 32] = (int)o;
     s[0] += wt; s[1] += fabs(wt); s[8] += wt * wt;
@@ -724,7 +735,9 @@ int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out) {
     c->n_partial_blocks = nblk(M);
     HIPCHK(hipMalloc(&c->d_partials, ((long long)c->n_partial_blocks * NSTAT + 128) * 8));
   }
-  for (int i = 0; i <= NTIMERS; i++) HIPCHK(hipEventCreate(&c->ev[i]));
+  for (int i = 0; i < NTIMERS; i++) { HIPCHK(hipEventCreate(&c->ev0[i])); HIPCHK(hipEventCreate(&c->ev1[i])); }
+  HIPCHK(hipStreamCreate(&c->st2));
+  HIPCHK(hipEventCreateWithFlags(&c->e_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->e_join, hipEventDisableTiming));
   *out = c;
   return SQMC_OK;
 }
@@ -743,8 +756,9 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x);
   hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den);
   hipFree(c->d_sc); hipHostFree(c->h_sc);
-  for (int i = 0; i <= NTIMERS; i++) hipEventDestroy(c->ev[i]);
-  hipStreamDestroy(c->st);
+  for (int i = 0; i < NTIMERS; i++) { hipEventDestroy(c->ev0[i]); hipEventDestroy(c->ev1[i]); }
+  hipEventDestroy(c->e_fork); hipEventDestroy(c->e_join);
+  hipStreamDestroy(c->st2); hipStreamDestroy(c->st);
   delete c;
   return SQMC_OK;
 }
@@ -807,8 +821,9 @@ int sqmc_gpu_upload_walkers(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, cons
     if (i && !(up[i - 1] < up[i] || (up[i - 1] == up[i] && dn[i - 1] < dn[i]))) return fail(SQMC_ERR_BAD_ARG, "walkers must be sorted by (up,dn) and unique");
   }
   HIPCHK(hipMemcpy(c->w.up, up, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.dn, dn, n * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->w.wt, wt, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.impd, impd, n, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->w.init, init, n, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.psign, psign, n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->w.wt, wt, n * 8, hipMemcpyHostToDevice));
+  { std::vector<u32> f(n); for (long long i = 0; i < n; i++) f[i] = pack_flg(impd[i], init[i], psign[i]);
+    HIPCHK(hipMemcpy(c->w.flg, f.data(), n * 4, hipMemcpyHostToDevice)); }
   HIPCHK(hipMemcpy(c->w.me, me, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.en, en, n * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->w.ed, ed, n * 8, hipMemcpyHostToDevice));
   c->nwalk = n;
@@ -831,8 +846,11 @@ int sqmc_gpu_download_walkers(sqmc_gpu_ctx *c, int64_t cap, int64_t *n, uint64_t
   if (up) HIPCHK(hipMemcpy(up, c->w.up, k * 8, hipMemcpyDeviceToHost));
   if (dn) HIPCHK(hipMemcpy(dn, c->w.dn, k * 8, hipMemcpyDeviceToHost));
   if (wt) HIPCHK(hipMemcpy(wt, c->w.wt, k * 8, hipMemcpyDeviceToHost));
-  if (impd) HIPCHK(hipMemcpy(impd, c->w.impd, k, hipMemcpyDeviceToHost));
-  if (init) HIPCHK(hipMemcpy(init, c->w.init, k, hipMemcpyDeviceToHost));
+  if (impd || init) {
+    std::vector<u32> f(k);
+    HIPCHK(hipMemcpy(f.data(), c->w.flg, k * 4, hipMemcpyDeviceToHost));
+    for (long long i = 0; i < k; i++) { if (impd) impd[i] = (int8_t)flg_impd(f[i]); if (init) init[i] = (int8_t)flg_init(f[i]); }
+  }
   if (me) HIPCHK(hipMemcpy(me, c->w.me, k * 8, hipMemcpyDeviceToHost));
   if (en) HIPCHK(hipMemcpy(en, c->w.en, k * 8, hipMemcpyDeviceToHost));
   if (ed) HIPCHK(hipMemcpy(ed, c->w.ed, k * 8, hipMemcpyDeviceToHost));
@@ -853,14 +871,21 @@ int sqmc_gpu_set_rng(sqmc_gpu_ctx *c, const int32_t seed[4]) {
   return SQMC_OK;
 }
 
-int sqmc_gpu_set_timing(sqmc_gpu_ctx *c, int on) { if (!c) return SQMC_ERR_BAD_ARG; c->timing = on; return SQMC_OK; }
-int sqmc_gpu_get_timing(sqmc_gpu_ctx *c, int32_t *n, const char **names, float *ms) {
+int sqmc_gpu_set_timing(sqmc_gpu_ctx *c, int on) {
   if (!c) return SQMC_ERR_BAD_ARG;
-  *n = c->nt;
-  for (int i = 0; i < c->nt; i++) { names[i] = c->tname[i]; ms[i] = c->tms[i]; }
+  c->timing = on; c->tsteps = 0; c->nt = 0;
+  for (int i = 0; i < NTIMERS; i++) c->tsum[i] = 0.0;
   return SQMC_OK;
 }
-#define TMARK(NAME) do { if (c->timing && c->nt < NTIMERS) { c->tname[c->nt] = NAME; hipEventRecord(c->ev[++c->nt], st); } } while (0)
+int sqmc_gpu_get_timing(sqmc_gpu_ctx *c, int32_t *n, const char **names, float *ms) {
+  if (!c) return SQMC_ERR_BAD_ARG;
+  *n = c->tsteps > 0 ? c->nt : 0;
+  for (int i = 0; i < *n; i++) { names[i] = c->tname[i]; ms[i] = (float)(c->tsum[i] / (double)c->tsteps); }
+  return SQMC_OK;
+}
+// stage timers: a pair of HIP events on the stream the stage runs on
+#define TBEG(NAME, STREAM) int t_##NAME = -1; do { if ((c->timing >= 2 || (c->timing == 1 && !strcmp(#NAME, "spawn"))) && c->nt < NTIMERS) { t_##NAME = c->nt++; c->tname[t_##NAME] = #NAME; hipEventRecord(c->ev0[t_##NAME], STREAM); } } while (0)
+#define TEND(NAME, STREAM) do { if (t_##NAME >= 0) hipEventRecord(c->ev1[t_##NAME], STREAM); } while (0)
 
 int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   if (!c || !sp || !out) return fail(SQMC_ERR_BAD_ARG, "null argument");
@@ -877,9 +902,10 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   const int mode = c->rng_mode; const u64 seed = c->seed64, step = c->step_no;
   ScanWork sw; sw.tile_sums = c->d_tile_sums; sw.cap_tiles = c->cap_tiles;
   c->nt = 0;
-  if (c->timing) hipEventRecord(c->ev[0], st);
+  hipStream_t st2 = c->st2;
   HIPCHK(hipMemsetAsync(&c->d_sc->n_children, 0, 4 * sizeof(u64) + 2 * sizeof(int), st));
   // ---- gate / child offsets
+  TBEG(gate_scan, st);
   if (mode == SQMC_RNG_REPLAY) {
     hipLaunchKernelGGL(k_replay_prepass, dim3(1), dim3(64), 0, st, c->d_tab, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_child_off,
                        c->d_child_state, n0, M - n0, p, c->d_sc);
@@ -887,52 +913,67 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->w.wt, c->d_nchild, c->d_wchild, n0, p, seed, step);
     device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw, st);
   }
-  TMARK("gate+scan");
-  hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.impd, c->w.me, n0, p, c->d_sc);
-  TMARK("diag");
+  TEND(gate_scan, st);
+  // ---- fork: death/clone and the deterministic projection only touch weights, which neither
+  //      the spawn kernel (it uses the child weights of the gate) nor the sort reads
+  HIPCHK(hipEventRecord(c->e_fork, st));
+  HIPCHK(hipStreamWaitEvent(st2, c->e_fork, 0));
+  TBEG(diag, st2);
+  hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, st2, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc);
+  TEND(diag, st2);
+  TBEG(project, st2);
+  if (p.semi) {
+    hipLaunchKernelGGL(k_prj_gather, dim3(nblk(c->n_imp)), dim3(TPB), 0, st2, c->w.wt, c->d_loc_imp, c->d_prj_x, c->n_imp);
+    hipLaunchKernelGGL(k_prj_apply, dim3(nblk(c->n_imp, TPB / 64)), dim3(TPB), 0, st2, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, c->d_prj_x, c->d_loc_imp, c->w.wt,
+                       c->n_imp, p.e_trial, p.tau);
+  }
+  TEND(project, st2);
+  HIPCHK(hipEventRecord(c->e_join, st2));
+  TBEG(sync, st);
   HIPCHK(hipMemcpyAsync(&c->h_sc->n_children, &c->d_sc->n_children, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  TMARK("sync");
+  TEND(sync, st);
   const long long nch = (long long)c->h_sc->n_children;
-  if (n0 + nch > M) return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
+  if (n0 + nch > M) { hipStreamSynchronize(st2); return fail(SQMC_ERR_MWALK, "nwalk>MWALK"); }
   const long long nall = n0 + nch;
-  // ---- spawn
+  // ---- spawn (exactly one k_spawn launch inside this timer: the per-launch time bench.py reports)
+  TBEG(spawn, st);
   if (nch > 0)
     hipLaunchKernelGGL(k_spawn, dim3(nblk(nch)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
                        n0, nch, p, mode, seed, step, c->invalid_key, c->d_sc);
-  TMARK("spawn");                     // exactly one k_spawn launch: the per-launch time bench.py reports
-  hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0);
-  // ---- deterministic projection
-  if (p.semi) {
-    hipLaunchKernelGGL(k_prj_gather, dim3(nblk(c->n_imp)), dim3(TPB), 0, st, c->w.wt, c->d_loc_imp, c->d_prj_x, c->n_imp);
-    hipLaunchKernelGGL(k_prj_apply, dim3(nblk(c->n_imp, TPB / 64)), dim3(TPB), 0, st, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, c->d_prj_x, c->d_loc_imp, c->w.wt,
-                       c->n_imp, p.e_trial, p.tau);
-  }
-  TMARK("project");
+  TEND(spawn, st);
   // ---- sort
+  TBEG(sort, st);
+  hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0);
   SortWork so; so.k_alt = c->d_keys_alt; so.v_alt = c->d_vals_alt; so.hist = c->d_hist; so.rowtot = c->d_rowtot; so.cap = M;
   u64 *skey = c->d_keys; u32 *perm = c->d_vals;
   device_radix_sort(skey, perm, nall, c->key_bits, so, st);
   if (skey != c->d_keys) { c->d_keys_alt = c->d_keys; c->d_vals_alt = c->d_vals; c->d_keys = skey; c->d_vals = perm; }
-  TMARK("sort");
-  // ---- |w| before merge
+  TEND(sort, st);
+  // ---- join: from here on weights are read
+  HIPCHK(hipStreamWaitEvent(st, c->e_join, 0));
+  TBEG(merge, st);
   hipLaunchKernelGGL(k_wabs, dim3(64), dim3(TPB), 0, st, c->w.wt, skey, c->invalid_key, nall, c->d_partials);
-  // ---- merge, round, compact
-  hipLaunchKernelGGL(k_merge, dim3(nblk(nall)), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, nall, p, c->invalid_key);
+  hipLaunchKernelGGL(k_merge, dim3(nblk(nall)), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, n0, nall, p, c->invalid_key);
   device_excl_scan_u64(c->d_flags, c->d_pos, nall, &c->d_sc->tot1, sw, st);
-  TMARK("merge");
+  TEND(merge, st);
+  TBEG(round, st);
   hipLaunchKernelGGL(k_round, dim3(nblk(nall)), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, c->d_flags2, nall, p, mode, seed, step, c->d_sc);
   device_excl_scan_u64(c->d_flags2, c->d_pos2, nall, &c->d_sc->tot2, sw, st);
-  TMARK("round");
+  TEND(round, st);
+  TBEG(estimate, st);
   const int nb = std::min(nblk(nall), 512);
   hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, st, c->m, c->w, c->d_flags2, c->d_pos2, c->d_loc_imp, c->d_ct_up, c->d_ct_dn, c->d_ct_num, c->d_ct_den,
                      c->n_ct, nall, p, c->d_partials + 128);
   hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials + 128, nb, c->d_partials, mode, c->d_sc);
-  TMARK("estimate");
+  TEND(estimate, st);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  if (c->timing) for (int i = 0; i < c->nt; i++) hipEventElapsedTime(&c->tms[i], c->ev[i], c->ev[i + 1]);
+  if (c->timing) {
+    for (int i = 0; i < c->nt; i++) { hipEventElapsedTime(&c->tms[i], c->ev0[i], c->ev1[i]); c->tsum[i] += c->tms[i]; }
+    c->tsteps++;
+  }
   c->step_no++;
   if (c->h_sc->err) return fail(c->h_sc->err, "diagonal_factor<0 after target population has been reached");
   const long long nfinal = (long long)(c->h_sc->tot2 & 0xFFFFFFFFull), nimp = (long long)(c->h_sc->tot2 >> 32);
@@ -940,6 +981,54 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   for (int i = 0; i < 16; i++) out[i] = c->h_sc->stats[i];
   if (nfinal == 0) return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0");
   if (p.semi && nimp != c->n_imp) return fail(SQMC_ERR_IMP_BROKEN, "locations of my imp broken");
+  return SQMC_OK;
+}
+
+int sqmc_gpu_run(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats, double totals[16]) {
+  if (!c || !pc || !totals || nsteps < 0) return fail(SQMC_ERR_BAD_ARG, "bad argument");
+  for (int k = 0; k < 16; k++) totals[k] = 0.0;
+  for (int64_t it = 0; it < nsteps; it++) {
+    // do_walk.f90:2175-2184
+    if (pc->reached_w_abs_gen == 0) {
+      const double f = 1.0 + log(pc->w_abs_gen_target / pc->w_abs_gen);
+      pc->tau = pc->tau_sav * f;
+      pc->r_initiator = pc->r_initiator_sav * pow(f, pc->initiator_rescale_power);
+      const double ratio = pc->tau / pc->tau_prev;
+      if (ratio != 1.0 && pc->semistochastic) { int r = sqmc_gpu_scale_projector(c, ratio); if (r) return r; }
+    }
+    sqmc_step_params sp;
+    sp.tau = pc->tau; sp.e_trial = pc->e_trial; sp.reweight_factor_inv = pc->reweight_factor_inv; sp.r_initiator = pc->r_initiator;
+    sp.min_wt = pc->min_wt; sp.always_spawn_cutoff_wt = pc->always_spawn_cutoff_wt; sp.initiator_power = pc->initiator_power;
+    sp.initiator_min_distance = pc->initiator_min_distance; sp.c_t_initiator = pc->c_t_initiator; sp.semistochastic = pc->semistochastic;
+    sp.reached_w_abs_gen = pc->reached_w_abs_gen; sp.reserved = 0;
+    double out[16];
+    int r = sqmc_gpu_step(c, &sp, out);
+    if (r) return r;
+    if (stats) memcpy(stats + it * 16, out, sizeof(out));
+    for (int k = 0; k < 16; k++) totals[k] += out[k];
+    // do_walk.f90:2880-2923
+    pc->istep++;
+    const double w_abs_gen = out[1], e_den_gen = out[2], e_num_gen = out[3];
+    if (e_den_gen != 0.0) pc->e_num_cum += e_num_gen * (e_den_gen > 0 ? 1.0 : -1.0);
+    pc->e_den_cum += fabs(e_den_gen);
+    if (pc->e_den_cum != 0.0) pc->e_est = pc->e_num_cum / pc->e_den_cum;
+    const double pw = fmin(1.0, pc->tau * pc->population_control_exponent);
+    if (pc->istep <= pc->n_equil) {
+      const double d = pc->e_est - pc->e_trial;
+      pc->e_trial = pc->e_trial + (d > 0 ? 1.0 : (d < 0 ? -1.0 : 0.0)) * fmin(fabs(d), 1.0);
+      pc->reweight_factor_inv = fmin(2.0, fmax(0.5, pow(pc->w_abs_gen_target / w_abs_gen, pw)));
+    } else {
+      pc->reweight_factor_inv = fmin(2.0, fmax(0.5, (1.0 / (1.0 + pc->tau * (pc->e_trial - pc->e_est))) * pow(pc->w_abs_gen_target / w_abs_gen, pw)));
+    }
+    pc->reweight_factor_inv = fmin(pc->reweight_factor_inv, pc->reweight_factor_inv_max);
+    if (pc->reached_w_abs_gen == 0 && w_abs_gen >= pc->w_abs_gen_target) {
+      pc->reached_w_abs_gen = 2;
+      const double ratio = pc->tau_sav / pc->tau;
+      pc->tau = pc->tau_sav; pc->r_initiator = pc->r_initiator_sav;
+      if (ratio != 1.0 && pc->semistochastic) { int r2 = sqmc_gpu_scale_projector(c, ratio); if (r2) return r2; }
+    }
+    pc->tau_prev = pc->tau; pc->w_abs_gen = w_abs_gen;
+  }
   return SQMC_OK;
 }
 

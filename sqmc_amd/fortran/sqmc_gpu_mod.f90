@@ -7,7 +7,7 @@ module sqmc_gpu_mod
   use iso_c_binding
   implicit none
   private
-  public :: sqmc_chem_cfg, sqmc_step_params
+  public :: sqmc_chem_cfg, sqmc_step_params, sqmc_popctl, sqmc_gpu_run
   public :: sqmc_gpu_set_device, sqmc_gpu_init_chem, sqmc_gpu_finalize, sqmc_gpu_last_error, sqmc_gpu_set_hb_tables
   public :: sqmc_gpu_set_projector, sqmc_gpu_scale_projector, sqmc_gpu_set_ct_table, sqmc_gpu_upload_walkers
   public :: sqmc_gpu_num_walkers, sqmc_gpu_download_walkers, sqmc_gpu_step, sqmc_gpu_get_rng, sqmc_gpu_set_rng
@@ -38,7 +38,19 @@ module sqmc_gpu_mod
     integer(c_int32_t) :: reserved
   end type
 
+  type, bind(C) :: sqmc_popctl
+    real(c_double) :: tau_sav, tau, tau_prev, e_trial, e_est, w_abs_gen_target, w_abs_gen
+    real(c_double) :: r_initiator_sav, r_initiator, initiator_rescale_power, population_control_exponent
+    real(c_double) :: reweight_factor_inv, reweight_factor_inv_max, e_num_cum, e_den_cum, min_wt, always_spawn_cutoff_wt
+    integer(c_int32_t) :: reached_w_abs_gen, initiator_power, initiator_min_distance, c_t_initiator, semistochastic, reserved
+    integer(c_int64_t) :: istep, n_equil
+  end type
+
   interface
+    integer(c_int) function sqmc_gpu_run(ctx, pc, nsteps, stats, totals) bind(C, name='sqmc_gpu_run')
+      import; type(c_ptr), value :: ctx; type(sqmc_popctl), intent(inout) :: pc; integer(c_int64_t), value :: nsteps
+      type(c_ptr), value :: stats; real(c_double), intent(out) :: totals(16)
+    end function
     integer(c_int) function sqmc_gpu_set_device(device) bind(C, name='sqmc_gpu_set_device')
       import; integer(c_int), value :: device
     end function

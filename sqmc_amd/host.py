@@ -15,7 +15,7 @@ Mirrors (file:line relative to the reference's src/):
 """
 import numpy as np
 
-from ._lib import GpuChem, SpmvPlan, RNG_COUNTER
+from ._lib import GpuChem, SpmvPlan, PopCtl, RNG_COUNTER
 
 _D2H = np.array([[1, 2, 3, 4, 5, 6, 7, 8], [2, 1, 4, 3, 6, 5, 8, 7], [3, 4, 1, 2, 7, 8, 5, 6], [4, 3, 2, 1, 8, 7, 6, 5],
                  [5, 6, 7, 8, 1, 2, 3, 4], [6, 5, 8, 7, 2, 1, 4, 3], [7, 8, 5, 6, 3, 4, 1, 2], [8, 7, 6, 5, 4, 3, 2, 1]])
@@ -361,6 +361,23 @@ class PopControl:
                     always_spawn_cutoff_wt=cutoff, initiator_power=initiator_power, initiator_min_distance=0, c_t_initiator=0,
                     semistochastic=semistochastic, reached_w_abs_gen=self.reached)
 
+    def to_c(self, w_abs_gen, min_wt=0.5, cutoff=0.5, initiator_power=0, semistochastic=1):
+        """the same state as a sqmc_popctl for sqmc_gpu_run"""
+        pc = PopCtl()
+        pc.tau_sav, pc.tau, pc.tau_prev, pc.e_trial, pc.e_est = self.tau_sav, self.tau, self.tau_prev, self.e_trial, self.e_est
+        pc.w_abs_gen_target, pc.w_abs_gen = self.w_target, w_abs_gen
+        pc.r_initiator_sav, pc.r_initiator, pc.initiator_rescale_power = self.r_init_sav, self.r_init, self.irp
+        pc.population_control_exponent, pc.reweight_factor_inv, pc.reweight_factor_inv_max = self.pop_exp, self.rfi, self.rfi_max
+        pc.e_num_cum, pc.e_den_cum, pc.min_wt, pc.always_spawn_cutoff_wt = self.e_num_cum, self.e_den_cum, min_wt, cutoff
+        pc.reached_w_abs_gen, pc.initiator_power, pc.initiator_min_distance, pc.c_t_initiator = self.reached, initiator_power, 0, 0
+        pc.semistochastic, pc.istep, pc.n_equil = semistochastic, self.istep, min(self.n_equil, 2**62)
+        return pc
+
+    def from_c(self, pc):
+        self.tau, self.tau_prev, self.e_trial, self.e_est = pc.tau, pc.tau_prev, pc.e_trial, pc.e_est
+        self.r_init, self.rfi, self.e_num_cum, self.e_den_cum = pc.r_initiator, pc.reweight_factor_inv, pc.e_num_cum, pc.e_den_cum
+        self.reached, self.istep, self.w_abs_gen = pc.reached_w_abs_gen, pc.istep, pc.w_abs_gen
+
 
 class GpuWalk:
     """A C2-style semistochastic walk resident on one GPU."""
@@ -393,6 +410,14 @@ class GpuWalk:
             self.g.scale_projector(r)
         self.w_abs, self.last = out[1], out
         return out
+
+    def run(self, nsteps, keep_stats=True):
+        """nsteps steps inside the library (sqmc_gpu_run): no Python between steps"""
+        pc = self.pc.to_c(self.w_abs, min_wt=self.min_wt)
+        stats, totals = self.g.run(pc, nsteps, keep_stats)
+        self.pc.from_c(pc)
+        self.w_abs = pc.w_abs_gen
+        return stats, totals
 
     def close(self):
         self.g.close()

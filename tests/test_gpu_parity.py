@@ -295,3 +295,37 @@ def test_fortran_host_example():
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_run_loop_equals_stepwise_population_control(oracle, c2_walk, c2_setup):
+    """sqmc_gpu_run (population control inside the library) walks the same trajectory as
+    sqmc_gpu_step driven by the host-side PopControl."""
+    from sqmc_amd import host as H
+    res = []
+    for mode in ("step", "run"):
+        g = gpu_ctx_from_oracle(c2_walk, rng_mode=1, seed=SEED, mwalk=400000)
+        g.set_projector(c2_setup.prj_counts, c2_setup.prj_indices, c2_setup.prj_values)
+        g.set_ct_table(c2_setup.ct_up, c2_setup.ct_dn, c2_setup.ct_num, c2_setup.ct_den)
+        wk = oracle.initial_walkers(c2_setup, 100)
+        g.upload_walkers(wk)
+        pc = H.PopControl(c2_setup.tau, -75.72, 3000, n_equil_steps=40)
+        w_abs = float(np.abs(wk["wt"]).sum())
+        if mode == "step":
+            for _ in range(80):
+                r = pc.pre_step(w_abs)
+                if r != 1.0: g.scale_projector(r)
+                out = g.step(pc.params())
+                r = pc.post_step(out)
+                if r != 1.0: g.scale_projector(r)
+                w_abs = out[1]
+        else:
+            cpc = pc.to_c(w_abs)
+            stats, totals = g.run(cpc, 80)
+            out = stats[-1]
+            assert np.allclose(totals, stats.sum(axis=0))
+        res.append((g.download_walkers(), out.copy()))
+        g.close()
+    (wa, oa), (wb, ob) = res
+    assert np.array_equal(wa["up"], wb["up"]) and np.array_equal(wa["dn"], wb["dn"])
+    assert np.allclose(wa["wt"], wb["wt"], rtol=1e-9)
+    assert np.allclose(oa, ob, rtol=1e-9)
