@@ -42,80 +42,95 @@ __device__ __forceinline__ u64 block_excl_scan_u64(u64 v, u64 *total) {
   return off + inc - v;
 }
 
-// phase 1: per-tile sums
-__global__ void __launch_bounds__(SCAN_BLOCK) scan_reduce_kernel(const u64 *__restrict__ in, u64 *__restrict__ tile_sums, long long n) {
-  long long base = (long long)blockIdx.x * SCAN_TILE;
-  u64 s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) {
-    long long i = base + (long long)k * SCAN_BLOCK + threadIdx.x;
-    if (i < n) s += in[i];
-  }
-  u64 tot; block_excl_scan_u64(s, &tot);
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
-}
-// phase 2: single block scans the tile sums in place (exclusive), writes grand total
-__global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(u64 *__restrict__ tile_sums, int ntiles, u64 *__restrict__ total_out) {
-  u64 carry = 0;
-  for (int base = 0; base < ntiles; base += SCAN_BLOCK) {
-    int i = base + threadIdx.x;
-    u64 v = (i < ntiles) ? tile_sums[i] : 0, tot;
-    u64 ex = block_excl_scan_u64(v, &tot);
-    if (i < ntiles) tile_sums[i] = carry + ex;
-    carry += tot;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0 && total_out) *total_out = carry;
-}
-// phase 3: per-tile exclusive scan + tile offset.  Thread-contiguous items keep order.
-__global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, const u64 *__restrict__ tile_sums, long long n) {
-  long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+// Single-pass exclusive scan with decoupled look-back.  Tiles are handed out by an atomic
+// ticket, so every predecessor of a tile is already running or finished (forward progress
+// without co-residency assumptions).  One 64-bit word per tile carries {status:2, value:62};
+// it is published and polled with device-scope atomics only, so no fence pairs with the
+// payload and the non-coherent per-XCD L2s are never in the way.  Values must stay < 2^62
+// (two packed counters < 2^30 each).  state[] and ticket must be zero on entry; the caller
+// re-zeroes them (the walker step does it inside k_finish for the next step).
+#define SCAN_ST_AGG (1ull << 62)
+#define SCAN_ST_INC (2ull << 62)
+#define SCAN_VAL_MASK ((1ull << 62) - 1ull)
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_lookback_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, long long n,
+                                                                   u64 *__restrict__ state, u32 *__restrict__ ticket, u64 *__restrict__ total_out) {
+  __shared__ u32 s_tile; __shared__ u64 s_excl;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const u32 tile = s_tile;
+  const long long base = (long long)tile * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
   u64 v[SCAN_ITEMS], s = 0;
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; k++) { long long i = base + k; v[k] = (i < n) ? in[i] : 0; s += v[k]; }
-  u64 tot; u64 ex = block_excl_scan_u64(s, &tot) + tile_sums[blockIdx.x];
+  u64 tot; u64 ex = block_excl_scan_u64(s, &tot);
+  if (threadIdx.x < 64) {                       // wave 0 publishes and looks back, 64 predecessors per poll
+    const int lane = threadIdx.x;
+    u64 excl = 0;
+    if (tile == 0) { if (lane == 0) atomicExch((unsigned long long *)&state[0], SCAN_ST_INC | tot); }
+    else {
+      if (lane == 0) atomicExch((unsigned long long *)&state[tile], SCAN_ST_AGG | tot);
+      long long p = (long long)tile - 1;
+      while (true) {
+        const long long idx = p - lane;
+        const u64 w = (idx >= 0) ? atomicAdd((unsigned long long *)&state[idx], 0ull) : SCAN_ST_INC;
+        const u64 st = w >> 62;
+        const u64 inc_mask = __ballot(st == 2), zero_mask = __ballot(st == 0);
+        const int first_inc = inc_mask ? __builtin_ctzll(inc_mask) : 64;
+        const u64 need = (first_inc >= 63) ? ~0ull : ((2ull << first_inc) - 1ull);
+        if (zero_mask & need) continue;           // some needed predecessor has not published yet
+        u64 val = (lane <= first_inc) ? (w & SCAN_VAL_MASK) : 0;
+        for (int o = 32; o > 0; o >>= 1) val += __shfl_down(val, o, 64);
+        excl += __shfl(val, 0, 64);
+        if (first_inc < 64) break;
+        p -= 64;
+      }
+      if (lane == 0) atomicExch((unsigned long long *)&state[tile], SCAN_ST_INC | (excl + tot));
+    }
+    if (lane == 0) {
+      s_excl = excl;
+      if (total_out && (long long)(tile + 1) * SCAN_TILE >= n) *total_out = excl + tot;
+    }
+  }
+  __syncthreads();
+  ex += s_excl;
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; k++) { long long i = base + k; if (i < n) out[i] = ex; ex += v[k]; }
 }
+__global__ void scan_clear_kernel(u64 *state, u32 *ticket, int ntiles) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ntiles) state[i] = 0;
+  if (i == 0) *ticket = 0;
+}
 
-struct ScanWork { u64 *tile_sums; long long cap_tiles; };
+struct ScanWork { u64 *state; u32 *ticket; long long cap_tiles; bool self_clear; };
 
-// exclusive scan of n u64 values; total (optional) is written on device
+// exclusive scan of n u64 values (< 2^62 in total); total (optional) is written on device
 static inline void device_excl_scan_u64(const u64 *in, u64 *out, long long n, u64 *total_out, ScanWork &w, hipStream_t st) {
   if (n <= 0) { if (total_out) hipMemsetAsync(total_out, 0, sizeof(u64), st); return; }
   int ntiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3(ntiles), dim3(SCAN_BLOCK), 0, st, in, w.tile_sums, n);
-  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, w.tile_sums, ntiles, total_out);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(SCAN_BLOCK), 0, st, in, out, w.tile_sums, n);
+  if (w.self_clear) hipLaunchKernelGGL(scan_clear_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, st, w.state, w.ticket, ntiles);
+  hipLaunchKernelGGL(scan_lookback_kernel, dim3(ntiles), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out);
 }
 
 // ------------------------------------------------------------------------ radix sort
 #define RS_MAX_RADIX 1024                   // 10-bit digits at most
-#define RS_WAVE_ITEMS 16                    // rounds of 64 keys per wave
-#define RS_TILE (64 * RS_WAVE_ITEMS)        // 1024 keys per wavefront
+#define RS_TILE 1024                        // keys per 256-thread block (4 waves x 4 rounds of 64)
 
-// histogram: hist[digit * ntiles + tile]
+// histogram: hist[digit * ntiles + tile]; one 256-thread block (4 waves) per tile of 1024 keys
 template <int BITS>
-__global__ void __launch_bounds__(64) rs_hist_kernel(const u64 *__restrict__ keys, u32 *__restrict__ hist, long long n, int ntiles, int shift) {
+__global__ void __launch_bounds__(256) rs_hist_kernel(const u64 *__restrict__ keys, u32 *__restrict__ hist, long long n, int ntiles, int shift) {
   constexpr int RS_RADIX = 1 << BITS;
   __shared__ u32 cnt[RS_RADIX];
-  const int lane = threadIdx.x;
-  for (int d = lane; d < RS_RADIX; d += 64) cnt[d] = 0;
+  for (int d = threadIdx.x; d < RS_RADIX; d += 256) cnt[d] = 0;
   __syncthreads();
-  long long base = (long long)blockIdx.x * RS_TILE;
-  u64 kreg[RS_WAVE_ITEMS];
+  const long long base = (long long)blockIdx.x * RS_TILE;
+  u64 kreg[RS_TILE / 256];
 #pragma unroll
-  for (int r = 0; r < RS_WAVE_ITEMS; r++) {          // all loads of the tile in flight at once
-    long long i = base + (long long)r * 64 + lane;
-    kreg[r] = (i < n) ? keys[i] : ~0ull;
-  }
+  for (int r = 0; r < RS_TILE / 256; r++) { long long i = base + r * 256 + threadIdx.x; kreg[r] = (i < n) ? keys[i] : ~0ull; }
 #pragma unroll
-  for (int r = 0; r < RS_WAVE_ITEMS; r++) {
-    long long i = base + (long long)r * 64 + lane;
-    if (i < n) atomicAdd(&cnt[(kreg[r] >> shift) & (RS_RADIX - 1)], 1u);
-  }
+  for (int r = 0; r < RS_TILE / 256; r++) { long long i = base + r * 256 + threadIdx.x; if (i < n) atomicAdd(&cnt[(kreg[r] >> shift) & (RS_RADIX - 1)], 1u); }
   __syncthreads();
-  for (int d = lane; d < RS_RADIX; d += 64) hist[(long long)d * ntiles + blockIdx.x] = cnt[d];
+  for (int d = threadIdx.x; d < RS_RADIX; d += 256) hist[(long long)d * ntiles + blockIdx.x] = cnt[d];
 }
 
 // one block per digit: in-place exclusive scan of that digit's row (ntiles entries) and the
@@ -137,52 +152,65 @@ __global__ void __launch_bounds__(SCAN_BLOCK) rs_scan_kernel(u32 *__restrict__ h
   if (threadIdx.x == 0) rowtot[blockIdx.x] = (u32)carry;
 }
 
+// Stable scatter: a 256-thread block owns a 1024-key tile; wave w owns keys [256w, 256w+256)
+// in 4 rounds of 64.  Rank among equal digits inside a round = popc(match & lanemask_lt) from
+// BITS ballots; per-wave digit counters live in LDS (private to the wave, in-order LDS queue),
+// then the four waves' counters are prefix-added once.  Only 4 sequential rounds per wave.
 template <int BITS>
-__global__ void __launch_bounds__(64) rs_scatter_kernel(const u64 *__restrict__ kin, const u32 *__restrict__ vin,
-                                                        u64 *__restrict__ kout, u32 *__restrict__ vout,
-                                                        const u32 *__restrict__ hist, const u32 *__restrict__ rowtot,
-                                                        long long n, int ntiles, int shift) {
-  constexpr int RS_RADIX = 1 << BITS, RS_BITS = BITS, PER = RS_RADIX / 64;
-  __shared__ u32 off[RS_RADIX];
-  const int lane = threadIdx.x;
-  {   // digit bases = exclusive scan of the row totals (PER per lane + wave scan)
+__global__ void __launch_bounds__(256) rs_scatter_kernel(const u64 *__restrict__ kin, const u32 *__restrict__ vin,
+                                                         u64 *__restrict__ kout, u32 *__restrict__ vout,
+                                                         const u32 *__restrict__ hist, const u32 *__restrict__ rowtot,
+                                                         long long n, int ntiles, int shift) {
+  constexpr int RS_RADIX = 1 << BITS, PER = RS_RADIX / 256, ROUNDS = RS_TILE / 256;
+  __shared__ u32 off[RS_RADIX];            // global base of each digit for this tile
+  __shared__ u32 wcnt[4][RS_RADIX];        // per-wave digit counts -> per-wave bases
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  {   // digit bases = exclusive scan of the row totals (PER per thread + block scan) + this tile's row prefix
     u32 t[PER]; u64 sum = 0;
 #pragma unroll
-    for (int q = 0; q < PER; q++) { t[q] = rowtot[lane * PER + q]; sum += t[q]; }
-    u32 ex = (u32)(wave_incl_scan_u64(sum, lane) - sum);
+    for (int q = 0; q < PER; q++) { t[q] = rowtot[tid * PER + q]; sum += t[q]; }
+    u64 tot; u32 ex = (u32)block_excl_scan_u64(sum, &tot);
 #pragma unroll
-    for (int q = 0; q < PER; q++) { off[lane * PER + q] = ex; ex += t[q]; }
+    for (int q = 0; q < PER; q++) { off[tid * PER + q] = ex + hist[(long long)(tid * PER + q) * ntiles + blockIdx.x]; ex += t[q]; }
   }
+  for (int d = tid; d < 4 * RS_RADIX; d += 256) (&wcnt[0][0])[d] = 0;
   __syncthreads();
-  for (int d = lane; d < RS_RADIX; d += 64) off[d] += hist[(long long)d * ntiles + blockIdx.x];
-  __syncthreads();
-  long long base = (long long)blockIdx.x * RS_TILE;
+  const long long base = (long long)blockIdx.x * RS_TILE + wv * (64 * ROUNDS);
   const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  u64 kreg[RS_WAVE_ITEMS]; u32 vreg[RS_WAVE_ITEMS];
+  u64 kreg[ROUNDS]; u32 vreg[ROUNDS], rnk[ROUNDS];
 #pragma unroll
-  for (int r = 0; r < RS_WAVE_ITEMS; r++) {          // the whole tile goes to registers first
-    long long i = base + (long long)r * 64 + lane;
-    kreg[r] = (i < n) ? kin[i] : 0; vreg[r] = (i < n) ? vin[i] : 0;
-  }
+  for (int r = 0; r < ROUNDS; r++) { long long i = base + r * 64 + lane; kreg[r] = (i < n) ? kin[i] : 0; vreg[r] = (i < n) ? vin[i] : 0; }
 #pragma unroll
-  for (int r = 0; r < RS_WAVE_ITEMS; r++) {
-    long long i = base + (long long)r * 64 + lane;
-    bool valid = i < n;
-    u64 key = kreg[r]; u32 val = vreg[r];
-    u32 dig = (u32)((key >> shift) & (RS_RADIX - 1));
+  for (int r = 0; r < ROUNDS; r++) {
+    const long long i = base + r * 64 + lane;
+    const bool valid = i < n;
+    const u32 dig = (u32)((kreg[r] >> shift) & (RS_RADIX - 1));
     u64 same = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < RS_BITS; b++) {
-      u64 m = __ballot((dig >> b) & 1);
-      same &= ((dig >> b) & 1) ? m : ~m;
+    for (int b = 0; b < BITS; b++) { u64 m = __ballot((dig >> b) & 1); same &= ((dig >> b) & 1) ? m : ~m; }
+    const u32 rank = (u32)__popcll(same & lt), cnt = (u32)__popcll(same);
+    u32 prev = 0;
+    if (valid) prev = wcnt[wv][dig];
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == 0) wcnt[wv][dig] = prev + cnt;
+    __builtin_amdgcn_wave_barrier();
+    rnk[r] = prev + rank;
+  }
+  __syncthreads();
+  for (int d = tid; d < RS_RADIX; d += 256) {   // turn per-wave counts into per-wave bases
+    u32 b = off[d];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { u32 c = wcnt[q][d]; wcnt[q][d] = b; b += c; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    const long long i = base + r * 64 + lane;
+    if (i < n) {
+      const u32 dig = (u32)((kreg[r] >> shift) & (RS_RADIX - 1));
+      const u32 dst = wcnt[wv][dig] + rnk[r];
+      kout[dst] = kreg[r]; vout[dst] = vreg[r];
     }
-    u32 rank = (u32)__popcll(same & lt), cnt = (u32)__popcll(same);
-    u32 dst = 0;
-    if (valid) dst = off[dig] + rank;
-    __syncthreads();                     // all lanes have read off[] before leaders bump it
-    if (valid && rank == 0) off[dig] += cnt;
-    __syncthreads();
-    if (valid) { kout[dst] = key; vout[dst] = val; }
   }
 }
 
@@ -192,9 +220,9 @@ struct SortWork { u64 *k_alt; u32 *v_alt; u32 *hist; u32 *rowtot; long long cap;
 // (either the inputs or the alternates).  Stable.
 template <int BITS>
 static inline void radix_pass(u64 *ka, u32 *va, u64 *kb, u32 *vb, long long n, int ntiles, int shift, SortWork &w, hipStream_t st) {
-  hipLaunchKernelGGL(rs_hist_kernel<BITS>, dim3(ntiles), dim3(64), 0, st, ka, w.hist, n, ntiles, shift);
+  hipLaunchKernelGGL(rs_hist_kernel<BITS>, dim3(ntiles), dim3(256), 0, st, ka, w.hist, n, ntiles, shift);
   hipLaunchKernelGGL(rs_scan_kernel, dim3(1 << BITS), dim3(SCAN_BLOCK), 0, st, w.hist, w.rowtot, ntiles);
-  hipLaunchKernelGGL(rs_scatter_kernel<BITS>, dim3(ntiles), dim3(64), 0, st, ka, va, kb, vb, w.hist, w.rowtot, n, ntiles, shift);
+  hipLaunchKernelGGL(rs_scatter_kernel<BITS>, dim3(ntiles), dim3(256), 0, st, ka, va, kb, vb, w.hist, w.rowtot, n, ntiles, shift);
 }
 // digit width: the fewest passes of at most 10 bits, then the narrowest digit that still
 // covers the key in that many passes (28-bit C2 keys: 3 passes of 10 bits)

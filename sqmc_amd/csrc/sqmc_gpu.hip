@@ -83,7 +83,7 @@ struct sqmc_gpu_ctx {
   WalkArr w, m;                        // walkers (main + appended spawns), merge results
   u64 *d_nchild; u64 *d_child_off; double *d_wchild; u64 *d_child_state;
   u64 *d_keys, *d_keys_alt; u32 *d_vals, *d_vals_alt; u32 *d_hist, *d_rowtot;
-  u64 *d_flags, *d_pos, *d_flags2, *d_pos2; u64 *d_tile_sums; long long cap_tiles;
+  u64 *d_flags, *d_pos, *d_flags2, *d_pos2; u64 *d_scan_state; u32 *d_scan_ticket; long long cap_tiles;   // 3 look-back scans per step
   // projector (full CSR, rows in the reference's accumulation order)
   long long n_imp, prj_nnz; int *d_prj_ptr, *d_prj_col; double *d_prj_val; int *d_loc_imp, *d_loc_imp_new; double *d_prj_x;
   // C(T)
@@ -399,7 +399,9 @@ __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64
 // final: sum block partials (fixed strided order + fixed tree: run-to-run reproducible);
 // publish stats; advance the REPLAY stream
 __global__ void __launch_bounds__(TPB) k_finish(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_blocks,
-                                                int mode, DevScalars *sc) {
+                                                int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words) {
+  for (int i = threadIdx.x; i < n_scan_words; i += TPB) scan_state[i] = 0;     // look-back states of this step's scans
+  if (threadIdx.x < 3) scan_ticket[threadIdx.x] = 0;
   __shared__ double red[TPB / 64][NSTAT + 2];
   __shared__ double tot[NSTAT + 2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -720,7 +722,7 @@ int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out) {
   HIPCHK(hipMemcpy(&c->d_sc->lcg, &s48, 8, hipMemcpyHostToDevice));
   if (c->mwalk > 0) {
     const long long M = c->mwalk;
-    if (M >= (1ll << 31)) { delete c; return fail(SQMC_ERR_UNSUPPORTED, "MWALK must be < 2^31"); }
+    if (M >= (1ll << 30)) { delete c; return fail(SQMC_ERR_UNSUPPORTED, "MWALK must be < 2^30"); }
     if (alloc_walk(c->w, M) || alloc_walk(c->m, M)) return SQMC_ERR_HIP;
     HIPCHK(hipMalloc(&c->d_nchild, (M + 1) * 8)); HIPCHK(hipMalloc(&c->d_child_off, (M + 1) * 8));
     HIPCHK(hipMalloc(&c->d_wchild, M * 8)); HIPCHK(hipMalloc(&c->d_child_state, M * 8));
@@ -731,7 +733,8 @@ int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out) {
     HIPCHK(hipMalloc(&c->d_flags, M * 8)); HIPCHK(hipMalloc(&c->d_pos, M * 8));
     HIPCHK(hipMalloc(&c->d_flags2, M * 8)); HIPCHK(hipMalloc(&c->d_pos2, M * 8));
     c->cap_tiles = (M + SCAN_TILE - 1) / SCAN_TILE + 1;
-    HIPCHK(hipMalloc(&c->d_tile_sums, c->cap_tiles * 8));
+    HIPCHK(hipMalloc(&c->d_scan_state, 3 * c->cap_tiles * 8)); HIPCHK(hipMalloc(&c->d_scan_ticket, 3 * 4));
+    HIPCHK(hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8)); HIPCHK(hipMemset(c->d_scan_ticket, 0, 3 * 4));
     c->n_partial_blocks = nblk(M);
     HIPCHK(hipMalloc(&c->d_partials, ((long long)c->n_partial_blocks * NSTAT + 128) * 8));
   }
@@ -749,7 +752,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
     free_walk(c->w); free_walk(c->m);
     hipFree(c->d_nchild); hipFree(c->d_child_off); hipFree(c->d_wchild); hipFree(c->d_child_state);
     hipFree(c->d_keys); hipFree(c->d_keys_alt); hipFree(c->d_vals); hipFree(c->d_vals_alt); hipFree(c->d_hist); hipFree(c->d_rowtot);
-    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_tile_sums); hipFree(c->d_partials);
+    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_partials);
   }
   hipFree(c->d_binom);
   hipFree(c->d_tab); hipFree(c->d_ints); hipFree(c->d_hb_r); hipFree(c->d_hb_s); hipFree(c->d_hb_absH); hipFree(c->d_pq_ind); hipFree(c->d_pq_count);
@@ -900,7 +903,8 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   p.semi = sp->semistochastic; p.reached = sp->reached_w_abs_gen;
   const long long n0 = c->nwalk, M = c->mwalk;
   const int mode = c->rng_mode; const u64 seed = c->seed64, step = c->step_no;
-  ScanWork sw; sw.tile_sums = c->d_tile_sums; sw.cap_tiles = c->cap_tiles;
+  ScanWork sw[3];      // one look-back state per scan of the step; k_finish re-zeroes them for the next step
+  for (int q = 0; q < 3; q++) { sw[q].state = c->d_scan_state + q * c->cap_tiles; sw[q].ticket = c->d_scan_ticket + q; sw[q].cap_tiles = c->cap_tiles; sw[q].self_clear = false; }
   c->nt = 0;
   hipStream_t st2 = c->st2;
   HIPCHK(hipMemsetAsync(&c->d_sc->n_children, 0, 4 * sizeof(u64) + 2 * sizeof(int), st));
@@ -911,7 +915,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
                        c->d_child_state, n0, M - n0, p, c->d_sc);
   } else {
     hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->w.wt, c->d_nchild, c->d_wchild, n0, p, seed, step);
-    device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw, st);
+    device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw[0], st);
   }
   TEND(gate_scan, st);
   // ---- fork: death/clone and the deterministic projection only touch weights, which neither
@@ -934,7 +938,11 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   HIPCHK(hipStreamSynchronize(st));
   TEND(sync, st);
   const long long nch = (long long)c->h_sc->n_children;
-  if (n0 + nch > M) { hipStreamSynchronize(st2); return fail(SQMC_ERR_MWALK, "nwalk>MWALK"); }
+  if (n0 + nch > M) {
+    hipStreamSynchronize(st2);
+    hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
+    return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
+  }
   const long long nall = n0 + nch;
   // ---- spawn (exactly one k_spawn launch inside this timer: the per-launch time bench.py reports)
   TBEG(spawn, st);
@@ -955,17 +963,18 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   TBEG(merge, st);
   hipLaunchKernelGGL(k_wabs, dim3(64), dim3(TPB), 0, st, c->w.wt, skey, c->invalid_key, nall, c->d_partials);
   hipLaunchKernelGGL(k_merge, dim3(nblk(nall)), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, n0, nall, p, c->invalid_key);
-  device_excl_scan_u64(c->d_flags, c->d_pos, nall, &c->d_sc->tot1, sw, st);
+  device_excl_scan_u64(c->d_flags, c->d_pos, nall, &c->d_sc->tot1, sw[1], st);
   TEND(merge, st);
   TBEG(round, st);
   hipLaunchKernelGGL(k_round, dim3(nblk(nall)), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, c->d_flags2, nall, p, mode, seed, step, c->d_sc);
-  device_excl_scan_u64(c->d_flags2, c->d_pos2, nall, &c->d_sc->tot2, sw, st);
+  device_excl_scan_u64(c->d_flags2, c->d_pos2, nall, &c->d_sc->tot2, sw[2], st);
   TEND(round, st);
   TBEG(estimate, st);
   const int nb = std::min(nblk(nall), 512);
   hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, st, c->m, c->w, c->d_flags2, c->d_pos2, c->d_loc_imp, c->d_ct_up, c->d_ct_dn, c->d_ct_num, c->d_ct_den,
                      c->n_ct, nall, p, c->d_partials + 128);
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials + 128, nb, c->d_partials, mode, c->d_sc);
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials + 128, nb, c->d_partials, mode, c->d_sc, c->d_scan_state, c->d_scan_ticket,
+                     (int)(3 * c->cap_tiles));
   TEND(estimate, st);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
@@ -1072,10 +1081,10 @@ int sqmc_gpu_build_sparse_ham(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, co
   u64 *du, *dd, *dcnt, *doff, *dtot, *dts;
   HIPCHK(hipMalloc(&du, n * 8)); HIPCHK(hipMalloc(&dd, n * 8)); HIPCHK(hipMalloc(&dcnt, n * 8)); HIPCHK(hipMalloc(&doff, n * 8)); HIPCHK(hipMalloc(&dtot, 8));
   long long tiles = (n + SCAN_TILE - 1) / SCAN_TILE + 1;
-  HIPCHK(hipMalloc(&dts, tiles * 8));
+  HIPCHK(hipMalloc(&dts, (tiles + 1) * 8));
   HIPCHK(hipMemcpy(du, up, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dd, dn, n * 8, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_build_ham, dim3(nblk(n)), dim3(TPB), 0, st, c->dev, du, dd, (long long)n, 0, dcnt, doff, (long long *)nullptr, (double *)nullptr);
-  ScanWork sw; sw.tile_sums = dts; sw.cap_tiles = tiles;
+  ScanWork sw; sw.state = dts; sw.ticket = (u32 *)(dts + tiles); sw.cap_tiles = tiles; sw.self_clear = true;
   device_excl_scan_u64(dcnt, doff, n, dtot, sw, st);
   u64 total = 0;
   HIPCHK(hipMemcpyAsync(&total, dtot, 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
@@ -1125,12 +1134,12 @@ int sqmc_gpu_hci_connections(sqmc_gpu_ctx *c, int64_t n_ref, const uint64_t *ref
   HIPCHK(hipMalloc(&dru, n_ref * 8)); HIPCHK(hipMalloc(&drd, n_ref * 8)); HIPCHK(hipMalloc(&dco, n_ref * 8));
   HIPCHK(hipMalloc(&dcnt, n_ref * 8)); HIPCHK(hipMalloc(&doff, n_ref * 8)); HIPCHK(hipMalloc(&dtot, 8));
   long long tiles = (n_ref + SCAN_TILE - 1) / SCAN_TILE + 1;
-  HIPCHK(hipMalloc(&dts, tiles * 8));
+  HIPCHK(hipMalloc(&dts, (tiles + 1) * 8));
   HIPCHK(hipMemcpy(dru, ref_up, n_ref * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(drd, ref_dn, n_ref * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dco, coeffs, n_ref * 8, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_hci_gen, dim3(nblk(n_ref)), dim3(TPB), 0, st, c->dev, dru, drd, dco, eps, diag_mode, (long long)n_ref, 0, dcnt, doff,
                      (u64 *)nullptr, (u64 *)nullptr, (double *)nullptr, (double *)nullptr);
-  ScanWork sw; sw.tile_sums = dts; sw.cap_tiles = tiles;
+  ScanWork sw; sw.state = dts; sw.ticket = (u32 *)(dts + tiles); sw.cap_tiles = tiles; sw.self_clear = true;
   device_excl_scan_u64(dcnt, doff, n_ref, dtot, sw, st);
   u64 total = 0;
   HIPCHK(hipMemcpyAsync(&total, dtot, 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
@@ -1148,9 +1157,9 @@ int sqmc_gpu_hci_connections(sqmc_gpu_ctx *c, int64_t n_ref, const uint64_t *ref
   device_radix_sort(skey, perm, T, c->key_bits, so, st);
   HIPCHK(hipMalloc(&flags, T * 8)); HIPCHK(hipMalloc(&pos, T * 8));
   long long tiles2 = (T + SCAN_TILE - 1) / SCAN_TILE + 1;
-  HIPCHK(hipMalloc(&dts2, tiles2 * 8)); HIPCHK(hipMalloc(&dtot2, 8));
+  HIPCHK(hipMalloc(&dts2, (tiles2 + 1) * 8)); HIPCHK(hipMalloc(&dtot2, 8));
   hipLaunchKernelGGL(k_hci_heads, dim3(nblk(T)), dim3(TPB), 0, st, skey, flags, T);
-  ScanWork sw2; sw2.tile_sums = dts2; sw2.cap_tiles = tiles2;
+  ScanWork sw2; sw2.state = dts2; sw2.ticket = (u32 *)(dts2 + tiles2); sw2.cap_tiles = tiles2; sw2.self_clear = true;
   device_excl_scan_u64(flags, pos, T, dtot2, sw2, st);
   u64 nuniq = 0;
   HIPCHK(hipMemcpyAsync(&nuniq, dtot2, 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
