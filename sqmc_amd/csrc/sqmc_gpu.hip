@@ -90,7 +90,7 @@ struct sqmc_gpu_ctx {
   long long n_ct; u64 *d_ct_up, *d_ct_dn; double *d_ct_num, *d_ct_den;
   int rng_mode; u64 seed64; u64 step_no;
   DevScalars *d_sc; DevScalars *h_sc;   // h_sc pinned
-  double *d_partials; int n_partial_blocks;
+  double *d_partials; int n_partial_blocks; double *d_wabs_part; u32 *d_done;
   int key_bits; u64 invalid_key; u64 *d_binom;
   // timing
   int timing; hipEvent_t ev0[NTIMERS], ev1[NTIMERS]; const char *tname[NTIMERS]; int nt; float tms[NTIMERS];
@@ -101,10 +101,12 @@ struct sqmc_gpu_ctx {
 // ===================================================================== step kernels
 
 // gate + child count (COUNTER discipline).  do_walk.f90:3577-3589
-__global__ void __launch_bounds__(TPB) k_gate(const double *__restrict__ wt, u64 *__restrict__ nchild, double *__restrict__ wchild,
+__global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, const double *__restrict__ wt,
+                                              u64 *__restrict__ nchild, double *__restrict__ wchild, u64 *__restrict__ keys, u32 *__restrict__ vals,
                                               long long n, StepP p, u64 seed, u64 step) {
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
+  keys[i] = det_key(dev, up[i], dn[i]); vals[i] = (u32)i;      // sort key of the walker itself
   double w = wt[i]; bool spawn, use_wt;
   if (fabs(w) < p.cutoff) {
     Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 0, (u64)i);
@@ -263,13 +265,28 @@ __device__ __forceinline__ double ipow_d(int b, int e) { double r = 1.0; for (in
 // (stable sort), so the pairwise combination below is the reference's left-to-right scan.
 // do_walk.f90:5866-6083, check_initiator 6838-6872.
 __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *__restrict__ skey, const u32 *__restrict__ perm,
-                                               u64 *__restrict__ flags, long long n0, long long n_all, StepP p, u64 invalid_key) {
+                                               u64 *__restrict__ flags, double *__restrict__ wabs_part, long long n0, long long n_all, StepP p, u64 invalid_key) {
   long long j = (long long)blockIdx.x * TPB + threadIdx.x;
   const long long n = n_all;
-  if (j >= n_all) return;
-  const u64 key = skey[j];
-  if (key == invalid_key) { flags[j] = 0; return; }     // children that produced no walker sort last
-  if (j > 0 && skey[j - 1] == key) { flags[j] = 0; return; }
+  // sum |w| and the number of real entries of the pre-merge list (my_w_abs_before_merge_cum,
+  // nwalk_before_merge; do_walk.f90:2347-2349): any order will do, so slot j itself is read
+  double wabs_j = 0.0, cnt_j = 0.0;
+  bool head = false; u64 key = 0;
+  if (j < n_all) {
+    key = skey[j];
+    wabs_j = fabs(w.wt[j]);
+    if (key == invalid_key) flags[j] = 0;               // children that produced no walker sort last
+    else { cnt_j = 1.0; if (j > 0 && skey[j - 1] == key) flags[j] = 0; else head = true; }
+  }
+  {
+    __shared__ double red[2][TPB / 64];
+    double v = wabs_j, q = cnt_j;
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); q += __shfl_down(q, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = v; red[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) { wabs_part[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3]; wabs_part[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3]; }
+  }
+  if (!head) return;
   u32 t = perm[j];
   const bool t_spawn = (long long)t >= n0;
   double wt = w.wt[t], me = t_spawn ? 1e51 : w.me[t], en = t_spawn ? 1e51 : w.en[t], ed = t_spawn ? 1e51 : w.ed[t];
@@ -346,6 +363,8 @@ __device__ __forceinline__ long long ct_search(const u64 *__restrict__ cu, const
 }
 
 #define NSTAT 13
+__device__ void finish_step(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
+                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words);
 // compaction into the walker arrays + reweight (2487) + estimator pieces (2573-2684 and
 // binary_search_list_and_update, more_tools.f90:4041-4098) + per-block partial sums
 __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64 *__restrict__ flags2, const u64 *__restrict__ pos2,
@@ -395,25 +414,32 @@ __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64
     partials[(long long)blockIdx.x * NSTAT + threadIdx.x] = v;
   }
 }
-
-// final: sum block partials (fixed strided order + fixed tree: run-to-run reproducible);
-// publish stats; advance the REPLAY stream
-__global__ void __launch_bounds__(TPB) k_finish(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_blocks,
+// The final reduction stays a kernel of its own: folding it into the last-arriving block of
+// k_compact needs an agent-scope release in every block and cost more than this launch.
+__global__ void __launch_bounds__(TPB) k_finish(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
                                                 int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words) {
-  for (int i = threadIdx.x; i < n_scan_words; i += TPB) scan_state[i] = 0;     // look-back states of this step's scans
-  if (threadIdx.x < 3) scan_ticket[threadIdx.x] = 0;
-  __shared__ double red[TPB / 64][NSTAT + 2];
+  finish_step(partials, nblocks, wabs_part, nwabs, mode, sc, scan_state, scan_ticket, n_scan_words);
+}
+
+// final reduction: sums block partials
+// (fixed strided order + fixed tree: reproducible run to run), publishes the step's sums,
+// advances the REPLAY stream and re-zeroes the look-back scan states for the next step
+__device__ void finish_step(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
+                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words) {
+  __shared__ double red2[TPB / 64][NSTAT + 2];
   __shared__ double tot[NSTAT + 2];
+  for (int i = threadIdx.x; i < n_scan_words; i += TPB) scan_state[i] = 0;
+  if (threadIdx.x < 3) scan_ticket[threadIdx.x] = 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int k = 0; k < NSTAT + 2; k++) {
     double v = 0.0;
     if (k < NSTAT) { for (int b = threadIdx.x; b < nblocks; b += TPB) v += partials[(long long)b * NSTAT + k]; }
-    else if (threadIdx.x < 64) v = wabs_blocks[(k - NSTAT) * 64 + threadIdx.x];
+    else { for (int b = threadIdx.x; b < nwabs; b += TPB) v += wabs_part[2 * b + (k - NSTAT)]; }
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if (lane == 0) red[wv][k] = v;
+    if (lane == 0) red2[wv][k] = v;
   }
   __syncthreads();
-  if (threadIdx.x < NSTAT + 2) { double v = 0.0; for (int q = 0; q < TPB / 64; q++) v += red[q][threadIdx.x]; tot[threadIdx.x] = v; }
+  if (threadIdx.x < NSTAT + 2) { double v = 0.0; for (int q = 0; q < TPB / 64; q++) v += red2[q][threadIdx.x]; tot[threadIdx.x] = v; }
   __syncthreads();
   if (threadIdx.x == 0) {
     double *o = sc->stats;
@@ -424,20 +450,6 @@ __global__ void __launch_bounds__(TPB) k_finish(const double *__restrict__ parti
     if (mode == 0) sc->lcg = lcg_skip(sc->lcg, sc->tot1 >> 32);
   }
 }
-// sum |w| over the pre-merge list (my_w_abs_before_merge_cum, do_walk.f90:2347) and count its
-// real entries (nwalk_before_merge): out[0..63] block sums of |w|, out[64..127] block counts
-__global__ void __launch_bounds__(TPB) k_wabs(const double *__restrict__ wt, const u64 *__restrict__ keys, u64 invalid_key, long long n, double *__restrict__ out) {
-  __shared__ double red[2][TPB / 64];
-  double v = 0.0, cnt = 0.0;
-  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
-    v += fabs(wt[i]); cnt += (keys[i] != invalid_key) ? 1.0 : 0.0;
-  }
-  for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); cnt += __shfl_down(cnt, o, 64); }
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = v; red[1][threadIdx.x >> 6] = cnt; }
-  __syncthreads();
-  if (threadIdx.x == 0) { out[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3]; out[64 + blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3]; }
-}
-
 // ============================================================ batch / test door kernels
 __global__ void __launch_bounds__(TPB) k_ham_batch(ChemDev dev, const u64 *iu, const u64 *id, const u64 *ju, const u64 *jd, double *h, long long n) {
   __shared__ ChemTab t;
@@ -737,6 +749,8 @@ int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out) {
     HIPCHK(hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8)); HIPCHK(hipMemset(c->d_scan_ticket, 0, 3 * 4));
     c->n_partial_blocks = nblk(M);
     HIPCHK(hipMalloc(&c->d_partials, ((long long)c->n_partial_blocks * NSTAT + 128) * 8));
+    HIPCHK(hipMalloc(&c->d_wabs_part, ((long long)c->n_partial_blocks * 2 + 2) * 8));
+    HIPCHK(hipMalloc(&c->d_done, 4)); HIPCHK(hipMemset(c->d_done, 0, 4));
   }
   for (int i = 0; i < NTIMERS; i++) { HIPCHK(hipEventCreate(&c->ev0[i])); HIPCHK(hipEventCreate(&c->ev1[i])); }
   HIPCHK(hipStreamCreate(&c->st2));
@@ -752,7 +766,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
     free_walk(c->w); free_walk(c->m);
     hipFree(c->d_nchild); hipFree(c->d_child_off); hipFree(c->d_wchild); hipFree(c->d_child_state);
     hipFree(c->d_keys); hipFree(c->d_keys_alt); hipFree(c->d_vals); hipFree(c->d_vals_alt); hipFree(c->d_hist); hipFree(c->d_rowtot);
-    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_partials);
+    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done);
   }
   hipFree(c->d_binom);
   hipFree(c->d_tab); hipFree(c->d_ints); hipFree(c->d_hb_r); hipFree(c->d_hb_s); hipFree(c->d_hb_absH); hipFree(c->d_pq_ind); hipFree(c->d_pq_count);
@@ -914,7 +928,8 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     hipLaunchKernelGGL(k_replay_prepass, dim3(1), dim3(64), 0, st, c->d_tab, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_child_off,
                        c->d_child_state, n0, M - n0, p, c->d_sc);
   } else {
-    hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->w.wt, c->d_nchild, c->d_wchild, n0, p, seed, step);
+    hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
+                       n0, p, seed, step);
     device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw[0], st);
   }
   TEND(gate_scan, st);
@@ -952,7 +967,8 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   TEND(spawn, st);
   // ---- sort
   TBEG(sort, st);
-  hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0);
+  if (mode == SQMC_RNG_REPLAY)
+    hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0);
   SortWork so; so.k_alt = c->d_keys_alt; so.v_alt = c->d_vals_alt; so.hist = c->d_hist; so.rowtot = c->d_rowtot; so.cap = M;
   u64 *skey = c->d_keys; u32 *perm = c->d_vals;
   device_radix_sort(skey, perm, nall, c->key_bits, so, st);
@@ -961,8 +977,8 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   // ---- join: from here on weights are read
   HIPCHK(hipStreamWaitEvent(st, c->e_join, 0));
   TBEG(merge, st);
-  hipLaunchKernelGGL(k_wabs, dim3(64), dim3(TPB), 0, st, c->w.wt, skey, c->invalid_key, nall, c->d_partials);
-  hipLaunchKernelGGL(k_merge, dim3(nblk(nall)), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, n0, nall, p, c->invalid_key);
+  const int nbm = nblk(nall);
+  hipLaunchKernelGGL(k_merge, dim3(nbm), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, c->d_wabs_part, n0, nall, p, c->invalid_key);
   device_excl_scan_u64(c->d_flags, c->d_pos, nall, &c->d_sc->tot1, sw[1], st);
   TEND(merge, st);
   TBEG(round, st);
@@ -972,8 +988,8 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   TBEG(estimate, st);
   const int nb = std::min(nblk(nall), 512);
   hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, st, c->m, c->w, c->d_flags2, c->d_pos2, c->d_loc_imp, c->d_ct_up, c->d_ct_dn, c->d_ct_num, c->d_ct_den,
-                     c->n_ct, nall, p, c->d_partials + 128);
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials + 128, nb, c->d_partials, mode, c->d_sc, c->d_scan_state, c->d_scan_ticket,
+                     c->n_ct, nall, p, c->d_partials);
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials, nb, c->d_wabs_part, nbm, mode, c->d_sc, c->d_scan_state, c->d_scan_ticket,
                      (int)(3 * c->cap_tiles));
   TEND(estimate, st);
   HIPCHK(hipGetLastError());
