@@ -448,3 +448,55 @@ def allreduce_step_sums(out, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     res[:7] = t.cpu().numpy()
     return res
+
+
+# ------------------------------------------------------------------------------- HCI
+def hci_variational(host, g, eps_var, eps_sched=(), n_states=1, max_iters=50, log=None, davidson_tol=1e-10):
+    """Variational stage of perform_hci (hci.f90:359-520) with get_next_det_list
+    (hci.f90:865-1040): every piece that scales with the number of determinants runs on the
+    GPU -- eps-screened connection generation + dedup (sqmc_gpu_hci_connections), sparse
+    Hamiltonian (sqmc_gpu_build_sparse_ham), Davidson matvec (sqmc_gpu_spmv_apply).
+    Returns (up, dn, coeffs[n, n_states], energies, history of ndets)."""
+    sched = list(eps_sched) + [eps_var]
+    up = np.array([host.hf_up], np.uint64); dn = np.array([host.hf_dn], np.uint64)
+    wts = np.zeros((1, n_states)); wts[0, 0] = 1.0
+    energy = np.zeros(n_states)
+    energy[0] = g.hamiltonian_batch(up, dn, up, dn)[0]
+    old_energy = energy.copy()
+    hist = [1]
+    eps = sched[0]
+    for it in range(1, max_iters + 1):
+        if it <= len(sched):
+            eps = sched[it - 1]
+        coeffs = np.abs(wts).max(axis=1) if it > 1 else wts[:, 0].copy()
+        cu, cd, _, _ = g.hci_connections(up, dn, coeffs, eps)              # sorted, unique, includes the old list
+        # append the new determinants behind the old list in sorted order (hci.f90:979-991)
+        okey = np.stack((up, dn), axis=1); nkey = np.stack((cu, cd), axis=1)
+        old_set = set(map(tuple, okey.tolist()))
+        is_new = np.fromiter((tuple(k) not in old_set for k in nkey.tolist()), bool, len(nkey))
+        n_old, n_new = len(up), len(up) + int(is_new.sum())
+        if n_new == n_old:
+            continue
+        if n_new <= int(1.00001 * n_old) and eps == sched[-1]:
+            break
+        up = np.concatenate((up, cu[is_new])); dn = np.concatenate((dn, cd[is_new]))
+        order = sort_dets(up, dn)
+        v0 = None
+        if it > 1:
+            v0 = np.zeros((n_new, n_states)); v0[np.argsort(order)[:n_old], :] = wts
+        counts, idx, val = g.build_sparse_ham(up[order], dn[order])
+        starts = np.concatenate(([0], np.cumsum(counts)))[:-1]
+        plan = SpmvPlan(counts, idx, val)
+        try:
+            w, X = davidson_lowest(plan, val[starts], k=n_states, v0=v0, tol=davidson_tol)
+        finally:
+            plan.close()
+        wts = np.zeros((n_new, n_states)); wts[order, :] = X
+        energy = np.array(w)
+        hist.append(n_new)
+        if log:
+            log("Iteration %3d eps1=%.1e ndets=%9d nnz=%10d energy=%s" % (it, eps, n_new, len(val), " ".join("%.9f" % e for e in energy)))
+        if np.max(np.abs(energy - old_energy)) < 1e-5 and eps == sched[-1]:
+            break
+        old_energy = energy.copy()
+    return up, dn, wts, energy, hist

@@ -329,3 +329,22 @@ def test_run_loop_equals_stepwise_population_control(oracle, c2_walk, c2_setup):
     assert np.array_equal(wa["up"], wb["up"]) and np.array_equal(wa["dn"], wb["dn"])
     assert np.allclose(wa["wt"], wb["wt"], rtol=1e-9)
     assert np.allclose(oa, ob, rtol=1e-9)
+
+
+def test_hci_variational_matches_reference_run():
+    """BASELINE.json configs[4]: HCI on C2 cc-pVDZ, eps1=1e-4 (schedule 2x2e-4), one state, the
+    shipped deck's conventions (time_sym, z=+1, hf_symmetry=1), everything heavy on the GPU.
+    The reference's own run recorded 694 -> 47038 -> 118626 -> 126386 -> 126708 determinants and
+    E_var = -75.727563003; the last two counts move by a few
+    determinants with the eigenvector's round-off at the selection threshold."""
+    from conftest import FCIDUMP
+    from sqmc_amd import host as H
+    h = H.ChemHost(FCIDUMP, 8, 4, "d2h", time_sym=True, z=1)
+    g = h.gpu()
+    g.set_hb_tables(*h.hb_tables(g))
+    up, dn, w, e, hist = H.hci_variational(h, g, 1e-4, eps_sched=(2e-4, 2e-4), n_states=1)
+    g.close()
+    assert hist[:4] == [1, 694, 47038, 118626]
+    assert abs(hist[4] - 126386) <= 3 and abs(hist[5] - 126708) <= 3
+    assert abs(e[0] - (-75.727563003)) < 2e-9
+    assert abs(np.dot(w[:, 0], w[:, 0]) - 1.0) < 1e-9

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Auxiliary measurement (not the driver's bench line): HCI variational stage of
+BASELINE.json configs[4] on one GPU + bandwidth of the Davidson matvec on the final matrix."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch            # before the HIP library: both must share one libamdhip64 (torch's copy is loaded first)
+import sqmc_amd
+from sqmc_amd import host as H
+
+FCIDUMP = os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP")
+t0 = time.perf_counter()
+h = H.ChemHost(FCIDUMP, 8, 4, "d2h", time_sym=True, z=1)
+g = h.gpu()
+g.set_hb_tables(*h.hb_tables(g))
+t1 = time.perf_counter()
+up, dn, w, e, hist = H.hci_variational(h, g, 1e-4, eps_sched=(2e-4, 2e-4))
+t2 = time.perf_counter()
+order = H.sort_dets(up, dn)
+ta = time.perf_counter(); counts, idx, val = g.build_sparse_ham(up[order], dn[order]); tb = time.perf_counter()
+plan = sqmc_amd.SpmvPlan(counts, idx, val)
+n, nnz = len(counts), len(val)
+nnz_full = 2 * nnz - n
+import ctypes as C
+L = sqmc_amd.load_library()
+x = torch.randn(n, dtype=torch.float64, device="cuda"); y = torch.empty_like(x)
+for _ in range(5):
+    L.sqmc_gpu_spmv_apply(plan.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), 1)
+torch.cuda.synchronize(); t3 = time.perf_counter()
+reps = 50
+for _ in range(reps):
+    L.sqmc_gpu_spmv_apply(plan.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), 1)
+torch.cuda.synchronize(); t4 = time.perf_counter()
+ms = (t4 - t3) / reps * 1e3
+alg = 20.0 * nnz + 20.0 * n            # 20 B per stored nonzero + 20 B per row
+print(json.dumps({"hci_variational_s": t2 - t1, "setup_s": t1 - t0, "ndets_history": hist, "e_var": float(e[0]),
+                  "build_sparse_ham_s": tb - ta, "n": n, "nnz_upper": nnz, "spmv_ms": ms,
+                  "spmv_algorithmic_GBs": alg / (ms * 1e-3) / 1e9, "spmv_frac_of_8TBs": alg / (ms * 1e-3) / 1e9 / 8000.0,
+                  "spmv_moved_GBs_full_csr": (12.0 * nnz_full + 8.0 * nnz_full + 20.0 * n) / (ms * 1e-3) / 1e9}))
