@@ -87,7 +87,7 @@ struct sqmc_gpu_ctx {
   // projector (full CSR, rows in the reference's accumulation order)
   long long n_imp, prj_nnz; int *d_prj_ptr, *d_prj_col; double *d_prj_val; int *d_loc_imp, *d_loc_imp_new; double *d_prj_x;
   // C(T)
-  long long n_ct; u64 *d_ct_up, *d_ct_dn; double *d_ct_num, *d_ct_den;
+  long long n_ct; u64 *d_ct_up, *d_ct_dn; double *d_ct_num, *d_ct_den; u64 *d_ct_hkey; u32 *d_ct_hidx; u64 ct_mask;
   int rng_mode; u64 seed64; u64 step_no;
   DevScalars *d_sc; DevScalars *h_sc;   // h_sc pinned
   double *d_partials; int n_partial_blocks; double *d_wabs_part; u32 *d_done;
@@ -352,14 +352,32 @@ __global__ void __launch_bounds__(TPB) k_round(WalkArr m, const u64 *__restrict_
   flags2[j] = f2;
 }
 
-__device__ __forceinline__ long long ct_search(const u64 *__restrict__ cu, const u64 *__restrict__ cd, long long n, u64 u, u64 d) {
-  long long lo = 0, hi = n - 1;
-  while (lo <= hi) {
-    long long mid = (lo + hi) >> 1; u64 a = cu[mid], b = cd[mid];
-    if (a == u && b == d) return mid;
-    if (a < u || (a == u && b < d)) lo = mid + 1; else hi = mid - 1;
+// C(T) lookup: open-addressed hash (linear probing, load <= 1/2) from the determinant's sort
+// key to its row in the C(T) arrays.  Replaces the binary search of
+// binary_search_list_and_update (more_tools.f90:4041-4098): one or two dependent reads
+// instead of log2(n_ct) ~ 17; the 2 MB table is L2-resident.
+#define CT_EMPTY (~0ull)
+__device__ __forceinline__ u64 ct_hash(u64 k) { return sq_mix64(k); }
+__global__ void __launch_bounds__(TPB) k_ct_build(ChemDev dev, const u64 *__restrict__ cu, const u64 *__restrict__ cd, long long n,
+                                                  u64 *__restrict__ hkey, u32 *__restrict__ hidx, u64 mask) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const u64 key = det_key(dev, cu[i], cd[i]);
+  u64 h = ct_hash(key) & mask;
+  while (true) {
+    u64 prev = atomicCAS((unsigned long long *)&hkey[h], CT_EMPTY, key);
+    if (prev == CT_EMPTY) { hidx[h] = (u32)i; return; }
+    h = (h + 1) & mask;
   }
-  return -1;
+}
+__device__ __forceinline__ long long ct_lookup(const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 mask, u64 key) {
+  u64 h = ct_hash(key) & mask;
+  while (true) {
+    const u64 k = hkey[h];
+    if (k == key) return (long long)hidx[h];
+    if (k == CT_EMPTY) return -1;
+    h = (h + 1) & mask;
+  }
 }
 
 #define NSTAT 13
@@ -368,8 +386,9 @@ __device__ void finish_step(const double *__restrict__ partials, int nblocks, co
 // compaction into the walker arrays + reweight (2487) + estimator pieces (2573-2684 and
 // binary_search_list_and_update, more_tools.f90:4041-4098) + per-block partial sums
 __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64 *__restrict__ flags2, const u64 *__restrict__ pos2,
-                                                 int *__restrict__ loc_imp, const u64 *__restrict__ cu, const u64 *__restrict__ cd,
-                                                 const double *__restrict__ cnum, const double *__restrict__ cden, long long n_ct,
+                                                 int *__restrict__ loc_imp, const u64 *__restrict__ skey, const u64 *__restrict__ hkey,
+                                                 const u32 *__restrict__ hidx, u64 hmask,
+                                                 const double *__restrict__ cnum, const double *__restrict__ cden,
                                                  long long n_all, StepP p, double *__restrict__ partials) {
   double s[NSTAT];
 #pragma unroll
@@ -382,7 +401,7 @@ __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64
     const u32 fj = m.flg[j]; const int d = flg_impd(fj), ini = flg_init(fj), psg = flg_psign(fj);
     double en = m.en[j], ed = m.ed[j];
     if (en > 1e50) {
-      long long q = ct_search(cu, cd, n_ct, u, dd);
+      long long q = ct_lookup(hkey, hidx, hmask, skey[j]);
       if (q < 0) { en = 0.0; ed = 0.0; } else { en = cnum[q]; ed = cden[q]; }
     }
     w.up[o] = u; w.dn[o] = dd; w.wt[o] = wt; w.flg[o] = fj;
@@ -771,7 +790,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   hipFree(c->d_binom);
   hipFree(c->d_tab); hipFree(c->d_ints); hipFree(c->d_hb_r); hipFree(c->d_hb_s); hipFree(c->d_hb_absH); hipFree(c->d_pq_ind); hipFree(c->d_pq_count);
   hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x);
-  hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den);
+  hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den); hipFree(c->d_ct_hkey); hipFree(c->d_ct_hidx);
   hipFree(c->d_sc); hipHostFree(c->h_sc);
   for (int i = 0; i < NTIMERS; i++) { hipEventDestroy(c->ev0[i]); hipEventDestroy(c->ev1[i]); }
   hipEventDestroy(c->e_fork); hipEventDestroy(c->e_join);
@@ -825,6 +844,20 @@ int sqmc_gpu_set_ct_table(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, const 
   HIPCHK(hipMalloc(&c->d_ct_up, (n + 1) * 8)); HIPCHK(hipMalloc(&c->d_ct_dn, (n + 1) * 8)); HIPCHK(hipMalloc(&c->d_ct_num, (n + 1) * 8)); HIPCHK(hipMalloc(&c->d_ct_den, (n + 1) * 8));
   HIPCHK(hipMemcpy(c->d_ct_up, up, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->d_ct_dn, dn, n * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->d_ct_num, num, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->d_ct_den, den, n * 8, hipMemcpyHostToDevice));
+  {
+    const u64 lim = c->htab.orb_mask;
+    for (long long i = 0; i < n; i++) {
+      if ((up[i] & ~lim) || (dn[i] & ~lim) || __builtin_popcountll(up[i]) != c->htab.nup || __builtin_popcountll(dn[i]) != c->htab.ndn)
+        return fail(SQMC_ERR_BAD_ARG, "C(T) determinant with the wrong number of electrons or orbitals beyond norb");
+    }
+    u64 cap = 64; while (cap < 2ull * (u64)n) cap <<= 1;
+    hipFree(c->d_ct_hkey); hipFree(c->d_ct_hidx);
+    HIPCHK(hipMalloc(&c->d_ct_hkey, cap * 8)); HIPCHK(hipMalloc(&c->d_ct_hidx, cap * 4));
+    HIPCHK(hipMemset(c->d_ct_hkey, 0xFF, cap * 8));
+    c->ct_mask = cap - 1;
+    if (n > 0) hipLaunchKernelGGL(k_ct_build, dim3(nblk(n)), dim3(TPB), 0, c->st, c->dev, c->d_ct_up, c->d_ct_dn, (long long)n, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask);
+    HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->st));
+  }
   return SQMC_OK;
 }
 
@@ -987,8 +1020,8 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   TEND(round, st);
   TBEG(estimate, st);
   const int nb = std::min(nblk(nall), 512);
-  hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, st, c->m, c->w, c->d_flags2, c->d_pos2, c->d_loc_imp, c->d_ct_up, c->d_ct_dn, c->d_ct_num, c->d_ct_den,
-                     c->n_ct, nall, p, c->d_partials);
+  hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, st, c->m, c->w, c->d_flags2, c->d_pos2, c->d_loc_imp, skey, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask,
+                     c->d_ct_num, c->d_ct_den, nall, p, c->d_partials);
   hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials, nb, c->d_wabs_part, nbm, mode, c->d_sc, c->d_scan_state, c->d_scan_ticket,
                      (int)(3 * c->cap_tiles));
   TEND(estimate, st);
