@@ -24,7 +24,7 @@ FCIDUMP = os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # HBM bytes per k_spawn launch from the PMC passes in profiles/ (FETCH_SIZE doubled as the guide
 # prescribes for gfx950, + WRITE_SIZE, KiB -> bytes); None until measured for the current kernel.
-TRAFFIC_K_SPAWN = None
+TRAFFIC_K_SPAWN = 2.13e7      # profiles/r01_bench_1e5_rocprof_summary.txt: (2*5965.7 + 8837.0) KiB
 
 
 def main():
