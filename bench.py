@@ -38,6 +38,8 @@ def main():
     args = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if "SQMC_BENCH_DEVICE" in os.environ:       # rehearsal of the N>1 path on a one-GPU box
+        local = int(os.environ["SQMC_BENCH_DEVICE"])
     import numpy as np
     import torch
     import sqmc_amd
@@ -46,17 +48,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("SQMC_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 path on a one-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    comm_dev = "cuda" if (world > 1 and backend == "nccl") else "cpu"
     sqmc_amd.set_device(local)
 
     hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
-    walk = H.GpuWalk(hst, args.target, seed=H.rank_seed((1346, 5634, 6635, 4361), rank))
-    dev = torch.device("cuda", local)
-
-    # equilibration + warmup (untimed), then EXACTLY --steps timed steps inside sqmc_gpu_run
-    walk.run(args.equil, keep_stats=False)
-    walk.run(args.warmup, keep_stats=False)
-    walk.g.set_timing(1)           # HIP events around the k_spawn launch only, accumulated over the timed steps
 
     def fence():
         torch.cuda.synchronize()
@@ -64,18 +64,65 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    stats, totals = walk.run(args.steps, keep_stats=True)
-    fence()
-    dt = time.perf_counter() - t0
-    nwalk_sum, spawn_sum = float(totals[5]), float(totals[15])
-    e_num, e_den = float((stats[:, 3] * np.sign(stats[:, 2])).sum()), float(np.abs(stats[:, 2]).sum())
-    spawn_ms = dict(walk.g.timing())["spawn"]          # mean ms per k_spawn launch over the K timed steps
-    walk.g.set_timing(2)                                # informational stage breakdown from an untimed tail
-    walk.run(20, keep_stats=False)
-    stage_ms = dict(walk.g.timing())
-    tot = torch.tensor([nwalk_sum, spawn_sum, dt], dtype=torch.float64, device="cuda")
+    parallelism = "single GPU"
+    walk = None
+    if world > 1:
+        # weak scaling: the global target grows with the number of GPUs, determinants are sharded by
+        # hash ownership and spawns cross ranks through one RCCL all-to-all per step
+        try:
+            walk = H.ShardedWalk(hst, args.target * world, rank, world, device_index=local, seed=(1346, 5634, 6635, 4361))
+            walk.step()
+            parallelism = "sharded x%d (hash-owned determinants, RCCL all-to-all of spawns)" % world
+            ok = torch.ones(1, device=comm_dev)
+        except Exception as exc:                      # keep the scaling run alive: independent replicas
+            sys.stderr.write("rank %d: sharded path failed (%r); falling back to replicas\n" % (rank, exc))
+            ok = torch.zeros(1, device=comm_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() < 1:
+            if walk is not None:
+                walk.close()
+            walk = None
+    if walk is None:
+        walk = H.GpuWalk(hst, args.target, seed=H.rank_seed((1346, 5634, 6635, 4361), rank))
+        if world > 1:
+            parallelism = "replicas x%d (sharded path unavailable)" % world
+    sharded = isinstance(walk, H.ShardedWalk)
+
+    if sharded:
+        for _ in range(args.equil + args.warmup):
+            walk.step()
+        walk.g.set_timing(1)
+        fence()
+        t0 = time.perf_counter()
+        rows = [walk.step() for _ in range(args.steps)]
+        fence()
+        dt = time.perf_counter() - t0
+        stats = np.array(rows)
+        # out[5] (nwalk) is already the all-reduced global count; spawns (out[15]) are rank-local
+        nwalk_sum, spawn_sum = float(stats[:, 5].sum()) / world, float(stats[:, 15].sum())
+        e_num, e_den = float((stats[:, 3] * np.sign(stats[:, 2])).sum()), float(np.abs(stats[:, 2]).sum())
+        spawn_ms = dict(walk.g.timing()).get("spawn", float("nan"))
+        walk.g.set_timing(2)
+        for _ in range(10):
+            walk.step()
+        stage_ms = dict(walk.g.timing())
+    else:
+        # equilibration + warmup (untimed), then EXACTLY --steps timed steps inside sqmc_gpu_run
+        walk.run(args.equil, keep_stats=False)
+        walk.run(args.warmup, keep_stats=False)
+        walk.g.set_timing(1)           # HIP events around the k_spawn launch only, accumulated over the timed steps
+        fence()
+        t0 = time.perf_counter()
+        stats, totals = walk.run(args.steps, keep_stats=True)
+        fence()
+        dt = time.perf_counter() - t0
+        nwalk_sum, spawn_sum = float(totals[5]), float(totals[15])
+        e_num, e_den = float((stats[:, 3] * np.sign(stats[:, 2])).sum()), float(np.abs(stats[:, 2]).sum())
+        spawn_ms = dict(walk.g.timing())["spawn"]          # mean ms per k_spawn launch over the K timed steps
+        walk.g.set_timing(2)                                # informational stage breakdown from an untimed tail
+        walk.run(20, keep_stats=False)
+        stage_ms = dict(walk.g.timing())
+    tot = torch.tensor([nwalk_sum, spawn_sum, dt], dtype=torch.float64, device=comm_dev)
     if world > 1:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot)
@@ -96,16 +143,16 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2 cc-pVDZ r=1.24253 (8e,26o, D2h) semistochastic walk, uniform2 proposal, w_abs_gen_target=%g, "
-                                   "size_deterministic=1000, Psi_T 100 dets, min_wt 0.5, r_initiator 1, tau_multiplier 0.1" % args.target,
+                                   "size_deterministic=1000, Psi_T 100 dets, min_wt 0.5, r_initiator 1, tau_multiplier 0.1" % (args.target * (world if sharded else 1)),
                        "occupied_dets_per_step": n_avg, "spawns_per_step": s_avg, "spawns_per_s": spawn_all / dt,
-                       "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": "replicas x%d" % world},
+                       "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": parallelism},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": TRAFFIC_K_SPAWN, "ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": 84.0 * s_avg,
                          "whole_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
                                         "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
                          "stage_ms_per_step": stage_ms},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(walk, hst, n_avg)
         print(json.dumps(line), flush=True)
     walk.close()

@@ -144,6 +144,26 @@ typedef struct {
  * totals[16] their sums over the nsteps steps.  pc is updated in place. */
 int sqmc_gpu_run(sqmc_gpu_ctx *ctx, sqmc_popctl *pc, int64_t nsteps, double *stats, double totals[16]);
 
+/* ---- multi-rank sharding: one process per GPU, walkers owned by hash(det) mod nranks, as the
+ * reference shards them over MPI ranks (get_det_owner, mpi_routines.f90:419-445).  The library
+ * does no communication itself: the step is cut at the reference's two exchange points and the
+ * host moves device buffers with its collective library (RCCL through torch.distributed in
+ * sqmc_amd/host.py; MPI in the reference):
+ *   shard_begin   gate, death/clone, spawn; owned deterministic-space weights -> x_global
+ *     [host: all-reduce SUM of x_global]                      (mpi_redscatt, do_walk.f90:2259-2260)
+ *   shard_pack    owned rows of the projection; spawns bucketed by owner into 32-byte records
+ *     [host: all-to-all of the counts, then of the records]   (mpi_sendnewwalks, do_walk.f90:2237)
+ *   shard_finish  received records appended; sort, annihilation, rounding, estimator sums
+ *     [host: all-reduce SUM of out_stats[0..6]]               (mpi_allred, do_walk.f90:2778)
+ * set_projector takes the GLOBAL projector on every rank; shard_config gives, for the k-th
+ * deterministic-space walker this rank owns (in its sorted order), its row in that matrix. */
+int sqmc_gpu_det_owner(sqmc_gpu_ctx *ctx, int64_t n, const uint64_t *up, const uint64_t *dn, int32_t nranks, int32_t *owner);
+int sqmc_gpu_shard_config(sqmc_gpu_ctx *ctx, int32_t rank, int32_t nranks, int64_t n_imp_local, const int32_t *global_row);
+int sqmc_gpu_shard_begin(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, double *x_global_dev, int64_t *n_children);
+int sqmc_gpu_shard_pack(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, const double *x_global_dev, uint64_t *send_dev,
+                        int64_t cap_records, int64_t *send_counts);
+int sqmc_gpu_shard_finish(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, const uint64_t *recv_dev, int64_t n_recv, double out_stats[16]);
+
 /* RNG state of the REPLAY stream (savern / setrn, rannyu.f90:11-21,77-87) */
 int sqmc_gpu_get_rng(sqmc_gpu_ctx *ctx, int32_t seed[4]);
 int sqmc_gpu_set_rng(sqmc_gpu_ctx *ctx, const int32_t seed[4]);

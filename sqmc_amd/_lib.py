@@ -14,7 +14,8 @@ _LIB = None
 EXPORTS = [
     "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_projector",
     "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
-    "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_spmv_prepare",
+    "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_det_owner", "sqmc_gpu_shard_config",
+    "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_spmv_prepare",
     "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
     "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
 ]
@@ -81,6 +82,11 @@ def load_library():
         L.sqmc_gpu_download_walkers.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 9
         L.sqmc_gpu_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.sqmc_gpu_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.sqmc_gpu_det_owner.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.sqmc_gpu_shard_config.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
+        L.sqmc_gpu_shard_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sqmc_gpu_shard_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.sqmc_gpu_shard_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.sqmc_gpu_hamiltonian_batch.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
         L.sqmc_gpu_hamiltonian_chem_batch.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
         L.sqmc_gpu_build_sparse_ham.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 6
@@ -199,6 +205,32 @@ class GpuChem:
         totals = np.zeros(16)
         _chk(self.L.sqmc_gpu_run(self.h, C.byref(pc), int(nsteps), _p(stats) if keep_stats else None, _p(totals)))
         return stats, totals
+
+    # ---- multi-rank sharding (device pointers come from the caller's collective library)
+    def det_owner(self, up, dn, nranks):
+        u, d = _u64(up), _u64(dn)
+        out = np.zeros(len(u), np.int32)
+        _chk(self.L.sqmc_gpu_det_owner(self.h, len(u), _p(u), _p(d), int(nranks), _p(out)))
+        return out
+
+    def shard_config(self, rank, nranks, global_rows):
+        gr = np.ascontiguousarray(global_rows, np.int32)
+        _chk(self.L.sqmc_gpu_shard_config(self.h, int(rank), int(nranks), len(gr), _p(gr) if len(gr) else None))
+
+    def shard_begin(self, params, x_global_ptr):
+        p = StepParams(**params); n = C.c_int64()
+        _chk(self.L.sqmc_gpu_shard_begin(self.h, C.byref(p), C.c_void_p(x_global_ptr), C.byref(n)))
+        return n.value
+
+    def shard_pack(self, params, x_global_ptr, send_ptr, cap_records, nranks):
+        p = StepParams(**params); cnt = np.zeros(nranks, np.int64)
+        _chk(self.L.sqmc_gpu_shard_pack(self.h, C.byref(p), C.c_void_p(x_global_ptr), C.c_void_p(send_ptr), int(cap_records), _p(cnt)))
+        return cnt
+
+    def shard_finish(self, params, recv_ptr, n_recv):
+        p = StepParams(**params); out = np.zeros(16)
+        _chk(self.L.sqmc_gpu_shard_finish(self.h, C.byref(p), C.c_void_p(recv_ptr), int(n_recv), _p(out)))
+        return out
 
     def rng_state(self):
         s = (C.c_int32 * 4)()

@@ -92,6 +92,8 @@ struct sqmc_gpu_ctx {
   DevScalars *d_sc; DevScalars *h_sc;   // h_sc pinned
   double *d_partials; int n_partial_blocks; double *d_wabs_part; u32 *d_done;
   int key_bits; u64 invalid_key; u64 *d_binom;
+  // multi-rank sharding (owner = hash(det) mod shard_n)
+  int shard_rank, shard_n; int *d_grow; long long n_imp_local; long long shard_n0, shard_nch;
   // timing
   int timing; hipEvent_t ev0[NTIMERS], ev1[NTIMERS]; const char *tname[NTIMERS]; int nt; float tms[NTIMERS];
   double tsum[NTIMERS]; long long tsteps;         // accumulated over the steps since sqmc_gpu_set_timing
@@ -792,7 +794,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
     hipFree(c->d_keys); hipFree(c->d_keys_alt); hipFree(c->d_vals); hipFree(c->d_vals_alt); hipFree(c->d_hist); hipFree(c->d_rowtot);
     hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done);
   }
-  hipFree(c->d_binom);
+  hipFree(c->d_binom); hipFree(c->d_grow);
   hipFree(c->d_tab); hipFree(c->d_ints); hipFree(c->d_hb_r); hipFree(c->d_hb_s); hipFree(c->d_hb_absH); hipFree(c->d_pq_ind); hipFree(c->d_pq_count);
   hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x);
   hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den); hipFree(c->d_ct_hkey); hipFree(c->d_ct_hidx);
@@ -883,10 +885,11 @@ int sqmc_gpu_upload_walkers(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, cons
   HIPCHK(hipMemcpy(c->w.ed, ed, n * 8, hipMemcpyHostToDevice));
   c->nwalk = n;
   if (c->n_imp > 0) {        // my_locations_of_imp_dets, do_walk.f90:2188-2212
-    std::vector<int> loc; loc.reserve(c->n_imp);
+    const long long expect = c->d_grow ? c->n_imp_local : c->n_imp;
+    std::vector<int> loc; loc.reserve(expect);
     for (long long i = 0; i < n; i++) if (impd[i] == 0) loc.push_back((int)i);
-    if ((long long)loc.size() != c->n_imp) return fail(SQMC_ERR_IMP_BROKEN, "number of imp_distance==0 walkers != n_imp");
-    HIPCHK(hipMemcpy(c->d_loc_imp, loc.data(), loc.size() * 4, hipMemcpyHostToDevice));
+    if ((long long)loc.size() != expect) return fail(SQMC_ERR_IMP_BROKEN, "number of imp_distance==0 walkers != n_imp (of this rank)");
+    if (!loc.empty()) HIPCHK(hipMemcpy(c->d_loc_imp, loc.data(), loc.size() * 4, hipMemcpyHostToDevice));
   }
   return SQMC_OK;
 }
@@ -942,9 +945,62 @@ int sqmc_gpu_get_timing(sqmc_gpu_ctx *c, int32_t *n, const char **names, float *
 #define TBEG(NAME, STREAM) int t_##NAME = -1; do { if ((c->timing >= 2 || (c->timing == 1 && !strcmp(#NAME, "spawn"))) && c->nt < NTIMERS) { t_##NAME = c->nt++; c->tname[t_##NAME] = #NAME; hipEventRecord(c->ev0[t_##NAME], STREAM); } } while (0)
 #define TEND(NAME, STREAM) do { if (t_##NAME >= 0) hipEventRecord(c->ev1[t_##NAME], STREAM); } while (0)
 
+// sort -> merge -> round -> compact/estimate -> readback; shared by the single-rank step and
+// the sharded step (where the spawns behind slot n0 arrived from other ranks)
+static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long nall, bool join_side_stream, double out[16]) {
+  hipStream_t st = c->st;
+  const long long M = c->mwalk;
+  const int mode = c->rng_mode; const u64 seed = c->seed64, step = c->step_no;
+  ScanWork sw[3];
+  for (int q = 0; q < 3; q++) { sw[q].state = c->d_scan_state + q * c->cap_tiles; sw[q].ticket = c->d_scan_ticket + q; sw[q].cap_tiles = c->cap_tiles; sw[q].self_clear = false; }
+  // ---- sort
+  TBEG(sort, st);
+  if (mode == SQMC_RNG_REPLAY)
+    hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0);
+  SortWork so; so.k_alt = c->d_keys_alt; so.v_alt = c->d_vals_alt; so.hist = c->d_hist; so.rowtot = c->d_rowtot; so.cap = M;
+  u64 *skey = c->d_keys; u32 *perm = c->d_vals;
+  device_radix_sort(skey, perm, nall, c->key_bits, so, st);
+  if (skey != c->d_keys) { c->d_keys_alt = c->d_keys; c->d_vals_alt = c->d_vals; c->d_keys = skey; c->d_vals = perm; }
+  TEND(sort, st);
+  // ---- join: from here on weights are read
+  if (join_side_stream) HIPCHK(hipStreamWaitEvent(st, c->e_join, 0));
+  TBEG(merge, st);
+  const int nbm = nblk(nall);
+  hipLaunchKernelGGL(k_merge, dim3(nbm), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, c->d_wabs_part, n0, nall, p, c->invalid_key);
+  device_excl_scan_u64(c->d_flags, c->d_pos, nall, &c->d_sc->tot1, sw[1], st);
+  TEND(merge, st);
+  TBEG(round, st);
+  hipLaunchKernelGGL(k_round, dim3(nblk(nall)), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, c->d_flags2, nall, p, mode, seed, step, c->d_sc);
+  device_excl_scan_u64(c->d_flags2, c->d_pos2, nall, &c->d_sc->tot2, sw[2], st);
+  TEND(round, st);
+  TBEG(estimate, st);
+  const int nb = std::min(nblk(nall), 512);
+  hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, st, c->m, c->w, c->d_flags2, c->d_pos2, c->d_loc_imp, skey, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask,
+                     c->d_ct_num, c->d_ct_den, nall, p, c->d_partials);
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials, nb, c->d_wabs_part, nbm, mode, c->d_sc, c->d_scan_state, c->d_scan_ticket,
+                     (int)(3 * c->cap_tiles));
+  TEND(estimate, st);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (c->timing) {
+    for (int i = 0; i < c->nt; i++) { hipEventElapsedTime(&c->tms[i], c->ev0[i], c->ev1[i]); c->tsum[i] += c->tms[i]; }
+    c->tsteps++;
+  }
+  c->step_no++;
+  if (c->h_sc->err) return fail(c->h_sc->err, "diagonal_factor<0 after target population has been reached");
+  const long long nfinal = (long long)(c->h_sc->tot2 & 0xFFFFFFFFull), nimp = (long long)(c->h_sc->tot2 >> 32);
+  c->nwalk = nfinal;
+  for (int i = 0; i < 16; i++) out[i] = c->h_sc->stats[i];
+  if (nfinal == 0) return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0");
+  if (p.semi && nimp != (c->shard_n > 1 || c->d_grow ? c->n_imp_local : c->n_imp)) return fail(SQMC_ERR_IMP_BROKEN, "locations of my imp broken");
+  return SQMC_OK;
+}
+
 int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   if (!c || !sp || !out) return fail(SQMC_ERR_BAD_ARG, "null argument");
   if (c->mwalk <= 0 || c->nwalk <= 0) return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0");
+  if (c->d_grow) return fail(SQMC_ERR_BAD_ARG, "context is configured for sharded steps: use sqmc_gpu_shard_begin/pack/finish");
   if (c->htab.time_sym) return fail(SQMC_ERR_UNSUPPORTED, "walk kernels implement time_sym=.false. only this round");
   if (sp->semistochastic && (c->n_imp <= 0 || !c->d_prj_ptr)) return fail(SQMC_ERR_BAD_ARG, "semistochastic step without projector");
   if (!c->d_ct_up) return fail(SQMC_ERR_BAD_ARG, "C(T) table not set");
@@ -1007,48 +1063,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
   }
   const long long nall = n0 + nch;
-  // ---- sort
-  TBEG(sort, st);
-  if (mode == SQMC_RNG_REPLAY)
-    hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0);
-  SortWork so; so.k_alt = c->d_keys_alt; so.v_alt = c->d_vals_alt; so.hist = c->d_hist; so.rowtot = c->d_rowtot; so.cap = M;
-  u64 *skey = c->d_keys; u32 *perm = c->d_vals;
-  device_radix_sort(skey, perm, nall, c->key_bits, so, st);
-  if (skey != c->d_keys) { c->d_keys_alt = c->d_keys; c->d_vals_alt = c->d_vals; c->d_keys = skey; c->d_vals = perm; }
-  TEND(sort, st);
-  // ---- join: from here on weights are read
-  HIPCHK(hipStreamWaitEvent(st, c->e_join, 0));
-  TBEG(merge, st);
-  const int nbm = nblk(nall);
-  hipLaunchKernelGGL(k_merge, dim3(nbm), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, c->d_wabs_part, n0, nall, p, c->invalid_key);
-  device_excl_scan_u64(c->d_flags, c->d_pos, nall, &c->d_sc->tot1, sw[1], st);
-  TEND(merge, st);
-  TBEG(round, st);
-  hipLaunchKernelGGL(k_round, dim3(nblk(nall)), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, c->d_flags2, nall, p, mode, seed, step, c->d_sc);
-  device_excl_scan_u64(c->d_flags2, c->d_pos2, nall, &c->d_sc->tot2, sw[2], st);
-  TEND(round, st);
-  TBEG(estimate, st);
-  const int nb = std::min(nblk(nall), 512);
-  hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, st, c->m, c->w, c->d_flags2, c->d_pos2, c->d_loc_imp, skey, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask,
-                     c->d_ct_num, c->d_ct_den, nall, p, c->d_partials);
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials, nb, c->d_wabs_part, nbm, mode, c->d_sc, c->d_scan_state, c->d_scan_ticket,
-                     (int)(3 * c->cap_tiles));
-  TEND(estimate, st);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  if (c->timing) {
-    for (int i = 0; i < c->nt; i++) { hipEventElapsedTime(&c->tms[i], c->ev0[i], c->ev1[i]); c->tsum[i] += c->tms[i]; }
-    c->tsteps++;
-  }
-  c->step_no++;
-  if (c->h_sc->err) return fail(c->h_sc->err, "diagonal_factor<0 after target population has been reached");
-  const long long nfinal = (long long)(c->h_sc->tot2 & 0xFFFFFFFFull), nimp = (long long)(c->h_sc->tot2 >> 32);
-  c->nwalk = nfinal;
-  for (int i = 0; i < 16; i++) out[i] = c->h_sc->stats[i];
-  if (nfinal == 0) return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0");
-  if (p.semi && nimp != c->n_imp) return fail(SQMC_ERR_IMP_BROKEN, "locations of my imp broken");
-  return SQMC_OK;
+  return step_tail(c, p, n0, nall, true, out);
 }
 
 int sqmc_gpu_run(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats, double totals[16]) {
@@ -1097,6 +1112,192 @@ int sqmc_gpu_run(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats
     pc->tau_prev = pc->tau; pc->w_abs_gen = w_abs_gen;
   }
   return SQMC_OK;
+}
+
+// ------------------------------------------------------------------ multi-rank sharding
+// owner of a determinant (the role of get_det_owner, mpi_routines.f90:419-445; any hash will
+// do for ownership)
+__host__ __device__ __forceinline__ int det_owner(u64 key, int nranks) { return (int)((sq_mix64(key ^ 0xA5A5A5A5A5A5A5A5ull) >> 17) % (u64)nranks); }
+__global__ void __launch_bounds__(TPB) k_owner_batch(ChemDev dev, const u64 *up, const u64 *dn, int *owner, long long n, int nranks) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) owner[i] = det_owner(det_key(dev, up[i], dn[i]), nranks);
+}
+// x_global(grow(k)) = w(loc(k)) for the deterministic-space walkers this rank owns
+__global__ void __launch_bounds__(TPB) k_prj_gather_rows(const double *__restrict__ wt, const int *__restrict__ loc, const int *__restrict__ grow,
+                                                         double *__restrict__ xg, long long n) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) xg[grow[i]] = wt[loc[i]];
+}
+// rows owned by this rank of y = A x_global, same ordered accumulation as k_prj_apply
+__global__ void __launch_bounds__(TPB) k_prj_apply_rows(const int *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val,
+                                                        const double *__restrict__ xg, const int *__restrict__ loc, const int *__restrict__ grow,
+                                                        double *__restrict__ wt, long long n, double e_trial, double tau) {
+  __shared__ double sprod[TPB / 64][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * (TPB / 64) + wv;
+  if (i >= n) return;
+  const int row = grow[i];
+  const int b = ptr[row], e = ptr[row + 1];
+  double y = 0.0;
+  for (int base = b; base < e; base += 64) {
+    const int k = base + lane;
+    sprod[wv][lane] = (k < e) ? val[k] * xg[col[k]] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    const int cnt = (e - base < 64) ? (e - base) : 64;
+    for (int l = 0; l < cnt; l++) y = y + sprod[wv][l];
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) { y = y + e_trial * tau * xg[row]; wt[loc[i]] = wt[loc[i]] + y; }
+}
+// destination rank of every child (nranks = "no walker": weight 0), as an 8-bit sort key
+__global__ void __launch_bounds__(TPB) k_child_owner(const u64 *__restrict__ keys, u64 *__restrict__ okey, u32 *__restrict__ oval,
+                                                     long long n0, long long nch, u64 invalid_key, int nranks) {
+  long long c = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (c >= nch) return;
+  const u64 k = keys[n0 + c];
+  okey[c] = (k == invalid_key) ? (u64)nranks : (u64)det_owner(k, nranks);
+  oval[c] = (u32)c;
+}
+// 32-byte wire record {up, dn, weight bits, flags}: the t_walk of mpi_routines.f90:29-34 without
+// the fields that are sentinels for fresh spawns
+__global__ void __launch_bounds__(TPB) k_pack_send(WalkArr w, const u32 *__restrict__ order, u64 *__restrict__ rec, long long n0, long long nsend) {
+  long long q = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (q >= nsend) return;
+  const long long k = n0 + order[q];
+  rec[4 * q] = w.up[k]; rec[4 * q + 1] = w.dn[k]; rec[4 * q + 2] = (u64)__double_as_longlong(w.wt[k]); rec[4 * q + 3] = (u64)w.flg[k];
+}
+__global__ void __launch_bounds__(TPB) k_unpack_recv(ChemDev dev, WalkArr w, const u64 *__restrict__ rec, u64 *__restrict__ keys, u32 *__restrict__ vals,
+                                                     long long n0, long long nrecv) {
+  long long q = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (q >= nrecv) return;
+  const long long k = n0 + q;
+  const u64 u = rec[4 * q], d = rec[4 * q + 1];
+  w.up[k] = u; w.dn[k] = d; w.wt[k] = __longlong_as_double((long long)rec[4 * q + 2]); w.flg[k] = (u32)rec[4 * q + 3];
+  keys[k] = det_key(dev, u, d); vals[k] = (u32)k;
+}
+
+int sqmc_gpu_det_owner(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, const uint64_t *dn, int32_t nranks, int32_t *owner) {
+  if (!c || nranks < 1 || nranks > 255) return fail(SQMC_ERR_BAD_ARG, "bad argument");
+  if (n <= 0) return SQMC_OK;
+  u64 *du, *dd; int *dout;
+  HIPCHK(hipMalloc(&du, n * 8)); HIPCHK(hipMalloc(&dd, n * 8)); HIPCHK(hipMalloc(&dout, n * 4));
+  HIPCHK(hipMemcpy(du, up, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dd, dn, n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_owner_batch, dim3(nblk(n)), dim3(TPB), 0, c->st, c->dev, du, dd, dout, (long long)n, (int)nranks);
+  HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->st));
+  HIPCHK(hipMemcpy(owner, dout, n * 4, hipMemcpyDeviceToHost));
+  hipFree(du); hipFree(dd); hipFree(dout);
+  return SQMC_OK;
+}
+
+int sqmc_gpu_shard_config(sqmc_gpu_ctx *c, int32_t rank, int32_t nranks, int64_t n_imp_local, const int32_t *global_row) {
+  if (!c || nranks < 1 || nranks > 255 || rank < 0 || rank >= nranks || n_imp_local < 0) return fail(SQMC_ERR_BAD_ARG, "bad argument");
+  if (n_imp_local > 0 && (!global_row || !c->d_prj_ptr)) return fail(SQMC_ERR_BAD_ARG, "set the (global) projector before shard_config");
+  for (long long i = 0; i < n_imp_local; i++) if (global_row[i] < 0 || global_row[i] >= c->n_imp) return fail(SQMC_ERR_BAD_ARG, "global row out of range");
+  c->shard_rank = rank; c->shard_n = nranks; c->n_imp_local = n_imp_local;
+  hipFree(c->d_grow); hipFree(c->d_loc_imp);
+  HIPCHK(hipMalloc(&c->d_grow, (n_imp_local + 1) * 4)); HIPCHK(hipMalloc(&c->d_loc_imp, (std::max<long long>(n_imp_local, c->n_imp) + 1) * 4));
+  if (n_imp_local > 0) HIPCHK(hipMemcpy(c->d_grow, global_row, n_imp_local * 4, hipMemcpyHostToDevice));
+  return SQMC_OK;
+}
+
+// phase 1 of a sharded step: gate, child offsets, death/clone, spawn (into local slots), and the
+// owned entries of the deterministic-space weight vector written into x_global (device pointer,
+// n_imp doubles, zeroed here) for the caller's all-reduce (do_walk.f90:2259-2260).
+int sqmc_gpu_shard_begin(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double *x_global_dev, int64_t *n_children) {
+  if (!c || !sp || !n_children) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  if (c->shard_n < 1 || !c->d_grow) return fail(SQMC_ERR_BAD_ARG, "sqmc_gpu_shard_config not called");
+  if (c->rng_mode != SQMC_RNG_COUNTER) return fail(SQMC_ERR_UNSUPPORTED, "sharded steps need the COUNTER RNG discipline");
+  if (c->htab.time_sym || !sp->semistochastic || !c->d_ct_up) return fail(SQMC_ERR_UNSUPPORTED, "sharded step: semistochastic, time_sym=.false., C(T) set");
+  if (c->mwalk <= 0) return fail(SQMC_ERR_BAD_ARG, "no walker arrays");
+  hipStream_t st = c->st;
+  StepP p; p.tau = sp->tau; p.e_trial = sp->e_trial; p.rfi = sp->reweight_factor_inv; p.r_init = sp->r_initiator; p.min_wt = sp->min_wt;
+  p.cutoff = sp->always_spawn_cutoff_wt; p.ipow = sp->initiator_power; p.imind = sp->initiator_min_distance; p.cti = sp->c_t_initiator;
+  p.semi = sp->semistochastic; p.reached = sp->reached_w_abs_gen;
+  const long long n0 = c->nwalk, M = c->mwalk;
+  ScanWork sw0; sw0.state = c->d_scan_state; sw0.ticket = c->d_scan_ticket; sw0.cap_tiles = c->cap_tiles; sw0.self_clear = false;
+  c->nt = 0;
+  HIPCHK(hipMemsetAsync(&c->d_sc->n_children, 0, 4 * sizeof(u64) + 2 * sizeof(int), st));
+  if (x_global_dev && c->n_imp > 0) HIPCHK(hipMemsetAsync(x_global_dev, 0, c->n_imp * 8, st));
+  if (n0 > 0) {
+    hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
+                       n0, p, c->seed64, c->step_no);
+    device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st);
+    hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc);
+    if (c->n_imp_local > 0)
+      hipLaunchKernelGGL(k_prj_gather_rows, dim3(nblk(c->n_imp_local)), dim3(TPB), 0, st, c->w.wt, c->d_loc_imp, c->d_grow, x_global_dev, c->n_imp_local);
+    TBEG(spawn, st);
+    if (M > n0)
+      hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                         n0, M, p, c->rng_mode, c->seed64, c->step_no, c->invalid_key, c->d_sc);
+    TEND(spawn, st);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(&c->h_sc->n_children, &c->d_sc->n_children, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const long long nch = (long long)c->h_sc->n_children;
+  if (n0 + nch > M) {
+    hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
+    return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
+  }
+  c->shard_n0 = n0; c->shard_nch = nch;
+  *n_children = nch;
+  return SQMC_OK;
+}
+
+// phase 2: apply the owned rows of the deterministic projection with the all-reduced x_global, then
+// bucket this step's children by owner rank (stable) into 32-byte records: send_counts[r] records
+// for rank r, contiguous in rank order in send_dev (capacity cap_records).
+int sqmc_gpu_shard_pack(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const double *x_global_dev, uint64_t *send_dev, int64_t cap_records,
+                        int64_t *send_counts) {
+  if (!c || !sp || !send_counts) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  hipStream_t st = c->st;
+  const long long n0 = c->shard_n0, nch = c->shard_nch; const int P = c->shard_n;
+  if (c->n_imp_local > 0)
+    hipLaunchKernelGGL(k_prj_apply_rows, dim3(nblk(c->n_imp_local, TPB / 64)), dim3(TPB), 0, st, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, x_global_dev,
+                       c->d_loc_imp, c->d_grow, c->w.wt, c->n_imp_local, sp->e_trial, sp->tau);
+  for (int r = 0; r < P; r++) send_counts[r] = 0;
+  if (nch > 0) {
+    u64 *okey = c->d_flags, *okey_alt = c->d_pos; u32 *oval = (u32 *)c->d_flags2, *oval_alt = (u32 *)c->d_pos2;
+    hipLaunchKernelGGL(k_child_owner, dim3(nblk(nch)), dim3(TPB), 0, st, c->d_keys, okey, oval, n0, nch, c->invalid_key, P);
+    SortWork so; so.k_alt = okey_alt; so.v_alt = oval_alt; so.hist = c->d_hist; so.rowtot = c->d_rowtot; so.cap = c->mwalk;
+    u64 *sk = okey; u32 *sv = oval;
+    device_radix_sort(sk, sv, nch, 8, so, st);               // one stable 8-bit pass; rowtot[d] = children per destination
+    u32 cnt[256];
+    HIPCHK(hipMemcpyAsync(cnt, c->d_rowtot, 256 * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    long long nsend = 0;
+    for (int r = 0; r < P; r++) { send_counts[r] = cnt[r]; nsend += cnt[r]; }
+    if (nsend > cap_records) return fail(SQMC_ERR_SPAWN_OVERFLOW, "send buffer too small for this step's spawns");
+    if (nsend > 0) hipLaunchKernelGGL(k_pack_send, dim3(nblk(nsend)), dim3(TPB), 0, st, c->w, sv, (u64 *)send_dev, n0, nsend);
+  }
+  HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(st));
+  return SQMC_OK;
+}
+
+// phase 3: the records received from all ranks (rank order, creation order inside a rank) become
+// the spawned walkers behind the occupied slots; then the usual sort / merge / round / estimate.
+int sqmc_gpu_shard_finish(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const uint64_t *recv_dev, int64_t n_recv, double out[16]) {
+  if (!c || !sp || !out || n_recv < 0) return fail(SQMC_ERR_BAD_ARG, "bad argument");
+  hipStream_t st = c->st;
+  StepP p; p.tau = sp->tau; p.e_trial = sp->e_trial; p.rfi = sp->reweight_factor_inv; p.r_init = sp->r_initiator; p.min_wt = sp->min_wt;
+  p.cutoff = sp->always_spawn_cutoff_wt; p.ipow = sp->initiator_power; p.imind = sp->initiator_min_distance; p.cti = sp->c_t_initiator;
+  p.semi = sp->semistochastic; p.reached = sp->reached_w_abs_gen;
+  const long long n0 = c->shard_n0;
+  if (n0 + n_recv > c->mwalk) {
+    hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
+    return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
+  }
+  if (n_recv > 0)
+    hipLaunchKernelGGL(k_unpack_recv, dim3(nblk(n_recv)), dim3(TPB), 0, st, c->dev, c->w, (const u64 *)recv_dev, c->d_keys, c->d_vals, n0, (long long)n_recv);
+  if (n0 + n_recv == 0) {           // an empty shard stays empty this step
+    for (int i = 0; i < 16; i++) out[i] = 0.0;
+    hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
+    c->step_no++;
+    return SQMC_OK;
+  }
+  int r = step_tail(c, p, n0, n0 + n_recv, false, out);
+  if (r == SQMC_ERR_NO_WALKERS) r = SQMC_OK;      // a shard may legitimately own nothing
+  return r;
 }
 
 // ---------------------------------------------------------------- batch doors

@@ -14,6 +14,7 @@ module sqmc_gpu_mod
   public :: sqmc_gpu_spmv_prepare, sqmc_gpu_spmv_apply, sqmc_gpu_spmv_free, sqmc_gpu_spmv_sym_upper
   public :: sqmc_gpu_hamiltonian_batch, sqmc_gpu_hamiltonian_chem_batch, sqmc_gpu_build_sparse_ham, sqmc_gpu_propose_batch
   public :: sqmc_gpu_hci_connections, sqmc_gpu_free, sqmc_gpu_set_timing, sqmc_gpu_get_timing
+  public :: sqmc_gpu_det_owner, sqmc_gpu_shard_config, sqmc_gpu_shard_begin, sqmc_gpu_shard_pack, sqmc_gpu_shard_finish
   public :: sqmc_gpu_check
 
   integer(c_int), parameter, public :: SQMC_RNG_REPLAY = 0, SQMC_RNG_COUNTER = 1
@@ -50,6 +51,26 @@ module sqmc_gpu_mod
     integer(c_int) function sqmc_gpu_run(ctx, pc, nsteps, stats, totals) bind(C, name='sqmc_gpu_run')
       import; type(c_ptr), value :: ctx; type(sqmc_popctl), intent(inout) :: pc; integer(c_int64_t), value :: nsteps
       type(c_ptr), value :: stats; real(c_double), intent(out) :: totals(16)
+    end function
+    integer(c_int) function sqmc_gpu_det_owner(ctx, n, up, dn, nranks, owner) bind(C, name='sqmc_gpu_det_owner')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n; integer(c_int64_t), intent(in) :: up(*), dn(*)
+      integer(c_int32_t), value :: nranks; integer(c_int32_t), intent(out) :: owner(*)
+    end function
+    integer(c_int) function sqmc_gpu_shard_config(ctx, rank, nranks, n_imp_local, global_row) bind(C, name='sqmc_gpu_shard_config')
+      import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: rank, nranks; integer(c_int64_t), value :: n_imp_local
+      integer(c_int32_t), intent(in) :: global_row(*)
+    end function
+    integer(c_int) function sqmc_gpu_shard_begin(ctx, p, x_global_dev, n_children) bind(C, name='sqmc_gpu_shard_begin')
+      import; type(c_ptr), value :: ctx; type(sqmc_step_params), intent(in) :: p; type(c_ptr), value :: x_global_dev
+      integer(c_int64_t), intent(out) :: n_children
+    end function
+    integer(c_int) function sqmc_gpu_shard_pack(ctx, p, x_global_dev, send_dev, cap_records, send_counts) bind(C, name='sqmc_gpu_shard_pack')
+      import; type(c_ptr), value :: ctx; type(sqmc_step_params), intent(in) :: p; type(c_ptr), value :: x_global_dev, send_dev
+      integer(c_int64_t), value :: cap_records; integer(c_int64_t), intent(out) :: send_counts(*)
+    end function
+    integer(c_int) function sqmc_gpu_shard_finish(ctx, p, recv_dev, n_recv, out_stats) bind(C, name='sqmc_gpu_shard_finish')
+      import; type(c_ptr), value :: ctx; type(sqmc_step_params), intent(in) :: p; type(c_ptr), value :: recv_dev
+      integer(c_int64_t), value :: n_recv; real(c_double), intent(out) :: out_stats(16)
     end function
     integer(c_int) function sqmc_gpu_set_device(device) bind(C, name='sqmc_gpu_set_device')
       import; integer(c_int), value :: device

@@ -435,16 +435,17 @@ def rank_seed(seed, rank):
 def allreduce_step_sums(out, device=None):
     """The MPI_Allreduce of do_walk.f90:2778 on the 7 per-step sums (w_gen, w_abs_gen,
     e_den_gen, e_num_gen, w_perm_initiator_gen, nwalk, w_abs_gen_imp): torch.distributed SUM
-    (RCCL when the group backend is nccl, gloo on CPU).  Returns the reduced copy; entries
-    7..15 stay rank-local.  No-op without an initialised process group."""
+    (RCCL when the group backend is nccl -- the 56 bytes then travel as a device tensor --
+    gloo on CPU).  Returns the reduced copy; entries 7..15 stay rank-local.  No-op without an
+    initialised process group."""
     import torch
     import torch.distributed as dist
     res = np.array(out, dtype=np.float64, copy=True)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return res
     t = torch.from_numpy(res[:7].copy())
-    if device is not None:
-        t = t.to(device)
+    if dist.get_backend() == "nccl":
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     res[:7] = t.cpu().numpy()
     return res
@@ -500,3 +501,113 @@ def hci_variational(host, g, eps_var, eps_sched=(), n_states=1, max_iters=50, lo
             break
         old_energy = energy.copy()
     return up, dn, wts, energy, hist
+
+
+# --------------------------------------------------------------------- sharded walk
+def _backend():
+    import torch.distributed as dist
+    return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
+
+
+def _allreduce_dev(t):
+    """SUM all-reduce of a device tensor: RCCL directly, or staged through the host for gloo."""
+    import torch.distributed as dist
+    if _backend() is None or dist.get_world_size() == 1:
+        return
+    if _backend() == "nccl":
+        dist.all_reduce(t)
+    else:
+        h = t.cpu(); dist.all_reduce(h); t.copy_(h)
+
+
+def exchange_records(send, send_counts, recv):
+    """Personalised all-to-all of 32-byte spawn records (rows of 4 int64), as mpi_sendnewwalks does
+    with MPI_Allgather(counts) + MPI_ALLTOALLV (mpi_routines.f90:2522-2622).  send: [cap,4] tensor
+    whose first sum(send_counts) rows are grouped by destination rank; returns the number of
+    rows received (rank order, sender's order inside a rank) now at the head of recv."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if _backend() else 1
+    sc = [int(x) for x in send_counts]
+    ns = sum(sc)
+    if world == 1:
+        recv[:ns].copy_(send[:ns])
+        return ns
+    cnt = torch.tensor(sc, dtype=torch.int64)
+    rcnt = torch.empty(world, dtype=torch.int64)
+    if _backend() == "nccl":
+        cd, rd = cnt.to(send.device), rcnt.to(send.device)
+        dist.all_to_all_single(rd, cd)
+        rcnt = rd.cpu()
+    else:
+        dist.all_to_all_single(rcnt, cnt)
+    rc = [int(x) for x in rcnt]
+    nr = sum(rc)
+    if nr > recv.shape[0]:
+        raise RuntimeError("receive buffer too small: %d > %d records" % (nr, recv.shape[0]))
+    if _backend() == "nccl":
+        dist.all_to_all_single(recv[:nr], send[:ns], output_split_sizes=rc, input_split_sizes=sc)
+    else:
+        hs, hr = send[:ns].cpu(), torch.empty((nr, 4), dtype=torch.int64)
+        dist.all_to_all_single(hr, hs, output_split_sizes=rc, input_split_sizes=sc)
+        recv[:nr].copy_(hr)
+    return nr
+
+
+class ShardedWalk:
+    """One rank of a walk whose determinants are sharded over ranks by hash ownership; RCCL (or
+    gloo, for tests) moves the deterministic-space weights, the spawned walkers and the seven
+    estimator sums, exactly the three exchanges of the reference's MPI walk."""
+
+    def __init__(self, host, w_target, rank, world, w_begin=None, mwalk=None, n_truncate_trial_wf=100, size_deterministic=1000,
+                 tau_multiplier=0.1, e_trial=None, seed=(1346, 5634, 6635, 4361), min_wt=0.5, device_index=0, n_equil_steps=10**9):
+        import torch
+        self.rank, self.world, self.min_wt = rank, world, min_wt
+        w_begin = w_begin if w_begin is not None else w_target
+        per_rank = w_target / world
+        mwalk = mwalk or int(max(6 * (per_rank / min_wt + size_deterministic), 200000))
+        self.g = g = host.gpu(rng_mode=RNG_COUNTER, seed=rank_seed(seed, rank), mwalk=mwalk)
+        host.hb_tables(g); g.set_hb_tables(*host.hb)
+        self.setup = s = setup_walk(host, g, n_truncate_trial_wf, size_deterministic, tau_multiplier)
+        g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
+        g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
+        wk = initial_walkers(s, w_begin)
+        own = g.det_owner(wk["up"], wk["dn"], world) == rank
+        mine = {k: v[own] for k, v in wk.items()}
+        # global row of every deterministic-space walker this rank owns (both lists sorted by (up,dn))
+        imp_index = {(int(a), int(b)): i for i, (a, b) in enumerate(zip(s.imp_up, s.imp_dn))}
+        rows = [imp_index[(int(a), int(b))] for a, b, d in zip(mine["up"], mine["dn"], mine["imp_distance"]) if d == 0]
+        g.shard_config(rank, world, rows)
+        g.upload_walkers(mine)
+        dev = torch.device("cuda", device_index)
+        self.dev = dev
+        self.xg = torch.zeros(max(len(s.imp_up), 1), dtype=torch.float64, device=dev)
+        cap = mwalk
+        self.send = torch.empty((cap, 4), dtype=torch.int64, device=dev)
+        self.recv = torch.empty((cap, 4), dtype=torch.int64, device=dev)
+        self.cap = cap
+        self.pc = PopControl(s.tau, e_trial if e_trial is not None else s.e_trial0, w_target, n_equil_steps=n_equil_steps)
+        self.w_abs = float(np.abs(wk["wt"]).sum())          # global
+        self.n_imp_global = len(s.imp_up)
+
+    def step(self):
+        import torch
+        r = self.pc.pre_step(self.w_abs)
+        if r != 1.0:
+            self.g.scale_projector(r)
+        prm = self.pc.params(min_wt=self.min_wt)
+        self.g.shard_begin(prm, self.xg.data_ptr())
+        _allreduce_dev(self.xg)
+        counts = self.g.shard_pack(prm, self.xg.data_ptr(), self.send.data_ptr(), self.cap, self.world)
+        nr = exchange_records(self.send, counts, self.recv)
+        torch.cuda.synchronize()
+        local = self.g.shard_finish(prm, self.recv.data_ptr(), nr)
+        out = allreduce_step_sums(local, device=self.dev)
+        r = self.pc.post_step(out)
+        if r != 1.0:
+            self.g.scale_projector(r)
+        self.w_abs, self.last_local = out[1], local
+        return out
+
+    def close(self):
+        self.g.close()

@@ -1,0 +1,116 @@
+"""Sharded (multi-rank) walk on ONE GPU: several processes share the card and exchange through
+gloo (host-staged), which exercises everything of the multi-GPU path except the RCCL transport
+itself -- owner hashing, per-destination bucketing, the three exchanges, local annihilation."""
+import os
+import sys
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FCIDUMP = os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP")
+SEED = (1346, 5634, 6635, 4361)
+NSTEPS, W_BEGIN, W_TARGET = 40, 2000, 20000
+
+
+def _worker(rank, world, port, outdir):
+    import torch                                   # before the HIP library (one libamdhip64 per process)
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sqmc_amd
+    from sqmc_amd import host as H
+    sqmc_amd.set_device(0)
+    hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+    w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
+    outs = []
+    for _ in range(NSTEPS):
+        outs.append(w.step().copy())
+    wk = w.g.download_walkers()
+    owner = w.g.det_owner(wk["up"], wk["dn"], world)
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), outs=np.array(outs), owner=owner, n_imp_global=w.n_imp_global,
+             local_last=w.last_local, **wk)
+    w.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, tmp_path, port):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in ps: p.start()
+    for p in ps: p.join(600)
+    assert all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
+    return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+
+
+def test_one_rank_sharded_equals_single_rank_step(tmp_path):
+    """With one rank the sharded pipeline (bucket -> exchange -> unpack) must reproduce the
+    single-rank step exactly."""
+    res = _run(1, tmp_path, 29541)[0]
+    from sqmc_amd import host as H
+    hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+    ref = H.GpuWalk(hst, W_TARGET, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
+    outs = np.array([ref.step().copy() for _ in range(NSTEPS)])
+    wk = ref.g.download_walkers()
+    ref.close()
+    assert np.array_equal(res["up"], wk["up"]) and np.array_equal(res["dn"], wk["dn"])
+    assert np.array_equal(res["wt"], wk["wt"]) and np.array_equal(res["initiator"], wk["initiator"])
+    assert np.allclose(res["outs"], outs, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_walk_invariants(tmp_path, world):
+    res = _run(world, tmp_path, 29541 + world)
+    # every rank saw the same all-reduced sums
+    for r in res[1:]:
+        assert np.array_equal(r["outs"][:, :7], res[0]["outs"][:, :7])
+    keys = []
+    n_imp = 0
+    for rank, r in enumerate(res):
+        assert np.all(r["owner"] == rank)                                   # ownership respected
+        k = [(int(a), int(b)) for a, b in zip(r["up"], r["dn"])]
+        assert k == sorted(set(k))                                          # sorted, unique locally
+        keys += k
+        n_imp += int((r["imp_distance"] == 0).sum())
+        assert len(r["up"]) == int(r["local_last"][5])
+    assert len(keys) == len(set(keys))                                      # a determinant lives on one rank only
+    assert n_imp == int(res[0]["n_imp_global"])                             # the deterministic space is complete
+    out = res[0]["outs"][-1]
+    assert int(out[5]) == len(keys)                                         # global nwalk = sum of the shards
+    wsum = sum(float(np.abs(r["wt"]).sum()) for r in res)
+    assert np.isclose(wsum, out[1], rtol=1e-12)
+    e = res[0]["outs"][10:, 3].sum() / res[0]["outs"][10:, 2].sum()
+    assert -75.80 < e < -75.55
+    assert out[1] > 1.5 * W_BEGIN                                           # the population grew towards the target
+
+
+def _nccl_worker(port, outdir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import sqmc_amd
+    from sqmc_amd import host as H
+    sqmc_amd.set_device(0)
+    w = H.ShardedWalk(H.ChemHost(FCIDUMP, 8, 4, "d2h"), W_TARGET, 0, 1, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
+    outs = np.array([w.step().copy() for _ in range(10)])
+    np.save(os.path.join(outdir, "nccl.npy"), outs)
+    w.close()
+    dist.destroy_process_group()
+
+
+def test_sharded_step_over_rccl_single_rank(tmp_path):
+    """The same orchestration with the nccl (= RCCL) backend and device tensors; one rank is all a
+    one-GPU box can host, it still runs every collective call on the RCCL code path."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_nccl_worker, args=(29561, str(tmp_path)))
+    p.start(); p.join(600)
+    assert p.exitcode == 0
+    outs = np.load(os.path.join(str(tmp_path), "nccl.npy"))
+    assert outs.shape == (10, 16) and np.all(outs[:, 5] > 1000)
