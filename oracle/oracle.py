@@ -305,6 +305,13 @@ class WalkSetup:
     pass
 
 
+def _reps(cu, cd):
+    """unique time-reversal representatives (up <= dn) of a list of determinants, sorted"""
+    a, b = np.minimum(cu, cd), np.maximum(cu, cd)
+    keys = sorted(set(zip(a.tolist(), b.tolist())))
+    return np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint64)
+
+
 def setup_walk(sysm, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1, coeffs="eig"):
     """Returns Psi_T, C(T), deterministic space + projector (-tau*H), tau.
     coeffs="eig": lowest eigenvector of H in {HF + connections} (the reference's scheme);
@@ -312,7 +319,11 @@ def setup_walk(sysm, n_truncate_trial_wf=100, size_deterministic=1000, tau_multi
     eigensolver/BLAS and are therefore bit-reproducible on any machine (golden fixtures)."""
     import math
     s = WalkSetup()
+    ts = bool(sysm.s.time_sym)
     cu, cd, el = sysm.connected(sysm.hf_up, sysm.hf_dn, with_elems=(coeffs == "pt1"))
+    if ts:      # time-reversal symmetry: work with the representatives up <= dn (chemistry.f90:7346-7386)
+        cu, cd = _reps(cu, cd)
+        el = np.array([sysm.ham(int(a), int(b), sysm.hf_up, sysm.hf_dn) for a, b in zip(cu, cd)])
     order = sort_dets(cu, cd)
     up, dn = cu[order], cd[order]
     if coeffs == "pt1":
@@ -344,7 +355,11 @@ def setup_walk(sysm, n_truncate_trial_wf=100, size_deterministic=1000, tau_multi
     acc = {}
     psi_index = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(s.psi_up, s.psi_dn))}
     for j in range(n_t):
-        xu, xd, el = sysm.connected(int(s.psi_up[j]), int(s.psi_dn[j]), with_elems=True, cap=40000)
+        pu, pd = int(s.psi_up[j]), int(s.psi_dn[j])
+        xu, xd, el = sysm.connected(pu, pd, with_elems=not ts, cap=40000)
+        if ts:
+            xu, xd = _reps(xu, xd)
+            el = np.array([sysm.ham(int(a), int(b), pu, pd) for a, b in zip(xu, xd)])
         for a, b, h in zip(xu.tolist(), xd.tolist(), el.tolist()):
             acc[(a, b)] = acc.get((a, b), 0.0) + h * s.psi_c[j]
     keys = sorted(acc)

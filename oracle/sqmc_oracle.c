@@ -578,7 +578,60 @@ static int nocc_sym(const orc_chem *s, det_t det, int sym) {
   for (det_t t = det; t; t &= t - 1) if (s->orbsym[trailz(t) + 1] == sym) c++;
   return c;
 }
-/* chemistry.f90:4237-5084, time_sym=.false., importance_sampling=0.  Returns det_j and
+/* chemistry.f90:2003-2200 (uniform-proposal branch): are det_i and det_j connected, at which
+ * excitation level, and with which probability would off_diagonal_move_chem have proposed
+ * det_j from det_i (without the level factor n_single/n_total or n_double/n_total). */
+static int is_connected_chem(const orc_chem *s, det_t iu, det_t id, det_t ju, det_t jd, int *level, double *prob) {
+  int upc = 0, dnc = 0, du1 = 0, du2 = 0, du3 = 0, du4 = 0, dd1 = 0, dd2 = 0, dd3 = 0, dd4 = 0;
+  *level = -1; *prob = 0.0;
+  if (iu != ju) {
+    det_t a = iu & ~ju, b = ju & ~iu;
+    upc = popcnt(a);
+    if (upc > 2 || upc != popcnt(b)) return 0;
+    du1 = trailz(a) + 1; du3 = trailz(b) + 1;
+    if (upc == 2) { du2 = trailz(a & (a - 1)) + 1; du4 = trailz(b & (b - 1)) + 1; }
+  }
+  if (id != jd) {
+    det_t a = id & ~jd, b = jd & ~id;
+    dnc = popcnt(a);
+    if (dnc > 2 || dnc != popcnt(b)) return 0;
+    dd1 = trailz(a) + 1; dd3 = trailz(b) + 1;
+    if (dnc == 2) { dd2 = trailz(a & (a - 1)) + 1; dd4 = trailz(b & (b - 1)) + 1; }
+  }
+  *level = upc + dnc;
+  if (*level > 2) { *level = -1; return 0; }
+  const int ne = s->nelec - 2 * s->n_core_orb;
+  const det_t orbs = maskr(s->norb);
+  if (*level == 1) {
+    det_t det = id; int d1 = dd1, d2 = dd3;
+    if (upc == 1) { det = iu; d1 = du1; d2 = du3; }
+    int sym1 = s->orbsym[d1];
+    if (sym1 != s->orbsym[d2]) return 0;
+    int i_open = 0;
+    for (int i = 1; i <= s->norb; i++) if (!btest(det, i - 1) && s->orbsym[i] == sym1) i_open++;
+    *prob = 1.0 / ((ne) * (i_open));
+    return 1;
+  }
+  if (*level == 2) {
+    int d1, d2, d3, d4; det_t det1, det2; double tp, tp2;
+    if (upc == 2) { d1 = du1; d2 = du2; d3 = du3; d4 = du4; det1 = iu | BIT(d3 - 1); det2 = iu | BIT(d4 - 1); tp = 2.0 / (s->norb - s->nup); tp2 = 2.0 / (s->norb - s->nup); }
+    else if (dnc == 2) { d1 = dd1; d2 = dd2; d3 = dd3; d4 = dd4; det1 = id | BIT(d3 - 1); det2 = id | BIT(d4 - 1); tp = 2.0 / (s->norb - s->ndn); tp2 = 2.0 / (s->norb - s->ndn); }
+    else { d1 = du1; d2 = dd1; d3 = du3; d4 = dd3; det2 = iu; det1 = id; tp = 1.0 / (s->norb - s->nup); tp2 = 1.0 / (s->norb - s->ndn); }
+    int sym1 = s->prod[s->orbsym[d1]][s->orbsym[d2]];
+    if (sym1 != s->prod[s->orbsym[d3]][s->orbsym[d4]]) return 0;
+    int i_open = 0, i_open2 = 0;
+    for (int i = 1; i <= s->norb; i++) if (!btest(det1, i - 1) && s->prod[s->orbsym[d3]][s->orbsym[i]] == sym1) i_open++;
+    for (int i = 1; i <= s->norb; i++) if (!btest(det2, i - 1) && s->prod[s->orbsym[i]][s->orbsym[d4]] == sym1) i_open2++;
+    (void)orbs;
+    if (i_open == 0 && i_open2 != 0) *prob = (1.0 / ((ne) * (ne - 1))) * ((tp2 / (i_open2)));
+    if (i_open2 == 0 && i_open != 0) *prob = (1.0 / ((ne) * (ne - 1))) * ((tp / (i_open)));
+    if (i_open2 != 0 && i_open != 0) *prob = (1.0 / ((ne) * (ne - 1))) * ((tp / (i_open)) + (tp2 / (i_open2)));
+    return 1;
+  }
+  return 1;      /* level 0: same determinant */
+}
+
+/* chemistry.f90:4237-5084, importance_sampling=0 (both time_sym branches).  Returns det_j and
  * weight_j = -tau*H_ij/proposal_prob (0 and det_j partly built if no valid move, exactly
  * like the reference's early returns).  n_draws = rannyu calls consumed. */
 void orc_off_diagonal_move_chem(const orc_chem *s, orc_rng *g, double tau, det_t iu, det_t id,
@@ -671,8 +724,31 @@ void orc_off_diagonal_move_chem(const orc_chem *s, orc_rng *g, double tau, det_t
     }
   }
   *pju = ju; *pjd = jd;
-  { double me = orc_hamiltonian_chem(s, iu, id, ju, jd, level);
-    *weight_j = -tau * me / prob; }
+  if (s->time_sym) {                               /* chemistry.f90:4988-5044 */
+    const double sqrt2 = sqrt(2.0);
+    const double norm_i = (iu == id) ? sqrt2 : 1.0;
+    double me;
+    if ((ju == iu && jd == id) || (jd == iu && ju == id)) goto done;     /* already in the diagonal */
+    if (ju == jd) {
+      if (s->z != 1) goto done;
+      me = orc_hamiltonian_chem(s, iu, id, ju, jd, level);
+      me = (sqrt2 / norm_i) * me;
+    } else {
+      double m1 = orc_hamiltonian_chem(s, iu, id, ju, jd, level), psym; int lsym;
+      if (is_connected_chem(s, iu, id, jd, ju, &lsym, &psym)) {
+        double m2 = orc_hamiltonian_chem(s, iu, id, jd, ju, lsym);
+        if (lsym == 1) prob = prob + (psym * (n_single / (double)n_total));
+        if (lsym == 2) prob = prob + (psym * (n_double / (double)n_total));
+        me = (1.0 / norm_i) * (m1 + s->z * m2);
+      } else me = (1.0 / norm_i) * (m1);
+    }
+    if (ju > jd) { det_t t = ju; ju = jd; jd = t; me = me * s->z; }
+    *pju = ju; *pjd = jd;
+    *weight_j = -tau * me / prob;
+  } else {
+    double me = orc_hamiltonian_chem(s, iu, id, ju, jd, level);
+    *weight_j = -tau * me / prob;
+  }
 done:
 #undef RI
   if (n_draws) *n_draws = draws;

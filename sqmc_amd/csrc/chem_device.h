@@ -304,3 +304,86 @@ __device__ inline int propose_uniform(const ChemTab &t, Rng &g, u64 iu, u64 id, 
   }
   return level;
 }
+
+// is_connected_chem, chemistry.f90:2003-2200 (uniform-proposal branch): excitation level of the
+// pair and the probability with which propose_uniform would have produced det_j from det_i
+// (without the n_single/n_total or n_double/n_total level factor).
+__device__ inline bool is_connected_prob(const ChemTab &t, u64 iu, u64 id, u64 ju, u64 jd, int &level, double &prob) {
+  int upc = 0, dnc = 0, du1 = 0, du2 = 0, du3 = 0, du4 = 0, dd1 = 0, dd2 = 0, dd3 = 0, dd4 = 0;
+  level = -1; prob = 0.0;
+  if (iu != ju) {
+    const u64 a = iu & ~ju, b = ju & ~iu;
+    upc = popc64(a);
+    if (upc > 2 || upc != popc64(b)) return false;
+    du1 = ctz64(a) + 1; du3 = ctz64(b) + 1;
+    if (upc == 2) { du2 = ctz64(a & (a - 1)) + 1; du4 = ctz64(b & (b - 1)) + 1; }
+  }
+  if (id != jd) {
+    const u64 a = id & ~jd, b = jd & ~id;
+    dnc = popc64(a);
+    if (dnc > 2 || dnc != popc64(b)) return false;
+    dd1 = ctz64(a) + 1; dd3 = ctz64(b) + 1;
+    if (dnc == 2) { dd2 = ctz64(a & (a - 1)) + 1; dd4 = ctz64(b & (b - 1)) + 1; }
+  }
+  level = upc + dnc;
+  if (level > 2) { level = -1; return false; }
+  const int ne = t.nelec - 2 * t.ncore;
+  if (level == 1) {
+    u64 det = id; int d1 = dd1, d2 = dd3;
+    if (upc == 1) { det = iu; d1 = du1; d2 = du3; }
+    const int sym1 = t.orbsym[d1];
+    if (sym1 != t.orbsym[d2]) return false;
+    const int i_open = popc64(t.sym_mask[sym1] & ~det);
+    prob = 1.0 / ((ne) * (i_open));
+    return true;
+  }
+  if (level == 2) {
+    int d1, d2, d3, d4; u64 det1, det2; double tp, tp2;
+    if (upc == 2) { d1 = du1; d2 = du2; d3 = du3; d4 = du4; det1 = iu | bit64(d3 - 1); det2 = iu | bit64(d4 - 1); tp = 2.0 / (t.norb - t.nup); tp2 = 2.0 / (t.norb - t.nup); }
+    else if (dnc == 2) { d1 = dd1; d2 = dd2; d3 = dd3; d4 = dd4; det1 = id | bit64(d3 - 1); det2 = id | bit64(d4 - 1); tp = 2.0 / (t.norb - t.ndn); tp2 = 2.0 / (t.norb - t.ndn); }
+    else { d1 = du1; d2 = dd1; d3 = du3; d4 = dd3; det2 = iu; det1 = id; tp = 1.0 / (t.norb - t.nup); tp2 = 1.0 / (t.norb - t.ndn); }
+    const int sym1 = t.prod[t.orbsym[d1]][t.orbsym[d2]];
+    if (sym1 != t.prod[t.orbsym[d3]][t.orbsym[d4]]) return false;
+    // orbitals i with product(sym(d3), sym(i)) == sym1 form one irrep in an abelian group
+    const int i_open = popc64(t.sym_mask[t.prod[t.orbsym[d3]][sym1]] & ~det1);
+    const int i_open2 = popc64(t.sym_mask[t.prod[t.orbsym[d4]][sym1]] & ~det2);
+    if (i_open == 0 && i_open2 != 0) prob = (1.0 / ((ne) * (ne - 1))) * ((tp2 / (i_open2)));
+    if (i_open2 == 0 && i_open != 0) prob = (1.0 / ((ne) * (ne - 1))) * ((tp / (i_open)));
+    if (i_open2 != 0 && i_open != 0) prob = (1.0 / ((ne) * (ne - 1))) * ((tp / (i_open)) + (tp2 / (i_open2)));
+    return true;
+  }
+  return true;
+}
+
+// weight_j = -tau * H_ij / p_gen of an accepted proposal; with time-reversal symmetry the matrix
+// element and the generation probability get the second pathway through the time-reversed
+// determinant and det_j is replaced by its representative (chemistry.f90:4988-5069).
+__device__ inline double proposal_weight(const ChemTab &t, const double *__restrict__ ints, double tau, u64 iu, u64 id, u64 &ju, u64 &jd,
+                                         int level, double prob) {
+  if (!t.time_sym) return -tau * h_level(t, ints, iu, id, ju, jd, level) / prob;
+  const double sqrt2 = sqrt(2.0);
+  const double norm_i = (iu == id) ? sqrt2 : 1.0;
+  if ((ju == iu && jd == id) || (jd == iu && ju == id)) return 0.0;
+  double me;
+  if (ju == jd) {
+    if (t.z != 1) return 0.0;
+    me = h_level(t, ints, iu, id, ju, jd, level);
+    me = (sqrt2 / norm_i) * me;
+  } else {
+    const double m1 = h_level(t, ints, iu, id, ju, jd, level);
+    int lsym; double psym;
+    if (is_connected_prob(t, iu, id, jd, ju, lsym, psym)) {
+      const double m2 = h_level(t, ints, iu, id, jd, ju, lsym);
+      const int nup = t.nup, ndn = t.ndn, norb = t.norb, nc = t.ncore;
+      const int n_single = (nup - nc) * (norb - nup) + (ndn - nc) * (norb - ndn);
+      const int n_double = (nup - nc) * (nup - nc - 1) * (norb - nup) * (norb - nup - 1) / 4 + (ndn - nc) * (ndn - nc - 1) * (norb - ndn) * (norb - ndn - 1) / 4
+                         + (nup - nc) * (norb - nup) * (ndn - nc) * (norb - ndn);
+      const int n_total = n_single + n_double;
+      if (lsym == 1) prob = prob + (psym * (n_single / (double)n_total));
+      if (lsym == 2) prob = prob + (psym * (n_double / (double)n_total));
+      me = (1.0 / norm_i) * (m1 + t.z * m2);
+    } else me = (1.0 / norm_i) * (m1);
+  }
+  if (ju > jd) { const u64 x = ju; ju = jd; jd = x; me = me * t.z; }
+  return -tau * me / prob;
+}

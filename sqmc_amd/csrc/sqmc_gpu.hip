@@ -192,8 +192,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   int level = propose_uniform(t, g, iu, id, ju, jd, prob);
   double wj = 0.0;
   if (level > 0) {
-    double mel = h_level(t, dev.integrals, iu, id, ju, jd, level);
-    wj = -p.tau * mel / prob;
+    wj = proposal_weight(t, dev.integrals, p.tau, iu, id, ju, jd, level, prob);
     wj = wchild[ip] * wj;
   }
   const long long k = n0 + c;
@@ -541,7 +540,7 @@ __global__ void __launch_bounds__(TPB) k_propose_batch(ChemDev dev, const u64 *u
   u64 a, b; double prob;
   int level = propose_uniform(t, g, up[i], dn[i], a, b, prob);
   double w = 0.0;
-  if (level > 0) w = -tau * h_level(t, dev.integrals, up[i], dn[i], a, b, level) / prob;
+  if (level > 0) w = proposal_weight(t, dev.integrals, tau, up[i], dn[i], a, b, level, prob);
   ju[i] = a; jd[i] = b; wj[i] = w; state_out[i] = g.x;
 }
 
@@ -1001,7 +1000,6 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   if (!c || !sp || !out) return fail(SQMC_ERR_BAD_ARG, "null argument");
   if (c->mwalk <= 0 || c->nwalk <= 0) return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0");
   if (c->d_grow) return fail(SQMC_ERR_BAD_ARG, "context is configured for sharded steps: use sqmc_gpu_shard_begin/pack/finish");
-  if (c->htab.time_sym) return fail(SQMC_ERR_UNSUPPORTED, "walk kernels implement time_sym=.false. only this round");
   if (sp->semistochastic && (c->n_imp <= 0 || !c->d_prj_ptr)) return fail(SQMC_ERR_BAD_ARG, "semistochastic step without projector");
   if (!c->d_ct_up) return fail(SQMC_ERR_BAD_ARG, "C(T) table not set");
   if (!sp->semistochastic) return fail(SQMC_ERR_UNSUPPORTED, "join_walker2 (non-semistochastic walk) is not implemented this round");
@@ -1207,7 +1205,7 @@ int sqmc_gpu_shard_begin(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double *x_
   if (!c || !sp || !n_children) return fail(SQMC_ERR_BAD_ARG, "null argument");
   if (c->shard_n < 1 || !c->d_grow) return fail(SQMC_ERR_BAD_ARG, "sqmc_gpu_shard_config not called");
   if (c->rng_mode != SQMC_RNG_COUNTER) return fail(SQMC_ERR_UNSUPPORTED, "sharded steps need the COUNTER RNG discipline");
-  if (c->htab.time_sym || !sp->semistochastic || !c->d_ct_up) return fail(SQMC_ERR_UNSUPPORTED, "sharded step: semistochastic, time_sym=.false., C(T) set");
+  if (!sp->semistochastic || !c->d_ct_up) return fail(SQMC_ERR_UNSUPPORTED, "sharded step: semistochastic walk with the C(T) table set");
   if (c->mwalk <= 0) return fail(SQMC_ERR_BAD_ARG, "no walker arrays");
   hipStream_t st = c->st;
   StepP p; p.tau = sp->tau; p.e_trial = sp->e_trial; p.rfi = sp->reweight_factor_inv; p.r_init = sp->r_initiator; p.min_wt = sp->min_wt;
@@ -1363,7 +1361,6 @@ int sqmc_gpu_build_sparse_ham(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, co
 int sqmc_gpu_propose_batch(sqmc_gpu_ctx *c, int64_t n, double tau, const uint64_t *up, const uint64_t *dn, const int32_t *seeds,
                            uint64_t *ju, uint64_t *jd, double *wj, int32_t *seeds_after) {
   if (!c) return fail(SQMC_ERR_BAD_ARG, "null ctx");
-  if (c->htab.time_sym) return fail(SQMC_ERR_UNSUPPORTED, "proposal kernel implements time_sym=.false. only");
   if (n <= 0) return SQMC_OK;
   std::vector<u64> s(n);
   for (long long i = 0; i < n; i++) s[i] = (((u64)seeds[4 * i] << 36) + ((u64)seeds[4 * i + 1] << 24) + ((u64)seeds[4 * i + 2] << 12) + (u64)seeds[4 * i + 3]) & SQ_MASK48;

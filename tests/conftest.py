@@ -42,3 +42,9 @@ def gpu_ctx_from_oracle(sysm, **kw):
     import sqmc_amd
     return sqmc_amd.GpuChem(sysm.norb, sysm.nup, sysm.ndn, sysm.orbsym(), sysm.prod().reshape(-1), sysm.combine_2().reshape(-1),
                             sysm.integrals(), n_group=sysm.s.n_group, time_sym=bool(sysm.s.time_sym), z=sysm.s.z, **kw)
+
+
+@pytest.fixture(scope="session")
+def c2_setup_ts(oracle, c2_hci):
+    """walk set-up with time-reversal symmetry (representatives up <= dn), as the shipped decks use it"""
+    return oracle.setup_walk(c2_hci, 100, 1000, 0.1)

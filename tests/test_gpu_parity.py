@@ -348,3 +348,41 @@ def test_hci_variational_matches_reference_run():
     assert abs(hist[4] - 126386) <= 3 and abs(hist[5] - 126708) <= 3
     assert abs(e[0] - (-75.727563003)) < 2e-9
     assert abs(np.dot(w[:, 0], w[:, 0]) - 1.0) < 1e-9
+
+
+def test_time_sym_proposals_bit_exact(oracle, c2_hci):
+    """off_diagonal_move_chem with time_sym=.true., z=+1: second pathway through the time-reversed
+    determinant in matrix element and generation probability, representative swap."""
+    L = oracle.lib()
+    g = gpu_ctx_from_oracle(c2_hci)
+    rng = np.random.default_rng(21)
+    n = 6000
+    up, dn = _random_dets(rng, 26, 4, n), _random_dets(rng, 26, 4, n)
+    up[::9] = dn[::9]                                   # closed-shell representatives too
+    sw = up > dn; up[sw], dn[sw] = dn[sw], up[sw]
+    seeds = rng.integers(0, 4096, size=(n, 4)).astype(np.int32); seeds[:, 3] |= 1
+    tau = 0.0053
+    ju, jd, wj, sa = g.propose_batch(tau, up, dn, seeds)
+    g.close()
+    r = oracle.Rng(); a, b, w, nd = C.c_uint64(), C.c_uint64(), C.c_double(), C.c_int()
+    nz = 0
+    for i in range(n):
+        L.orc_setrn(C.byref(r), (C.c_int * 4)(*seeds[i]))
+        L.orc_off_diagonal_move_chem(c2_hci.h, C.byref(r), tau, int(up[i]), int(dn[i]), C.byref(a), C.byref(b), C.byref(w), C.byref(nd))
+        assert w.value == wj[i], (i, w.value, wj[i])
+        if w.value != 0.0:
+            nz += 1
+            assert (a.value, b.value) == (int(ju[i]), int(jd[i])) and a.value <= b.value
+    assert nz > n // 3
+
+
+@pytest.mark.parametrize("rng_mode,nsteps", [(0, 40), (1, 100)])
+def test_time_sym_walk_trajectory_bit_exact(oracle, c2_hci, c2_setup_ts, rng_mode, nsteps):
+    wg, wc, rng_g, rng_c, og, oc = _run_pair(oracle, c2_hci, c2_setup_ts, rng_mode, nsteps, 20, 5000)
+    if rng_mode == 0:
+        assert rng_g == rng_c
+    for k in ("up", "dn", "imp_distance", "initiator"):
+        assert np.array_equal(wg[k], wc[k]), k
+    assert np.array_equal(wg["wt"], wc["wt"])
+    assert np.all(wg["up"] <= wg["dn"]) and len(wg["up"]) > 1100
+    assert -75.85 < og[3] / og[2] < -75.5
