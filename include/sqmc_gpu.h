@@ -72,6 +72,20 @@ int sqmc_gpu_set_device(int device);
 
 /* replaces: system_setup_chem + init_move table setup.  Copies everything to HBM. */
 int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out);
+/* Homogeneous electron gas in a plane-wave basis (hamiltonian_type 'heg'): the tables
+ * system_setup_heg / generate_k_vectors build (heg.f90:168-215, 643-749).  k_vectors is the
+ * reference's k_vectors(n_dim, norb) in its own (column-major) memory order, orbitals sorted by
+ * |k| exactly as the reference sorts them; the walk then uses off_diagonal_move_heg
+ * (heg.f90:1344-1598) and hamiltonian_heg (heg.f90:845-1011) in place of the chemistry pair. */
+typedef struct {
+  int32_t n_dim, norb, nup, ndn;
+  double length_cell;
+  const double *k_vectors;          /* [norb * n_dim] */
+  int32_t rng_mode;
+  int32_t irand_seed[4];
+  int64_t mwalk;
+} sqmc_heg_cfg;
+int sqmc_gpu_init_heg(const sqmc_heg_cfg *cfg, sqmc_gpu_ctx **out);
 int sqmc_gpu_finalize(sqmc_gpu_ctx *ctx);
 const char *sqmc_gpu_last_error(void);
 

@@ -1,7 +1,8 @@
-﻿!mod$ v1 sum:30cb159b0fe03601
+﻿!mod$ v1 sum:bc21d31206536f60
 !need$ 1774047b7d99e66e n tools
-!need$ 34bfdfda242a4e50 n types
+!need$ 821e2c31b61140dc n generic_sort
 !need$ 0bde2ac47243ead2 i iso_c_binding
+!need$ 34bfdfda242a4e50 n types
 module ref_shim
 use types,only:ik
 use tools,only:permutation_factor
@@ -9,6 +10,7 @@ use tools,only:permutation_factor2
 use tools,only:count_excitations
 use tools,only:random_int
 use tools,only:merge_sort2_up_dn
+use generic_sort,only:sort
 use,intrinsic::iso_c_binding,only:c_associated
 use,intrinsic::iso_c_binding,only:c_funloc
 use,intrinsic::iso_c_binding,only:c_funptr
@@ -84,6 +86,8 @@ use,intrinsic::iso_c_binding,only:c_uint_least32_t
 use,intrinsic::iso_c_binding,only:c_uint_least64_t
 use,intrinsic::iso_c_binding,only:c_uint_least128_t
 use,intrinsic::iso_c_binding,only:c_f_procpointer
+use generic_sort,only:generic_sort$generic_sort$shell_sort_real_rank2=>shell_sort_real_rank2
+private::generic_sort$generic_sort$shell_sort_real_rank2
 contains
 subroutine ref_setrn(seed) bind(c,name="ref_setrn")
 integer(4),intent(in)::seed(1_8:4_8)
@@ -117,5 +121,10 @@ integer(4),value::n
 integer(8),intent(inout)::up(1_8:int(n,kind=8))
 integer(8),intent(inout)::dn(1_8:int(n,kind=8))
 integer(4),intent(out)::iorder(1_8:int(n,kind=8))
+end
+subroutine ref_sort_real_rank2(ndim,n,arr) bind(c,name="ref_sort_real_rank2")
+integer(4),value::ndim
+integer(4),value::n
+real(8),intent(inout)::arr(1_8:int(ndim,kind=8),1_8:int(n,kind=8))
 end
 end

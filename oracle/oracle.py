@@ -458,7 +458,8 @@ class OracleWalk:
     def step(self, params):
         out = np.zeros(16)
         p = StepParams(**params)
-        st = self.L.orc_walk_step(self.sysm.h, self.h, C.byref(p), _p(out))
+        fn = self.L.orc_walk_step_heg if isinstance(self.sysm, HegSystem) else self.L.orc_walk_step
+        st = fn(self.sysm.h, self.h, C.byref(p), _p(out))
         return st, out
 
     def walkers(self):
@@ -533,3 +534,104 @@ class PopControl:
         return dict(tau=self.tau, e_trial=self.e_trial, reweight_factor_inv=self.rfi, r_initiator=self.r_init, min_wt=min_wt,
                     always_spawn_cutoff_wt=cutoff, initiator_power=initiator_power, initiator_min_distance=0, c_t_initiator=0,
                     semistochastic=semistochastic, reached_w_abs_gen=self.reached)
+
+
+# ------------------------------------------------------------------------------ HEG
+class Heg(C.Structure):
+    _fields_ = [("n_dim", C.c_int), ("nelec", C.c_int), ("nup", C.c_int), ("ndn", C.c_int), ("norb", C.c_int), ("n_max", C.c_int),
+                ("r_s", C.c_double), ("length_cell", C.c_double), ("k", (C.c_double * 3) * (ORC_MAXORB + 1)), ("krel", (C.c_int * 3) * (ORC_MAXORB + 1))]
+
+
+class HegSystem:
+    """orc_heg handle: 3D/2D electron gas in a plane-wave basis (heg.f90)."""
+
+    def __init__(self, n_dim, r_s, nelec, nup, cutoff_radius):
+        L = lib()
+        L.orc_heg_new.restype = C.c_void_p
+        L.orc_heg_new.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int, C.c_double]
+        L.orc_hamiltonian_heg.restype = C.c_double
+        L.orc_hamiltonian_heg.argtypes = [C.c_void_p] + [C.c_uint64] * 4
+        L.orc_off_diagonal_move_heg.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_uint64, C.c_uint64] + [C.c_void_p] * 4
+        L.orc_connected_heg.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_build_sparse_ham_heg.restype = C.c_int64
+        L.orc_build_sparse_ham_heg.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+        L.orc_walk_step_heg.argtypes = [C.c_void_p] * 4
+        self.h = L.orc_heg_new(n_dim, r_s, nelec, nup, cutoff_radius)
+        if not self.h:
+            raise RuntimeError("orc_heg_new failed")
+        self.s = Heg.from_address(self.h)
+        self.norb, self.nelec, self.nup, self.ndn = self.s.norb, nelec, nup, nelec - nup
+        self.hf_up, self.hf_dn = (1 << nup) - 1, (1 << (nelec - nup)) - 1
+        self.length_cell, self.n_dim = self.s.length_cell, n_dim
+
+    def k_vectors(self):
+        """k_vectors(n_dim? -> 3, norb) as [norb, 3] (row i-1 = orbital i)"""
+        return np.array([[self.s.k[i][j] for j in range(3)] for i in range(1, self.norb + 1)])
+
+    def ham(self, iu, id_, ju, jd):
+        return lib().orc_hamiltonian_heg(self.h, iu, id_, ju, jd)
+
+    def connected(self, up, dn, with_elems=True, cap=400000):
+        cu = np.zeros(cap, np.uint64); cd = np.zeros(cap, np.uint64); el = np.zeros(cap)
+        n = lib().orc_connected_heg(self.h, up, dn, _p(cu), _p(cd), _p(el) if with_elems else None, cap)
+        assert n <= cap
+        return cu[:n], cd[:n], el[:n]
+
+    def build_sparse_ham(self, up, dn):
+        up = np.ascontiguousarray(up, np.uint64); dn = np.ascontiguousarray(dn, np.uint64)
+        n = len(up)
+        rc = C.c_void_p(); ix = C.c_void_p(); vl = C.c_void_p()
+        nnz = lib().orc_build_sparse_ham_heg(self.h, n, _p(up), _p(dn), C.byref(rc), C.byref(ix), C.byref(vl))
+        counts = np.ctypeslib.as_array(C.cast(rc, C.POINTER(C.c_int64)), shape=(n,)).copy()
+        idx = np.ctypeslib.as_array(C.cast(ix, C.POINTER(C.c_int64)), shape=(nnz,)).copy()
+        val = np.ctypeslib.as_array(C.cast(vl, C.POINTER(C.c_double)), shape=(nnz,)).copy()
+        for q in (rc, ix, vl):
+            lib().orc_free(q)
+        return counts, idx, val
+
+    def diag_lowest_highest(self):
+        """heg.f90 has no tau_multiplier rule of its own in the walk decks here: tau is chosen from the
+        spread between the HF determinant and the determinant with the highest orbitals filled."""
+        n = self.norb
+        mu = ((1 << n) - 1) ^ ((1 << (n - self.nup)) - 1)
+        md = ((1 << n) - 1) ^ ((1 << (n - self.ndn)) - 1)
+        return self.ham(self.hf_up, self.hf_dn, self.hf_up, self.hf_dn), self.ham(mu, md, mu, md)
+
+
+def setup_walk_heg(hsys, size_deterministic=500, tau_multiplier=0.1, n_truncate_trial_wf=1):
+    """HEG walk set-up: Psi_T = the largest-|c| determinants of the ground state in {HF + its
+    double excitations} (n_truncate_trial_wf = 1: HF alone, the usual choice for a closed shell),
+    deterministic space = the size_deterministic largest, C(T) = connections of Psi_T."""
+    import math
+    s = WalkSetup()
+    cu, cd, _ = hsys.connected(hsys.hf_up, hsys.hf_dn, with_elems=False)
+    order = sort_dets(cu, cd)
+    up, dn = cu[order], cd[order]
+    counts, idx, val = hsys.build_sparse_ham(up, dn)
+    w, v = lowest_eigs(counts, idx, val, k=1)
+    c = v[:, 0]
+    if c[np.argmax(np.abs(c))] < 0:
+        c = -c
+    by = np.argsort(-np.abs(c), kind="stable")
+    up_s, dn_s, c_s = up[by], dn[by], c[by]
+    n_t, n_i = _truncate_at_csf(c_s, n_truncate_trial_wf), _truncate_at_csf(c_s, size_deterministic)
+    norm = 1.0 / math.sqrt(math.fsum(float(x) * float(x) for x in c_s[:n_t]))
+    s.psi_up, s.psi_dn, s.psi_c = up_s[:n_t].copy(), dn_s[:n_t].copy(), c_s[:n_t] * norm
+    o = sort_dets(up_s[:n_i], dn_s[:n_i])
+    s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
+    lo, hi = hsys.diag_lowest_highest()
+    s.tau, s.e_var = tau_multiplier / (hi - lo), float(w[0])
+    pc, pi, pv = hsys.build_sparse_ham(s.imp_up, s.imp_dn)
+    s.prj_counts, s.prj_indices, s.prj_values = pc, pi, -s.tau * pv
+    acc = {}
+    psi_index = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(s.psi_up, s.psi_dn))}
+    for j in range(n_t):
+        xu, xd, el = hsys.connected(int(s.psi_up[j]), int(s.psi_dn[j]), with_elems=True, cap=100000)
+        for a, b, h in zip(xu.tolist(), xd.tolist(), el.tolist()):
+            acc[(a, b)] = acc.get((a, b), 0.0) + h * s.psi_c[j]
+    keys = sorted(acc)
+    s.ct_up = np.array([k[0] for k in keys], np.uint64); s.ct_dn = np.array([k[1] for k in keys], np.uint64)
+    s.ct_num = np.array([acc[k] for k in keys])
+    s.ct_den = np.array([s.psi_c[psi_index[k]] if k in psi_index else 0.0 for k in keys])
+    s.e_trial0 = float(math.fsum(a * b for a, b in zip(s.ct_num, s.ct_den)) / math.fsum(b * b for b in s.ct_den))
+    return s

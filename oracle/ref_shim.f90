@@ -5,6 +5,7 @@ module ref_shim
   use iso_c_binding
   use types, only : ik
   use tools, only : permutation_factor, permutation_factor2, count_excitations, random_int, merge_sort2_up_dn
+  use generic_sort, only : sort
   implicit none
 contains
 
@@ -80,6 +81,14 @@ contains
     do i = 1, n
       up(i) = int(ku(i), c_int64_t); dn(i) = int(kd(i), c_int64_t); iorder(i) = io(i)
     enddo
+  end subroutine
+
+  ! shell sort of column vectors by magnitude: the routine that orders the HEG k-points
+  ! (generic_sort.f90:554-591, called at heg.f90:700)
+  subroutine ref_sort_real_rank2(ndim, n, arr) bind(C, name='ref_sort_real_rank2')
+    integer(c_int), value :: ndim, n
+    real(c_double), intent(inout) :: arr(ndim, n)
+    call sort(arr)
   end subroutine
 
 end module ref_shim

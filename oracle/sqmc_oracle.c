@@ -884,9 +884,19 @@ int64_t orc_reduce_my_walker(orc_walk *w, int64_t n, const orc_step_params *p) {
   return n - nshift;
 }
 
-/* do_walk.f90:3538-3800, chem + uniform2 proposal, hf_to_psit=.false.  Returns status
+/* system dispatch of the walk: 'chem' or 'heg' (do_walk.f90:3599-3633, 3745-3769) */
+typedef struct { const orc_chem *chem; const orc_heg *heg; } orc_sys;
+static double sys_diag(const orc_sys *y, det_t u, det_t d) {
+  return y->chem ? orc_hamiltonian(y->chem, u, d, u, d) : orc_hamiltonian_heg(y->heg, u, d, u, d);
+}
+static void sys_move(const orc_sys *y, orc_rng *g, double tau, det_t u, det_t d, det_t *ju, det_t *jd, double *wj, int *nd) {
+  if (y->chem) orc_off_diagonal_move_chem(y->chem, g, tau, u, d, ju, jd, wj, nd);
+  else orc_off_diagonal_move_heg(y->heg, g, tau, u, d, ju, jd, wj, nd);
+}
+
+/* do_walk.f90:3538-3800, uniform2 proposal, hf_to_psit=.false.  Returns status
  * (0 ok, 1 nwalk>MWALK, 3 negative diagonal factor after equilibration). */
-static int move_uniform2(const orc_chem *s, orc_walk *w, const orc_step_params *p, int64_t iw, int64_t *attempts) {
+static int move_uniform2(const orc_sys *s, orc_walk *w, const orc_step_params *p, int64_t iw, int64_t *attempts) {
   int spawn, use_wt;
   if (fabs(w->wt[iw]) < p->always_spawn_cutoff_wt) {
     orc_rng_seek(&w->rng, 0, (uint64_t)iw);
@@ -899,7 +909,7 @@ static int move_uniform2(const orc_chem *s, orc_walk *w, const orc_step_params *
     for (long c = 1; c <= nchild; c++) {
       det_t ju, jd; double wj; int nd;
       orc_rng_seek(&w->rng, 1, (uint64_t)(*attempts));
-      orc_off_diagonal_move_chem(s, &w->rng, p->tau, w->up[iw], w->dn[iw], &ju, &jd, &wj, &nd);
+      sys_move(s, &w->rng, p->tau, w->up[iw], w->dn[iw], &ju, &jd, &wj, &nd);
       w->n_spawn_draws += nd; (*attempts)++;
       wj = wchild * wj;
       if (wj != 0) {
@@ -919,7 +929,7 @@ static int move_uniform2(const orc_chem *s, orc_walk *w, const orc_step_params *
   if (!p->semistochastic || w->imp_distance[iw] >= 1) {
     double hii;
     if (w->matrix_elements[iw] > 1e50) {
-      hii = orc_hamiltonian(s, w->up[iw], w->dn[iw], w->up[iw], w->dn[iw]);
+      hii = sys_diag(s, w->up[iw], w->dn[iw]);
       w->matrix_elements[iw] = hii;
     } else hii = w->matrix_elements[iw];
     double f = 1.0 + p->tau * (p->e_trial - hii);
@@ -950,7 +960,16 @@ static void search_list_and_update(orc_walk *w, int64_t n, double acc[7]) {
 
 /* One MC step, do_walk.f90:2186-2790 for semistochastic chem, ncores=1, hf_to_psit=.false.,
  * run_type 'none'.  Population control (2880-2901) stays with the caller. */
-int orc_walk_step(const orc_chem *s, orc_walk *w, const orc_step_params *p, double out[16]) {
+static int walk_step_sys(const orc_sys *s, orc_walk *w, const orc_step_params *p, double out[16]);
+int orc_walk_step(const orc_chem *c, orc_walk *w, const orc_step_params *p, double out[16]) {
+  orc_sys y = {c, NULL};
+  return walk_step_sys(&y, w, p, out);
+}
+int orc_walk_step_heg(const orc_heg *h, orc_walk *w, const orc_step_params *p, double out[16]) {
+  orc_sys y = {NULL, h};
+  return walk_step_sys(&y, w, p, out);
+}
+static int walk_step_sys(const orc_sys *s, orc_walk *w, const orc_step_params *p, double out[16]) {
   int64_t n0 = w->nwalk, nimp = 0, attempts = 0;
   int64_t *loc = NULL; double *impw = NULL, *dw = NULL;
   w->n_spawn_draws = 0;
@@ -994,4 +1013,183 @@ int orc_walk_step(const orc_chem *s, orc_walk *w, const orc_step_params *p, doub
   out[11] = acc[4]; out[12] = acc[5]; out[13] = acc[6]; out[14] = wabs_before; out[15] = (double)attempts;
   w->rng.step++;
   return 0;
+}
+
+
+/* ==================================================================== HEG */
+static double sum_sq3(const double *v, int n) { double s = 0; for (int j = 0; j < n; j++) s = s + v[j] * v[j]; return s; }
+/* generate_k_vectors, heg.f90:643-749; ordering = shell_sort_real_rank2, generic_sort.f90:554-591 */
+orc_heg *orc_heg_new(int n_dim, double r_s, int nelec, int nup, double cutoff_radius) {
+  const double EPS = 1.0e-15, pi = 4.0 * atan(1.0);
+  if (n_dim != 2 && n_dim != 3) return NULL;
+  orc_heg *h = calloc(1, sizeof(orc_heg));
+  h->n_dim = n_dim; h->r_s = r_s; h->nelec = nelec; h->nup = nup; h->ndn = nelec - nup;
+  double density = (n_dim == 2) ? 1.0 / (pi * (r_s * r_s)) : 3.0 / (4.0 * pi * (r_s * r_s * r_s));
+  h->length_cell = pow(nelec / density, 1.0 / n_dim);
+  int n_max = (int)(cutoff_radius + EPS); h->n_max = n_max;
+  int side = 2 * n_max + 1, ntot = 1; for (int j = 0; j < n_dim; j++) ntot *= side;
+  double *kv = malloc((size_t)ntot * 3 * sizeof(double)), *values = malloc(side * sizeof(double));
+  for (int i = -n_max; i <= n_max; i++) values[i + n_max] = 2 * pi / h->length_cell * i;
+  int idx = 0;
+  if (n_dim == 3) { for (int i = 0; i < side; i++) for (int j = 0; j < side; j++) for (int k = 0; k < side; k++) { kv[3 * idx] = values[i]; kv[3 * idx + 1] = values[j]; kv[3 * idx + 2] = values[k]; idx++; } }
+  else { for (int i = 0; i < side; i++) for (int j = 0; j < side; j++) { kv[3 * idx] = values[i]; kv[3 * idx + 1] = values[j]; kv[3 * idx + 2] = 0.0; idx++; } }
+  /* shell sort on |k|^2, increments n/2, *5/11 (2 -> 1) */
+  for (int inc = ntot / 2; inc > 0; inc = (inc == 2) ? 1 : inc * 5 / 11) {
+    for (int i = inc; i < ntot; i++) {
+      int j = i; double t[3] = {kv[3 * i], kv[3 * i + 1], kv[3 * i + 2]};
+      while (j >= inc) {
+        if (sum_sq3(kv + 3 * (j - inc), n_dim) <= sum_sq3(t, n_dim)) break;
+        memcpy(kv + 3 * j, kv + 3 * (j - inc), 3 * sizeof(double));
+        j -= inc;
+      }
+      kv[3 * j] = t[0]; kv[3 * j + 1] = t[1]; kv[3 * j + 2] = t[2];
+    }
+  }
+  int norb = 0;
+  for (int i = 0; i < ntot; i++) { if (sqrt(sum_sq3(kv + 3 * i, n_dim)) > 2 * pi / h->length_cell * cutoff_radius + EPS) break; norb++; }
+  if (norb > ORC_MAXORB) { free(kv); free(values); free(h); return NULL; }
+  h->norb = norb;
+  for (int i = 1; i <= norb; i++) for (int j = 0; j < 3; j++) {
+    h->k[i][j] = kv[3 * (i - 1) + j];
+    h->krel[i][j] = (int)lround(h->k[i][j] * h->length_cell / (2 * pi));
+  }
+  free(kv); free(values);
+  return h;
+}
+void orc_heg_free(orc_heg *h) { free(h); }
+
+static double inv_k2(const orc_heg *h, int p, int q) {   /* FOUR_PI / sum((k_p - k_q)**2) */
+  const double FOUR_PI = 4.0 * (4.0 * atan(1.0));
+  double s = 0; for (int j = 0; j < h->n_dim; j++) { double d = h->k[p][j] - h->k[q][j]; s = s + d * d; }
+  return FOUR_PI / s;
+}
+/* get_gamma_exp, heg.f90:811-842: for each listed orbital present in det, the number of occupied orbitals below it */
+static int gamma_exp(det_t det, det_t eor) {
+  int g = 0;
+  for (det_t e = eor & det; e; e &= e - 1) { int o = trailz(e); g += popcnt(det & maskr(o)); }
+  return g;
+}
+/* heg.f90:845-1011 */
+double orc_hamiltonian_heg(const orc_heg *h, det_t iu, det_t id, det_t ju, det_t jd) {
+  const double EPS = 1.0e-15, L = h->length_cell; const int nd = h->n_dim;
+  double me = 0.0;
+  if (iu == ju && id == jd) {
+    for (det_t d = iu; d; d &= d - 1) { int p = trailz(d) + 1; me = me + sum_sq3(h->k[p], nd) * 0.5; }
+    for (det_t d = id; d; d &= d - 1) { int p = trailz(d) + 1; me = me + sum_sq3(h->k[p], nd) * 0.5; }
+    double pot = 0.0;
+    for (det_t a = iu; a; a &= a - 1) for (det_t b = a & (a - 1); b; b &= b - 1) pot = pot + inv_k2(h, trailz(a) + 1, trailz(b) + 1);
+    for (det_t a = id; a; a &= a - 1) for (det_t b = a & (a - 1); b; b &= b - 1) pot = pot + inv_k2(h, trailz(a) + 1, trailz(b) + 1);
+    return me - pot / (L * L * L);
+  }
+  det_t eu = iu ^ ju, ed = id ^ jd;
+  int neu = popcnt(eu), ned = popcnt(ed);
+  if (neu + ned != 4) return 0.0;
+  double mc[3] = {0, 0, 0}; int op = 0, oq = 0, os = 0;
+  for (int sp = 0; sp < 2; sp++) {
+    det_t e = sp ? ed : eu, di = sp ? id : iu;
+    for (; e; e &= e - 1) {
+      int o = trailz(e) + 1;
+      if (btest(di, o - 1)) { for (int j = 0; j < nd; j++) mc[j] = mc[j] - h->k[o][j]; if (!op) op = o; }
+      else { for (int j = 0; j < nd; j++) mc[j] = mc[j] + h->k[o][j]; if (!oq) oq = o; else if (!os) os = o; }
+    }
+  }
+  if (sum_sq3(mc, nd) * (L * L) > EPS) return 0.0;
+  double pot = inv_k2(h, op, oq);
+  if (neu != 2) pot = pot - inv_k2(h, op, os);
+  int g = gamma_exp(iu, eu) + gamma_exp(ju, eu) + gamma_exp(id, ed) + gamma_exp(jd, ed);
+  if (g & 1) pot = -pot;
+  return pot / (L * L * L);
+}
+
+/* heg.f90:1344-1598 */
+void orc_off_diagonal_move_heg(const orc_heg *h, orc_rng *g, double tau, det_t iu, det_t id,
+                               det_t *pju, det_t *pjd, double *weight_j, int *n_draws) {
+  const double EPS = 1.0e-15;
+  const int nelec = h->nelec, nup = h->nup, ndn = h->ndn, norb = h->norb, nd = h->n_dim;
+  int draws = 0;
+#define RI(n) (draws++, orc_random_int(g, (n)))
+  det_t ju = iu, jd = id;
+  int e1 = RI(nelec), e2;
+  do { e2 = RI(nelec); } while (e1 == e2);
+  int spin = ((e1 > nup) ? -1 : 1) + ((e2 > nup) ? -1 : 1);
+  double from[3] = {0, 0, 0}, to1[3] = {0, 0, 0};
+  int ie = 0;
+  for (int i = 1; i <= norb; i++) if (btest(iu, i - 1)) { ie++; if (ie == e1 || ie == e2) { for (int j = 0; j < nd; j++) from[j] = from[j] + h->k[i][j]; ju &= ~BIT(i - 1); } }
+  for (int i = 1; i <= norb; i++) if (btest(id, i - 1)) { ie++; if (ie == e1 || ie == e2) { for (int j = 0; j < nd; j++) from[j] = from[j] + h->k[i][j]; jd &= ~BIT(i - 1); } }
+  int found = 0; double prob = 1.0;
+  /* first hole in channel A (k-th empty orbital of det_i), partner hole in channel B by momentum conservation */
+  int first_up, second_up, to1n; float denom;
+  if (spin == 2) { to1n = RI(norb - nup); first_up = 1; second_up = 1; denom = (float)(nelec * (nelec - 1) * (norb - nup)); }
+  else if (spin == -2) { to1n = RI(norb - ndn); first_up = 0; second_up = 0; denom = (float)(nelec * (nelec - 1) * (norb - ndn)); }
+  else {
+    to1n = RI(2 * norb - nup - ndn); denom = (float)(nelec * (nelec - 1) * (2 * norb - nelec));
+    if (to1n <= norb - nup) { first_up = 1; second_up = 0; } else { to1n -= (norb - nup); first_up = 0; second_up = 1; }
+  }
+  { det_t di = first_up ? iu : id; int io = 0;
+    for (int i = 1; i <= norb; i++) if (!btest(di, i - 1)) { io++; if (io == to1n) { for (int j = 0; j < nd; j++) to1[j] = to1[j] + h->k[i][j]; if (first_up) ju |= BIT(i - 1); else jd |= BIT(i - 1); } } }
+  { det_t busy = second_up ? (iu | ju) : (id | jd);
+    for (int i = 1; i <= norb; i++) if (!btest(busy, i - 1)) {
+      int ok = 0;
+      for (int j = 0; j < nd; j++) if (fabs(from[j] - (to1[j] + h->k[i][j])) < EPS) ok++;
+      if (ok == nd) { if (second_up) ju |= BIT(i - 1); else jd |= BIT(i - 1); prob = (double)(4.0f / denom); found = 1; break; }
+    } }
+  *weight_j = 0; *pju = ju; *pjd = jd;
+  if (found) {
+    double me = orc_hamiltonian_heg(h, iu, id, ju, jd);
+    double acc = tau * fabs(me) / prob;
+    *weight_j = acc * copysign(1.0, -me);
+  }
+#undef RI
+  if (n_draws) *n_draws = draws;
+}
+
+int orc_connected_heg(const orc_heg *h, det_t up, det_t dn, det_t *cu, det_t *cd, double *el, int cap) {
+  int n = 0, norb = h->norb;
+#define PUSH(U, D) do { if (n < cap) { cu[n] = (U); cd[n] = (D); if (el) el[n] = orc_hamiltonian_heg(h, up, dn, (U), (D)); } n++; } while (0)
+  PUSH(up, dn);
+  /* all pairs of electrons (p,q) and holes (r,s) with k_p + k_q = k_r + k_s (integer k) */
+  int occ[2 * ORC_MAXORB], nocc = 0;
+  for (det_t d = up; d; d &= d - 1) occ[nocc++] = trailz(d) + 1;
+  int nu = nocc;
+  for (det_t d = dn; d; d &= d - 1) occ[nocc++] = trailz(d) + 1 + norb;
+  for (int a = 0; a < nocc; a++) for (int b = a + 1; b < nocc; b++) {
+    int p = occ[a], q = occ[b], pu = p <= norb, qu = q <= norb;
+    int ps = pu ? p : p - norb, qs = qu ? q : q - norb;
+    for (int r = 1; r <= norb; r++) for (int s_ = 1; s_ <= norb; s_++) {
+      /* r takes p's spin, s takes q's spin; same-spin pairs need r < s to avoid double counting */
+      if (pu == qu && s_ <= r) continue;
+      det_t ru = pu ? up : dn, su = qu ? up : dn;
+      if (btest(ru, r - 1) || btest(su, s_ - 1)) continue;
+      int ok = 1;
+      for (int j = 0; j < 3; j++) if (h->krel[ps][j] + h->krel[qs][j] != h->krel[r][j] + h->krel[s_][j]) ok = 0;
+      if (!ok) continue;
+      det_t nu_ = up, nd_ = dn;
+      if (pu) nu_ &= ~BIT(ps - 1); else nd_ &= ~BIT(ps - 1);
+      if (qu) nu_ &= ~BIT(qs - 1); else nd_ &= ~BIT(qs - 1);
+      if (pu) nu_ |= BIT(r - 1); else nd_ |= BIT(r - 1);
+      if (qu) nu_ |= BIT(s_ - 1); else nd_ |= BIT(s_ - 1);
+      PUSH(nu_, nd_);
+    }
+  }
+  (void)nu;
+#undef PUSH
+  return n;
+}
+
+int64_t orc_build_sparse_ham_heg(const orc_heg *h, int64_t n, const det_t *up, const det_t *dn,
+                                 int64_t **row_counts, int64_t **indices, double **values) {
+  int64_t cap = n * 64 + 1024, nnz = 0;
+  int64_t *rc = calloc(n, sizeof(int64_t)), *idx = malloc(cap * sizeof(int64_t)); double *val = malloc(cap * sizeof(double));
+  for (int64_t i = 0; i < n; i++) {
+    if (nnz + i + 2 > cap) { cap = 2 * cap + i; idx = realloc(idx, cap * sizeof(int64_t)); val = realloc(val, cap * sizeof(double)); }
+    idx[nnz] = i + 1; val[nnz] = orc_hamiltonian_heg(h, up[i], dn[i], up[i], dn[i]); nnz++; rc[i] = 1;
+    for (int64_t j = 0; j < i; j++) {
+      if (popcnt(up[i] ^ up[j]) + popcnt(dn[i] ^ dn[j]) != 4) continue;
+      double v = orc_hamiltonian_heg(h, up[i], dn[i], up[j], dn[j]);
+      if (v == 0.0) continue;
+      idx[nnz] = j + 1; val[nnz] = v; nnz++; rc[i]++;
+    }
+  }
+  *row_counts = rc; *indices = idx; *values = val;
+  return nnz;
 }

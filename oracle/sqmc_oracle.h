@@ -136,3 +136,26 @@ int64_t orc_merge_original_with_spawned2(orc_walk *w, int64_t n, const orc_step_
 int64_t orc_reduce_my_walker(orc_walk *w, int64_t n, const orc_step_params *p);            /* 7196-7254 */
 
 #endif
+
+/* ---- homogeneous electron gas in k-space: heg.f90 (read_heg 119-166, system_setup_heg 168-215,
+ * generate_k_vectors 643-749, hamiltonian_heg 845-1011, off_diagonal_move_heg 1344-1598) ---- */
+#ifndef SQMC_ORACLE_HEG_H
+#define SQMC_ORACLE_HEG_H
+typedef struct {
+  int n_dim, nelec, nup, ndn, norb, n_max;
+  double r_s, length_cell;
+  double k[ORC_MAXORB + 1][3];        /* k_vectors(:, i), 1-based orbital index */
+  int krel[ORC_MAXORB + 1][3];        /* k in units of 2 pi / L */
+} orc_heg;
+orc_heg *orc_heg_new(int n_dim, double r_s, int nelec, int nup, double cutoff_radius);
+void   orc_heg_free(orc_heg *h);
+double orc_hamiltonian_heg(const orc_heg *h, det_t iu, det_t id, det_t ju, det_t jd);
+void   orc_off_diagonal_move_heg(const orc_heg *h, orc_rng *g, double tau, det_t iu, det_t id,
+                                 det_t *ju, det_t *jd, double *weight_j, int *n_draws);
+/* the determinant itself + every momentum-conserving double excitation (any order) */
+int    orc_connected_heg(const orc_heg *h, det_t up, det_t dn, det_t *cu, det_t *cd, double *elems, int cap);
+int64_t orc_build_sparse_ham_heg(const orc_heg *h, int64_t n, const det_t *up, const det_t *dn,
+                                 int64_t **row_counts, int64_t **indices, double **values);
+/* one MC step with the HEG as the system (same step logic as orc_walk_step) */
+int  orc_walk_step_heg(const orc_heg *h, orc_walk *w, const orc_step_params *p, double out[16]);
+#endif

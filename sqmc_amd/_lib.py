@@ -12,7 +12,7 @@ RNG_REPLAY, RNG_COUNTER = 0, 1
 _LIB = None
 
 EXPORTS = [
-    "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_projector",
+    "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_init_heg", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_projector",
     "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
     "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_det_owner", "sqmc_gpu_shard_config",
     "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_spmv_prepare",
@@ -45,6 +45,11 @@ class ChemCfg(C.Structure):
                 ("product_table", C.c_void_p), ("orbital_symmetries", C.c_void_p), ("combine_2", C.c_void_p),
                 ("n_integrals", C.c_int64), ("integrals", C.c_void_p), ("rng_mode", C.c_int32),
                 ("irand_seed", C.c_int32 * 4), ("mwalk", C.c_int64)]
+
+
+class HegCfg(C.Structure):
+    _fields_ = [("n_dim", C.c_int32), ("norb", C.c_int32), ("nup", C.c_int32), ("ndn", C.c_int32), ("length_cell", C.c_double),
+                ("k_vectors", C.c_void_p), ("rng_mode", C.c_int32), ("irand_seed", C.c_int32 * 4), ("mwalk", C.c_int64)]
 
 
 class StepParams(C.Structure):
@@ -150,6 +155,23 @@ class GpuChem:
         h = C.c_void_p()
         _chk(L.sqmc_gpu_init_chem(C.byref(cfg), C.byref(h)))
         self.h, self.norb, self.mwalk = h, norb, mwalk
+
+    @classmethod
+    def heg(cls, n_dim, norb, nup, ndn, length_cell, k_vectors, rng_mode=RNG_COUNTER, seed=(1346, 5634, 6635, 4361), mwalk=0):
+        """context for the homogeneous electron gas: k_vectors[norb, n_dim] (orbital-major)"""
+        self = cls.__new__(cls)
+        self.L = L = load_library()
+        kv = _f64(np.asarray(k_vectors)[:, :n_dim])
+        self._tabs = [kv]
+        cfg = HegCfg()
+        cfg.n_dim, cfg.norb, cfg.nup, cfg.ndn, cfg.length_cell = n_dim, norb, nup, ndn, float(length_cell)
+        cfg.k_vectors, cfg.rng_mode, cfg.mwalk = kv.ctypes.data, rng_mode, mwalk
+        for i in range(4):
+            cfg.irand_seed[i] = seed[i]
+        h = C.c_void_p()
+        _chk(L.sqmc_gpu_init_heg(C.byref(cfg), C.byref(h)))
+        self.h, self.norb, self.mwalk = h, norb, mwalk
+        return self
 
     def close(self):
         if self.h:

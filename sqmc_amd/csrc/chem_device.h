@@ -28,6 +28,10 @@ struct ChemTab {
   unsigned char prod[SQ_MAXSYM + 1][SQ_MAXSYM + 1];
   unsigned char orbsym[SQ_MAXORB + 1]; // 1-based
   double nuclear;
+  // homogeneous electron gas (sys_type 1): plane-wave orbitals k_vectors(:, i), heg.f90:643-749
+  int sys_type, n_dim;                 // 0 = 'chem', 1 = 'heg'
+  double length_cell;
+  double kvec[SQ_MAXORB + 1][3];       // 1-based
   int c2_stride, c2_pad;               // combine_2 is stored packed: c2[i*c2_stride + j], 1-based
   unsigned short c2[(SQ_MAXORB + 2) * (SQ_MAXORB + 2)];   // only the first c2_stride^2 entries are used/staged
 };
@@ -205,7 +209,52 @@ __device__ inline double h_time_sym(const ChemTab &t, const double *__restrict__
   return (norm_bra * norm_ketinv) * (m1 + (t.z * m2));
 }
 // dispatcher semistoch.f90:2234-2302
+// ---- HEG matrix elements, heg.f90:845-1011 (same operation order as the reference)
+__device__ __forceinline__ double heg_sumsq(const ChemTab &t, const double *v) { double s = 0.0; for (int j = 0; j < t.n_dim; j++) s = s + v[j] * v[j]; return s; }
+__device__ __forceinline__ double heg_inv_k2(const ChemTab &t, int p, int q) {
+  const double FOUR_PI = 4.0 * (4.0 * atan(1.0));
+  double s = 0.0;
+  for (int j = 0; j < t.n_dim; j++) { const double d = t.kvec[p][j] - t.kvec[q][j]; s = s + d * d; }
+  return FOUR_PI / s;
+}
+__device__ __forceinline__ int heg_gamma_exp(u64 det, u64 eor) {
+  int g = 0;
+  for (u64 e = eor & det; e; e &= e - 1) { const int o = ctz64(e); g += popc64(det & maskr64(o)); }
+  return g;
+}
+__device__ inline double h_heg(const ChemTab &t, u64 iu, u64 id, u64 ju, u64 jd) {
+  const double L = t.length_cell;
+  if (iu == ju && id == jd) {
+    double me = 0.0;
+    for (u64 d = iu; d; d &= d - 1) me = me + heg_sumsq(t, t.kvec[ctz64(d) + 1]) * 0.5;
+    for (u64 d = id; d; d &= d - 1) me = me + heg_sumsq(t, t.kvec[ctz64(d) + 1]) * 0.5;
+    double pot = 0.0;
+    for (u64 a = iu; a; a &= a - 1) for (u64 b = a & (a - 1); b; b &= b - 1) pot = pot + heg_inv_k2(t, ctz64(a) + 1, ctz64(b) + 1);
+    for (u64 a = id; a; a &= a - 1) for (u64 b = a & (a - 1); b; b &= b - 1) pot = pot + heg_inv_k2(t, ctz64(a) + 1, ctz64(b) + 1);
+    return me - pot / (L * L * L);
+  }
+  const u64 eu = iu ^ ju, ed = id ^ jd;
+  const int neu = popc64(eu), ned = popc64(ed);
+  if (neu + ned != 4) return 0.0;
+  double mc[3] = {0.0, 0.0, 0.0}; int op = 0, oq = 0, os = 0;
+  for (int sp = 0; sp < 2; sp++) {
+    u64 e = sp ? ed : eu; const u64 di = sp ? id : iu;
+    for (; e; e &= e - 1) {
+      const int o = ctz64(e) + 1;
+      if ((di >> (o - 1)) & 1) { for (int j = 0; j < t.n_dim; j++) mc[j] = mc[j] - t.kvec[o][j]; if (!op) op = o; }
+      else { for (int j = 0; j < t.n_dim; j++) mc[j] = mc[j] + t.kvec[o][j]; if (!oq) oq = o; else if (!os) os = o; }
+    }
+  }
+  if (heg_sumsq(t, mc) * (L * L) > 1.0e-15) return 0.0;
+  double pot = heg_inv_k2(t, op, oq);
+  if (neu != 2) pot = pot - heg_inv_k2(t, op, os);
+  const int g = heg_gamma_exp(iu, eu) + heg_gamma_exp(ju, eu) + heg_gamma_exp(id, ed) + heg_gamma_exp(jd, ed);
+  if (g & 1) pot = -pot;
+  return pot / (L * L * L);
+}
+
 __device__ inline double h_any(const ChemTab &t, const double *__restrict__ ints, u64 iu, u64 id, u64 ju, u64 jd) {
+  if (t.sys_type == 1) return h_heg(t, iu, id, ju, jd);
   if (t.time_sym) return h_time_sym(t, ints, iu, id, ju, jd);
   int lev = excitation_level(iu, id, ju, jd);
   return lev < 0 ? 0.0 : h_level(t, ints, iu, id, ju, jd, lev);
@@ -360,6 +409,11 @@ __device__ inline bool is_connected_prob(const ChemTab &t, u64 iu, u64 id, u64 j
 // determinant and det_j is replaced by its representative (chemistry.f90:4988-5069).
 __device__ inline double proposal_weight(const ChemTab &t, const double *__restrict__ ints, double tau, u64 iu, u64 id, u64 &ju, u64 &jd,
                                          int level, double prob) {
+  if (t.sys_type == 1) {                 // heg.f90:1592-1596
+    const double me = h_heg(t, iu, id, ju, jd);
+    const double acc = tau * fabs(me) / prob;
+    return acc * copysign(1.0, -me);
+  }
   if (!t.time_sym) return -tau * h_level(t, ints, iu, id, ju, jd, level) / prob;
   const double sqrt2 = sqrt(2.0);
   const double norm_i = (iu == id) ? sqrt2 : 1.0;
@@ -386,4 +440,47 @@ __device__ inline double proposal_weight(const ChemTab &t, const double *__restr
   }
   if (ju > jd) { const u64 x = ju; ju = jd; jd = x; me = me * t.z; }
   return -tau * me / prob;
+}
+
+// off_diagonal_move_heg, heg.f90:1344-1598: two electrons uniformly (rejection on equal picks),
+// one hole uniformly among the orbitals empty in det_i of the right spin, the second hole fixed
+// by momentum conservation (first match scanning orbitals upwards).  Returns 2 or 0.
+__device__ inline int propose_heg(const ChemTab &t, Rng &g, u64 iu, u64 id, u64 &ju, u64 &jd, double &prob) {
+  const int nelec = t.nelec, nup = t.nup, ndn = t.ndn, norb = t.norb, nd = t.n_dim;
+  ju = iu; jd = id;
+  const int e1 = rng_int(g, nelec);
+  int e2;
+  do { e2 = rng_int(g, nelec); } while (e1 == e2);
+  const int spin = ((e1 > nup) ? -1 : 1) + ((e2 > nup) ? -1 : 1);
+  double from[3] = {0.0, 0.0, 0.0}, to1[3] = {0.0, 0.0, 0.0};
+  int ie = 0;
+  for (u64 d = iu; d; d &= d - 1) { const int i = ctz64(d) + 1; ie++; if (ie == e1 || ie == e2) { for (int j = 0; j < nd; j++) from[j] = from[j] + t.kvec[i][j]; ju &= ~bit64(i - 1); } }
+  for (u64 d = id; d; d &= d - 1) { const int i = ctz64(d) + 1; ie++; if (ie == e1 || ie == e2) { for (int j = 0; j < nd; j++) from[j] = from[j] + t.kvec[i][j]; jd &= ~bit64(i - 1); } }
+  bool first_up, second_up; int to1n; float denom;
+  if (spin == 2) { to1n = rng_int(g, norb - nup); first_up = true; second_up = true; denom = (float)(nelec * (nelec - 1) * (norb - nup)); }
+  else if (spin == -2) { to1n = rng_int(g, norb - ndn); first_up = false; second_up = false; denom = (float)(nelec * (nelec - 1) * (norb - ndn)); }
+  else {
+    to1n = rng_int(g, 2 * norb - nup - ndn); denom = (float)(nelec * (nelec - 1) * (2 * norb - nelec));
+    if (to1n <= norb - nup) { first_up = true; second_up = false; } else { to1n -= (norb - nup); first_up = false; second_up = true; }
+  }
+  {
+    const int i = kth_set(t.orb_mask & ~(first_up ? iu : id), to1n);
+    for (int j = 0; j < nd; j++) to1[j] = to1[j] + t.kvec[i][j];
+    if (first_up) ju |= bit64(i - 1); else jd |= bit64(i - 1);
+  }
+  for (u64 fr = t.orb_mask & ~(second_up ? (iu | ju) : (id | jd)); fr; fr &= fr - 1) {
+    const int i = ctz64(fr) + 1;
+    int ok = 0;
+    for (int j = 0; j < nd; j++) if (fabs(from[j] - (to1[j] + t.kvec[i][j])) < 1.0e-15) ok++;
+    if (ok == nd) {
+      if (second_up) ju |= bit64(i - 1); else jd |= bit64(i - 1);
+      prob = (double)(4.0f / denom);      // the reference evaluates 4./(integer) in single precision
+      return 2;
+    }
+  }
+  return 0;
+}
+// proposal of the system at hand (the procedure pointer `move`, do_walk.f90:126-134, 3599-3633)
+__device__ __forceinline__ int propose_any(const ChemTab &t, Rng &g, u64 iu, u64 id, u64 &ju, u64 &jd, double &prob) {
+  return (t.sys_type == 1) ? propose_heg(t, g, iu, id, ju, jd, prob) : propose_uniform(t, g, iu, id, ju, jd, prob);
 }

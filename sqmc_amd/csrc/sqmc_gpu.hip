@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(64) k_replay_prepass(const ChemTab *__restrict
     for (long long k = 0; k < nc; k++) {
       if ((long long)c < cap_children) child_state[c] = g.x;
       u64 ju, jd; double pr;
-      propose_uniform(t, g, iu, id, ju, jd, pr);
+      propose_any(t, g, iu, id, ju, jd, pr);
       c++;
     }
   }
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   g.x = (mode == 0) ? child_state[c] : sq_counter_key(seed, step, 1, (u64)c);
   const u64 iu = w.up[ip], id = w.dn[ip];
   u64 ju, jd; double prob;
-  int level = propose_uniform(t, g, iu, id, ju, jd, prob);
+  int level = propose_any(t, g, iu, id, ju, jd, prob);
   double wj = 0.0;
   if (level > 0) {
     wj = proposal_weight(t, dev.integrals, p.tau, iu, id, ju, jd, level, prob);
@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(TPB) k_propose_batch(ChemDev dev, const u64 *u
   if (i >= n) return;
   Rng g; g.mode = 0; g.x = state_in[i];
   u64 a, b; double prob;
-  int level = propose_uniform(t, g, up[i], dn[i], a, b, prob);
+  int level = propose_any(t, g, up[i], dn[i], a, b, prob);
   double w = 0.0;
   if (level > 0) w = proposal_weight(t, dev.integrals, tau, up[i], dn[i], a, b, level, prob);
   ju[i] = a; jd[i] = b; wj[i] = w; state_out[i] = g.x;
@@ -699,37 +699,15 @@ int sqmc_gpu_set_device(int device) {
 }
 void sqmc_gpu_free(void *p) { free(p); }
 
-int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out) {
-  if (!cfg || !out) return fail(SQMC_ERR_BAD_ARG, "null argument");
-  if (cfg->norb < 1 || cfg->norb > SQ_MAXORB) return fail(SQMC_ERR_UNSUPPORTED, "norb must be in 1..64 (one 64-bit word per spin)");
-  if (cfg->n_group < 1 || cfg->n_group > SQ_MAXSYM) return fail(SQMC_ERR_UNSUPPORTED, "point group order must be <= 8");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SQMC_ERR_HIP, "no HIP device: libsqmc_gpu has no CPU fallback");
-  sqmc_gpu_ctx *c = new sqmc_gpu_ctx();
-  memset((void *)c, 0, sizeof(*c));
-  HIPCHK(hipStreamCreate(&c->st));
-  ChemTab &t = c->htab;
-  t.norb = cfg->norb; t.nup = cfg->nup; t.ndn = cfg->ndn; t.ncore = cfg->n_core_orb; t.nelec = cfg->nup + cfg->ndn;
-  t.time_sym = cfg->time_sym; t.z = cfg->z; t.ngroup = cfg->n_group;
-  t.orb_mask = (cfg->norb >= 64) ? ~0ull : ((1ull << cfg->norb) - 1ull);
-  for (int i = 1; i <= cfg->n_group; i++) for (int j = 1; j <= cfg->n_group; j++) t.prod[i][j] = (unsigned char)cfg->product_table[i * 9 + j];
-  for (int i = 1; i <= cfg->norb; i++) {
-    int s = cfg->orbital_symmetries[i];
-    if (s < 1 || s > cfg->n_group) { delete c; return fail(SQMC_ERR_BAD_ARG, "orbital symmetry out of range"); }
-    t.orbsym[i] = (unsigned char)s; t.sym_mask[s] |= 1ull << (i - 1);
-  }
-  const int n2 = cfg->norb + 2;
-  t.c2_stride = n2;
-  for (int i = 1; i <= cfg->norb + 1; i++) for (int j = 1; j <= cfg->norb + 1; j++) t.c2[i * n2 + j] = (unsigned short)cfg->combine_2[i * n2 + j];
-  {
-    int a = t.c2[(cfg->norb + 1) * n2 + cfg->norb + 1]; long long ix = ((long long)a * (a - 1)) / 2 + a;
-    if (ix > cfg->n_integrals) { delete c; return fail(SQMC_ERR_BAD_ARG, "integral table shorter than integral_index(norb+1,...)"); }
-    t.nuclear = cfg->integrals[ix];
-  }
+// everything that does not depend on the kind of system: device copy of the tables, sort-key
+// width, RNG, walker arrays and work buffers
+static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode, const int32_t seed_in[4], long long mwalk_in, sqmc_gpu_ctx **out) {
+  const ChemTab &t = c->htab;
+  struct { int norb, nup, ndn, rng_mode; int32_t irand_seed[4]; long long mwalk; } cfgv = {norb, nup, ndn, rng_mode, {seed_in[0], seed_in[1], seed_in[2], seed_in[3]}, mwalk_in};
+  auto *cfg = &cfgv;
+  (void)t;
   HIPCHK(hipMalloc(&c->d_tab, sizeof(ChemTab)));
-  HIPCHK(hipMemcpy(c->d_tab, &t, sizeof(ChemTab), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc(&c->d_ints, (cfg->n_integrals + 1) * sizeof(double)));
-  HIPCHK(hipMemcpy(c->d_ints, cfg->integrals, (cfg->n_integrals + 1) * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_tab, &c->htab, sizeof(ChemTab), hipMemcpyHostToDevice));
   c->dev.tab = c->d_tab; c->dev.integrals = c->d_ints; c->dev.max_double = 0.0;
   {   // binomial table + width of the colex sort key
     std::vector<u64> bn(64 * SQ_BINOM_STRIDE, 0);
@@ -782,6 +760,56 @@ int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out) {
   HIPCHK(hipEventCreateWithFlags(&c->e_cnt, hipEventDisableTiming));
   *out = c;
   return SQMC_OK;
+}
+
+int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out) {
+  if (!cfg || !out) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  if (cfg->norb < 1 || cfg->norb > SQ_MAXORB) return fail(SQMC_ERR_UNSUPPORTED, "norb must be in 1..64 (one 64-bit word per spin)");
+  if (cfg->n_group < 1 || cfg->n_group > SQ_MAXSYM) return fail(SQMC_ERR_UNSUPPORTED, "point group order must be <= 8");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SQMC_ERR_HIP, "no HIP device: libsqmc_gpu has no CPU fallback");
+  sqmc_gpu_ctx *c = new sqmc_gpu_ctx();
+  memset((void *)c, 0, sizeof(*c));
+  HIPCHK(hipStreamCreate(&c->st));
+  ChemTab &t = c->htab;
+  t.norb = cfg->norb; t.nup = cfg->nup; t.ndn = cfg->ndn; t.ncore = cfg->n_core_orb; t.nelec = cfg->nup + cfg->ndn;
+  t.time_sym = cfg->time_sym; t.z = cfg->z; t.ngroup = cfg->n_group;
+  t.orb_mask = (cfg->norb >= 64) ? ~0ull : ((1ull << cfg->norb) - 1ull);
+  for (int i = 1; i <= cfg->n_group; i++) for (int j = 1; j <= cfg->n_group; j++) t.prod[i][j] = (unsigned char)cfg->product_table[i * 9 + j];
+  for (int i = 1; i <= cfg->norb; i++) {
+    int s = cfg->orbital_symmetries[i];
+    if (s < 1 || s > cfg->n_group) { delete c; return fail(SQMC_ERR_BAD_ARG, "orbital symmetry out of range"); }
+    t.orbsym[i] = (unsigned char)s; t.sym_mask[s] |= 1ull << (i - 1);
+  }
+  const int n2 = cfg->norb + 2;
+  t.c2_stride = n2;
+  for (int i = 1; i <= cfg->norb + 1; i++) for (int j = 1; j <= cfg->norb + 1; j++) t.c2[i * n2 + j] = (unsigned short)cfg->combine_2[i * n2 + j];
+  {
+    int a = t.c2[(cfg->norb + 1) * n2 + cfg->norb + 1]; long long ix = ((long long)a * (a - 1)) / 2 + a;
+    if (ix > cfg->n_integrals) { delete c; return fail(SQMC_ERR_BAD_ARG, "integral table shorter than integral_index(norb+1,...)"); }
+    t.nuclear = cfg->integrals[ix];
+  }
+  HIPCHK(hipMalloc(&c->d_ints, (cfg->n_integrals + 1) * sizeof(double)));
+  HIPCHK(hipMemcpy(c->d_ints, cfg->integrals, (cfg->n_integrals + 1) * sizeof(double), hipMemcpyHostToDevice));
+  return init_common(c, cfg->norb, cfg->nup, cfg->ndn, cfg->rng_mode, cfg->irand_seed, cfg->mwalk, out);
+}
+
+int sqmc_gpu_init_heg(const sqmc_heg_cfg *cfg, sqmc_gpu_ctx **out) {
+  if (!cfg || !out || !cfg->k_vectors) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  if (cfg->norb < 1 || cfg->norb > SQ_MAXORB) return fail(SQMC_ERR_UNSUPPORTED, "norb must be in 1..64 (one 64-bit word per spin)");
+  if (cfg->n_dim != 2 && cfg->n_dim != 3) return fail(SQMC_ERR_BAD_ARG, "n_dim must be 2 or 3");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SQMC_ERR_HIP, "no HIP device: libsqmc_gpu has no CPU fallback");
+  sqmc_gpu_ctx *c = new sqmc_gpu_ctx();
+  memset((void *)c, 0, sizeof(*c));
+  HIPCHK(hipStreamCreate(&c->st));
+  ChemTab &t = c->htab;
+  t.sys_type = 1; t.n_dim = cfg->n_dim; t.length_cell = cfg->length_cell;
+  t.norb = cfg->norb; t.nup = cfg->nup; t.ndn = cfg->ndn; t.ncore = 0; t.nelec = cfg->nup + cfg->ndn; t.time_sym = 0; t.z = 1; t.ngroup = 1;
+  t.orb_mask = (cfg->norb >= 64) ? ~0ull : ((1ull << cfg->norb) - 1ull);
+  t.c2_stride = 0;
+  for (int i = 1; i <= cfg->norb; i++) for (int j = 0; j < 3; j++) t.kvec[i][j] = (j < cfg->n_dim) ? cfg->k_vectors[(i - 1) * cfg->n_dim + j] : 0.0;
+  return init_common(c, cfg->norb, cfg->nup, cfg->ndn, cfg->rng_mode, cfg->irand_seed, cfg->mwalk, out);
 }
 
 int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {

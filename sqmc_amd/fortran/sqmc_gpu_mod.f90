@@ -7,7 +7,7 @@ module sqmc_gpu_mod
   use iso_c_binding
   implicit none
   private
-  public :: sqmc_chem_cfg, sqmc_step_params, sqmc_popctl, sqmc_gpu_run
+  public :: sqmc_chem_cfg, sqmc_heg_cfg, sqmc_gpu_init_heg, sqmc_step_params, sqmc_popctl, sqmc_gpu_run
   public :: sqmc_gpu_set_device, sqmc_gpu_init_chem, sqmc_gpu_finalize, sqmc_gpu_last_error, sqmc_gpu_set_hb_tables
   public :: sqmc_gpu_set_projector, sqmc_gpu_scale_projector, sqmc_gpu_set_ct_table, sqmc_gpu_upload_walkers
   public :: sqmc_gpu_num_walkers, sqmc_gpu_download_walkers, sqmc_gpu_step, sqmc_gpu_get_rng, sqmc_gpu_set_rng
@@ -28,6 +28,15 @@ module sqmc_gpu_mod
     type(c_ptr) :: combine_2           ! int32 (0:norb+1,0:norb+1) stored [i*(norb+2)+j]
     integer(c_int64_t) :: n_integrals
     type(c_ptr) :: integrals           ! real(c_double) (0:n_integrals)
+    integer(c_int32_t) :: rng_mode
+    integer(c_int32_t) :: irand_seed(4)
+    integer(c_int64_t) :: mwalk
+  end type
+
+  type, bind(C) :: sqmc_heg_cfg
+    integer(c_int32_t) :: n_dim, norb, nup, ndn
+    real(c_double) :: length_cell
+    type(c_ptr) :: k_vectors           ! real(c_double) k_vectors(n_dim, norb), as in module heg
     integer(c_int32_t) :: rng_mode
     integer(c_int32_t) :: irand_seed(4)
     integer(c_int64_t) :: mwalk
@@ -77,6 +86,9 @@ module sqmc_gpu_mod
     end function
     integer(c_int) function sqmc_gpu_init_chem(cfg, ctx) bind(C, name='sqmc_gpu_init_chem')
       import; type(sqmc_chem_cfg), intent(in) :: cfg; type(c_ptr), intent(out) :: ctx
+    end function
+    integer(c_int) function sqmc_gpu_init_heg(cfg, ctx) bind(C, name='sqmc_gpu_init_heg')
+      import; type(sqmc_heg_cfg), intent(in) :: cfg; type(c_ptr), intent(out) :: ctx
     end function
     integer(c_int) function sqmc_gpu_finalize(ctx) bind(C, name='sqmc_gpu_finalize')
       import; type(c_ptr), value :: ctx

@@ -48,3 +48,19 @@ def gpu_ctx_from_oracle(sysm, **kw):
 def c2_setup_ts(oracle, c2_hci):
     """walk set-up with time-reversal symmetry (representatives up <= dn), as the shipped decks use it"""
     return oracle.setup_walk(c2_hci, 100, 1000, 0.1)
+
+
+@pytest.fixture(scope="session")
+def heg14(oracle):
+    """14 electrons (7 up, 7 dn), r_s = 0.5, cutoff 1.49: the reference's e2e HEG system (19 plane waves)"""
+    return oracle.HegSystem(3, 0.5, 14, 7, 1.49)
+
+
+@pytest.fixture(scope="session")
+def heg_setup(oracle, heg14):
+    return oracle.setup_walk_heg(heg14, 250, 0.1)
+
+
+def gpu_ctx_heg(hsys, **kw):
+    import sqmc_amd
+    return sqmc_amd.GpuChem.heg(hsys.n_dim, hsys.norb, hsys.nup, hsys.ndn, hsys.length_cell, hsys.k_vectors(), **kw)

@@ -386,3 +386,72 @@ def test_time_sym_walk_trajectory_bit_exact(oracle, c2_hci, c2_setup_ts, rng_mod
     assert np.array_equal(wg["wt"], wc["wt"])
     assert np.all(wg["up"] <= wg["dn"]) and len(wg["up"]) > 1100
     assert -75.85 < og[3] / og[2] < -75.5
+
+
+def test_heg_matrix_elements_and_proposals_bit_exact(oracle, heg14):
+    from conftest import gpu_ctx_heg
+    L = oracle.lib()
+    g = gpu_ctx_heg(heg14)
+    rng = np.random.default_rng(31)
+    cu, cd, _ = heg14.connected(heg14.hf_up, heg14.hf_dn, with_elems=False)
+    # pairs: every connection of HF, plus connections of connections, plus unrelated pairs
+    iu = np.concatenate((np.full(len(cu), heg14.hf_up, np.uint64), cu[1:200], _random_dets(rng, 19, 7, 300)))
+    id_ = np.concatenate((np.full(len(cu), heg14.hf_dn, np.uint64), cd[1:200], _random_dets(rng, 19, 7, 300)))
+    ju = np.concatenate((cu, cu[2:201], _random_dets(rng, 19, 7, 300)))
+    jd = np.concatenate((cd, cd[2:201], _random_dets(rng, 19, 7, 300)))
+    h_gpu = g.hamiltonian_batch(iu, id_, ju, jd)
+    h_cpu = np.array([heg14.ham(int(a), int(b), int(c), int(d)) for a, b, c, d in zip(iu, id_, ju, jd)])
+    assert np.array_equal(h_gpu, h_cpu) and np.count_nonzero(h_cpu) > len(cu) // 2
+    n = 8000
+    up, dn = _random_dets(rng, 19, 7, n), _random_dets(rng, 19, 7, n)
+    seeds = rng.integers(0, 4096, size=(n, 4)).astype(np.int32); seeds[:, 3] |= 1
+    tau = 0.0012
+    pju, pjd, wj, sa = g.propose_batch(tau, up, dn, seeds)
+    g.close()
+    r = oracle.Rng(); a, b, w, nd = C.c_uint64(), C.c_uint64(), C.c_double(), C.c_int()
+    nz = 0
+    for i in range(n):
+        L.orc_setrn(C.byref(r), (C.c_int * 4)(*seeds[i]))
+        L.orc_off_diagonal_move_heg(heg14.h, C.byref(r), tau, int(up[i]), int(dn[i]), C.byref(a), C.byref(b), C.byref(w), C.byref(nd))
+        assert w.value == wj[i], (i, w.value, wj[i])
+        assert [r.l[k] for k in range(4)] == list(sa[i])
+        if w.value != 0.0:
+            nz += 1
+            assert (a.value, b.value) == (int(pju[i]), int(pjd[i]))
+    assert nz > n // 10
+
+
+@pytest.mark.parametrize("rng_mode,nsteps", [(0, 60), (1, 120)])
+def test_heg_walk_trajectory_bit_exact(oracle, heg14, heg_setup, rng_mode, nsteps):
+    """BASELINE.json configs[3] system (14-electron 3D HEG) at a size the oracle runs: the same
+    step pipeline with off_diagonal_move_heg / hamiltonian_heg as the operator plugin."""
+    from conftest import gpu_ctx_heg
+    s = heg_setup
+    g = gpu_ctx_heg(heg14, rng_mode=rng_mode, seed=SEED, mwalk=400000)
+    g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
+    g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
+    wk = oracle.initial_walkers(s, 20)
+    g.upload_walkers(wk)
+    ow = oracle.OracleWalk(heg14, s, wk, 400000, SEED, rng_mode=rng_mode)
+    pc = oracle.PopControl(s.tau, s.e_trial0, 3000)
+    w_abs = float(np.abs(wk["wt"]).sum())
+    for it in range(nsteps):
+        r = pc.pre_step(w_abs)
+        if r != 1.0:
+            ow.scale_projector(r); g.scale_projector(r)
+        st, oc = ow.step(pc.params())
+        og = g.step(pc.params())
+        assert st == 0 and og[5] == oc[5] and og[7] == oc[7] and og[15] == oc[15], (it, og, oc)
+        assert np.allclose(og, oc, rtol=1e-11, atol=1e-11)
+        r = pc.post_step(oc)
+        if r != 1.0:
+            ow.scale_projector(r); g.scale_projector(r)
+        w_abs = oc[1]
+    wg, wc = g.download_walkers(), ow.walkers()
+    if rng_mode == 0:
+        assert g.rng_state() == ow.rng_state()
+    g.close(); ow.close()
+    for k in ("up", "dn", "imp_distance", "initiator"):
+        assert np.array_equal(wg[k], wc[k]), k
+    assert np.array_equal(wg["wt"], wc["wt"])
+    assert 58.0 < og[3] / og[2] < 58.6
