@@ -142,6 +142,13 @@ class ChemHost:
         hi = g.hamiltonian_chem_batch([mu], [md], [mu], [md])[0]
         return float(lo), float(hi)
 
+    def setup_walk(self, g, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1):
+        """Psi_T, C(T), deterministic space for a walk of this molecule on context g"""
+        if not hasattr(self, "hb"):
+            self.hb_tables(g)
+        g.set_hb_tables(*self.hb)
+        return setup_walk(self, g, n_truncate_trial_wf, size_deterministic, tau_multiplier)
+
     def hb_tables(self, g):
         """dtm_hb: for every electron-pair class (p,q) the (r,s,|H|) list, |H| descending.
         Matrix elements come from the GPU (hamiltonian_chem on two-electron determinants,
@@ -388,9 +395,7 @@ class GpuWalk:
         w_begin = w_begin if w_begin is not None else w_target
         mwalk = mwalk or int(max(4 * (w_target / min_wt + size_deterministic), 200000))
         self.g = host.gpu(rng_mode=rng_mode, seed=seed, mwalk=mwalk)
-        host.hb_tables(self.g)
-        self.g.set_hb_tables(*host.hb)
-        self.setup = s = setup_walk(host, self.g, n_truncate_trial_wf, size_deterministic, tau_multiplier)
+        self.setup = s = host.setup_walk(self.g, n_truncate_trial_wf, size_deterministic, tau_multiplier)
         self.g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
         self.g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
         wk = initial_walkers(s, w_begin)
@@ -567,8 +572,7 @@ class ShardedWalk:
         per_rank = w_target / world
         mwalk = mwalk or int(max(6 * (per_rank / min_wt + size_deterministic), 200000))
         self.g = g = host.gpu(rng_mode=RNG_COUNTER, seed=rank_seed(seed, rank), mwalk=mwalk)
-        host.hb_tables(g); g.set_hb_tables(*host.hb)
-        self.setup = s = setup_walk(host, g, n_truncate_trial_wf, size_deterministic, tau_multiplier)
+        self.setup = s = host.setup_walk(g, n_truncate_trial_wf, size_deterministic, tau_multiplier)
         g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
         g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
         wk = initial_walkers(s, w_begin)
@@ -611,3 +615,122 @@ class ShardedWalk:
 
     def close(self):
         self.g.close()
+
+
+
+# ------------------------------------------------------------------------------ HEG host
+class HegHost:
+    """Homogeneous electron gas in a plane-wave basis: the tables of read_heg / system_setup_heg /
+    generate_k_vectors (heg.f90:119-215, 643-749) and the walk set-up on the GPU path."""
+
+    def __init__(self, n_dim, r_s, nelec, nup, cutoff_radius):
+        import math
+        eps, pi = 1.0e-15, 4.0 * math.atan(1.0)
+        self.n_dim, self.r_s, self.nelec, self.nup, self.ndn = n_dim, r_s, nelec, nup, nelec - nup
+        density = 1.0 / (pi * (r_s * r_s)) if n_dim == 2 else 3.0 / (4.0 * pi * (r_s * r_s * r_s))
+        self.length_cell = L = math.pow(nelec / density, 1.0 / n_dim)
+        n_max = int(cutoff_radius + eps)
+        vals = [2 * pi / L * i for i in range(-n_max, n_max + 1)]
+        import itertools
+        kv = [list(t) for t in itertools.product(vals, repeat=n_dim)]            # last index fastest, heg.f90:676-697
+        n = len(kv)
+        sq = lambda v: sum_left(x * x for x in v)
+        inc = n // 2                                                             # shell_sort_real_rank2, generic_sort.f90:554-591
+        while inc > 0:
+            for i in range(inc, n):
+                j, t = i, kv[i]
+                while j >= inc:
+                    if sq(kv[j - inc]) <= sq(t):
+                        break
+                    kv[j] = kv[j - inc]
+                    j -= inc
+                kv[j] = t
+            inc = 1 if inc == 2 else inc * 5 // 11
+        norb = 0
+        for v in kv:
+            if math.sqrt(sq(v)) > 2 * pi / L * cutoff_radius + eps:
+                break
+            norb += 1
+        if norb > 64:
+            raise ValueError("more than 64 plane waves need two-word determinants (later round)")
+        self.norb = norb
+        self.k_vectors = np.zeros((norb, 3)); self.k_vectors[:, :n_dim] = np.array(kv[:norb])
+        self.k_rel = np.rint(self.k_vectors * L / (2 * pi)).astype(np.int64)
+        self.hf_up, self.hf_dn = (1 << nup) - 1, (1 << self.ndn) - 1
+
+    def gpu(self, **kw):
+        return GpuChem.heg(self.n_dim, self.norb, self.nup, self.ndn, self.length_cell, self.k_vectors, **kw)
+
+    def connected(self, up, dn):
+        """the determinant + all momentum-conserving double excitations (unique, unsorted)"""
+        n, kr = self.norb, self.k_rel
+        lut = {tuple(kr[i]): i for i in range(n)}
+        occ = [(o, 0) for o in range(n) if (up >> o) & 1] + [(o, 1) for o in range(n) if (dn >> o) & 1]
+        out = {(up, dn)}
+        for a in range(len(occ)):
+            for b in range(a + 1, len(occ)):
+                (p, sp), (q, sq_) = occ[a], occ[b]
+                for r in range(n):
+                    det_r = dn if sp else up
+                    if (det_r >> r) & 1:
+                        continue
+                    s_ = lut.get(tuple(kr[p] + kr[q] - kr[r]))
+                    if s_ is None:
+                        continue
+                    det_s = dn if sq_ else up
+                    if (det_s >> s_) & 1 or (sp == sq_ and s_ == r):
+                        continue
+                    nu, nd = up, dn
+                    if sp: nd &= ~(1 << p)
+                    else: nu &= ~(1 << p)
+                    if sq_: nd &= ~(1 << q)
+                    else: nu &= ~(1 << q)
+                    if sp: nd |= (1 << r)
+                    else: nu |= (1 << r)
+                    if sq_: nd |= (1 << s_)
+                    else: nu |= (1 << s_)
+                    out.add((nu, nd))
+        keys = sorted(out)
+        return np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint64)
+
+    def setup_walk(self, g, n_truncate_trial_wf=1, size_deterministic=500, tau_multiplier=0.1):
+        s = WalkSetup()
+        up, dn = self.connected(self.hf_up, self.hf_dn)
+        w, X, _ = lowest_state(g, up, dn)
+        c = X[:, 0]
+        if c[np.argmax(np.abs(c))] < 0:
+            c = -c
+        by = np.argsort(-np.abs(c), kind="stable")
+        up_s, dn_s, c_s = up[by], dn[by], c[by]
+        n_t, n_i = _truncate_at_csf(c_s, n_truncate_trial_wf), _truncate_at_csf(c_s, size_deterministic)
+        s.psi_up, s.psi_dn = up_s[:n_t].copy(), dn_s[:n_t].copy()
+        s.psi_c = c_s[:n_t] / np.sqrt(np.dot(c_s[:n_t], c_s[:n_t]))
+        o = sort_dets(up_s[:n_i], dn_s[:n_i])
+        s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
+        n = self.norb
+        mu = ((1 << n) - 1) ^ ((1 << (n - self.nup)) - 1); md = ((1 << n) - 1) ^ ((1 << (n - self.ndn)) - 1)
+        d = g.hamiltonian_batch([self.hf_up, mu], [self.hf_dn, md], [self.hf_up, mu], [self.hf_dn, md])
+        s.tau, s.e_var = tau_multiplier / float(d[1] - d[0]), float(w[0])
+        pc, pi_, pv = g.build_sparse_ham(s.imp_up, s.imp_dn)
+        s.prj_counts, s.prj_indices, s.prj_values = pc, pi_, -s.tau * pv
+        acc = {}
+        psi_index = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(s.psi_up, s.psi_dn))}
+        for j in range(n_t):
+            cu, cd = self.connected(int(s.psi_up[j]), int(s.psi_dn[j]))
+            h = g.hamiltonian_batch(cu, cd, np.full(len(cu), s.psi_up[j]), np.full(len(cu), s.psi_dn[j]))
+            for a, b, v in zip(cu.tolist(), cd.tolist(), h.tolist()):
+                acc[(a, b)] = acc.get((a, b), 0.0) + v * s.psi_c[j]
+        keys = sorted(acc)
+        s.ct_up = np.array([k[0] for k in keys], np.uint64); s.ct_dn = np.array([k[1] for k in keys], np.uint64)
+        s.ct_num = np.array([acc[k] for k in keys])
+        s.ct_den = np.array([s.psi_c[psi_index[k]] if k in psi_index else 0.0 for k in keys])
+        s.e_trial0 = float(np.dot(s.ct_num, s.ct_den) / np.dot(s.ct_den, s.ct_den))
+        return s
+
+
+def sum_left(it):
+    """left-to-right floating sum (Fortran SUM over a tiny array)"""
+    t = 0.0
+    for x in it:
+        t = t + x
+    return t

@@ -455,3 +455,21 @@ def test_heg_walk_trajectory_bit_exact(oracle, heg14, heg_setup, rng_mode, nstep
         assert np.array_equal(wg[k], wc[k]), k
     assert np.array_equal(wg["wt"], wc["wt"])
     assert 58.0 < og[3] / og[2] < 58.6
+
+
+def test_heg_host_setup_matches_oracle(oracle, heg14, heg_setup):
+    """sqmc_amd.host.HegHost builds the same plane-wave table as the oracle and an equivalent walk set-up"""
+    from sqmc_amd import host as H
+    hh = H.HegHost(3, 0.5, 14, 7, 1.49)
+    assert hh.norb == heg14.norb and hh.length_cell == heg14.length_cell
+    assert np.array_equal(hh.k_vectors, heg14.k_vectors())
+    cu, cd, _ = heg14.connected(heg14.hf_up, heg14.hf_dn, with_elems=False)
+    pu, pd = hh.connected(hh.hf_up, hh.hf_dn)
+    assert sorted(zip(cu.tolist(), cd.tolist())) == list(zip(pu.tolist(), pd.tolist()))
+    w = H.GpuWalk(hh, 20000, w_begin=200, size_deterministic=250, n_truncate_trial_wf=1)
+    s = w.setup
+    assert abs(s.e_var - heg_setup.e_var) < 1e-9 and abs(s.tau - heg_setup.tau) < 1e-15 and len(s.ct_up) == len(heg_setup.ct_up)
+    stats, tot = w.run(300)
+    e = (stats[100:, 3] * np.sign(stats[100:, 2])).sum() / np.abs(stats[100:, 2]).sum()
+    w.close()
+    assert 58.26 < e < 58.29          # the reference's HCI total energy for this system: 58.27597 (o_det_ref:436)
