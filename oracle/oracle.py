@@ -635,3 +635,22 @@ def setup_walk_heg(hsys, size_deterministic=500, tau_multiplier=0.1, n_truncate_
     s.ct_den = np.array([s.psi_c[psi_index[k]] if k in psi_index else 0.0 for k in keys])
     s.e_trial0 = float(math.fsum(a * b for a, b in zip(s.ct_num, s.ct_den)) / math.fsum(b * b for b in s.ct_den))
     return s
+
+
+def hci_pt2(sysm, up, dn, coeffs, e_var, eps_pt):
+    """second_order_pt (hci.f90:1100-1182) with the oracle's generator; Python accumulation, so
+    meant for variational spaces of ~10^4 determinants."""
+    sysm.setup_hb()
+    vset = set(zip(np.asarray(up).tolist(), np.asarray(dn).tolist()))
+    acc = {}
+    for a, b, c in zip(np.asarray(up).tolist(), np.asarray(dn).tolist(), np.asarray(coeffs).tolist()):
+        if c == 0.0:
+            continue
+        cu, cd, el = sysm.important_connected(a, b, eps_pt / abs(c), cap=60000)
+        for p, q, h in zip(cu.tolist(), cd.tolist(), el.tolist()):
+            if (p, q) not in vset:
+                acc[(p, q)] = acc.get((p, q), 0.0) + h * c
+    delta = 0.0
+    for (p, q), v in acc.items():
+        delta += v * v / (e_var - sysm.ham(p, q, p, q))
+    return delta, len(acc)

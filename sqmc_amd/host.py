@@ -734,3 +734,65 @@ def sum_left(it):
     for x in it:
         t = t + x
     return t
+
+
+def hci_pt2(host, g, up, dn, coeffs, e_var, eps_pt):
+    """Deterministic Epstein-Nesbet second-order correction, second_order_pt (hci.f90:1100-1182):
+    delta_E = sum over determinants a outside the variational space of
+    (sum_i H_ai c_i)^2 / (E_var - H_aa), the inner sum screened by |H_ai c_i| >= eps_pt.
+    Connections, their dedup-sum and the diagonal elements all come from the GPU.
+    Returns (delta_E, number of connected determinants)."""
+    up, dn = np.ascontiguousarray(up, np.uint64), np.ascontiguousarray(dn, np.uint64)
+    cu, cd, num, den = g.hci_connections(up, dn, coeffs, eps_pt)
+    # membership in the variational space (binary_search at hci.f90:1159): merge of two sorted key lists
+    order = sort_dets(up, dn)
+    vu, vd = up[order], dn[order]
+    pos = np.searchsorted(vu, cu, side="left")          # first candidate with the same up string
+    in_v = np.zeros(len(cu), bool)
+    if host.norb <= 32:
+        kv = (vu << np.uint64(32)) | vd
+        kc = (cu << np.uint64(32)) | cd
+        in_v = np.isin(kc, kv, assume_unique=True)
+    else:
+        vset = set(zip(vu.tolist(), vd.tolist()))
+        in_v = np.fromiter(((a, b) in vset for a, b in zip(cu.tolist(), cd.tolist())), bool, len(cu))
+    out = ~in_v
+    h_aa = g.hamiltonian_batch(cu[out], cd[out], cu[out], cd[out])
+    delta = float(np.sum(num[out] ** 2 / (e_var - h_aa)))
+    return delta, len(cu)
+
+
+def time_symmetrized_to_dets(up, dn, coeffs, z=1):
+    """convert_time_symmetrized_to_dets (hci.f90:4365-4564): each time-reversal-symmetrised
+    combination with up != dn becomes the two determinants (up,dn) and (dn,up) with
+    coefficients c/sqrt2 and z*c/sqrt2; the reference leaves time symmetry this way before PT."""
+    up, dn, c = np.asarray(up, np.uint64), np.asarray(dn, np.uint64), np.asarray(coeffs, float)
+    inv_sqrt2 = 1.0 / np.sqrt(2.0)
+    same = up == dn
+    ou = np.concatenate((up[same], up[~same], dn[~same]))
+    od = np.concatenate((dn[same], dn[~same], up[~same]))
+    oc = np.concatenate((c[same], inv_sqrt2 * c[~same], z * inv_sqrt2 * c[~same]))
+    order = sort_dets(ou, od)
+    return ou[order], od[order], oc[order]
+
+
+def hci_pt2_determinant_basis(host, up, dn, coeffs, e_var, eps_pt):
+    """do_pt as the reference runs it for a time-symmetric variational stage: back to the
+    determinant basis, time_sym off from then on (hci.f90:648-659), then second_order_pt."""
+    import copy
+    if not host.time_sym:
+        g = host.gpu()
+        g.set_hb_tables(*host.hb_tables(g))
+        try:
+            return hci_pt2(host, g, up, dn, coeffs, e_var, eps_pt)
+        finally:
+            g.close()
+    plain = copy.copy(host)
+    plain.time_sym = False
+    du, dd, dc = time_symmetrized_to_dets(up, dn, coeffs, host.z)
+    g = plain.gpu()
+    try:
+        g.set_hb_tables(*plain.hb_tables(g))
+        return hci_pt2(plain, g, du, dd, dc, e_var, eps_pt)
+    finally:
+        g.close()

@@ -473,3 +473,27 @@ def test_heg_host_setup_matches_oracle(oracle, heg14, heg_setup):
     e = (stats[100:, 3] * np.sign(stats[100:, 2])).sum() / np.abs(stats[100:, 2]).sum()
     w.close()
     assert 58.26 < e < 58.29          # the reference's HCI total energy for this system: 58.27597 (o_det_ref:436)
+
+
+def test_hci_pt2_matches_oracle_and_reference_run(oracle, c2_hci):
+    """Epstein-Nesbet PT2 on the GPU path: against the oracle on a ~4k-determinant space, and
+    against the reference's own run at eps1=1e-4 / eps2=1e-6 (dE_PT = -0.000979165,
+    E_total = -75.728542168)."""
+    from conftest import FCIDUMP
+    from sqmc_amd import host as H
+    h = H.ChemHost(FCIDUMP, 8, 4, "d2h", time_sym=True, z=1)
+    g = h.gpu()
+    g.set_hb_tables(*h.hb_tables(g))
+    up, dn, w, e, hist = H.hci_variational(h, g, 2e-3, eps_sched=(2e-3,), n_states=1, max_iters=2)
+    assert 1500 < len(up) < 6000
+    d_gpu, n_gpu = H.hci_pt2(h, g, up, dn, w[:, 0], float(e[0]), 2e-5)
+    d_cpu, n_cpu = oracle.hci_pt2(c2_hci, up, dn, w[:, 0], float(e[0]), 2e-5)
+    assert n_gpu - len(up) == n_cpu
+    assert abs(d_gpu - d_cpu) < 1e-12 and -0.05 < d_gpu < -0.005
+    up, dn, w, e, hist = H.hci_variational(h, g, 1e-4, eps_sched=(2e-4, 2e-4), n_states=1)
+    g.close()
+    # the reference converts to the determinant basis before PT (hci.f90:648-659): 6.56 M connections there
+    d, n = H.hci_pt2_determinant_basis(h, up, dn, w[:, 0], float(e[0]), 1e-6)
+    assert 6.4e6 < n < 6.8e6
+    assert abs(d - (-0.000979165)) < 2e-8
+    assert abs(e[0] + d - (-75.728542168)) < 2e-8
