@@ -29,6 +29,7 @@
 #include "scan_sort.h"
 
 #define TPB 256
+#define SPAWN_WIN 1024
 static thread_local std::string g_err;
 static int fail(int code, const std::string &m) { g_err = m; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(SQMC_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
@@ -180,11 +181,40 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   if ((long long)blockIdx.x * TPB >= nchildren || n0 + nchildren > cap_all) return;
   __shared__ ChemTab t;
   stage_tab(&t, dev.tab);
-  long long c = (long long)blockIdx.x * TPB + threadIdx.x;
+  // Parent of child c = largest i with child_off[i] <= c.  The 256 children of a block have
+  // neighbouring parents, so the block narrows [0,n0) for its first child with 256-way splits
+  // staged in LDS (one global round trip per level instead of log2(n0) dependent loads), then
+  // every thread finishes inside a 1024-entry LDS window (global search only if it runs past it).
+  __shared__ u64 s_win[SPAWN_WIN];
+  const long long c0 = (long long)blockIdx.x * TPB;
+  long long wlo = 0, whi = n0;                       // invariant: child_off[wlo] <= c0, answer for c0 in [wlo, whi)
+  while (whi - wlo > SPAWN_WIN) {
+    const long long stepw = (whi - wlo + TPB - 1) / TPB;
+    const long long probe = wlo + (long long)threadIdx.x * stepw;
+    const int le = (probe < whi && child_off[probe] <= (u64)c0) ? 1 : 0;
+    const int cnt = __syncthreads_count(le);           // probes are sorted: the first cnt of them are <= c0
+    const long long nlo = wlo + (long long)(cnt - 1) * stepw;
+    whi = (nlo + stepw < whi) ? nlo + stepw : whi; wlo = nlo;
+  }
+  const int wn = (int)(whi - wlo);
+  for (int k = threadIdx.x; k < SPAWN_WIN; k += TPB) {  // window keeps going past whi: later children of the block live there
+    const long long i = wlo + k;
+    s_win[k] = (i < n0) ? child_off[i] : ~0ull;
+  }
+  __syncthreads();
+  (void)wn;
+  long long c = c0 + threadIdx.x;
   if (c >= nchildren) return;
-  long long lo = 0, hi = n0;                  // largest i with child_off[i] <= c
-  while (hi - lo > 1) { long long mid = (lo + hi) >> 1; if (child_off[mid] <= (u64)c) lo = mid; else hi = mid; }
-  const long long ip = lo;
+  long long ip;
+  if (s_win[SPAWN_WIN - 1] <= (u64)c) {                 // beyond the window (many childless parents in between)
+    long long lo = wlo + SPAWN_WIN - 1, hi = n0;
+    while (hi - lo > 1) { long long mid = (lo + hi) >> 1; if (child_off[mid] <= (u64)c) lo = mid; else hi = mid; }
+    ip = lo;
+  } else {
+    int lo = 0, hi = SPAWN_WIN - 1;                     // s_win[lo] <= c < s_win[hi]
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s_win[mid] <= (u64)c) lo = mid; else hi = mid; }
+    ip = wlo + lo;
+  }
   Rng g; g.mode = mode;
   g.x = (mode == 0) ? child_state[c] : sq_counter_key(seed, step, 1, (u64)c);
   const u64 iu = w.up[ip], id = w.dn[ip];
