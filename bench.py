@@ -7,10 +7,12 @@ rounding, estimators) over the whole walker population resident in HBM; metric =
 sum over timed steps of occupied determinants after the merge (the nwalk column of the
 reference's walkalize file, do_walk.f90:2930) / wall time.
 
-N>1 (round 1): every rank propagates its own population of the same target size with a
-rank-offset seed (as the reference offsets seed 2 by the rank, do_walk.f90:234) and the
-per-step estimator sums are all-reduced over RCCL like do_walk.f90:2778; cross-rank
-annihilation is not sharded yet ("replicas", DESIGN.md section Multi-GPU).
+N>1: weak scaling.  The global target grows with the number of GPUs, determinants are sharded
+over ranks by hash ownership (as the reference shards them over MPI ranks) and every step runs
+three exchanges over RCCL issued by the library itself (sqmc_gpu_shard_run): all-reduce of the
+deterministic-space weights, all-to-all of the spawned walkers, all-reduce of the seven sums.
+If the library's communicator cannot be created the same step runs with the exchanges driven
+from Python through torch.distributed; if that fails too, independent replicas.
 """
 import argparse
 import json
@@ -71,24 +73,38 @@ def main():
         # hash ownership and spawns cross ranks through one RCCL all-to-all per step
         try:
             walk = H.ShardedWalk(hst, args.target * world, rank, world, device_index=local, seed=(1346, 5634, 6635, 4361))
-            walk.step()
-            parallelism = "sharded x%d (hash-owned determinants, RCCL all-to-all of spawns)" % world
             ok = torch.ones(1, device=comm_dev)
         except Exception as exc:                      # keep the scaling run alive: independent replicas
-            sys.stderr.write("rank %d: sharded path failed (%r); falling back to replicas\n" % (rank, exc))
+            sys.stderr.write("rank %d: sharded set-up failed (%r); falling back to replicas\n" % (rank, exc))
             ok = torch.zeros(1, device=comm_dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() < 1:
             if walk is not None:
                 walk.close()
             walk = None
+        if walk is not None:
+            parallelism = "sharded x%d (hash-owned determinants), exchanges driven through torch.distributed" % world
+            if backend == "nccl" and not os.environ.get("SQMC_BENCH_NO_INLIB"):
+                try:
+                    walk.attach_rccl()
+                    walk.step()
+                    ok = torch.ones(1, device=comm_dev)
+                except Exception as exc:
+                    sys.stderr.write("rank %d: in-library RCCL exchange unavailable (%r)\n" % (rank, exc))
+                    ok = torch.zeros(1, device=comm_dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if ok.item() >= 1:
+                    parallelism = "sharded x%d (hash-owned determinants), in-library RCCL: all-reduce + all-to-all of spawns + all-reduce per step" % world
+                else:                                     # same walk, exchanges from Python
+                    walk.close()
+                    walk = H.ShardedWalk(hst, args.target * world, rank, world, device_index=local, seed=(1346, 5634, 6635, 4361))
     if walk is None:
         walk = H.GpuWalk(hst, args.target, seed=H.rank_seed((1346, 5634, 6635, 4361), rank))
         if world > 1:
             parallelism = "replicas x%d (sharded path unavailable)" % world
     sharded = isinstance(walk, H.ShardedWalk)
 
-    if sharded:
+    if sharded and not walk.in_library:
         for _ in range(args.equil + args.warmup):
             walk.step()
         walk.g.set_timing(1)
@@ -116,7 +132,7 @@ def main():
         stats, totals = walk.run(args.steps, keep_stats=True)
         fence()
         dt = time.perf_counter() - t0
-        nwalk_sum, spawn_sum = float(totals[5]), float(totals[15])
+        nwalk_sum, spawn_sum = float(totals[5]) / (world if sharded else 1), float(totals[15])      # sharded: nwalk is the global count
         e_num, e_den = float((stats[:, 3] * np.sign(stats[:, 2])).sum()), float(np.abs(stats[:, 2]).sum())
         spawn_ms = dict(walk.g.timing())["spawn"]          # mean ms per k_spawn launch over the K timed steps
         walk.g.set_timing(2)                                # informational stage breakdown from an untimed tail

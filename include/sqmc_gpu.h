@@ -178,6 +178,23 @@ int sqmc_gpu_shard_pack(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, const doub
                         int64_t cap_records, int64_t *send_counts);
 int sqmc_gpu_shard_finish(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, const uint64_t *recv_dev, int64_t n_recv, double out_stats[16]);
 
+/* The same sharded step with the three exchanges issued by the library itself over RCCL/xGMI
+ * (replaces mpi_allred of the deterministic weights do_walk.f90:2259-2260, mpi_snd_list /
+ * mpi_sendnewwalks mpi_routines.f90:1147-1270, and the mpi_allred of the sums
+ * do_walk.f90:2778-2790).  Rank 0 obtains an id with sqmc_gpu_comm_unique_id and hands it to the
+ * other ranks by any means (MPI_Bcast in the reference's build); every rank then calls
+ * sqmc_gpu_comm_init after sqmc_gpu_shard_config.  sqmc_gpu_shard_step = begin + all-reduce +
+ * pack + all-to-all + finish + all-reduce: out_stats[0..6] are sums over all ranks,
+ * out_stats[7..15] stay local.  sqmc_gpu_shard_run is sqmc_gpu_run over sharded steps (every
+ * rank carries the same population-control state, as the reference's ranks do).  Once a
+ * communicator is attached, sqmc_gpu_shard_finish also all-reduces; use either the three-phase
+ * calls without a communicator or shard_step with one. */
+#define SQMC_COMM_ID_BYTES 128
+int sqmc_gpu_comm_unique_id(uint8_t id[SQMC_COMM_ID_BYTES]);
+int sqmc_gpu_comm_init(sqmc_gpu_ctx *ctx, const uint8_t id[SQMC_COMM_ID_BYTES]);
+int sqmc_gpu_shard_step(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, double out_stats[16]);
+int sqmc_gpu_shard_run(sqmc_gpu_ctx *ctx, sqmc_popctl *pc, int64_t nsteps, double *stats /* nsteps*16 or NULL */, double totals[16]);
+
 /* RNG state of the REPLAY stream (savern / setrn, rannyu.f90:11-21,77-87) */
 int sqmc_gpu_get_rng(sqmc_gpu_ctx *ctx, int32_t seed[4]);
 int sqmc_gpu_set_rng(sqmc_gpu_ctx *ctx, const int32_t seed[4]);

@@ -15,7 +15,8 @@ EXPORTS = [
     "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_init_heg", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_projector",
     "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
     "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_det_owner", "sqmc_gpu_shard_config",
-    "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_spmv_prepare",
+    "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init",
+    "sqmc_gpu_shard_step", "sqmc_gpu_shard_run", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_spmv_prepare",
     "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
     "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
 ]
@@ -253,6 +254,32 @@ class GpuChem:
         p = StepParams(**params); out = np.zeros(16)
         _chk(self.L.sqmc_gpu_shard_finish(self.h, C.byref(p), C.c_void_p(recv_ptr), int(n_recv), _p(out)))
         return out
+
+    # ---- the same with the exchanges inside the library (RCCL)
+    @staticmethod
+    def comm_unique_id():
+        L = load_library(); buf = (C.c_uint8 * 128)()
+        L.sqmc_gpu_comm_unique_id.argtypes = [C.c_void_p]
+        _chk(L.sqmc_gpu_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self.L.sqmc_gpu_comm_init.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(self.L.sqmc_gpu_comm_init(self.h, buf))
+
+    def shard_step(self, params):
+        p = StepParams(**params); out = np.zeros(16)
+        self.L.sqmc_gpu_shard_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(self.L.sqmc_gpu_shard_step(self.h, C.byref(p), _p(out)))
+        return out
+
+    def shard_run(self, pc, nsteps, keep_stats=True):
+        stats = np.zeros((nsteps, 16)) if keep_stats else None
+        totals = np.zeros(16)
+        self.L.sqmc_gpu_shard_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        _chk(self.L.sqmc_gpu_shard_run(self.h, C.byref(pc), int(nsteps), _p(stats) if keep_stats else None, _p(totals)))
+        return stats, totals
 
     def rng_state(self):
         s = (C.c_int32 * 4)()

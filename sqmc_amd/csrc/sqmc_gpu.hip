@@ -16,6 +16,8 @@
 //
 // Everything is HBM/latency bound integer + fp64 work: no MFMA anywhere.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -95,6 +97,8 @@ struct sqmc_gpu_ctx {
   int key_bits; u64 invalid_key; u64 *d_binom;
   // multi-rank sharding (owner = hash(det) mod shard_n)
   int shard_rank, shard_n; int *d_grow; long long n_imp_local; long long shard_n0, shard_nch;
+  // in-library exchange over RCCL (sqmc_gpu_comm_init): communicator + device staging
+  ncclComm_t comm; double *d_xg; u64 *d_send, *d_recv; long long xch_cap; u32 *d_cnt_mine, *d_cnt_all; u32 *h_cnt_all;
   // timing
   int timing; hipEvent_t ev0[NTIMERS], ev1[NTIMERS]; const char *tname[NTIMERS]; int nt; float tms[NTIMERS];
   double tsum[NTIMERS]; long long tsteps;         // accumulated over the steps since sqmc_gpu_set_timing
@@ -842,6 +846,7 @@ int sqmc_gpu_init_heg(const sqmc_heg_cfg *cfg, sqmc_gpu_ctx **out) {
   return init_common(c, cfg->norb, cfg->nup, cfg->ndn, cfg->rng_mode, cfg->irand_seed, cfg->mwalk, out);
 }
 
+static void comm_release(sqmc_gpu_ctx *c);
 int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   if (!c) return SQMC_OK;
   hipStreamSynchronize(c->st);
@@ -852,6 +857,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
     hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done);
   }
   hipFree(c->d_binom); hipFree(c->d_grow);
+  comm_release(c);
   hipFree(c->d_tab); hipFree(c->d_ints); hipFree(c->d_hb_r); hipFree(c->d_hb_s); hipFree(c->d_hb_absH); hipFree(c->d_pq_ind); hipFree(c->d_pq_count);
   hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x);
   hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den); hipFree(c->d_ct_hkey); hipFree(c->d_ct_hidx);
@@ -1002,6 +1008,7 @@ int sqmc_gpu_get_timing(sqmc_gpu_ctx *c, int32_t *n, const char **names, float *
 #define TBEG(NAME, STREAM) int t_##NAME = -1; do { if ((c->timing >= 2 || (c->timing == 1 && !strcmp(#NAME, "spawn"))) && c->nt < NTIMERS) { t_##NAME = c->nt++; c->tname[t_##NAME] = #NAME; hipEventRecord(c->ev0[t_##NAME], STREAM); } } while (0)
 #define TEND(NAME, STREAM) do { if (t_##NAME >= 0) hipEventRecord(c->ev1[t_##NAME], STREAM); } while (0)
 
+static int comm_allreduce_stats(sqmc_gpu_ctx *c);
 // sort -> merge -> round -> compact/estimate -> readback; shared by the single-rank step and
 // the sharded step (where the spawns behind slot n0 arrived from other ranks)
 static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long nall, bool join_side_stream, double out[16]) {
@@ -1038,6 +1045,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long na
                      (int)(3 * c->cap_tiles));
   TEND(estimate, st);
   HIPCHK(hipGetLastError());
+  if (c->comm) { int rr = comm_allreduce_stats(c); if (rr) return rr; }      // do_walk.f90:2778-2790: the sums every rank needs
   HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   if (c->timing) {
@@ -1122,7 +1130,8 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   return step_tail(c, p, n0, nall, true, out);
 }
 
-int sqmc_gpu_run(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats, double totals[16]) {
+typedef int (*step_fn)(sqmc_gpu_ctx *, const sqmc_step_params *, double *);
+static int run_steps(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats, double totals[16], step_fn one_step) {
   if (!c || !pc || !totals || nsteps < 0) return fail(SQMC_ERR_BAD_ARG, "bad argument");
   for (int k = 0; k < 16; k++) totals[k] = 0.0;
   for (int64_t it = 0; it < nsteps; it++) {
@@ -1140,7 +1149,7 @@ int sqmc_gpu_run(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats
     sp.initiator_min_distance = pc->initiator_min_distance; sp.c_t_initiator = pc->c_t_initiator; sp.semistochastic = pc->semistochastic;
     sp.reached_w_abs_gen = pc->reached_w_abs_gen; sp.reserved = 0;
     double out[16];
-    int r = sqmc_gpu_step(c, &sp, out);
+    int r = one_step(c, &sp, out);
     if (r) return r;
     if (stats) memcpy(stats + it * 16, out, sizeof(out));
     for (int k = 0; k < 16; k++) totals[k] += out[k];
@@ -1168,6 +1177,9 @@ int sqmc_gpu_run(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats
     pc->tau_prev = pc->tau; pc->w_abs_gen = w_abs_gen;
   }
   return SQMC_OK;
+}
+int sqmc_gpu_run(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats, double totals[16]) {
+  return run_steps(c, pc, nsteps, stats, totals, sqmc_gpu_step);
 }
 
 // ------------------------------------------------------------------ multi-rank sharding
@@ -1303,28 +1315,45 @@ int sqmc_gpu_shard_begin(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double *x_
 // phase 2: apply the owned rows of the deterministic projection with the all-reduced x_global, then
 // bucket this step's children by owner rank (stable) into 32-byte records: send_counts[r] records
 // for rank r, contiguous in rank order in send_dev (capacity cap_records).
-int sqmc_gpu_shard_pack(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const double *x_global_dev, uint64_t *send_dev, int64_t cap_records,
-                        int64_t *send_counts) {
-  if (!c || !sp || !send_counts) return fail(SQMC_ERR_BAD_ARG, "null argument");
+//
+// device part of phase 2; leaves the per-destination counts in d_rowtot[0..P) (valid when nch > 0)
+// and the permutation of the children by destination in *order.  Children that produced no
+// walker sort behind the last rank.
+static int shard_bucket(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const double *x_global_dev, u32 **order) {
   hipStream_t st = c->st;
   const long long n0 = c->shard_n0, nch = c->shard_nch; const int P = c->shard_n;
   if (c->n_imp_local > 0)
     hipLaunchKernelGGL(k_prj_apply_rows, dim3(nblk(c->n_imp_local, TPB / 64)), dim3(TPB), 0, st, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, x_global_dev,
                        c->d_loc_imp, c->d_grow, c->w.wt, c->n_imp_local, sp->e_trial, sp->tau);
-  for (int r = 0; r < P; r++) send_counts[r] = 0;
+  *order = nullptr;
   if (nch > 0) {
     u64 *okey = c->d_flags, *okey_alt = c->d_pos; u32 *oval = (u32 *)c->d_flags2, *oval_alt = (u32 *)c->d_pos2;
     hipLaunchKernelGGL(k_child_owner, dim3(nblk(nch)), dim3(TPB), 0, st, c->d_keys, okey, oval, n0, nch, c->invalid_key, P);
     SortWork so; so.k_alt = okey_alt; so.v_alt = oval_alt; so.hist = c->d_hist; so.rowtot = c->d_rowtot; so.cap = c->mwalk;
     u64 *sk = okey; u32 *sv = oval;
     device_radix_sort(sk, sv, nch, 8, so, st);               // one stable 8-bit pass; rowtot[d] = children per destination
+    *order = sv;
+  }
+  HIPCHK(hipGetLastError());
+  return SQMC_OK;
+}
+
+int sqmc_gpu_shard_pack(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const double *x_global_dev, uint64_t *send_dev, int64_t cap_records,
+                        int64_t *send_counts) {
+  if (!c || !sp || !send_counts) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  hipStream_t st = c->st;
+  const long long n0 = c->shard_n0, nch = c->shard_nch; const int P = c->shard_n;
+  u32 *order;
+  int r = shard_bucket(c, sp, x_global_dev, &order); if (r) return r;
+  for (int q = 0; q < P; q++) send_counts[q] = 0;
+  if (nch > 0) {
     u32 cnt[256];
     HIPCHK(hipMemcpyAsync(cnt, c->d_rowtot, 256 * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     long long nsend = 0;
-    for (int r = 0; r < P; r++) { send_counts[r] = cnt[r]; nsend += cnt[r]; }
+    for (int q = 0; q < P; q++) { send_counts[q] = cnt[q]; nsend += cnt[q]; }
     if (nsend > cap_records) return fail(SQMC_ERR_SPAWN_OVERFLOW, "send buffer too small for this step's spawns");
-    if (nsend > 0) hipLaunchKernelGGL(k_pack_send, dim3(nblk(nsend)), dim3(TPB), 0, st, c->w, sv, (u64 *)send_dev, n0, nsend);
+    if (nsend > 0) hipLaunchKernelGGL(k_pack_send, dim3(nblk(nsend)), dim3(TPB), 0, st, c->w, order, (u64 *)send_dev, n0, nsend);
   }
   HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(st));
   return SQMC_OK;
@@ -1349,11 +1378,142 @@ int sqmc_gpu_shard_finish(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const uin
     for (int i = 0; i < 16; i++) out[i] = 0.0;
     hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
     c->step_no++;
+    if (c->comm) {                  // still a party to the all-reduce of the sums
+      HIPCHK(hipMemsetAsync(c->d_sc->stats, 0, 16 * 8, st));
+      int rr = comm_allreduce_stats(c); if (rr) return rr;
+      HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      for (int i = 0; i < 7; i++) out[i] = c->h_sc->stats[i];
+    }
     return SQMC_OK;
   }
   int r = step_tail(c, p, n0, n0 + n_recv, false, out);
   if (r == SQMC_ERR_NO_WALKERS) r = SQMC_OK;      // a shard may legitimately own nothing
   return r;
+}
+
+
+// ------------------------------------------------------------------ in-library exchange (RCCL over xGMI)
+// The three exchanges of a sharded step issued from the library on its own stream, so a step
+// costs no Python and no extra host round trips: all-reduce of the deterministic-space vector
+// (do_walk.f90:2259-2260), all-to-all of the spawned walkers (mpi_snd_list, mpi_routines.f90:
+// 1147-1270 -- here grouped ncclSend/ncclRecv of 32-byte records straight between HBMs), and
+// the all-reduce of the seven sums (do_walk.f90:2778-2790).  RCCL is bound at run time from
+// the copy already in the process (torch's) or the ROCm one, so single-GPU users never load it.
+struct RcclApi {
+  void *lib;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*GroupStart)();
+  ncclResult_t (*GroupEnd)();
+  const char *(*GetErrorString)(ncclResult_t);
+};
+static RcclApi g_rccl;
+static int rccl_bind() {
+  if (g_rccl.lib) return SQMC_OK;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *h = nullptr;
+  for (const char *nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+  if (!h) return fail(SQMC_ERR_UNSUPPORTED, std::string("cannot load RCCL: ") + dlerror());
+#define BIND(F) do { *(void **)(&g_rccl.F) = dlsym(h, "nccl" #F); if (!g_rccl.F) return fail(SQMC_ERR_UNSUPPORTED, "RCCL lacks nccl" #F); } while (0)
+  BIND(GetUniqueId); BIND(CommInitRank); BIND(CommDestroy); BIND(AllReduce); BIND(AllGather); BIND(Send); BIND(Recv); BIND(GroupStart); BIND(GroupEnd);
+  BIND(GetErrorString);
+#undef BIND
+  g_rccl.lib = h;
+  return SQMC_OK;
+}
+#define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail(SQMC_ERR_HIP, std::string(#x) + ": " + g_rccl.GetErrorString(r_)); } while (0)
+
+static void comm_release(sqmc_gpu_ctx *c) {
+  if (c->comm && g_rccl.lib) g_rccl.CommDestroy(c->comm);
+  c->comm = nullptr;
+  hipFree(c->d_xg); hipFree(c->d_send); hipFree(c->d_recv); hipFree(c->d_cnt_mine); hipFree(c->d_cnt_all);
+  if (c->h_cnt_all) hipHostFree(c->h_cnt_all);
+  c->d_xg = nullptr; c->d_send = c->d_recv = nullptr; c->d_cnt_mine = c->d_cnt_all = nullptr; c->h_cnt_all = nullptr;
+}
+static int comm_allreduce_stats(sqmc_gpu_ctx *c) {
+  NCCLCHK(g_rccl.AllReduce(c->d_sc->stats, c->d_sc->stats, 7, ncclDouble, ncclSum, c->comm, c->st));
+  return SQMC_OK;
+}
+
+int sqmc_gpu_comm_unique_id(uint8_t id[SQMC_COMM_ID_BYTES]) {
+  if (!id) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  static_assert(sizeof(ncclUniqueId) <= SQMC_COMM_ID_BYTES, "unique id size");
+  int r = rccl_bind(); if (r) return r;
+  ncclUniqueId u;
+  NCCLCHK(g_rccl.GetUniqueId(&u));
+  memset(id, 0, SQMC_COMM_ID_BYTES); memcpy(id, &u, sizeof(u));
+  return SQMC_OK;
+}
+
+int sqmc_gpu_comm_init(sqmc_gpu_ctx *c, const uint8_t id[SQMC_COMM_ID_BYTES]) {
+  if (!c || !id) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  if (c->shard_n < 1 || !c->d_grow) return fail(SQMC_ERR_BAD_ARG, "sqmc_gpu_shard_config not called");
+  if (c->mwalk <= 0) return fail(SQMC_ERR_BAD_ARG, "no walker arrays");
+  int r = rccl_bind(); if (r) return r;
+  comm_release(c);
+  ncclUniqueId u; memcpy(&u, id, sizeof(u));
+  NCCLCHK(g_rccl.CommInitRank(&c->comm, c->shard_n, u, c->shard_rank));
+  const int P = c->shard_n;
+  c->xch_cap = c->mwalk;             // a rank can neither spawn nor hold more than MWALK walkers
+  HIPCHK(hipMalloc(&c->d_xg, (c->n_imp + 1) * 8));
+  HIPCHK(hipMalloc(&c->d_send, c->xch_cap * 32)); HIPCHK(hipMalloc(&c->d_recv, c->xch_cap * 32));
+  HIPCHK(hipMalloc(&c->d_cnt_mine, P * 4)); HIPCHK(hipMalloc(&c->d_cnt_all, (size_t)P * P * 4));
+  HIPCHK(hipHostMalloc(&c->h_cnt_all, (size_t)P * P * 4 + P * 4));
+  return SQMC_OK;
+}
+
+// One sharded MC step with the exchanges inside: out[0..6] are the global sums, out[7..15] local.
+int sqmc_gpu_shard_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
+  if (!c || !sp || !out) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  if (!c->comm) return fail(SQMC_ERR_BAD_ARG, "sqmc_gpu_comm_init not called");
+  hipStream_t st = c->st;
+  const int P = c->shard_n, me = c->shard_rank;
+  int64_t nch = 0;
+  int r = sqmc_gpu_shard_begin(c, sp, c->d_xg, &nch);
+  if (r) return r;
+  if (c->n_imp > 0) NCCLCHK(g_rccl.AllReduce(c->d_xg, c->d_xg, (size_t)c->n_imp, ncclDouble, ncclSum, c->comm, st));
+  // bucket + pack without a host round trip: every child is packed in destination order (the
+  // ones that made no walker sort last and are never sent), the counts stay on the device and go
+  // straight into the all-gather that tells every rank who sends how much to whom
+  u32 *order;
+  r = shard_bucket(c, sp, c->d_xg, &order); if (r) return r;
+  const long long nch_l = c->shard_nch;
+  if (nch_l > c->xch_cap) return fail(SQMC_ERR_SPAWN_OVERFLOW, "send buffer too small for this step's spawns");
+  if (nch_l > 0) {
+    hipLaunchKernelGGL(k_pack_send, dim3(nblk(nch_l)), dim3(TPB), 0, st, c->w, order, c->d_send, c->shard_n0, nch_l);
+    HIPCHK(hipMemcpyAsync(c->d_cnt_mine, c->d_rowtot, P * 4, hipMemcpyDeviceToDevice, st));
+  } else HIPCHK(hipMemsetAsync(c->d_cnt_mine, 0, P * 4, st));
+  NCCLCHK(g_rccl.AllGather(c->d_cnt_mine, c->d_cnt_all, (size_t)P, ncclUint32, c->comm, st));
+  HIPCHK(hipMemcpyAsync(c->h_cnt_all, c->d_cnt_all, (size_t)P * P * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  long long scnt[256];
+  for (int q = 0; q < P; q++) scnt[q] = c->h_cnt_all[(size_t)me * P + q];
+  long long soff[257], roff[257]; soff[0] = roff[0] = 0;
+  for (int q = 0; q < P; q++) { soff[q + 1] = soff[q] + scnt[q]; roff[q + 1] = roff[q] + c->h_cnt_all[(size_t)q * P + me]; }
+  const long long n_recv = roff[P];
+  if (n_recv > c->xch_cap || c->shard_n0 + n_recv > c->mwalk) return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
+  // the walkers themselves, HBM to HBM; records from rank q land at roff[q] (rank order,
+  // creation order inside a rank: the order the merge rules see, do_walk.f90:5866-6083)
+  NCCLCHK(g_rccl.GroupStart());
+  for (int q = 0; q < P; q++) {
+    if (q == me) continue;
+    if (scnt[q] > 0) NCCLCHK(g_rccl.Send(c->d_send + 4 * soff[q], (size_t)(4 * scnt[q]), ncclUint64, q, c->comm, st));
+    const long long rc = roff[q + 1] - roff[q];
+    if (rc > 0) NCCLCHK(g_rccl.Recv(c->d_recv + 4 * roff[q], (size_t)(4 * rc), ncclUint64, q, c->comm, st));
+  }
+  NCCLCHK(g_rccl.GroupEnd());
+  if (scnt[me] > 0) HIPCHK(hipMemcpyAsync(c->d_recv + 4 * roff[me], c->d_send + 4 * soff[me], (size_t)scnt[me] * 32, hipMemcpyDeviceToDevice, st));
+  return sqmc_gpu_shard_finish(c, sp, (const uint64_t *)c->d_recv, n_recv, out);
+}
+
+int sqmc_gpu_shard_run(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats, double totals[16]) {
+  return run_steps(c, pc, nsteps, stats, totals, sqmc_gpu_shard_step);
 }
 
 // ---------------------------------------------------------------- batch doors

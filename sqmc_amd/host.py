@@ -593,6 +593,28 @@ class ShardedWalk:
         self.pc = PopControl(s.tau, e_trial if e_trial is not None else s.e_trial0, w_target, n_equil_steps=n_equil_steps)
         self.w_abs = float(np.abs(wk["wt"]).sum())          # global
         self.n_imp_global = len(s.imp_up)
+        self.in_library = False
+
+    def attach_rccl(self):
+        """Give the library its own RCCL communicator (sqmc_gpu_comm_init) so that run() issues
+        the three exchanges of a step itself.  The unique id travels over the caller's
+        torch.distributed group (any backend) -- MPI_Bcast in the reference's build."""
+        import torch.distributed as dist
+        box = [self.g.comm_unique_id() if self.rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0)
+        self.g.comm_init(box[0])
+        self.in_library = True
+
+    def run(self, nsteps, keep_stats=True):
+        """nsteps sharded steps inside the library (sqmc_gpu_shard_run); needs attach_rccl()"""
+        if not self.in_library:
+            raise RuntimeError("ShardedWalk.run needs attach_rccl(); use step() for the caller-driven exchange")
+        pc = self.pc.to_c(self.w_abs, min_wt=self.min_wt)
+        stats, totals = self.g.shard_run(pc, nsteps, keep_stats)
+        self.pc.from_c(pc)
+        self.w_abs = pc.w_abs_gen
+        return stats, totals
 
     def step(self):
         import torch
@@ -600,6 +622,13 @@ class ShardedWalk:
         if r != 1.0:
             self.g.scale_projector(r)
         prm = self.pc.params(min_wt=self.min_wt)
+        if self.in_library:
+            out = self.g.shard_step(prm)
+            r = self.pc.post_step(out)
+            if r != 1.0:
+                self.g.scale_projector(r)
+            self.w_abs, self.last_local = out[1], out
+            return out
         self.g.shard_begin(prm, self.xg.data_ptr())
         _allreduce_dev(self.xg)
         counts = self.g.shard_pack(prm, self.xg.data_ptr(), self.send.data_ptr(), self.cap, self.world)

@@ -114,3 +114,40 @@ def test_sharded_step_over_rccl_single_rank(tmp_path):
     assert p.exitcode == 0
     outs = np.load(os.path.join(str(tmp_path), "nccl.npy"))
     assert outs.shape == (10, 16) and np.all(outs[:, 5] > 1000)
+
+
+def _inlib_worker(port, outdir):
+    import torch                                   # noqa: F401  (its librccl/libamdhip64 first)
+    sys.path.insert(0, ROOT)
+    import sqmc_amd
+    from sqmc_amd import host as H
+    sqmc_amd.set_device(0)
+    hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+    w = H.ShardedWalk(hst, W_TARGET, 0, 1, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
+    w.attach_rccl()
+    a = np.array([w.step().copy() for _ in range(NSTEPS // 2)])        # sqmc_gpu_shard_step
+    b, _ = w.run(NSTEPS - NSTEPS // 2)                                 # sqmc_gpu_shard_run
+    wk = w.g.download_walkers()
+    np.savez(os.path.join(outdir, "inlib.npz"), outs=np.concatenate([a, b]), **wk)
+    w.close()
+
+
+def test_in_library_rccl_exchange_single_rank(tmp_path):
+    """sqmc_gpu_comm_init / shard_step / shard_run: the exchanges issued by the library itself on
+    an RCCL communicator (one rank is what a one-GPU box can host: every RCCL call still runs).
+    Must reproduce the plain single-rank walk exactly."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_inlib_worker, args=(29571, str(tmp_path)))
+    p.start(); p.join(600)
+    assert p.exitcode == 0
+    res = np.load(os.path.join(str(tmp_path), "inlib.npz"))
+    from sqmc_amd import host as H
+    hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+    ref = H.GpuWalk(hst, W_TARGET, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
+    outs = np.array([ref.step().copy() for _ in range(NSTEPS)])
+    wk = ref.g.download_walkers()
+    ref.close()
+    assert np.array_equal(res["up"], wk["up"]) and np.array_equal(res["dn"], wk["dn"])
+    assert np.array_equal(res["wt"], wk["wt"])
+    assert np.allclose(res["outs"], outs, rtol=1e-12, atol=1e-12)
