@@ -35,7 +35,7 @@ def build_library(force=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value",
-           "-I" + os.path.join(_ROOT, "include"), src[0], "-o", LIB_PATH]
+           "-I" + os.path.join(_ROOT, "include")] + os.environ.get("SQMC_EXTRA_CFLAGS", "").split() + [src[0], "-o", LIB_PATH]
     subprocess.check_call(cmd)
     return LIB_PATH
 

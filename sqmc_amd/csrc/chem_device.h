@@ -38,7 +38,7 @@ struct ChemTab {
 
 #define SQ_BINOM_STRIDE 33
 struct ChemDev {                        // pointers into HBM, passed by value
-  const ChemTab *tab;
+  const ChemTab *tab; int tab_words;
   const u64 *binom;                     // C(c, i) at [c*SQ_BINOM_STRIDE + i], c < 64, i <= 32
   u64 n_dn_strings;                     // C(norb, ndn)
   const double *integrals;              // 1-based packed
@@ -47,13 +47,25 @@ struct ChemDev {                        // pointers into HBM, passed by value
   double max_double;
 };
 
-__device__ __forceinline__ void stage_tab(ChemTab *dst, const ChemTab *src) {
-  // header + the used part of combine_2 only (norb=26: 2.3 KB instead of 9.4 KB per block)
-  const int used = src->c2_stride * src->c2_stride;
-  const int n = (int)((offsetof(ChemTab, c2) + (size_t)used * sizeof(unsigned short) + sizeof(int) - 1) / sizeof(int));
+// 32-bit words of a ChemTab that are in use: header + the used part of combine_2 only (norb=26:
+// 2.3 KB instead of 9.4 KB per block).  The host computes it once (ChemDev::tab_words) so that a
+// kernel can issue the staging loads without first reading c2_stride from HBM.
+__host__ __device__ __forceinline__ int tab_words_used(int c2_stride) {
+  return (int)((offsetof(ChemTab, c2) + (size_t)(c2_stride * c2_stride) * sizeof(unsigned short) + sizeof(int) - 1) / sizeof(int));
+}
+__device__ __forceinline__ void stage_tab(ChemTab *dst, const ChemTab *src, int n) {
   const int *s = reinterpret_cast<const int *>(src);
   int *d = reinterpret_cast<int *>(dst);
-  for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+  // the first four words per thread are loaded before any is stored: one HBM/L2 round trip for
+  // tables up to 4*blockDim words (norb <= 42 with 256 threads), not one per loop iteration
+  const int i0 = threadIdx.x, nt = blockDim.x;
+  const int r0 = (i0 < n) ? s[i0] : 0, r1 = (i0 + nt < n) ? s[i0 + nt] : 0;
+  const int r2 = (i0 + 2 * nt < n) ? s[i0 + 2 * nt] : 0, r3 = (i0 + 3 * nt < n) ? s[i0 + 3 * nt] : 0;
+  if (i0 < n) d[i0] = r0;
+  if (i0 + nt < n) d[i0 + nt] = r1;
+  if (i0 + 2 * nt < n) d[i0 + 2 * nt] = r2;
+  if (i0 + 3 * nt < n) d[i0 + 3 * nt] = r3;
+  for (int i = i0 + 4 * nt; i < n; i += nt) d[i] = s[i];
   __syncthreads();
 }
 
@@ -69,11 +81,31 @@ __device__ __forceinline__ u64 maskr64(int n) { return n >= 64 ? ~0ull : ((1ull 
 // (28 instead of 52 for C2 cc-pVDZ): fewer radix passes.
 __device__ __forceinline__ u64 colex_rank(const u64 *__restrict__ binom, u64 det) {
   u64 r = 0; int i = 1;
-  for (; det; det &= det - 1, i++) r += binom[ctz64(det) * SQ_BINOM_STRIDE + i];
+  while (det) {     // four electrons per round so that the four table loads are in flight together; C(0,i>=1) = 0 pads
+    const u64 d1 = det & (det - 1), d2 = d1 & (d1 - 1), d3 = d2 & (d2 - 1);
+    const int c0 = ctz64(det), c1 = d1 ? ctz64(d1) : 0, c2 = d2 ? ctz64(d2) : 0, c3 = d3 ? ctz64(d3) : 0;
+    const u64 b0 = binom[c0 * SQ_BINOM_STRIDE + i], b1 = binom[c1 * SQ_BINOM_STRIDE + i + 1];
+    const u64 b2 = binom[c2 * SQ_BINOM_STRIDE + i + 2], b3 = binom[c3 * SQ_BINOM_STRIDE + i + 3];
+    r += (b0 + b1) + (b2 + b3);
+    det = d3 & (d3 - 1); i += 4;
+  }
   return r;
 }
 __device__ __forceinline__ u64 det_key(const ChemDev &dev, u64 up, u64 dn) {
-  return colex_rank(dev.binom, up) * dev.n_dn_strings + colex_rank(dev.binom, dn);
+  // both strings advance together: eight table loads per round trip
+  const u64 *__restrict__ binom = dev.binom;
+  u64 ru = 0, rd = 0; int i = 1;
+  while (up | dn) {
+    const u64 u1 = up & (up - 1), u2 = u1 & (u1 - 1), u3 = u2 & (u2 - 1);
+    const u64 d1 = dn & (dn - 1), d2 = d1 & (d1 - 1), d3 = d2 & (d2 - 1);
+    const int a0 = up ? ctz64(up) : 0, a1 = u1 ? ctz64(u1) : 0, a2 = u2 ? ctz64(u2) : 0, a3 = u3 ? ctz64(u3) : 0;
+    const int b0 = dn ? ctz64(dn) : 0, b1 = d1 ? ctz64(d1) : 0, b2 = d2 ? ctz64(d2) : 0, b3 = d3 ? ctz64(d3) : 0;
+    const u64 x0 = binom[a0 * SQ_BINOM_STRIDE + i], x1 = binom[a1 * SQ_BINOM_STRIDE + i + 1], x2 = binom[a2 * SQ_BINOM_STRIDE + i + 2], x3 = binom[a3 * SQ_BINOM_STRIDE + i + 3];
+    const u64 y0 = binom[b0 * SQ_BINOM_STRIDE + i], y1 = binom[b1 * SQ_BINOM_STRIDE + i + 1], y2 = binom[b2 * SQ_BINOM_STRIDE + i + 2], y3 = binom[b3 * SQ_BINOM_STRIDE + i + 3];
+    ru += (x0 + x1) + (x2 + x3); rd += (y0 + y1) + (y2 + y3);
+    up = u3 & (u3 - 1); dn = d3 & (d3 - 1); i += 4;
+  }
+  return ru * dev.n_dn_strings + rd;
 }
 
 // ----------------------------------------------------------------------------- RNG
@@ -104,6 +136,23 @@ __host__ __device__ __forceinline__ u64 lcg_skip(u64 x, u64 k) {
   u64 m = SQ_LCG_MULT;
   while (k) { if (k & 1) x = (x * m) & SQ_MASK48; m = (m * m) & SQ_MASK48; k >>= 1; }
   return x;
+}
+
+__device__ __forceinline__ int kth_set(u64 bits, int k) {   // 1-based orbital of the k-th set bit
+  for (int i = 1; i < k; i++) bits &= bits - 1;
+  return ctz64(bits) + 1;
+}
+// the same by halving (no data-dependent loop: lanes of a wave pick very different k among the holes)
+__device__ __forceinline__ int kth_set_wide(u64 bits, int k) {
+  unsigned int x = (unsigned int)bits; int pos = 0;
+  int pc = __popc(x);
+  if (k > pc) { k -= pc; x = (unsigned int)(bits >> 32); pos = 32; }
+  pc = __popc(x & 0xFFFFu); if (k > pc) { k -= pc; x >>= 16; pos += 16; }
+  pc = __popc(x & 0xFFu);   if (k > pc) { k -= pc; x >>= 8;  pos += 8; }
+  pc = __popc(x & 0xFu);    if (k > pc) { k -= pc; x >>= 4;  pos += 4; }
+  pc = __popc(x & 0x3u);    if (k > pc) { k -= pc; x >>= 2;  pos += 2; }
+  pc = (int)(x & 1u);       if (k > pc) { pos += 1; }
+  return pos + 1;
 }
 
 // ------------------------------------------------------------------------ integrals
@@ -174,11 +223,9 @@ __device__ inline double h_single(const ChemTab &t, const double *__restrict__ i
 
 __device__ inline double h_double(const ChemTab &t, const double *__restrict__ ints, u64 iu, u64 id, u64 ju, u64 jd) {
   int g, i1, i2, j1, j2;
-  if (iu == ju) {
-    permutation_factor2(id, jd, g, i1, i2, j1, j2);
-    return g * (IVAL(i1 + 1, j1 + 1, i2 + 1, j2 + 1) - IVAL(i1 + 1, j2 + 1, i2 + 1, j1 + 1));
-  } else if (id == jd) {
-    permutation_factor2(iu, ju, g, i1, i2, j1, j2);
+  if (iu == ju || id == jd) {            // both electrons in one spin string (dn if up is untouched)
+    const bool in_dn = (iu == ju);
+    permutation_factor2(in_dn ? id : iu, in_dn ? jd : ju, g, i1, i2, j1, j2);
     return g * (IVAL(i1 + 1, j1 + 1, i2 + 1, j2 + 1) - IVAL(i1 + 1, j2 + 1, i2 + 1, j1 + 1));
   }
   i1 = ctz64(iu & ~ju); j1 = ctz64(ju & ~iu);
@@ -261,10 +308,6 @@ __device__ inline double h_any(const ChemTab &t, const double *__restrict__ ints
 }
 
 // ------------------------------------------------------------------------- proposal
-__device__ __forceinline__ int kth_set(u64 bits, int k) {   // 1-based orbital of the k-th set bit
-  for (int i = 1; i < k; i++) bits &= bits - 1;
-  return ctz64(bits) + 1;
-}
 // One uniform symmetry-aware proposal from det_i.  Returns excitation level (1/2) with
 // det_j and the generation probability, or 0 when the reference returns with weight 0.
 // Consumes exactly the reference's random_int calls, in its order.
@@ -294,12 +337,14 @@ __device__ inline int propose_uniform(const ChemTab &t, Rng &g, u64 iu, u64 id, 
   const int n_occ_up = popc64(iu);
   int sym1, o;
   {
-    o = (e2 <= n_occ_up) ? kth_set(iu, e2) : kth_set(id, e2 - n_occ_up);
-    if (e2 <= n_occ_up) ju &= ~bit64(o - 1); else jd &= ~bit64(o - 1);
+    const bool up2 = (e2 <= n_occ_up);
+    o = kth_set(up2 ? iu : id, up2 ? e2 : e2 - n_occ_up);
+    if (up2) ju &= ~bit64(o - 1); else jd &= ~bit64(o - 1);
     sym1 = t.orbsym[o];
     if (level == 2) {
-      int o1 = (e1 <= n_occ_up) ? kth_set(iu, e1) : kth_set(id, e1 - n_occ_up);
-      if (e1 <= n_occ_up) ju &= ~bit64(o1 - 1); else jd &= ~bit64(o1 - 1);
+      const bool up1 = (e1 <= n_occ_up);
+      const int o1 = kth_set(up1 ? iu : id, up1 ? e1 : e1 - n_occ_up);
+      if (up1) ju &= ~bit64(o1 - 1); else jd &= ~bit64(o1 - 1);
       sym1 = t.prod[t.orbsym[o1]][sym1];
     }
   }
@@ -311,45 +356,37 @@ __device__ inline int propose_uniform(const ChemTab &t, Rng &g, u64 iu, u64 id, 
     i_open = popc64(open);
     if (i_open == 0) return 0;
     int to1 = rng_int(g, i_open); prob = prob / i_open;
-    o = kth_set(open, to1);
+    o = kth_set_wide(open, to1);
     if (tot_spin == 1) ju |= bit64(o - 1); else jd |= bit64(o - 1);
   } else {
     prob = prob * 2.0 / (1.0 * (nelec - 2 * nc) * (nelec - 2 * nc - 1));
-    if (tot_spin == 2 || tot_spin == -2) {
-      const u64 occdet = (tot_spin == 2) ? iu : id; const int nsp = (tot_spin == 2) ? nup : ndn;
-      int to1 = rng_int(g, norb - nsp); prob = prob / (norb - nsp);
-      sp1 = kth_set(t.orb_mask & ~occdet, to1);
-      if (tot_spin == 2) ju |= bit64(sp1 - 1); else jd |= bit64(sp1 - 1);
-      sym2 = t.prod[t.orbsym[sp1]][sym1];
-      const bool same = (sym2 == t.orbsym[sp1]);
-      u64 open = t.sym_mask[sym2] & ~occdet; if (same) open &= ~bit64(sp1 - 1);
-      i_open = popc64(open);
-      if (i_open == 0) return 0;
-      int to2 = rng_int(g, i_open); temp1 = 1.0 / i_open;
-      o = kth_set(open, to2);
-      if (tot_spin == 2) ju |= bit64(o - 1); else jd |= bit64(o - 1);
-      const int sy = t.prod[sym2][sym1];
-      i_open = popc64(t.sym_mask[sy] & ~occdet) - (same ? 1 : 0);
-      if (i_open == 0) prob = prob * temp1; else prob = prob * (temp1 + (1.0 / i_open));
-    } else {
-      prob = prob * 1.0 / (2 * norb - ndn - nup);
-      int to1 = rng_int(g, 2 * norb - nup - ndn);
-      const bool first_up = (to1 <= norb - nup);
-      u64 d1, d2;
+    // One code path for the three spin cases (every wave holds all of them): d1 / d2 are the
+    // strings the first / second hole is drawn from; for equal spins the second hole may not
+    // repeat the first.  chemistry.f90:4716-4985
+    const bool same_spin = (tot_spin != 0);
+    bool first_up = (tot_spin == 2); u64 d1 = first_up ? iu : id, d2 = d1; int nchoice;
+    if (same_spin) { nchoice = norb - (first_up ? nup : ndn); prob = prob / nchoice; }
+    else { nchoice = 2 * norb - nup - ndn; prob = prob * 1.0 / (2 * norb - ndn - nup); }
+    int to1 = rng_int(g, nchoice);
+    if (!same_spin) {
+      first_up = (to1 <= norb - nup);
       if (first_up) { d1 = iu; d2 = id; } else { d1 = id; d2 = iu; to1 -= (norb - nup); }
-      sp1 = kth_set(t.orb_mask & ~d1, to1);
-      if (first_up) ju |= bit64(sp1 - 1); else jd |= bit64(sp1 - 1);
-      sym2 = t.prod[sym1][t.orbsym[sp1]];
-      const u64 open = t.sym_mask[sym2] & ~d2;
-      i_open = popc64(open);
-      if (i_open == 0) return 0;
-      int to2 = rng_int(g, i_open); temp1 = 1.0 / i_open;
-      o = kth_set(open, to2);
-      if (first_up) jd |= bit64(o - 1); else ju |= bit64(o - 1);
-      const int sy = t.prod[sym2][sym1];
-      i_open = popc64(t.sym_mask[sy] & ~d1);
-      if (i_open != 0) prob = prob * (temp1 + (1.0 / i_open)); else prob = prob * temp1;
     }
+    const bool second_up = same_spin ? first_up : !first_up;
+    sp1 = kth_set_wide(t.orb_mask & ~d1, to1);
+    if (first_up) ju |= bit64(sp1 - 1); else jd |= bit64(sp1 - 1);
+    const int s1 = t.orbsym[sp1];
+    sym2 = same_spin ? t.prod[s1][sym1] : t.prod[sym1][s1];
+    const bool same = same_spin && (sym2 == s1);
+    u64 open = t.sym_mask[sym2] & ~d2; if (same) open &= ~bit64(sp1 - 1);
+    i_open = popc64(open);
+    if (i_open == 0) return 0;
+    const int to2 = rng_int(g, i_open); temp1 = 1.0 / i_open;
+    o = kth_set_wide(open, to2);
+    if (second_up) ju |= bit64(o - 1); else jd |= bit64(o - 1);
+    const int sy = t.prod[sym2][sym1];
+    i_open = popc64(t.sym_mask[sy] & ~d1) - (same ? 1 : 0);
+    if (i_open == 0) prob = prob * temp1; else prob = prob * (temp1 + (1.0 / i_open));
   }
   return level;
 }

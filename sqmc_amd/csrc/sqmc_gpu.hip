@@ -16,6 +16,7 @@
 //
 // Everything is HBM/latency bound integer + fp64 work: no MFMA anywhere.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <stdint.h>
@@ -77,6 +78,14 @@ struct DevScalars {
   double stats[16];
 };
 
+// Mailbox in pinned host memory that the GPU writes directly (no copy kernel, no interrupt): the
+// child count as soon as k_spawn starts, the step's sums at the end of k_finish.  The host spins
+// on the sequence words.  Data first, system-scope fence, then the sequence word.
+struct HostMail {
+  volatile u64 seq; u64 tot2; long long err; double stats[16];
+  volatile u64 cnt_seq; u64 n_children;
+};
+
 #define NTIMERS 32
 struct sqmc_gpu_ctx {
   hipStream_t st;
@@ -93,6 +102,8 @@ struct sqmc_gpu_ctx {
   long long n_ct; u64 *d_ct_up, *d_ct_dn; double *d_ct_num, *d_ct_den; u64 *d_ct_hkey; u32 *d_ct_hidx; u64 ct_mask;
   int rng_mode; u64 seed64; u64 step_no;
   DevScalars *d_sc; DevScalars *h_sc;   // h_sc pinned
+  HostMail *h_mail, *d_mail; u64 mail_seq, cnt_seq;      // the same pinned words seen from host and device
+  bool timers_pending;
   double *d_partials; int n_partial_blocks; double *d_wabs_part; u32 *d_done;
   int key_bits; u64 invalid_key; u64 *d_binom;
   // multi-rank sharding (owner = hash(det) mod shard_n)
@@ -110,8 +121,9 @@ struct sqmc_gpu_ctx {
 // gate + child count (COUNTER discipline).  do_walk.f90:3577-3589
 __global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, const double *__restrict__ wt,
                                               u64 *__restrict__ nchild, double *__restrict__ wchild, u64 *__restrict__ keys, u32 *__restrict__ vals,
-                                              long long n, StepP p, u64 seed, u64 step) {
+                                              long long n, StepP p, u64 seed, u64 step, DevScalars *sc) {
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i == 0) { sc->n_invalid = 0; sc->tot1 = 0; sc->tot2 = 0; sc->err = 0; }   // every writer of these runs after this kernel
   if (i >= n) return;
   keys[i] = det_key(dev, up[i], dn[i]); vals[i] = (u32)i;      // sort key of the walker itself
   double w = wt[i]; bool spawn, use_wt;
@@ -134,8 +146,9 @@ __global__ void __launch_bounds__(64) k_replay_prepass(const ChemTab *__restrict
                                                        u64 *__restrict__ child_off, u64 *__restrict__ child_state, long long n,
                                                        long long cap_children, StepP p, DevScalars *sc) {
   __shared__ ChemTab t;
-  stage_tab(&t, gtab);
+  stage_tab(&t, gtab, tab_words_used(gtab->c2_stride));
   if (threadIdx.x != 0) return;
+  sc->n_invalid = 0; sc->tot1 = 0; sc->tot2 = 0; sc->err = 0;
   Rng g; g.mode = 0; g.x = sc->lcg;
   u64 c = 0;
   for (long long i = 0; i < n; i++) {
@@ -164,7 +177,7 @@ __global__ void __launch_bounds__(64) k_replay_prepass(const ChemTab *__restrict
 __global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, double *__restrict__ wt,
                                               const u32 *__restrict__ flg, double *__restrict__ me, long long n, StepP p, DevScalars *sc) {
   __shared__ ChemTab t;
-  stage_tab(&t, dev.tab);
+  stage_tab(&t, dev.tab, dev.tab_words);
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
   if (p.semi && flg_impd(flg[i]) < 1) return;
@@ -175,63 +188,12 @@ __global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict
   wt[i] = wt[i] * f;
 }
 
-// one thread per child proposal; parent found by binary search in the child offsets
-__global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
-                                               const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
-                                               long long n0, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc) {
-  // the grid covers the free capacity of the walker arrays; the number of children is read from
-  // device memory so that the launch does not wait for the host to learn it
-  const long long nchildren = (long long)sc->n_children;
-  if ((long long)blockIdx.x * TPB >= nchildren || n0 + nchildren > cap_all) return;
-  __shared__ ChemTab t;
-  stage_tab(&t, dev.tab);
-  // Parent of child c = largest i with child_off[i] <= c.  The 256 children of a block have
-  // neighbouring parents, so the block narrows [0,n0) for its first child with 256-way splits
-  // staged in LDS (one global round trip per level instead of log2(n0) dependent loads), then
-  // every thread finishes inside a 1024-entry LDS window (global search only if it runs past it).
-  __shared__ u64 s_win[SPAWN_WIN];
-  const long long c0 = (long long)blockIdx.x * TPB;
-  long long wlo = 0, whi = n0;                       // invariant: child_off[wlo] <= c0, answer for c0 in [wlo, whi)
-  while (whi - wlo > SPAWN_WIN) {
-    const long long stepw = (whi - wlo + TPB - 1) / TPB;
-    const long long probe = wlo + (long long)threadIdx.x * stepw;
-    const int le = (probe < whi && child_off[probe] <= (u64)c0) ? 1 : 0;
-    const int cnt = __syncthreads_count(le);           // probes are sorted: the first cnt of them are <= c0
-    const long long nlo = wlo + (long long)(cnt - 1) * stepw;
-    whi = (nlo + stepw < whi) ? nlo + stepw : whi; wlo = nlo;
-  }
-  const int wn = (int)(whi - wlo);
-  for (int k = threadIdx.x; k < SPAWN_WIN; k += TPB) {  // window keeps going past whi: later children of the block live there
-    const long long i = wlo + k;
-    s_win[k] = (i < n0) ? child_off[i] : ~0ull;
-  }
-  __syncthreads();
-  (void)wn;
-  long long c = c0 + threadIdx.x;
-  if (c >= nchildren) return;
-  long long ip;
-  if (s_win[SPAWN_WIN - 1] <= (u64)c) {                 // beyond the window (many childless parents in between)
-    long long lo = wlo + SPAWN_WIN - 1, hi = n0;
-    while (hi - lo > 1) { long long mid = (lo + hi) >> 1; if (child_off[mid] <= (u64)c) lo = mid; else hi = mid; }
-    ip = lo;
-  } else {
-    int lo = 0, hi = SPAWN_WIN - 1;                     // s_win[lo] <= c < s_win[hi]
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s_win[mid] <= (u64)c) lo = mid; else hi = mid; }
-    ip = wlo + lo;
-  }
-  Rng g; g.mode = mode;
-  g.x = (mode == 0) ? child_state[c] : sq_counter_key(seed, step, 1, (u64)c);
-  const u64 iu = w.up[ip], id = w.dn[ip];
-  u64 ju, jd; double prob;
-  int level = propose_any(t, g, iu, id, ju, jd, prob);
-  double wj = 0.0;
-  if (level > 0) {
-    wj = proposal_weight(t, dev.integrals, p.tau, iu, id, ju, jd, level, prob);
-    wj = wchild[ip] * wj;
-  }
+// a spawned walker (or the "no walker" marker) into slot n0 + c.  do_walk.f90:3700-3731
+__device__ __forceinline__ void spawn_emit(const ChemDev &dev, const WalkArr &w, u64 *__restrict__ keys, u32 *__restrict__ vals, long long n0, long long c,
+                                           u32 pf, u64 ju, u64 jd, double wj, const StepP &p, u64 invalid_key) {
   const long long k = n0 + c;
   if (wj != 0.0) {
-    const u32 pf = w.flg[ip]; const int pd = flg_impd(pf), pi = flg_init(pf);
+    const int pd = flg_impd(pf), pi = flg_init(pf);
     int d;
     if (pd == -2) d = p.cti ? 1 : 2; else d = (pd < 126 ? pd : 126) + 1;
     if (p.semi && pd == 0) d = -1;
@@ -243,9 +205,93 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
     w.up[k] = ju; w.dn[k] = jd; w.wt[k] = wj; w.flg[k] = pack_flg(d, ini, 0);
     keys[k] = det_key(dev, ju, jd);
   } else {
-    w.wt[k] = 0.0; keys[k] = invalid_key;     // sorts behind every real determinant; counted by k_wabs
+    w.wt[k] = 0.0; keys[k] = invalid_key;     // sorts behind every real determinant
   }
   vals[k] = (u32)k;
+}
+
+#ifdef SPAWN_PROF
+__device__ unsigned long long g_prof[8 * 8192];
+#define PROF(K) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_prof[blockIdx.x * 8 + (K)] = wall_clock64(); } while (0)
+extern "C" int sqmc_gpu_debug_prof(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)); }
+#else
+#define PROF(K)
+#endif
+// one thread per child proposal; parent found by binary search in the child offsets
+__global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
+                                               const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
+                                               long long n0, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc,
+                                               HostMail *mail, u64 cnt_seq) {
+  // the grid covers the free capacity of the walker arrays; the number of children is read from
+  // device memory so that the launch does not wait for the host to learn it
+  PROF(0);
+  __shared__ ChemTab t;
+  __shared__ u64 s_win[SPAWN_WIN];
+  // Parent of child c = largest i with child_off[i] <= c.  The 256 children of a block have
+  // neighbouring parents, so the block narrows [0,n0) for its first child with 256-way splits
+  // (one round trip per level instead of log2(n0) dependent loads), then every thread finishes
+  // inside a 1024-entry LDS window (global search only if it runs past it).  The first probe, the
+  // table staging and the child count do not depend on each other: they are issued together.
+  const long long c0 = (long long)blockIdx.x * TPB;
+  long long wlo = 0, whi = n0;                       // invariant: child_off[wlo] <= c0, answer for c0 in [wlo, whi)
+  u64 pv = 0;
+  if (whi - wlo > SPAWN_WIN) {
+    const long long stepw = (whi - wlo + TPB - 1) / TPB, probe = wlo + (long long)threadIdx.x * stepw;
+    pv = (probe < whi) ? child_off[probe] : ~0ull;
+  }
+  stage_tab(&t, dev.tab, dev.tab_words);
+  const long long nchildren = (long long)sc->n_children;
+  if (mail && blockIdx.x == 0 && threadIdx.x == 0) {      // the host sizes the sort from this while the kernel runs
+    mail->n_children = (u64)nchildren; __threadfence_system(); mail->cnt_seq = cnt_seq;
+  }
+  if (c0 >= nchildren || n0 + nchildren > cap_all) return;
+  PROF(1);
+  while (whi - wlo > SPAWN_WIN) {
+    const long long stepw = (whi - wlo + TPB - 1) / TPB, probe = wlo + (long long)threadIdx.x * stepw;
+    const int le = (probe < whi && pv <= (u64)c0) ? 1 : 0;
+    const int cnt = __syncthreads_count(le);           // probes are sorted: the first cnt of them are <= c0
+    const long long nlo = wlo + (long long)(cnt - 1) * stepw;
+    whi = (nlo + stepw < whi) ? nlo + stepw : whi; wlo = nlo;
+    if (whi - wlo > SPAWN_WIN) {
+      const long long stepw2 = (whi - wlo + TPB - 1) / TPB, probe2 = wlo + (long long)threadIdx.x * stepw2;
+      pv = (probe2 < whi) ? child_off[probe2] : ~0ull;
+    }
+  }
+  for (int k = threadIdx.x; k < SPAWN_WIN; k += TPB) {  // window keeps going past whi: later children of the block live there
+    const long long i = wlo + k;
+    s_win[k] = (i < n0) ? child_off[i] : ~0ull;
+  }
+  __syncthreads();
+  PROF(2);
+  const long long c = c0 + threadIdx.x;
+  const bool active = c < nchildren;
+  if (active) {
+    long long ip;
+    if (s_win[SPAWN_WIN - 1] <= (u64)c) {                 // beyond the window (many childless parents in between)
+      long long lo = wlo + SPAWN_WIN - 1, hi = n0;
+      while (hi - lo > 1) { long long mid = (lo + hi) >> 1; if (child_off[mid] <= (u64)c) lo = mid; else hi = mid; }
+      ip = lo;
+    } else {
+      int lo = 0, hi = SPAWN_WIN - 1;                     // s_win[lo] <= c < s_win[hi]
+      while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s_win[mid] <= (u64)c) lo = mid; else hi = mid; }
+      ip = wlo + lo;
+    }
+    Rng g; g.mode = mode;
+    g.x = (mode == 0) ? child_state[c] : sq_counter_key(seed, step, 1, (u64)c);
+    const u64 iu = w.up[ip], id = w.dn[ip];
+    const u32 pflg = w.flg[ip]; const double wch = wchild[ip];     // needed at the end: fetched in the same round trip
+    u64 ju, jd; double prob;
+    PROF(3);
+    const int level = propose_any(t, g, iu, id, ju, jd, prob);
+    PROF(4);
+    double wj = 0.0;
+    if (level > 0) {
+      wj = proposal_weight(t, dev.integrals, p.tau, iu, id, ju, jd, level, prob);
+      wj = wch * wj;
+    }
+    spawn_emit(dev, w, keys, vals, n0, c, pflg, ju, jd, wj, p, invalid_key);
+  }
+  PROF(5);
 }
 
 __global__ void __launch_bounds__(TPB) k_main_keys(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, u64 *__restrict__ keys,
@@ -475,8 +521,15 @@ __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64
 // The final reduction stays a kernel of its own: folding it into the last-arriving block of
 // k_compact needs an agent-scope release in every block and cost more than this launch.
 __global__ void __launch_bounds__(TPB) k_finish(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
-                                                int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words) {
+                                                int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words,
+                                                HostMail *mail, u64 seq) {
   finish_step(partials, nblocks, wabs_part, nwabs, mode, sc, scan_state, scan_ticket, n_scan_words);
+  if (mail && threadIdx.x == 0) {
+    for (int i = 0; i < 16; i++) mail->stats[i] = sc->stats[i];
+    mail->tot2 = sc->tot2; mail->err = sc->err;
+    __threadfence_system();
+    mail->seq = seq;
+  }
 }
 
 // final reduction: sums block partials
@@ -489,10 +542,21 @@ __device__ void finish_step(const double *__restrict__ partials, int nblocks, co
   for (int i = threadIdx.x; i < n_scan_words; i += TPB) scan_state[i] = 0;
   if (threadIdx.x < 3) scan_ticket[threadIdx.x] = 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // every thread first adds up its rows (a row's 13 loads, and several rows, are in flight
+  // together), then one shuffle tree per statistic
+  double acc[NSTAT + 2];
+#pragma unroll
+  for (int k = 0; k < NSTAT + 2; k++) acc[k] = 0.0;
+#pragma unroll 4
+  for (int b = threadIdx.x; b < nblocks; b += TPB) {
+#pragma unroll
+    for (int k = 0; k < NSTAT; k++) acc[k] += partials[(long long)b * NSTAT + k];
+  }
+#pragma unroll 4
+  for (int b = threadIdx.x; b < nwabs; b += TPB) { acc[NSTAT] += wabs_part[2 * b]; acc[NSTAT + 1] += wabs_part[2 * b + 1]; }
+#pragma unroll
   for (int k = 0; k < NSTAT + 2; k++) {
-    double v = 0.0;
-    if (k < NSTAT) { for (int b = threadIdx.x; b < nblocks; b += TPB) v += partials[(long long)b * NSTAT + k]; }
-    else { for (int b = threadIdx.x; b < nwabs; b += TPB) v += wabs_part[2 * b + (k - NSTAT)]; }
+    double v = acc[k];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if (lane == 0) red2[wv][k] = v;
   }
@@ -511,13 +575,13 @@ __device__ void finish_step(const double *__restrict__ partials, int nblocks, co
 // ============================================================ batch / test door kernels
 __global__ void __launch_bounds__(TPB) k_ham_batch(ChemDev dev, const u64 *iu, const u64 *id, const u64 *ju, const u64 *jd, double *h, long long n) {
   __shared__ ChemTab t;
-  stage_tab(&t, dev.tab);
+  stage_tab(&t, dev.tab, dev.tab_words);
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i < n) h[i] = h_any(t, dev.integrals, iu[i], id[i], ju[i], jd[i]);
 }
 __global__ void __launch_bounds__(TPB) k_ham_chem_batch(ChemDev dev, const u64 *iu, const u64 *id, const u64 *ju, const u64 *jd, double *h, long long n) {
   __shared__ ChemTab t;
-  stage_tab(&t, dev.tab);
+  stage_tab(&t, dev.tab, dev.tab_words);
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
   int lev = excitation_level(iu[i], id[i], ju[i], jd[i]);
@@ -534,7 +598,7 @@ __global__ void __launch_bounds__(TPB) k_build_ham(ChemDev dev, const u64 *__res
                                                    u64 *__restrict__ counts, const u64 *__restrict__ offs, long long *__restrict__ idx, double *__restrict__ val) {
   __shared__ ChemTab t;
   __shared__ u64 su[TPB], sd[TPB];
-  stage_tab(&t, dev.tab);
+  stage_tab(&t, dev.tab, dev.tab_words);
   const long long r0 = (long long)blockIdx.x * TPB, i = r0 + threadIdx.x;
   const bool live = i < n;
   const u64 ui = live ? up[i] : 0, di = live ? dn[i] : 0;
@@ -567,7 +631,7 @@ __global__ void __launch_bounds__(TPB) k_build_ham(ChemDev dev, const u64 *__res
 __global__ void __launch_bounds__(TPB) k_propose_batch(ChemDev dev, const u64 *up, const u64 *dn, const u64 *state_in, u64 *ju, u64 *jd,
                                                        double *wj, u64 *state_out, long long n, double tau) {
   __shared__ ChemTab t;
-  stage_tab(&t, dev.tab);
+  stage_tab(&t, dev.tab, dev.tab_words);
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
   Rng g; g.mode = 0; g.x = state_in[i];
@@ -587,7 +651,7 @@ __global__ void __launch_bounds__(TPB) k_hci_gen(ChemDev dev, const u64 *__restr
                                                  const u64 *__restrict__ offs, u64 *__restrict__ ou, u64 *__restrict__ od,
                                                  double *__restrict__ onum, double *__restrict__ oden) {
   __shared__ ChemTab t;
-  stage_tab(&t, dev.tab);
+  stage_tab(&t, dev.tab, dev.tab_words);
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i >= n_ref) return;
   const double c = coef[i];
@@ -742,7 +806,7 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
   (void)t;
   HIPCHK(hipMalloc(&c->d_tab, sizeof(ChemTab)));
   HIPCHK(hipMemcpy(c->d_tab, &c->htab, sizeof(ChemTab), hipMemcpyHostToDevice));
-  c->dev.tab = c->d_tab; c->dev.integrals = c->d_ints; c->dev.max_double = 0.0;
+  c->dev.tab = c->d_tab; c->dev.tab_words = tab_words_used(c->htab.c2_stride); c->dev.integrals = c->d_ints; c->dev.max_double = 0.0;
   {   // binomial table + width of the colex sort key
     std::vector<u64> bn(64 * SQ_BINOM_STRIDE, 0);
     for (int a = 0; a < 64; a++) { bn[a * SQ_BINOM_STRIDE] = 1; for (int b = 1; b <= 32 && b <= a; b++) bn[a * SQ_BINOM_STRIDE + b] = (b == a) ? 1 : bn[(a - 1) * SQ_BINOM_STRIDE + b - 1] + bn[(a - 1) * SQ_BINOM_STRIDE + b]; }
@@ -766,6 +830,9 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
   HIPCHK(hipMemset(c->d_sc, 0, sizeof(DevScalars)));
   HIPCHK(hipHostMalloc(&c->h_sc, sizeof(DevScalars)));
   memset(c->h_sc, 0, sizeof(DevScalars));
+  HIPCHK(hipHostMalloc(&c->h_mail, sizeof(HostMail), hipHostMallocMapped));
+  memset((void *)c->h_mail, 0, sizeof(HostMail));
+  HIPCHK(hipHostGetDevicePointer((void **)&c->d_mail, (void *)c->h_mail, 0));
   c->h_sc->lcg = s48;
   HIPCHK(hipMemcpy(&c->d_sc->lcg, &s48, 8, hipMemcpyHostToDevice));
   if (c->mwalk > 0) {
@@ -861,7 +928,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   hipFree(c->d_tab); hipFree(c->d_ints); hipFree(c->d_hb_r); hipFree(c->d_hb_s); hipFree(c->d_hb_absH); hipFree(c->d_pq_ind); hipFree(c->d_pq_count);
   hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x);
   hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den); hipFree(c->d_ct_hkey); hipFree(c->d_ct_hidx);
-  hipFree(c->d_sc); hipHostFree(c->h_sc);
+  hipFree(c->d_sc); hipHostFree(c->h_sc); if (c->h_mail) hipHostFree((void *)c->h_mail);
   for (int i = 0; i < NTIMERS; i++) { hipEventDestroy(c->ev0[i]); hipEventDestroy(c->ev1[i]); }
   hipEventDestroy(c->e_fork); hipEventDestroy(c->e_join); hipEventDestroy(c->e_cnt);
   hipStreamDestroy(c->st2); hipStreamDestroy(c->st);
@@ -992,14 +1059,17 @@ int sqmc_gpu_set_rng(sqmc_gpu_ctx *c, const int32_t seed[4]) {
   return SQMC_OK;
 }
 
+static void collect_timers(sqmc_gpu_ctx *c);
 int sqmc_gpu_set_timing(sqmc_gpu_ctx *c, int on) {
   if (!c) return SQMC_ERR_BAD_ARG;
+  hipStreamSynchronize(c->st); hipStreamSynchronize(c->st2); c->timers_pending = false;
   c->timing = on; c->tsteps = 0; c->nt = 0;
   for (int i = 0; i < NTIMERS; i++) c->tsum[i] = 0.0;
   return SQMC_OK;
 }
 int sqmc_gpu_get_timing(sqmc_gpu_ctx *c, int32_t *n, const char **names, float *ms) {
   if (!c) return SQMC_ERR_BAD_ARG;
+  collect_timers(c);
   *n = c->tsteps > 0 ? c->nt : 0;
   for (int i = 0; i < *n; i++) { names[i] = c->tname[i]; ms[i] = (float)(c->tsum[i] / (double)c->tsteps); }
   return SQMC_OK;
@@ -1009,6 +1079,29 @@ int sqmc_gpu_get_timing(sqmc_gpu_ctx *c, int32_t *n, const char **names, float *
 #define TEND(NAME, STREAM) do { if (t_##NAME >= 0) hipEventRecord(c->ev1[t_##NAME], STREAM); } while (0)
 
 static int comm_allreduce_stats(sqmc_gpu_ctx *c);
+// Spin on a mailbox word the GPU writes into pinned host memory.  Returns 0 when it arrived, -1
+// if the stream drained without it, a hipError_t > 0 if the stream reports an error.
+static int wait_mail(volatile u64 *flag, u64 expect, hipStream_t st) {
+  for (unsigned long it = 1;; it++) {
+    if (*flag == expect) return 0;
+    if ((it & 0x3FFF) == 0) {
+      hipError_t e = hipStreamQuery(st);
+      if (e != hipErrorNotReady) { if (*flag == expect) return 0; return e == hipSuccess ? -1 : (int)e; }
+    }
+    __builtin_ia32_pause();
+  }
+}
+// stage timers of the last step are read when the next step starts (or when they are asked for):
+// by then their events have completed and no extra synchronisation is paid inside the step
+static void collect_timers(sqmc_gpu_ctx *c) {
+  if (!c->timers_pending) return;
+  c->timers_pending = false;
+  for (int i = 0; i < c->nt; i++) {
+    if (hipEventSynchronize(c->ev1[i]) != hipSuccess) continue;
+    if (hipEventElapsedTime(&c->tms[i], c->ev0[i], c->ev1[i]) == hipSuccess) c->tsum[i] += c->tms[i];
+  }
+  c->tsteps++;
+}
 // sort -> merge -> round -> compact/estimate -> readback; shared by the single-rank step and
 // the sharded step (where the spawns behind slot n0 arrived from other ranks)
 static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long nall, bool join_side_stream, double out[16]) {
@@ -1038,20 +1131,27 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long na
   device_excl_scan_u64(c->d_flags2, c->d_pos2, nall, &c->d_sc->tot2, sw[2], st);
   TEND(round, st);
   TBEG(estimate, st);
-  const int nb = std::min(nblk(nall), 512);
+  const int nb = std::min(nblk(nall), 2048);
   hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, st, c->m, c->w, c->d_flags2, c->d_pos2, c->d_loc_imp, skey, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask,
                      c->d_ct_num, c->d_ct_den, nall, p, c->d_partials);
+  const bool use_mail = (c->comm == nullptr);          // with a communicator the sums are all-reduced on the device first
+  const u64 seq = ++c->mail_seq;
   hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials, nb, c->d_wabs_part, nbm, mode, c->d_sc, c->d_scan_state, c->d_scan_ticket,
-                     (int)(3 * c->cap_tiles));
+                     (int)(3 * c->cap_tiles), use_mail ? c->d_mail : (HostMail *)nullptr, seq);
   TEND(estimate, st);
   HIPCHK(hipGetLastError());
-  if (c->comm) { int rr = comm_allreduce_stats(c); if (rr) return rr; }      // do_walk.f90:2778-2790: the sums every rank needs
-  HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  if (c->timing) {
-    for (int i = 0; i < c->nt; i++) { hipEventElapsedTime(&c->tms[i], c->ev0[i], c->ev1[i]); c->tsum[i] += c->tms[i]; }
-    c->tsteps++;
+  if (use_mail) {
+    int wr = wait_mail(&c->h_mail->seq, seq, st);
+    if (wr > 0) return fail(SQMC_ERR_HIP, std::string("step failed on the device: ") + hipGetErrorString((hipError_t)wr));
+    if (wr < 0) {            // stream drained without the mail: read the scalars the slow way
+      HIPCHK(hipMemcpy(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost));
+    } else { c->h_sc->tot2 = c->h_mail->tot2; c->h_sc->err = (int)c->h_mail->err; for (int i = 0; i < 16; i++) c->h_sc->stats[i] = c->h_mail->stats[i]; }
+  } else {
+    int rr = comm_allreduce_stats(c); if (rr) return rr;      // do_walk.f90:2778-2790: the sums every rank needs
+    HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
   }
+  c->timers_pending = (c->timing != 0);
   c->step_no++;
   if (c->h_sc->err) return fail(c->h_sc->err, "diagonal_factor<0 after target population has been reached");
   const long long nfinal = (long long)(c->h_sc->tot2 & 0xFFFFFFFFull), nimp = (long long)(c->h_sc->tot2 >> 32);
@@ -1077,27 +1177,40 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   const int mode = c->rng_mode; const u64 seed = c->seed64, step = c->step_no;
   ScanWork sw[3];      // one look-back state per scan of the step; k_finish re-zeroes them for the next step
   for (int q = 0; q < 3; q++) { sw[q].state = c->d_scan_state + q * c->cap_tiles; sw[q].ticket = c->d_scan_ticket + q; sw[q].cap_tiles = c->cap_tiles; sw[q].self_clear = false; }
+  collect_timers(c);
   c->nt = 0;
   hipStream_t st2 = c->st2;
-  HIPCHK(hipMemsetAsync(&c->d_sc->n_children, 0, 4 * sizeof(u64) + 2 * sizeof(int), st));
-  // ---- gate / child offsets
+  // ---- gate / child offsets (the gate kernel also clears the step's device scalars)
   TBEG(gate_scan, st);
   if (mode == SQMC_RNG_REPLAY) {
     hipLaunchKernelGGL(k_replay_prepass, dim3(1), dim3(64), 0, st, c->d_tab, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_child_off,
                        c->d_child_state, n0, M - n0, p, c->d_sc);
   } else {
     hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
-                       n0, p, seed, step);
+                       n0, p, seed, step, c->d_sc);
     device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw[0], st);
   }
   TEND(gate_scan, st);
+  // ---- spawn goes out first: the host is the slower side at the start of a step, and k_spawn
+  //      is on the critical path (exactly one k_spawn launch inside this timer: the per-launch time
+  //      bench.py reports, taken from the kernel's own start/stop timestamps).  It is launched
+  //      over the whole free capacity with a device-side child count and posts that count to the
+  //      host mailbox as soon as it starts.
+  HIPCHK(hipEventRecord(c->e_fork, st));
+  const u64 cseq = ++c->cnt_seq;
+  int t_spawn = -1;
+  if (c->timing >= 1 && c->nt < NTIMERS) { t_spawn = c->nt++; c->tname[t_spawn] = "spawn"; }
+  if (M > n0) {
+    if (t_spawn >= 0)
+      hipExtLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->ev0[t_spawn], c->ev1[t_spawn], 0, c->dev, c->w, c->d_child_off, c->d_wchild,
+                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq);
+    else
+      hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                         n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq);
+  } else if (t_spawn >= 0) { hipEventRecord(c->ev0[t_spawn], st); hipEventRecord(c->ev1[t_spawn], st); }
   // ---- fork: death/clone and the deterministic projection only touch weights, which neither
   //      the spawn kernel (it uses the child weights of the gate) nor the sort reads
-  HIPCHK(hipEventRecord(c->e_fork, st));
   HIPCHK(hipStreamWaitEvent(st2, c->e_fork, 0));
-  // the child count travels to the host on the side stream while k_spawn (device-side count) runs
-  HIPCHK(hipMemcpyAsync(&c->h_sc->n_children, &c->d_sc->n_children, 8, hipMemcpyDeviceToHost, st2));
-  HIPCHK(hipEventRecord(c->e_cnt, st2));
   TBEG(diag, st2);
   hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, st2, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc);
   TEND(diag, st2);
@@ -1109,20 +1222,17 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   }
   TEND(project, st2);
   HIPCHK(hipEventRecord(c->e_join, st2));
-  // ---- spawn (exactly one k_spawn launch inside this timer: the per-launch time bench.py reports).
-  //      Launched over the whole free capacity with a device-side child count, so the host learns
-  //      the count while the kernel runs.
-  TBEG(spawn, st);
-  if (M > n0)
-    hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                       n0, M, p, mode, seed, step, c->invalid_key, c->d_sc);
-  TEND(spawn, st);
-  TBEG(sync, st);
-  HIPCHK(hipEventSynchronize(c->e_cnt));
-  TEND(sync, st);
-  const long long nch = (long long)c->h_sc->n_children;
+  HIPCHK(hipGetLastError());
+  // ---- the child count, from the mailbox (or the slow way when there was no k_spawn launch)
+  long long nch;
+  if (M > n0) {
+    int wr = wait_mail(&c->h_mail->cnt_seq, cseq, st);
+    if (wr > 0) return fail(SQMC_ERR_HIP, std::string("step failed on the device: ") + hipGetErrorString((hipError_t)wr));
+    if (wr < 0) { u64 v; HIPCHK(hipMemcpy(&v, &c->d_sc->n_children, 8, hipMemcpyDeviceToHost)); nch = (long long)v; }
+    else nch = (long long)c->h_mail->n_children;
+  } else { u64 v; HIPCHK(hipMemcpyAsync(&v, &c->d_sc->n_children, 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); nch = (long long)v; }
   if (n0 + nch > M) {
-    hipStreamSynchronize(st2);
+    hipStreamSynchronize(st); hipStreamSynchronize(st2);
     hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
     return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
   }
@@ -1284,11 +1394,12 @@ int sqmc_gpu_shard_begin(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double *x_
   const long long n0 = c->nwalk, M = c->mwalk;
   ScanWork sw0; sw0.state = c->d_scan_state; sw0.ticket = c->d_scan_ticket; sw0.cap_tiles = c->cap_tiles; sw0.self_clear = false;
   c->nt = 0;
-  HIPCHK(hipMemsetAsync(&c->d_sc->n_children, 0, 4 * sizeof(u64) + 2 * sizeof(int), st));
+  collect_timers(c);
+  if (n0 == 0) HIPCHK(hipMemsetAsync(&c->d_sc->n_children, 0, 4 * sizeof(u64) + 2 * sizeof(int), st));   // otherwise k_gate clears them
   if (x_global_dev && c->n_imp > 0) HIPCHK(hipMemsetAsync(x_global_dev, 0, c->n_imp * 8, st));
   if (n0 > 0) {
     hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
-                       n0, p, c->seed64, c->step_no);
+                       n0, p, c->seed64, c->step_no, c->d_sc);
     device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st);
     hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc);
     if (c->n_imp_local > 0)
@@ -1296,7 +1407,7 @@ int sqmc_gpu_shard_begin(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double *x_
     TBEG(spawn, st);
     if (M > n0)
       hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, c->rng_mode, c->seed64, c->step_no, c->invalid_key, c->d_sc);
+                         n0, M, p, c->rng_mode, c->seed64, c->step_no, c->invalid_key, (const DevScalars *)c->d_sc, (HostMail *)nullptr, 0ull);
     TEND(spawn, st);
   }
   HIPCHK(hipGetLastError());
