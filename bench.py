@@ -26,7 +26,7 @@ FCIDUMP = os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # HBM bytes per k_spawn launch from the PMC passes in profiles/ (FETCH_SIZE doubled as the guide
 # prescribes for gfx950, + WRITE_SIZE, KiB -> bytes); None until measured for the current kernel.
-TRAFFIC_K_SPAWN = 2.13e7      # profiles/r01_bench_1e5_rocprof_summary.txt: (2*5965.7 + 8837.0) KiB
+TRAFFIC_K_SPAWN = 1.97e7      # profiles/r01_bench_1e5_rocprof_summary.txt: (2*6466.8 + 6328.9) KiB
 
 
 def main():
@@ -148,7 +148,8 @@ def main():
     if rank == 0:
         value = nwalk_all / dt
         # dominant single kernel of the step: k_spawn (one launch per step; the "spawn" timer is the
-        # pair of HIP events recorded on the library's stream right around that launch).
+        # pair of HIP events hipExtLaunchKernelGGL attaches to that launch on the library's stream:
+        # the kernel's own start/stop timestamps, what rocprofv3 --kernel-trace reports).
         # Algorithmic bytes per launch = 84 B per child proposal x children.
         n_avg, s_avg = nwalk_sum / args.steps, spawn_sum / args.steps
         dom, dom_ms = "k_spawn", spawn_ms
