@@ -518,6 +518,14 @@ __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64
     partials[(long long)blockIdx.x * NSTAT + threadIdx.x] = v;
   }
 }
+// posts the (all-reduced) scalars of a sharded step to the host mailbox
+__global__ void k_post_mail(const DevScalars *sc, HostMail *mail, u64 seq) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 16; i++) mail->stats[i] = sc->stats[i];
+  mail->tot2 = sc->tot2; mail->err = sc->err;
+  __threadfence_system();
+  mail->seq = seq;
+}
 // The final reduction stays a kernel of its own: folding it into the last-arriving block of
 // k_compact needs an agent-scope release in every block and cost more than this launch.
 __global__ void __launch_bounds__(TPB) k_finish(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
@@ -1140,16 +1148,16 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long na
                      (int)(3 * c->cap_tiles), use_mail ? c->d_mail : (HostMail *)nullptr, seq);
   TEND(estimate, st);
   HIPCHK(hipGetLastError());
-  if (use_mail) {
+  if (!use_mail) {
+    int rr = comm_allreduce_stats(c); if (rr) return rr;      // do_walk.f90:2778-2790: the sums every rank needs
+    hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(64), 0, st, (const DevScalars *)c->d_sc, c->d_mail, seq);
+  }
+  {
     int wr = wait_mail(&c->h_mail->seq, seq, st);
     if (wr > 0) return fail(SQMC_ERR_HIP, std::string("step failed on the device: ") + hipGetErrorString((hipError_t)wr));
     if (wr < 0) {            // stream drained without the mail: read the scalars the slow way
       HIPCHK(hipMemcpy(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost));
     } else { c->h_sc->tot2 = c->h_mail->tot2; c->h_sc->err = (int)c->h_mail->err; for (int i = 0; i < 16; i++) c->h_sc->stats[i] = c->h_mail->stats[i]; }
-  } else {
-    int rr = comm_allreduce_stats(c); if (rr) return rr;      // do_walk.f90:2778-2790: the sums every rank needs
-    HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
   }
   c->timers_pending = (c->timing != 0);
   c->step_no++;
@@ -1381,7 +1389,7 @@ int sqmc_gpu_shard_config(sqmc_gpu_ctx *c, int32_t rank, int32_t nranks, int64_t
 // phase 1 of a sharded step: gate, child offsets, death/clone, spawn (into local slots), and the
 // owned entries of the deterministic-space weight vector written into x_global (device pointer,
 // n_imp doubles, zeroed here) for the caller's all-reduce (do_walk.f90:2259-2260).
-int sqmc_gpu_shard_begin(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double *x_global_dev, int64_t *n_children) {
+static int shard_begin_impl(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double *x_global_dev, int64_t *n_children, bool full_sync) {
   if (!c || !sp || !n_children) return fail(SQMC_ERR_BAD_ARG, "null argument");
   if (c->shard_n < 1 || !c->d_grow) return fail(SQMC_ERR_BAD_ARG, "sqmc_gpu_shard_config not called");
   if (c->rng_mode != SQMC_RNG_COUNTER) return fail(SQMC_ERR_UNSUPPORTED, "sharded steps need the COUNTER RNG discipline");
@@ -1393,27 +1401,32 @@ int sqmc_gpu_shard_begin(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double *x_
   p.semi = sp->semistochastic; p.reached = sp->reached_w_abs_gen;
   const long long n0 = c->nwalk, M = c->mwalk;
   ScanWork sw0; sw0.state = c->d_scan_state; sw0.ticket = c->d_scan_ticket; sw0.cap_tiles = c->cap_tiles; sw0.self_clear = false;
-  c->nt = 0;
   collect_timers(c);
+  c->nt = 0;
   if (n0 == 0) HIPCHK(hipMemsetAsync(&c->d_sc->n_children, 0, 4 * sizeof(u64) + 2 * sizeof(int), st));   // otherwise k_gate clears them
   if (x_global_dev && c->n_imp > 0) HIPCHK(hipMemsetAsync(x_global_dev, 0, c->n_imp * 8, st));
+  const bool mail = (n0 > 0 && M > n0);
+  const u64 cseq = ++c->cnt_seq;
   if (n0 > 0) {
     hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
                        n0, p, c->seed64, c->step_no, c->d_sc);
     device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st);
+    TBEG(spawn, st);
+    if (M > n0)      // first: it posts the child count to the host mailbox as soon as it starts
+      hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                         n0, M, p, c->rng_mode, c->seed64, c->step_no, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq);
+    TEND(spawn, st);
     hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc);
     if (c->n_imp_local > 0)
       hipLaunchKernelGGL(k_prj_gather_rows, dim3(nblk(c->n_imp_local)), dim3(TPB), 0, st, c->w.wt, c->d_loc_imp, c->d_grow, x_global_dev, c->n_imp_local);
-    TBEG(spawn, st);
-    if (M > n0)
-      hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, c->rng_mode, c->seed64, c->step_no, c->invalid_key, (const DevScalars *)c->d_sc, (HostMail *)nullptr, 0ull);
-    TEND(spawn, st);
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(&c->h_sc->n_children, &c->d_sc->n_children, 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  const long long nch = (long long)c->h_sc->n_children;
+  long long nch = 0;
+  int wr = mail ? wait_mail(&c->h_mail->cnt_seq, cseq, st) : -1;
+  if (wr > 0) return fail(SQMC_ERR_HIP, std::string("step failed on the device: ") + hipGetErrorString((hipError_t)wr));
+  if (wr == 0) nch = (long long)c->h_mail->n_children;
+  else if (n0 > 0) { u64 v; HIPCHK(hipMemcpyAsync(&v, &c->d_sc->n_children, 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); nch = (long long)v; }
+  if (full_sync) HIPCHK(hipStreamSynchronize(st));      // the caller's collective library reads x_global on its own stream
   if (n0 + nch > M) {
     hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
     return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
@@ -1421,6 +1434,10 @@ int sqmc_gpu_shard_begin(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double *x_
   c->shard_n0 = n0; c->shard_nch = nch;
   *n_children = nch;
   return SQMC_OK;
+}
+
+int sqmc_gpu_shard_begin(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double *x_global_dev, int64_t *n_children) {
+  return shard_begin_impl(c, sp, x_global_dev, n_children, true);
 }
 
 // phase 2: apply the owned rows of the deterministic projection with the all-reduced x_global, then
@@ -1494,6 +1511,7 @@ int sqmc_gpu_shard_finish(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const uin
       int rr = comm_allreduce_stats(c); if (rr) return rr;
       HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
+      c->mail_seq++;
       for (int i = 0; i < 7; i++) out[i] = c->h_sc->stats[i];
     }
     return SQMC_OK;
@@ -1586,7 +1604,7 @@ int sqmc_gpu_shard_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[
   hipStream_t st = c->st;
   const int P = c->shard_n, me = c->shard_rank;
   int64_t nch = 0;
-  int r = sqmc_gpu_shard_begin(c, sp, c->d_xg, &nch);
+  int r = shard_begin_impl(c, sp, c->d_xg, &nch, false);
   if (r) return r;
   if (c->n_imp > 0) NCCLCHK(g_rccl.AllReduce(c->d_xg, c->d_xg, (size_t)c->n_imp, ncclDouble, ncclSum, c->comm, st));
   // bucket + pack without a host round trip: every child is packed in destination order (the
