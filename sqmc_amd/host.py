@@ -825,3 +825,30 @@ def hci_pt2_determinant_basis(host, up, dn, coeffs, e_var, eps_pt):
         return hci_pt2(plain, g, du, dd, dc, e_var, eps_pt)
     finally:
         g.close()
+
+
+# ------------------------------------------------------------------------- Fortran host deck
+def dump_walk_deck(path, host, setup, walkers, w_target, e_trial, seed=(1346, 5634, 6635, 4361), mwalk=400000, rng_mode=RNG_COUNTER):
+    """Everything a compiled host needs to start the same walk through the C ABI, as one
+    little-endian stream file (read by sqmc_amd/fortran/example_walk.f90 with access='stream'):
+    an int64 header, then the tables in the order of the header.  This is test plumbing for the
+    Fortran binding: the reference builds these tables itself."""
+    prod, osym, c2 = (np.ascontiguousarray(a, np.int32).reshape(-1) for a in (host.prod, host.orbsym, host.combine_2))
+    ints = _np_f64(host.integrals)
+    cnt, idx, val = np.ascontiguousarray(setup.prj_counts, np.int64), np.ascontiguousarray(setup.prj_indices, np.int64), _np_f64(setup.prj_values)
+    n = len(walkers["up"])
+    hdr = np.array([0x73716D63, host.norb, host.nup, host.ndn, host.n_core_orb, int(host.time_sym), host.z, host.n_group, len(ints) - 1,
+                    rng_mode, seed[0], seed[1], seed[2], seed[3], mwalk, len(cnt), len(idx), len(setup.ct_up), n, len(prod), len(osym), len(c2)], np.int64)
+    scal = np.array([setup.tau, e_trial, w_target, float(np.abs(walkers["wt"]).sum())], np.float64)
+    with open(path, "wb") as f:
+        for a in (hdr, scal, prod, osym, c2, ints, cnt, idx, val,
+                  np.ascontiguousarray(setup.ct_up, np.uint64), np.ascontiguousarray(setup.ct_dn, np.uint64), _np_f64(setup.ct_num), _np_f64(setup.ct_den),
+                  np.ascontiguousarray(walkers["up"], np.uint64), np.ascontiguousarray(walkers["dn"], np.uint64), _np_f64(walkers["wt"]),
+                  np.ascontiguousarray(walkers["imp_distance"], np.int8), np.ascontiguousarray(walkers["initiator"], np.int8),
+                  np.ascontiguousarray(walkers["perm_sign"], np.int8), _np_f64(walkers["matrix_elements"]), _np_f64(walkers["e_num"]),
+                  _np_f64(walkers["e_den"])):
+            f.write(a.tobytes())
+
+
+def _np_f64(a):
+    return np.ascontiguousarray(a, np.float64)

@@ -497,3 +497,30 @@ def test_hci_pt2_matches_oracle_and_reference_run(oracle, c2_hci):
     assert 6.4e6 < n < 6.8e6
     assert abs(d - (-0.000979165)) < 2e-8
     assert abs(e[0] + d - (-75.728542168)) < 2e-8
+
+
+def test_fortran_host_walk(tmp_path):
+    """A Fortran host (sqmc_amd/fortran/example_walk.f90, iso_c_binding module only) starts the
+    C2 walk from the same tables and must land on exactly the state the Python-driven run reaches:
+    the boundary is the C ABI, not the Python around it."""
+    import os, subprocess
+    from sqmc_amd import host as H
+    root = os.path.dirname(os.path.dirname(__file__))
+    exe = os.path.join(root, "sqmc_amd", "fortran", "example_walk")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran example not built")
+    hst = H.ChemHost(os.path.join(root, "tests", "golden", "C2_r1.24253_FCIDUMP"), 8, 4, "d2h")
+    walk = H.GpuWalk(hst, 20000, w_begin=2000, seed=SEED, mwalk=400000)
+    wk = H.initial_walkers(walk.setup, 2000)
+    deck = str(tmp_path / "c2.deck")
+    H.dump_walk_deck(deck, hst, walk.setup, wk, 20000, walk.pc.e_trial, seed=SEED, mwalk=400000)
+    out = subprocess.run([exe, deck, "60", "20"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    last = [l for l in out.stdout.splitlines() if l.startswith("fortran walk:")][0].split()
+    f_steps, f_nwalk = int(last[2]), int(last[3])
+    f_wabs, f_etrial, f_num, f_den = (float(x) for x in last[4:8])
+    walk.run(60)
+    assert f_steps == 60 and f_nwalk == walk.g.num_walkers()
+    assert f_wabs == walk.w_abs and f_etrial == walk.pc.e_trial
+    assert f_num == walk.pc.e_num_cum and f_den == walk.pc.e_den_cum
+    walk.close()
