@@ -158,6 +158,15 @@ typedef struct {
  * totals[16] their sums over the nsteps steps.  pc is updated in place. */
 int sqmc_gpu_run(sqmc_gpu_ctx *ctx, sqmc_popctl *pc, int64_t nsteps, double *stats, double totals[16]);
 
+/* replaces: merge_sort2_up_dn + merge_original_with_spawned2 + reduce_my_walker and the estimator
+ * sums, do_walk.f90:2364-2487, 2573-2790, as one call for a host that produces its spawns itself:
+ * the n_spawn walkers (in creation order; weight 0 = no walker; imp_distance / initiator as
+ * move_uniform2 sets them, do_walk.f90:3700-3727) are appended behind the resident walkers, then
+ * sort, annihilation with the initiator rules, stochastic rounding, reweighting and the sums of
+ * sqmc_gpu_step.  out_stats as in sqmc_gpu_step (entry 15 = 0). */
+int sqmc_gpu_annihilate(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, int64_t n_spawn, const uint64_t *up, const uint64_t *dn,
+                        const double *wt, const int8_t *imp_distance, const int8_t *initiator, double out_stats[16]);
+
 /* ---- multi-rank sharding: one process per GPU, walkers owned by hash(det) mod nranks, as the
  * reference shards them over MPI ranks (get_det_owner, mpi_routines.f90:419-445).  The library
  * does no communication itself: the step is cut at the reference's two exchange points and the

@@ -14,7 +14,7 @@ _LIB = None
 EXPORTS = [
     "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_init_heg", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_projector",
     "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
-    "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_det_owner", "sqmc_gpu_shard_config",
+    "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_annihilate", "sqmc_gpu_det_owner", "sqmc_gpu_shard_config",
     "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init",
     "sqmc_gpu_shard_step", "sqmc_gpu_shard_run", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_spmv_prepare",
     "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
@@ -220,6 +220,16 @@ class GpuChem:
         out = np.zeros(16)
         code = self.L.sqmc_gpu_step(self.h, C.byref(p), _p(out))
         _chk(code)
+        return out
+
+    def annihilate(self, params, spawns):
+        """sqmc_gpu_annihilate: caller-supplied spawns (dict up/dn/wt/imp_distance/initiator) through
+        sort, merge, rounding and the estimator sums"""
+        p = StepParams(**params); out = np.zeros(16)
+        arrs = [_u64(spawns["up"]), _u64(spawns["dn"]), _f64(spawns["wt"]), np.ascontiguousarray(spawns["imp_distance"], np.int8),
+                np.ascontiguousarray(spawns["initiator"], np.int8)]
+        self.L.sqmc_gpu_annihilate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 6
+        _chk(self.L.sqmc_gpu_annihilate(self.h, C.byref(p), len(arrs[0]), *[_p(a) for a in arrs], _p(out)))
         return out
 
     def run(self, pc, nsteps, keep_stats=True):

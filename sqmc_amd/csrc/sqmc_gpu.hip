@@ -1300,6 +1300,50 @@ int sqmc_gpu_run(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats
   return run_steps(c, pc, nsteps, stats, totals, sqmc_gpu_step);
 }
 
+
+// keys of caller-supplied spawns (the "no walker" marker for weight 0, as k_spawn writes it)
+__global__ void __launch_bounds__(TPB) k_spawn_keys(ChemDev dev, WalkArr w, u64 *__restrict__ keys, u32 *__restrict__ vals, long long n0, long long nall, u64 invalid_key) {
+  long long k = n0 + (long long)blockIdx.x * TPB + threadIdx.x;
+  if (k >= nall) return;
+  keys[k] = (w.wt[k] != 0.0) ? det_key(dev, w.up[k], w.dn[k]) : invalid_key;
+  vals[k] = (u32)k;
+}
+
+// The second half of a step on its own: the caller's spawned walkers (creation order) are appended
+// behind the resident walkers, then sort -> merge_original_with_spawned2 -> reduce_my_walker ->
+// estimator sums run as in sqmc_gpu_step.  do_walk.f90:2364-2487 as one call; also the door the
+// parity tests use to put hand-built collision cases through k_merge.
+int sqmc_gpu_annihilate(sqmc_gpu_ctx *c, const sqmc_step_params *sp, int64_t n_spawn, const uint64_t *up, const uint64_t *dn, const double *wt,
+                        const int8_t *impd, const int8_t *init, double out[16]) {
+  if (!c || !sp || !out || n_spawn < 0) return fail(SQMC_ERR_BAD_ARG, "bad argument");
+  if (n_spawn > 0 && (!up || !dn || !wt || !impd || !init)) return fail(SQMC_ERR_BAD_ARG, "null spawn array");
+  if (c->mwalk <= 0 || c->nwalk <= 0) return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0");
+  if (c->d_grow) return fail(SQMC_ERR_BAD_ARG, "context is configured for sharded steps");
+  if (!c->d_ct_up) return fail(SQMC_ERR_BAD_ARG, "C(T) table not set");
+  if (!sp->semistochastic) return fail(SQMC_ERR_UNSUPPORTED, "join_walker2 (non-semistochastic walk) is not implemented this round");
+  const long long n0 = c->nwalk, nall = n0 + n_spawn;
+  if (nall > c->mwalk) return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
+  const u64 lim = c->htab.orb_mask;
+  for (long long i = 0; i < n_spawn; i++) if ((up[i] & ~lim) || (dn[i] & ~lim)) return fail(SQMC_ERR_BAD_ARG, "determinant has bits beyond norb");
+  hipStream_t st = c->st;
+  StepP p; p.tau = sp->tau; p.e_trial = sp->e_trial; p.rfi = sp->reweight_factor_inv; p.r_init = sp->r_initiator; p.min_wt = sp->min_wt;
+  p.cutoff = sp->always_spawn_cutoff_wt; p.ipow = sp->initiator_power; p.imind = sp->initiator_min_distance; p.cti = sp->c_t_initiator;
+  p.semi = sp->semistochastic; p.reached = sp->reached_w_abs_gen;
+  collect_timers(c);
+  c->nt = 0;
+  HIPCHK(hipStreamSynchronize(st));
+  if (n_spawn > 0) {
+    HIPCHK(hipMemcpy(c->w.up + n0, up, n_spawn * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.dn + n0, dn, n_spawn * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->w.wt + n0, wt, n_spawn * 8, hipMemcpyHostToDevice));
+    std::vector<u32> f(n_spawn); for (long long i = 0; i < n_spawn; i++) f[i] = pack_flg(impd[i], init[i], 0);
+    HIPCHK(hipMemcpy(c->w.flg + n0, f.data(), n_spawn * 4, hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipMemsetAsync(&c->d_sc->n_children, 0, 4 * sizeof(u64) + 2 * sizeof(int), st));
+  hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0);
+  if (n_spawn > 0) hipLaunchKernelGGL(k_spawn_keys, dim3(nblk(n_spawn)), dim3(TPB), 0, st, c->dev, c->w, c->d_keys, c->d_vals, n0, nall, c->invalid_key);
+  return step_tail(c, p, n0, nall, false, out);
+}
+
 // ------------------------------------------------------------------ multi-rank sharding
 // owner of a determinant (the role of get_det_owner, mpi_routines.f90:419-445; any hash will
 // do for ownership)

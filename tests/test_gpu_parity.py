@@ -524,3 +524,125 @@ def test_fortran_host_walk(tmp_path):
     assert f_wabs == walk.w_abs and f_etrial == walk.pc.e_trial
     assert f_num == walk.pc.e_num_cum and f_den == walk.pc.e_den_cum
     walk.close()
+
+
+@pytest.mark.parametrize("rng_mode,rfi", [(0, 1.0), (1, 1.0), (1, 0.93)])
+def test_annihilate_door_matches_oracle_merge(oracle, c2_walk, c2_setup, rng_mode, rfi):
+    """sqmc_gpu_annihilate against merge_sort2_up_dn + merge_original_with_spawned2 +
+    reduce_my_walker of the oracle on a collision-heavy hand-made spawn list: many spawns per
+    determinant in both signs, exact cancellations, spawns onto deterministic-space and onto the
+    permanent-initiator determinant, spawns from the deterministic space (imp_distance -1),
+    non-initiator spawns onto empty determinants, zero-weight proposals."""
+    rs = np.random.RandomState(1234 + rng_mode)
+    main = oracle.initial_walkers(c2_setup, 300)
+    n0 = len(main["up"])
+    pool = rs.choice(len(c2_setup.ct_up), 80, replace=False)
+    ns = 4000
+    from_main = rs.rand(ns) < 0.4
+    im, ip = rs.randint(0, n0, ns), pool[rs.randint(0, len(pool), ns)]
+    up = np.where(from_main, main["up"][im], c2_setup.ct_up[ip]).astype(np.uint64)
+    dn = np.where(from_main, main["dn"][im], c2_setup.ct_dn[ip]).astype(np.uint64)
+    wt = rs.choice([-1.0, 1.0], ns) * rs.choice([0.05, 0.2, 0.25, 0.4, 0.5, 0.75, 1.0, 1.5], ns)     # few distinct values: exact cancellations happen
+    wt[rs.rand(ns) < 0.05] = 0.0
+    impd = rs.choice([-1, 1, 2, 3, 5], ns).astype(np.int8)
+    init = np.where(impd == -1, 1, rs.randint(0, 2, ns)).astype(np.int8)
+    prm = dict(tau=c2_setup.tau, e_trial=-75.7, reweight_factor_inv=rfi, r_initiator=1.0, min_wt=0.5, always_spawn_cutoff_wt=0.5,
+               initiator_power=0, initiator_min_distance=0, c_t_initiator=0, semistochastic=1, reached_w_abs_gen=2)
+    # ---- oracle: the three routines in the order of do_walk.f90:2335-2473, then the reweighting of :2487
+    ow = oracle.OracleWalk(c2_walk, c2_setup, main, 50000, list(SEED), rng_mode=rng_mode)
+    w, nz = ow.w, np.nonzero(wt)[0]
+    for k, j in enumerate(nz):
+        i = n0 + k
+        w.up[i], w.dn[i], w.wt[i], w.imp_distance[i], w.initiator[i] = int(up[j]), int(dn[j]), float(wt[j]), int(impd[j]), int(init[j])
+        w.matrix_elements[i] = w.e_num_walker[i] = w.e_den_walker[i] = 1e51
+    n = n0 + len(nz)
+    p = oracle.StepParams(**prm)
+    L = oracle.lib()
+    L.orc_reduce_my_walker.restype = C.c_int64
+    L.orc_reduce_my_walker.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    L.orc_merge_sort_walkers(ow.h, n)
+    n = L.orc_merge_original_with_spawned2(ow.h, n, C.byref(p))
+    n = L.orc_reduce_my_walker(ow.h, n, C.byref(p))
+    ow.w.nwalk = n
+    ref = ow.walkers(); ow.close()
+    ref["wt"] = ref["wt"] * rfi
+    # ---- GPU door
+    g = gpu_ctx_from_oracle(c2_walk, rng_mode=rng_mode, seed=SEED, mwalk=50000)
+    g.set_projector(c2_setup.prj_counts, c2_setup.prj_indices, c2_setup.prj_values)
+    g.set_ct_table(c2_setup.ct_up, c2_setup.ct_dn, c2_setup.ct_num, c2_setup.ct_den)
+    g.upload_walkers(main)
+    out = g.annihilate(prm, dict(up=up, dn=dn, wt=wt, imp_distance=impd, initiator=init))
+    got = g.download_walkers(); g.close()
+    assert len(got["up"]) == n == int(out[5])
+    for k in ("up", "dn", "wt", "imp_distance", "initiator"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert int(out[7]) == n0 + len(nz)                      # nwalk_before_merge: zero-weight proposals are no walkers
+    assert n < n0 + len(nz) - 1000                          # the list really collided
+
+
+def test_error_statuses_match_reference_stops(oracle, c2_walk, c2_setup):
+    """The reference's own `stop`s come back as status codes with its texts, on
+    the same inputs for which the oracle reports them."""
+    from sqmc_amd import SqmcGpuError
+    main = oracle.initial_walkers(c2_setup, 300)
+    n0 = len(main["up"])
+    prm = dict(tau=c2_setup.tau, e_trial=-75.7, reweight_factor_inv=1.0, r_initiator=1.0, min_wt=0.5, always_spawn_cutoff_wt=0.5,
+               initiator_power=0, initiator_min_distance=0, c_t_initiator=0, semistochastic=1, reached_w_abs_gen=2)
+
+    def ctx(mwalk, ct=True, walkers=main):
+        g = gpu_ctx_from_oracle(c2_walk, rng_mode=1, seed=SEED, mwalk=mwalk)
+        g.set_projector(c2_setup.prj_counts, c2_setup.prj_indices, c2_setup.prj_values)
+        if ct:
+            g.set_ct_table(c2_setup.ct_up, c2_setup.ct_dn, c2_setup.ct_num, c2_setup.ct_den)
+        g.upload_walkers(walkers)
+        return g
+
+    # 'nwalk>MWALK' (do_walk.f90:3690): room for the walkers but not for their spawns
+    g = ctx(n0 + 50)
+    with pytest.raises(SqmcGpuError) as e:
+        g.step(prm)
+    assert e.value.code == 1 and "nwalk>MWALK" in str(e.value)
+    g.close()
+    ow = oracle.OracleWalk(c2_walk, c2_setup, main, n0 + 50, list(SEED), rng_mode=1)
+    assert ow.step(prm)[0] == 1
+    ow.close()
+    # 'diagonal_factor<0 after target population has been reached' (do_walk.f90:3788)
+    # (needs walkers outside the deterministic space: a few ordinary steps first, the same on both sides)
+    big = dict(prm, tau=50.0)
+    g = ctx(200000)
+    ow = oracle.OracleWalk(c2_walk, c2_setup, main, 200000, list(SEED), rng_mode=1)
+    for _ in range(5):
+        g.step(prm)
+        assert ow.step(prm)[0] == 0
+    with pytest.raises(SqmcGpuError) as e:
+        g.step(big)
+    assert e.value.code == 3 and "diagonal_factor<0" in str(e.value)
+    g.close()
+    assert ow.step(big)[0] == 3
+    ow.close()
+    # 'locations of my imp broken' (do_walk.f90:2204): a deterministic-space walker is missing
+    keep = np.ones(n0, bool); keep[np.nonzero(main["imp_distance"] == 0)[0][3]] = False
+    broken = {k: v[keep] for k, v in main.items()}
+    with pytest.raises(SqmcGpuError) as e:
+        ctx(200000, walkers=broken)
+    assert e.value.code == 5
+    # argument errors: unsorted walkers, no C(T) table, the walk variant that is not on the GPU
+    swapped = {k: v.copy() for k, v in main.items()}
+    for k in swapped:
+        swapped[k][[5, 6]] = swapped[k][[6, 5]]
+    with pytest.raises(SqmcGpuError) as e:
+        ctx(200000, walkers=swapped)
+    assert e.value.code == -1 and "sorted" in str(e.value)
+    g = ctx(200000, ct=False)
+    with pytest.raises(SqmcGpuError) as e:
+        g.step(prm)
+    assert e.value.code == -1
+    g.close()
+    g = ctx(200000)
+    with pytest.raises(SqmcGpuError) as e:
+        g.step(dict(prm, semistochastic=0))
+    assert e.value.code == -3
+    # and the context is still usable after a refused call
+    out = g.step(prm)
+    assert out[5] > 0
+    g.close()
