@@ -133,6 +133,48 @@ class ChemHost:
         return GpuChem(self.norb, self.nup, self.ndn, self.orbsym, self.prod.reshape(-1), self.combine_2.reshape(-1), self.integrals,
                        n_group=self.n_group, time_sym=self.time_sym, z=self.z, n_core_orb=self.n_core_orb, **kw)
 
+    def connected_all(self, up, dn):
+        """Every symmetry-allowed single and double excitation of one determinant, the determinant
+        itself first -- find_connected_dets_chem, chemistry.f90:6471-6815: membership is decided by
+        the irreps alone, the matrix element may be zero (which the heat-bath lists would skip).
+        With time-reversal symmetry the unique representatives (up <= dn).  Run-once host set-up."""
+        n, nc, os_, pr = self.norb, self.n_core_orb, self.orbsym, self.prod
+        fu = [i for i in range(n) if (up >> i) & 1]; eu = [i for i in range(n) if not (up >> i) & 1]
+        fd = [i for i in range(n) if (dn >> i) & 1]; ed = [i for i in range(n) if not (dn >> i) & 1]
+        sy = lambda o: int(os_[o + 1])
+        out = [(up, dn)]
+        for occ, emp, is_up in ((fu, eu, True), (fd, ed, False)):
+            det = up if is_up else dn
+            for a in range(nc, len(occ) - 1):
+                for b in range(a + 1, len(occ)):
+                    ps = pr[sy(occ[a]), sy(occ[b])]
+                    base = det & ~(1 << occ[a]) & ~(1 << occ[b])
+                    for k in range(len(emp) - 1):
+                        for l in range(k + 1, len(emp)):
+                            if ps == pr[sy(emp[k]), sy(emp[l])]:
+                                t = base | (1 << emp[k]) | (1 << emp[l])
+                                out.append((t, dn) if is_up else (up, t))
+        for a in range(nc, len(fu)):
+            for b in range(nc, len(fd)):
+                ps = pr[sy(fu[a]), sy(fd[b])]
+                for k in eu:
+                    tu = (up & ~(1 << fu[a])) | (1 << k)
+                    for l in ed:
+                        if ps == pr[sy(k), sy(l)]:
+                            out.append((tu, (dn & ~(1 << fd[b])) | (1 << l)))
+        for a in range(nc, len(fu)):
+            for k in eu:
+                if sy(fu[a]) == sy(k):
+                    out.append(((up & ~(1 << fu[a])) | (1 << k), dn))
+        for a in range(nc, len(fd)):
+            for k in ed:
+                if sy(fd[a]) == sy(k):
+                    out.append((up, (dn & ~(1 << fd[a])) | (1 << k)))
+        if self.time_sym:
+            out = [(min(a, b), max(a, b)) for a, b in out]
+        keys = sorted(set(out))
+        return np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint64)
+
     def diag_lowest_highest(self, g):
         nc, n = self.n_core_orb, self.norb
         mk = lambda k: (1 << k) - 1
@@ -270,7 +312,9 @@ def setup_walk(host, g, n_truncate_trial_wf=100, size_deterministic=1000, tau_mu
     """Psi_T, C(T) and the deterministic space from one connect-diagonalise-truncate pass."""
     s = WalkSetup()
     tiny = 1e-300
-    up, dn, _, _ = g.hci_connections([host.hf_up], [host.hf_dn], [1.0], tiny)     # sorted, unique
+    # the first-order space of the HF determinant by symmetry alone (zero matrix elements included:
+    # such determinants still couple to the rest of the space), as the reference builds it
+    up, dn = host.connected_all(host.hf_up, host.hf_dn)                            # sorted, unique
     w, X, _ = lowest_state(g, up, dn)
     c = X[:, 0]
     if c[np.argmax(np.abs(c))] < 0:

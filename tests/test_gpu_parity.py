@@ -125,14 +125,14 @@ def test_hci_connections_match_oracle(oracle, c2_walk, c2_hci, which, eps):
     assert np.allclose(gden, [den[k] for k in ks], rtol=0, atol=0)
 
 
-def _run_pair(oracle, sysm, setup, rng_mode, nsteps, w_begin, w_target, mwalk=400000, n_equil=10**9):
+def _run_pair(oracle, sysm, setup, rng_mode, nsteps, w_begin, w_target, mwalk=400000, n_equil=10**9, e_trial=-75.72):
     g = gpu_ctx_from_oracle(sysm, rng_mode=rng_mode, seed=SEED, mwalk=mwalk)
     g.set_projector(setup.prj_counts, setup.prj_indices, setup.prj_values)
     g.set_ct_table(setup.ct_up, setup.ct_dn, setup.ct_num, setup.ct_den)
     wk = oracle.initial_walkers(setup, w_begin)
     g.upload_walkers(wk)
     ow = oracle.OracleWalk(sysm, setup, wk, mwalk, SEED, rng_mode=rng_mode)
-    pc = oracle.PopControl(setup.tau, -75.72, w_target, n_equil_steps=n_equil)
+    pc = oracle.PopControl(setup.tau, e_trial, w_target, n_equil_steps=n_equil)
     w_abs = np.abs(wk["wt"]).sum()
     for it in range(nsteps):
         r = pc.pre_step(w_abs)
@@ -646,3 +646,29 @@ def test_error_statuses_match_reference_stops(oracle, c2_walk, c2_setup):
     out = g.step(prm)
     assert out[5] > 0
     g.close()
+
+
+@pytest.mark.parametrize("r", ["1.0", "1.6", "2.0"])
+def test_binding_curve_geometries_bit_exact(oracle, r):
+    """BASELINE.json configs[2]: other points of the C2 binding curve (different orbital orders and
+    symmetry labels in the FCIDUMP, stretched bonds with a multi-reference Psi_T).  Tables, Psi_T /
+    deterministic space from the host path, and a counter-mode trajectory, all against the oracle."""
+    import os
+    from sqmc_amd import host as H
+    path = os.path.join(os.path.dirname(__file__), "golden", "curve", "C2_r%s_FCIDUMP" % r)
+    sysm = oracle.ChemSystem(path, 8, 4, "d2h", time_sym=False, hf_mode=0)
+    setup = oracle.setup_walk(sysm, 100, 1000, 0.1)
+    # host-side tables of the product path agree with the oracle's for this geometry
+    hst = H.ChemHost(path, 8, 4, "d2h")
+    assert np.array_equal(hst.combine_2.reshape(-1), sysm.combine_2().reshape(-1))
+    assert np.array_equal(np.asarray(hst.orbsym), np.asarray(sysm.orbsym())) and np.array_equal(hst.integrals, sysm.integrals())
+    g = hst.gpu(mwalk=0)
+    s2 = hst.setup_walk(g, 100, 1000, 0.1)
+    g.close()
+    assert len(s2.psi_up) == len(setup.psi_up) and len(s2.imp_up) == len(setup.imp_up)
+    assert abs(s2.e_var - setup.e_var) < 1e-9 and abs(s2.tau - setup.tau) < 1e-15 and abs(s2.e_trial0 - setup.e_trial0) < 1e-8
+    wg, wc, _, _, og, oc = _run_pair(oracle, sysm, setup, 1, 60, 50, 5000, e_trial=setup.e_trial0)
+    for k in ("up", "dn", "imp_distance", "initiator"):
+        assert np.array_equal(wg[k], wc[k]), k
+    assert np.array_equal(wg["wt"], wc["wt"])
+    assert len(wg["up"]) > 1500
