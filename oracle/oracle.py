@@ -215,9 +215,12 @@ def sort_dets(up, dn):
 
 
 def lowest_eigs(counts, idx, val, k=1, v0=None, tol=1e-12):
-    """Lowest k eigenpairs of the symmetric matrix stored as lower-tri CSR.  The reference
-    uses its own Davidson (more_tools.f90:2018) + LAPACK dsyev; any converged eigensolver
-    gives the same pair to round-off, so the oracle uses scipy (dense below 600 rows)."""
+    """Lowest k eigenpairs of the symmetric matrix stored as lower-tri CSR with a library
+    eigensolver (scipy; dense below 600 rows).  Only used where the state asked for is
+    unambiguous (tests of the matvec/builder); the HCI and walk set-up paths use davidson_sparse
+    below, because a generic solver returns the GLOBAL lowest state while the reference's Davidson
+    stays in the symmetry sector of its starting vector (they differ where states of D_inf_h
+    symmetry that D2h cannot tell apart cross, e.g. C2 between r = 1.3 and 1.6 A)."""
     import scipy.sparse as sp
     import scipy.sparse.linalg as spl
     n = len(counts)
@@ -231,6 +234,88 @@ def lowest_eigs(counts, idx, val, k=1, v0=None, tol=1e-12):
     w, v = spl.eigsh(A, k=k, which="SA", v0=v0, tol=tol, ncv=max(2 * k + 1, 40))
     o = np.argsort(w)
     return w[o], v[:, o]
+
+
+def davidson_sparse(counts, idx, val, n_states=1, initial_vectors=None, epsilon=1.0e-10):
+    """davidson_sparse, more_tools.f90:2018-2244 (and its one-state twin davidson_sparse_single,
+    :3056-3230): diagonally preconditioned Davidson on the upper-triangular sparse storage.
+    Start: the given vectors (Gram-Schmidt in order, :2066-2082) or unit vectors on the first
+    n_states determinants (:2084-2088); one correction vector per state and sweep,
+    (H w - e w)/(e - H_ii) with -1 where the denominator vanishes (:2166-2169), orthogonalised
+    against the whole basis; dsyev on the Krylov matrix after every n_states additions; stop when
+    the eigenvalues move by less than epsilon (=1e-10, more_tools.f90:73) or the summed squared
+    correction norms fall below 1e-12; the basis of 50 vectors per state is recycled from the
+    current best vectors (:2142-2160).  Returns (eigenvalues[n_states], vectors[n, n_states])."""
+    n = len(counts)
+    counts = np.ascontiguousarray(counts, np.int64); idx = np.ascontiguousarray(idx, np.int64); val = np.ascontiguousarray(val, np.float64)
+    if n == 1:
+        return np.array([val[0]]), np.ones((1, 1))
+    mv = lambda x: spmv_sym_upper(counts, idx, val, x)
+    iterations = min(n, 50)
+    v = np.zeros((n, n_states * iterations)); Hv = np.zeros_like(v)
+    if initial_vectors is not None:
+        iv = np.asarray(initial_vectors, float).reshape(n, -1)
+        for i in range(n_states):
+            v[:, i] = iv[:, i] / np.sqrt(np.dot(iv[:, i], iv[:, i]))
+            if i > 0:
+                for j in range(i):
+                    v[:, i] -= np.dot(v[:, i], v[:, j]) * v[:, j]
+                v[:, i] /= np.sqrt(np.dot(v[:, i], v[:, i]))
+    else:
+        for i in range(n_states):
+            v[i, i] = 1.0
+    starts = np.concatenate(([0], np.cumsum(counts)))[:-1]
+    diag = val[starts]
+    hk = np.zeros((n_states * iterations, n_states * iterations))
+    for i in range(n_states):
+        Hv[:, i] = mv(v[:, i])
+    low = np.zeros(n_states)
+    for i in range(n_states):
+        low[i] = np.dot(v[:, i], Hv[:, i]); hk[i, i] = low[i]
+        for j in range(i + 1, n_states):
+            hk[i, j] = hk[j, i] = np.dot(v[:, i], Hv[:, j])
+    w, Hw = v[:, :n_states].copy(), Hv[:, :n_states].copy()
+    res = np.ones(n_states)
+    niter = min(n, n_states * iterations)
+    low_prev = np.full(n_states, np.inf)
+    converged = False
+    it = n_states
+    while it < niter * 10:
+        it += 1
+        itc = (it - 1) % niter + 1
+        if it > niter and itc == 1:
+            v[:, :n_states], Hv[:, :n_states] = w, Hw
+            for i in range(n_states):
+                low[i] = np.dot(v[:, i], Hv[:, i]); hk[i, i] = low[i]
+                for j in range(i + 1, n_states):
+                    hk[i, j] = hk[j, i] = np.dot(v[:, i], Hv[:, j])
+            continue
+        i = (itc - 1) % n_states
+        den = low[i] - diag
+        small = np.abs(den) < 1e-8
+        t = (Hw[:, i] - low[i] * w[:, i]) / np.where(small, 1.0, den)
+        t[small] = -1.0
+        res[i] = np.dot(t, t)
+        if res.sum() < 1.0e-12:
+            converged = True
+        for j in range(itc - 1):
+            t -= np.dot(t, v[:, j]) * v[:, j]
+        t /= np.sqrt(np.dot(t, t))
+        v[:, itc - 1] = t
+        Hv[:, itc - 1] = mv(t)
+        for j in range(itc):
+            hk[j, itc - 1] = hk[itc - 1, j] = np.dot(v[:, j], Hv[:, itc - 1])
+        if itc % n_states == 0:
+            ev, y = np.linalg.eigh(hk[:itc, :itc])
+            low = ev[:n_states].copy()
+            w = v[:, :itc] @ y[:, :n_states]
+            Hw = Hv[:, :itc] @ y[:, :n_states]
+            if np.max(np.abs(low - low_prev)) < epsilon:
+                break
+            low_prev = low.copy()
+            if converged:
+                break
+    return low, w
 
 
 def hci_variational(sysm, eps_var, eps_sched=(), n_states=1, max_iters=50, log=None):
@@ -265,13 +350,19 @@ def hci_variational(sysm, eps_var, eps_sched=(), n_states=1, max_iters=50, log=N
             break
         up = np.concatenate((up, np.array([a for a, _ in add], np.uint64)))
         dn = np.concatenate((dn, np.array([b for _, b in add], np.uint64)))
-        # diagonalise in sorted order, report in list order
+        # hci.f90:453-476 + iterative_diagonalize 1042-1095: the list keeps its order (old determinants,
+        # then the new ones sorted); the sparse H builder wants sorted labels, so rows are permuted
+        # back and forth around it.  Starting vectors: the previous eigenvectors padded with zeros;
+        # in iteration 1 unit vectors on the first n_states determinants of the list.
         order = sort_dets(up, dn)
         counts, idx, val = sysm.build_sparse_ham(up[order], dn[order])
-        v0 = np.zeros(n_new); v0[np.argsort(order)[:n_old]] = wts[:, 0] if it > 1 else 0.0
-        if it == 1 or not np.any(v0):
-            v0 = None
-        w, v = lowest_eigs(counts, idx, val, k=n_states, v0=v0)
+        start = np.zeros((n_new, n_states))
+        if it == 1:
+            for i in range(min(n_states, n_new)):
+                start[i, i] = 1.0
+        else:
+            start[:n_old, :] = wts
+        w, v = davidson_sparse(counts, idx, val, n_states, initial_vectors=start[order, :])
         wts = np.zeros((n_new, n_states)); wts[order, :] = v
         energy = w.copy()
         hist.append(n_new)
@@ -333,7 +424,7 @@ def setup_walk(sysm, n_truncate_trial_wf=100, size_deterministic=1000, tau_multi
         w = np.array([h00])
     else:
         counts, idx, val = sysm.build_sparse_ham(up, dn)
-        w, v = lowest_eigs(counts, idx, val, k=1)
+        w, v = davidson_sparse(counts, idx, val, 1)          # starts on the first (= HF) determinant, more_tools.f90:3113-3114
         c = v[:, 0]
         if c[np.argmax(np.abs(c))] < 0:
             c = -c
@@ -608,7 +699,7 @@ def setup_walk_heg(hsys, size_deterministic=500, tau_multiplier=0.1, n_truncate_
     order = sort_dets(cu, cd)
     up, dn = cu[order], cd[order]
     counts, idx, val = hsys.build_sparse_ham(up, dn)
-    w, v = lowest_eigs(counts, idx, val, k=1)
+    w, v = davidson_sparse(counts, idx, val, 1)
     c = v[:, 0]
     if c[np.argmax(np.abs(c))] < 0:
         c = -c

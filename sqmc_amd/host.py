@@ -45,7 +45,10 @@ def _dets_to_bits(det):
 class ChemHost:
     """Tables of module chemistry for one FCIDUMP, in the reference's conventions."""
 
-    def __init__(self, fcidump, nelec, nup, point_group="d2h", time_sym=False, z=1, n_core_orb=0):
+    def __init__(self, fcidump, nelec, nup, point_group="d2h", time_sym=False, z=1, n_core_orb=0, hf_symmetry=None):
+        """hf_symmetry: the `&hf_det hf_symmetry=k /` line of the HCI decks -- the starting determinant
+        is then found by the reference's descent (needs the GPU for the matrix elements); None keeps
+        the first orbitals of the file (the walk decks)."""
         self.norb, orbsym, vals, idx = read_fcidump(fcidump)
         n, n1 = self.norb, self.norb + 1
         self.nelec, self.nup, self.ndn = nelec, nup, nelec - nup
@@ -71,7 +74,82 @@ class ChemHost:
         self.orbsym_file = np.array([0] + list(orbsym), np.int32)
         # starting determinant: first orbitals (chemistry.f90:700-712)
         hf_up, hf_dn = (1 << self.nup) - 1, (1 << self.ndn) - 1
+        if hf_symmetry is not None:
+            hf_up, hf_dn = self._auto_hf(hf_up, hf_dn, int(hf_symmetry))
         self._finish(hf_up, hf_dn)
+
+    def _auto_hf(self, hu, hd, hf_symmetry):
+        """auto_assign_hci0_occs with a starting determinant (chemistry.f90:10359-10522): move to the
+        lowest-diagonal determinant of total symmetry hf_symmetry among the current determinant and
+        all its single and double excitations (first one wins a tie, in the generation order of
+        find_connected_dets_chem), until nothing lower is found.  File orbital order."""
+        self.orbsym, self.combine_2 = self.orbsym_file.copy(), self._c2_id
+        g = self.gpu()
+        try:
+            du = dd = 0
+            while (hu, hd) != (du, dd):
+                if du != 0:
+                    hu, hd = du, dd
+                cand = [(a, b) for a, b in self._connected_in_order(hu, hd, hf_symmetry)
+                        if not (self.time_sym and self.z < 0 and a == b)]
+                cu = np.array([a for a, _ in cand], np.uint64); cd = np.array([b for _, b in cand], np.uint64)
+                e = g.hamiltonian_batch(cu, cd, cu, cd)
+                k = int(np.argmin(e))                     # first minimum
+                du, dd = cand[k]
+        finally:
+            g.close()
+        return hu, hd
+
+    def _det_sym(self, up, dn):
+        sym = 1
+        for det in (up, dn):
+            for k in _dets_to_bits(det):
+                sym = int(self.prod[sym, self.orbsym[k + 1]])
+        return sym
+
+    def _connected_in_order(self, up, dn, sym_filter=0):
+        """find_connected_dets_chem, chemistry.f90:6471-6815, in its own order: the determinant, up-up,
+        dn-dn and up-dn doubles, up singles, dn singles.  sym_filter = 0: excitations allowed by the
+        irreps of the orbitals involved (the matrix element may still vanish); > 0: every excitation
+        whose determinant has that total symmetry."""
+        n, nc, os_, pr = self.norb, self.n_core_orb, self.orbsym, self.prod
+        fu = [i for i in range(n) if (up >> i) & 1]; eu = [i for i in range(n) if not (up >> i) & 1]
+        fd = [i for i in range(n) if (dn >> i) & 1]; ed = [i for i in range(n) if not (dn >> i) & 1]
+        sy = lambda o: int(os_[o + 1])
+        ok = (lambda a, b, pair: self._det_sym(a, b) == sym_filter) if sym_filter else (lambda a, b, pair: pair)
+        out = [(up, dn)]
+        for occ, emp, is_up in ((fu, eu, True), (fd, ed, False)):
+            det = up if is_up else dn
+            for a in range(nc, len(occ) - 1):
+                for b in range(a + 1, len(occ)):
+                    ps = pr[sy(occ[a]), sy(occ[b])]
+                    base = det & ~(1 << occ[a]) & ~(1 << occ[b])
+                    for k in range(len(emp) - 1):
+                        for l in range(k + 1, len(emp)):
+                            t = base | (1 << emp[k]) | (1 << emp[l])
+                            d2 = (t, dn) if is_up else (up, t)
+                            if ok(d2[0], d2[1], ps == pr[sy(emp[k]), sy(emp[l])]):
+                                out.append(d2)
+        for a in range(nc, len(fu)):
+            for b in range(nc, len(fd)):
+                ps = pr[sy(fu[a]), sy(fd[b])]
+                for k in eu:
+                    tu = (up & ~(1 << fu[a])) | (1 << k)
+                    for l in ed:
+                        td = (dn & ~(1 << fd[b])) | (1 << l)
+                        if ok(tu, td, ps == pr[sy(k), sy(l)]):
+                            out.append((tu, td))
+        for a in range(nc, len(fu)):
+            for k in eu:
+                t = (up & ~(1 << fu[a])) | (1 << k)
+                if ok(t, dn, sy(fu[a]) == sy(k)):
+                    out.append((t, dn))
+        for a in range(nc, len(fd)):
+            for k in ed:
+                t = (dn & ~(1 << fd[a])) | (1 << k)
+                if ok(up, t, sy(fd[a]) == sy(k)):
+                    out.append((up, t))
+        return out
 
     @staticmethod
     def _index(c2, i, j, k, l):
@@ -134,42 +212,10 @@ class ChemHost:
                        n_group=self.n_group, time_sym=self.time_sym, z=self.z, n_core_orb=self.n_core_orb, **kw)
 
     def connected_all(self, up, dn):
-        """Every symmetry-allowed single and double excitation of one determinant, the determinant
-        itself first -- find_connected_dets_chem, chemistry.f90:6471-6815: membership is decided by
-        the irreps alone, the matrix element may be zero (which the heat-bath lists would skip).
-        With time-reversal symmetry the unique representatives (up <= dn).  Run-once host set-up."""
-        n, nc, os_, pr = self.norb, self.n_core_orb, self.orbsym, self.prod
-        fu = [i for i in range(n) if (up >> i) & 1]; eu = [i for i in range(n) if not (up >> i) & 1]
-        fd = [i for i in range(n) if (dn >> i) & 1]; ed = [i for i in range(n) if not (dn >> i) & 1]
-        sy = lambda o: int(os_[o + 1])
-        out = [(up, dn)]
-        for occ, emp, is_up in ((fu, eu, True), (fd, ed, False)):
-            det = up if is_up else dn
-            for a in range(nc, len(occ) - 1):
-                for b in range(a + 1, len(occ)):
-                    ps = pr[sy(occ[a]), sy(occ[b])]
-                    base = det & ~(1 << occ[a]) & ~(1 << occ[b])
-                    for k in range(len(emp) - 1):
-                        for l in range(k + 1, len(emp)):
-                            if ps == pr[sy(emp[k]), sy(emp[l])]:
-                                t = base | (1 << emp[k]) | (1 << emp[l])
-                                out.append((t, dn) if is_up else (up, t))
-        for a in range(nc, len(fu)):
-            for b in range(nc, len(fd)):
-                ps = pr[sy(fu[a]), sy(fd[b])]
-                for k in eu:
-                    tu = (up & ~(1 << fu[a])) | (1 << k)
-                    for l in ed:
-                        if ps == pr[sy(k), sy(l)]:
-                            out.append((tu, (dn & ~(1 << fd[b])) | (1 << l)))
-        for a in range(nc, len(fu)):
-            for k in eu:
-                if sy(fu[a]) == sy(k):
-                    out.append(((up & ~(1 << fu[a])) | (1 << k), dn))
-        for a in range(nc, len(fd)):
-            for k in ed:
-                if sy(fd[a]) == sy(k):
-                    out.append((up, (dn & ~(1 << fd[a])) | (1 << k)))
+        """Every symmetry-allowed single and double excitation of one determinant plus itself, sorted
+        and unique (with time-reversal symmetry: the representatives up <= dn).  Membership is decided
+        by the irreps alone; the matrix element may be zero, which the heat-bath lists would skip."""
+        out = self._connected_in_order(up, dn)
         if self.time_sym:
             out = [(min(a, b), max(a, b)) for a, b in out]
         keys = sorted(set(out))
@@ -234,47 +280,77 @@ class ChemHost:
 
 
 # ----------------------------------------------------------------------------- Davidson
-def davidson_lowest(plan, diag, k=1, v0=None, tol=1e-10, max_iter=200, max_space=40):
-    """Lowest k eigenpairs with the GPU matvec (davidson_sparse, more_tools.f90:2018-2244:
-    diagonal preconditioner, small Krylov matrix diagonalised on the host)."""
+def davidson_lowest(plan, diag, k=1, v0=None, tol=1e-10):
+    """Lowest k eigenpairs with the GPU matvec, following the reference's own iteration so that
+    the SAME state is tracked (davidson_sparse, more_tools.f90:2018-2244; one-state twin
+    davidson_sparse_single :3056-3230).  Start: v0 (Gram-Schmidt in order) or unit vectors on the
+    first k rows; per sweep one correction vector per state, (H w - e w)/(e - H_ii) with -1 where
+    the denominator vanishes, orthogonalised against the whole basis; the small Krylov matrix is
+    diagonalised on the host after every k additions; stop when the eigenvalues move by less than
+    tol (epsilon = 1e-10, more_tools.f90:73) or the summed squared correction norms fall below
+    1e-12; the 50-vectors-per-state basis is recycled from the current best vectors.  A start in
+    one symmetry sector stays there: a generic "lowest eigenvalue" solver would not."""
     n = len(diag)
-    if v0 is None:
-        v0 = np.zeros((n, k))
-        for j, i in enumerate(np.argsort(diag)[:k]):
-            v0[i, j] = 1.0
-    V = np.linalg.qr(v0.reshape(n, -1))[0]
-    AV = np.stack([plan.apply(V[:, j]) for j in range(V.shape[1])], axis=1)
-    for it in range(max_iter):
-        G = V.T @ AV
-        w, y = np.linalg.eigh((G + G.T) / 2)
-        w, y = w[:k], y[:, :k]
-        X, AX = V @ y, AV @ y
-        R = AX - X * w
-        res = np.linalg.norm(R, axis=0)
-        if np.all(res < tol):
-            return w, X
-        if V.shape[1] + k > max_space:
-            V, AV = np.linalg.qr(X)[0], None
-            AV = np.stack([plan.apply(V[:, j]) for j in range(V.shape[1])], axis=1)
+    if n == 1:
+        return np.array([diag[0]]), np.ones((1, 1))
+    iterations = min(n, 50)
+    v = np.zeros((n, k * iterations)); Hv = np.zeros_like(v)
+    if v0 is not None:
+        iv = np.asarray(v0, float).reshape(n, -1)
+        for i in range(k):
+            v[:, i] = iv[:, i] / np.sqrt(np.dot(iv[:, i], iv[:, i]))
+            if i > 0:
+                for j in range(i):
+                    v[:, i] -= np.dot(v[:, i], v[:, j]) * v[:, j]
+                v[:, i] /= np.sqrt(np.dot(v[:, i], v[:, i]))
+    else:
+        for i in range(k):
+            v[i, i] = 1.0
+    hk = np.zeros((k * iterations, k * iterations))
+    low = np.zeros(k)
+
+    def seed_block():
+        for i in range(k):
+            low[i] = np.dot(v[:, i], Hv[:, i]); hk[i, i] = low[i]
+            for j in range(i + 1, k):
+                hk[i, j] = hk[j, i] = np.dot(v[:, i], Hv[:, j])
+    for i in range(k):
+        Hv[:, i] = plan.apply(v[:, i])
+    seed_block()
+    w, Hw = v[:, :k].copy(), Hv[:, :k].copy()
+    res, low_prev, converged = np.ones(k), np.full(k, np.inf), False
+    niter = min(n, k * iterations)
+    it = k
+    while it < niter * 10:
+        it += 1
+        itc = (it - 1) % niter + 1
+        if it > niter and itc == 1:
+            v[:, :k], Hv[:, :k] = w, Hw
+            seed_block()
             continue
-        new = []
-        for j in range(k):
-            if res[j] < tol:
-                continue
-            d = diag - w[j]
-            d[np.abs(d) < 1e-8] = 1e-8
-            t = R[:, j] / d
-            t -= V @ (V.T @ t); t -= V @ (V.T @ t)
-            nt = np.linalg.norm(t)
-            if nt > 1e-12:
-                new.append(t / nt)
-        if not new:
-            return w, X
-        Vn = np.stack(new, axis=1)
-        Vn = np.linalg.qr(Vn - V @ (V.T @ Vn))[0]
-        AV = np.concatenate((AV, np.stack([plan.apply(Vn[:, j]) for j in range(Vn.shape[1])], axis=1)), axis=1)
-        V = np.concatenate((V, Vn), axis=1)
-    return w, X
+        i = (itc - 1) % k
+        den = low[i] - diag
+        small = np.abs(den) < 1e-8
+        t = (Hw[:, i] - low[i] * w[:, i]) / np.where(small, 1.0, den)
+        t[small] = -1.0
+        res[i] = np.dot(t, t)
+        if res.sum() < 1.0e-12:
+            converged = True
+        for j in range(itc - 1):
+            t -= np.dot(t, v[:, j]) * v[:, j]
+        t /= np.sqrt(np.dot(t, t))
+        v[:, itc - 1] = t
+        Hv[:, itc - 1] = plan.apply(t)
+        for j in range(itc):
+            hk[j, itc - 1] = hk[itc - 1, j] = np.dot(v[:, j], Hv[:, itc - 1])
+        if itc % k == 0:
+            ev, y = np.linalg.eigh(hk[:itc, :itc])
+            low = ev[:k].copy()
+            w, Hw = v[:, :itc] @ y[:, :k], Hv[:, :itc] @ y[:, :k]
+            if np.max(np.abs(low - low_prev)) < tol or converged:
+                break
+            low_prev = low.copy()
+    return low, w
 
 
 def sort_dets(up, dn):

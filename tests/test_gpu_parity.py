@@ -339,7 +339,7 @@ def test_hci_variational_matches_reference_run():
     determinants with the eigenvector's round-off at the selection threshold."""
     from conftest import FCIDUMP
     from sqmc_amd import host as H
-    h = H.ChemHost(FCIDUMP, 8, 4, "d2h", time_sym=True, z=1)
+    h = H.ChemHost(FCIDUMP, 8, 4, "d2h", time_sym=True, z=1, hf_symmetry=1)
     g = h.gpu()
     g.set_hb_tables(*h.hb_tables(g))
     up, dn, w, e, hist = H.hci_variational(h, g, 1e-4, eps_sched=(2e-4, 2e-4), n_states=1)
@@ -348,6 +348,24 @@ def test_hci_variational_matches_reference_run():
     assert abs(hist[4] - 126386) <= 3 and abs(hist[5] - 126708) <= 3
     assert abs(e[0] - (-75.727563003)) < 2e-9
     assert abs(np.dot(w[:, 0], w[:, 0]) - 1.0) < 1e-9
+
+
+def test_hci_two_states_match_reference_run():
+    """The deck exactly as shipped (C2_v2z_curve/r1.24253/i_1sigma_g: eps_var 1e-3 after two
+    iterations at 2e-3, TWO states, time_sym): the reference's run went 650 -> 3767 -> 11787 ->
+    12705 -> 12776 determinants with E_var(1) = -75.719473642, E_var(2) = -75.631097209
+    (BASELINE.md section 2).  Needs the reference's own Davidson iteration: the second root is
+    tracked from a unit vector on the second determinant of the list."""
+    from conftest import FCIDUMP
+    from sqmc_amd import host as H
+    h = H.ChemHost(FCIDUMP, 8, 4, "d2h", time_sym=True, z=1, hf_symmetry=1)
+    g = h.gpu()
+    g.set_hb_tables(*h.hb_tables(g))
+    up, dn, w, e, hist = H.hci_variational(h, g, 1e-3, eps_sched=(2e-3, 2e-3), n_states=2)
+    g.close()
+    assert hist == [1, 650, 3767, 11787, 12705, 12776]
+    assert abs(e[0] - (-75.719473642)) < 2e-9 and abs(e[1] - (-75.631097209)) < 2e-9
+    assert abs(np.dot(w[:, 0], w[:, 1])) < 1e-8
 
 
 def test_time_sym_proposals_bit_exact(oracle, c2_hci):
@@ -481,7 +499,7 @@ def test_hci_pt2_matches_oracle_and_reference_run(oracle, c2_hci):
     E_total = -75.728542168)."""
     from conftest import FCIDUMP
     from sqmc_amd import host as H
-    h = H.ChemHost(FCIDUMP, 8, 4, "d2h", time_sym=True, z=1)
+    h = H.ChemHost(FCIDUMP, 8, 4, "d2h", time_sym=True, z=1, hf_symmetry=1)
     g = h.gpu()
     g.set_hb_tables(*h.hb_tables(g))
     up, dn, w, e, hist = H.hci_variational(h, g, 2e-3, eps_sched=(2e-3,), n_states=1, max_iters=2)
@@ -672,3 +690,25 @@ def test_binding_curve_geometries_bit_exact(oracle, r):
         assert np.array_equal(wg[k], wc[k]), k
     assert np.array_equal(wg["wt"], wc["wt"])
     assert len(wg["up"]) > 1500
+
+
+@pytest.mark.parametrize("r", ["1.3", "1.6"])
+def test_hci_deck_conventions_across_curve(oracle, r):
+    """The shipped HCI decks say `&hf_det hf_symmetry=1 /`: the starting determinant comes from the
+    reference's descent, and between r = 1.3 and 1.6 A (3 sigma_g / 1 pi_u crossing) it is NOT the
+    first four orbitals of the FCIDUMP.  Host tables and the HCI iteration (reference Davidson from
+    that determinant) against the oracle."""
+    import os
+    from sqmc_amd import host as H
+    path = os.path.join(os.path.dirname(__file__), "golden", "curve", "C2_r%s_FCIDUMP" % r)
+    sysm = oracle.ChemSystem(path, 8, 4, "d2h", time_sym=True, z=1, hf_mode=1, hf_symmetry=1)
+    h = H.ChemHost(path, 8, 4, "d2h", time_sym=True, z=1, hf_symmetry=1)
+    assert (h.hf_up, h.hf_dn) == (sysm.hf_up, sysm.hf_dn)
+    assert np.array_equal(h.orbsym, sysm.orbsym()) and np.array_equal(h.combine_2, sysm.combine_2())
+    g = h.gpu()
+    g.set_hb_tables(*h.hb_tables(g))
+    up, dn, w, e, hist = H.hci_variational(h, g, 2e-3, n_states=1)
+    g.close()
+    ou, od, ow_, oe, ohist = oracle.hci_variational(sysm, 2e-3, n_states=1)
+    assert hist == ohist and abs(e[0] - oe[0]) < 1e-9
+    assert np.array_equal(up, ou) and np.array_equal(dn, od)

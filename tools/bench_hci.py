@@ -11,7 +11,7 @@ from sqmc_amd import host as H
 
 FCIDUMP = os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP")
 t0 = time.perf_counter()
-h = H.ChemHost(FCIDUMP, 8, 4, "d2h", time_sym=True, z=1)
+h = H.ChemHost(FCIDUMP, 8, 4, "d2h", time_sym=True, z=1, hf_symmetry=1)
 g = h.gpu()
 g.set_hb_tables(*h.hb_tables(g))
 t1 = time.perf_counter()

@@ -40,7 +40,7 @@ def main():
     for r in args.geoms.split(","):
         rec = {"r_A": float(r)}
         # ---- HCI + PT2 (shipped deck conventions: time_sym=t, z=1, hf_symmetry=1)
-        h = H.ChemHost(fcidump(r), 8, 4, "d2h", time_sym=True, z=1)
+        h = H.ChemHost(fcidump(r), 8, 4, "d2h", time_sym=True, z=1, hf_symmetry=1)
         g = h.gpu()
         g.set_hb_tables(*h.hb_tables(g))
         t0 = time.perf_counter()
