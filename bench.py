@@ -37,6 +37,10 @@ def main():
     ap.add_argument("--target", type=float, default=1e5, help="w_abs_gen_target")
     ap.add_argument("--equil", type=int, default=400, help="untimed equilibration steps before warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--system", default="c2", choices=["c2", "heg"], help="c2 = BASELINE.json configs[1] (the metric's config, default); "
+                    "heg = the 14-electron 3D electron gas of configs[3] (auxiliary; no CPU baseline leg)")
+    ap.add_argument("--heg-rs", type=float, default=1.0)
+    ap.add_argument("--heg-cutoff", type=float, default=2.3, help="plane-wave cutoff radius (2.3 -> 57 orbitals; the GPU path holds at most 64)")
     args = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
@@ -58,7 +62,12 @@ def main():
     comm_dev = "cuda" if (world > 1 and backend == "nccl") else "cpu"
     sqmc_amd.set_device(local)
 
-    hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+    if args.system == "heg":
+        hst = H.HegHost(3, args.heg_rs, 14, 7, args.heg_cutoff)
+        workload = "3D HEG r_s=%g, 14 electrons in %d plane waves, semistochastic walk" % (args.heg_rs, hst.norb)
+    else:
+        hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+        workload = "C2 cc-pVDZ r=1.24253 (8e,26o, D2h) semistochastic walk, uniform2 proposal"
 
     def fence():
         torch.cuda.synchronize()
@@ -72,7 +81,8 @@ def main():
         # weak scaling: the global target grows with the number of GPUs, determinants are sharded by
         # hash ownership and spawns cross ranks through one RCCL all-to-all per step
         try:
-            walk = H.ShardedWalk(hst, args.target * world, rank, world, device_index=local, seed=(1346, 5634, 6635, 4361))
+            skw = dict(w_begin=min(args.target * world, 1e4), n_truncate_trial_wf=1, size_deterministic=500) if args.system == "heg" else {}
+            walk = H.ShardedWalk(hst, args.target * world, rank, world, device_index=local, seed=(1346, 5634, 6635, 4361), **skw)
             ok = torch.ones(1, device=comm_dev)
         except Exception as exc:                      # keep the scaling run alive: independent replicas
             sys.stderr.write("rank %d: sharded set-up failed (%r); falling back to replicas\n" % (rank, exc))
@@ -97,9 +107,10 @@ def main():
                     parallelism = "sharded x%d (hash-owned determinants), in-library RCCL: all-reduce + all-to-all of spawns + all-reduce per step" % world
                 else:                                     # same walk, exchanges from Python
                     walk.close()
-                    walk = H.ShardedWalk(hst, args.target * world, rank, world, device_index=local, seed=(1346, 5634, 6635, 4361))
+                    walk = H.ShardedWalk(hst, args.target * world, rank, world, device_index=local, seed=(1346, 5634, 6635, 4361), **skw)
     if walk is None:
-        walk = H.GpuWalk(hst, args.target, seed=H.rank_seed((1346, 5634, 6635, 4361), rank))
+        kw = dict(w_begin=min(args.target, 1e4), n_truncate_trial_wf=1, size_deterministic=500) if args.system == "heg" else {}
+        walk = H.GpuWalk(hst, args.target, seed=H.rank_seed((1346, 5634, 6635, 4361), rank), **kw)
         if world > 1:
             parallelism = "replicas x%d (sharded path unavailable)" % world
     sharded = isinstance(walk, H.ShardedWalk)
@@ -159,17 +170,17 @@ def main():
             "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2 cc-pVDZ r=1.24253 (8e,26o, D2h) semistochastic walk, uniform2 proposal, w_abs_gen_target=%g, "
-                                   "size_deterministic=1000, Psi_T 100 dets, min_wt 0.5, r_initiator 1, tau_multiplier 0.1" % (args.target * (world if sharded else 1)),
+            "config": {"workload": workload + ", w_abs_gen_target=%g, size_deterministic=1000, Psi_T 100 dets, min_wt 0.5, r_initiator 1, "
+                                   "tau_multiplier 0.1" % (args.target * (world if sharded else 1)),
                        "occupied_dets_per_step": n_avg, "spawns_per_step": s_avg, "spawns_per_s": spawn_all / dt,
                        "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": parallelism},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": TRAFFIC_K_SPAWN, "ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": 84.0 * s_avg,
+                         "traffic": TRAFFIC_K_SPAWN if (args.system == "c2" and args.target == 1e5 and world == 1) else None, "ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": 84.0 * s_avg,
                          "whole_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
                                         "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
                          "stage_ms_per_step": stage_ms},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.system == "c2":
             line["cpu_baseline"] = cpu_baseline(walk, hst, n_avg)
         print(json.dumps(line), flush=True)
     walk.close()

@@ -13,7 +13,7 @@ SEED = (1346, 5634, 6635, 4361)
 NSTEPS, W_BEGIN, W_TARGET = 40, 2000, 20000
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, system="c2"):
     import torch                                   # before the HIP library (one libamdhip64 per process)
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -22,8 +22,12 @@ def _worker(rank, world, port, outdir):
     import sqmc_amd
     from sqmc_amd import host as H
     sqmc_amd.set_device(0)
-    hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
-    w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
+    if system == "heg":       # 14 electrons, 19 plane waves: the reference's e2e HEG system (BASELINE.json configs[3] is its big brother)
+        hst = H.HegHost(3, 0.5, 14, 7, 1.49)
+        w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000, n_truncate_trial_wf=1, size_deterministic=250)
+    else:
+        hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+        w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
     outs = []
     for _ in range(NSTEPS):
         outs.append(w.step().copy())
@@ -36,10 +40,10 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def _run(world, tmp_path, port):
+def _run(world, tmp_path, port, system="c2"):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    ps = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), system)) for r in range(world)]
     for p in ps: p.start()
     for p in ps: p.join(600)
     assert all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
@@ -151,3 +155,25 @@ def test_in_library_rccl_exchange_single_rank(tmp_path):
     assert np.array_equal(res["up"], wk["up"]) and np.array_equal(res["dn"], wk["dn"])
     assert np.array_equal(res["wt"], wk["wt"])
     assert np.allclose(res["outs"], outs, rtol=1e-12, atol=1e-12)
+
+
+def test_sharded_heg_walk_invariants(tmp_path):
+    """BASELINE.json configs[3] in miniature: the homogeneous electron gas walk sharded over two
+    ranks (momentum-conserving proposals, hamiltonian_heg), same invariants as for C2."""
+    res = _run(2, tmp_path, 29581, system="heg")
+    for r in res[1:]:
+        assert np.array_equal(r["outs"][:, :7], res[0]["outs"][:, :7])
+    keys, n_imp = [], 0
+    for rank, r in enumerate(res):
+        assert np.all(r["owner"] == rank)
+        k = [(int(a), int(b)) for a, b in zip(r["up"], r["dn"])]
+        assert k == sorted(set(k))
+        keys += k
+        n_imp += int((r["imp_distance"] == 0).sum())
+    assert len(keys) == len(set(keys)) and n_imp == int(res[0]["n_imp_global"])
+    out = res[0]["outs"][-1]
+    assert int(out[5]) == len(keys)
+    assert np.isclose(sum(float(np.abs(r["wt"]).sum()) for r in res), out[1], rtol=1e-12)
+    e = res[0]["outs"][10:, 3].sum() / res[0]["outs"][10:, 2].sum()
+    assert 58.0 < e < 58.7                  # HF energy 58.592675 (heg.f90 e2e reference), correlation lowers it
+    assert out[1] > 1.5 * W_BEGIN
