@@ -884,6 +884,43 @@ int64_t orc_reduce_my_walker(orc_walk *w, int64_t n, const orc_step_params *p) {
   return n - nshift;
 }
 
+/* join_walker2, do_walk.f90:6990-7103: walkers of one sign with |w| < min_wt (permanent initiators
+ * excepted) are joined along the list -- the pair's weight goes to one of the two with probability
+ * proportional to its own weight, one rannyu per join -- until the running weight exceeds min_wt;
+ * all positive ones first, then the negative ones; zero-weight walkers are then removed. */
+int64_t orc_join_walker2(orc_walk *w, int64_t n, const orc_step_params *p) {
+  for (int pass = 0; pass < 2; pass++) {
+    int ipair = 0; int64_t i2 = 0;
+    for (int64_t i = 0; i < n; i++) {
+      const double wi = w->wt[i];
+      if (!((pass == 0 ? wi > 0.0 : wi < 0.0) && fabs(wi) < p->min_wt && w->initiator[i] < 3)) continue;
+      if (!ipair) { ipair = 1; i2 = i; continue; }
+      const double wttot = fabs(wi) + fabs(w->wt[i2]);
+      orc_rng_seek(&w->rng, 2, (uint64_t)i);
+      if (orc_rannyu(&w->rng) > (fabs(wi) / wttot)) {
+        w->wt[i2] = copysign(wttot, w->wt[i2]); w->wt[i] = 0.0;
+        w->e_num_walker[i] = 1e51; w->e_den_walker[i] = 1e51;
+      } else {
+        w->wt[i] = copysign(wttot, wi); w->wt[i2] = 0.0;
+        w->e_num_walker[i2] = 1e51; w->e_den_walker[i2] = 1e51;
+        i2 = i;
+      }
+      if (wttot > p->min_wt) ipair = 0;
+    }
+  }
+  int64_t nshift = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (w->wt[i] == 0.0) nshift++;
+    else if (nshift) {
+      int64_t u = i - nshift;
+      w->wt[u] = w->wt[i]; w->up[u] = w->up[i]; w->dn[u] = w->dn[i];
+      w->e_num_walker[u] = w->e_num_walker[i]; w->e_den_walker[u] = w->e_den_walker[i];
+      w->initiator[u] = w->initiator[i]; w->imp_distance[u] = w->imp_distance[i]; w->matrix_elements[u] = w->matrix_elements[i];
+    }
+  }
+  return n - nshift;
+}
+
 /* system dispatch of the walk: 'chem' or 'heg' (do_walk.f90:3599-3633, 3745-3769) */
 typedef struct { const orc_chem *chem; const orc_heg *heg; } orc_sys;
 static double sys_diag(const orc_sys *y, det_t u, det_t d) {
@@ -997,6 +1034,7 @@ static int walk_step_sys(const orc_sys *s, orc_walk *w, const orc_step_params *p
   int64_t nbefore = n;
   n = orc_merge_original_with_spawned2(w, n, p);   /* 2373 */
   if (p->semistochastic) n = orc_reduce_my_walker(w, n, p);   /* 2473 */
+  else n = orc_join_walker2(w, n, p);                          /* 2475 */
   w->nwalk = n;
   for (int64_t i = 0; i < n; i++) w->wt[i] = w->wt[i] * p->reweight_factor_inv;   /* 2487 */
   if (n == 0) return 4;

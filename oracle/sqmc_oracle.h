@@ -134,6 +134,7 @@ int  orc_walk_step(const orc_chem *s, orc_walk *w, const orc_step_params *p, dou
 void orc_merge_sort_walkers(orc_walk *w, int64_t n);                       /* do_walk.f90:5169-5197 */
 int64_t orc_merge_original_with_spawned2(orc_walk *w, int64_t n, const orc_step_params *p); /* 5866-6083 */
 int64_t orc_reduce_my_walker(orc_walk *w, int64_t n, const orc_step_params *p);            /* 7196-7254 */
+int64_t orc_join_walker2(orc_walk *w, int64_t n, const orc_step_params *p);                /* 6990-7103 */
 
 #endif
 

@@ -433,8 +433,57 @@ __global__ void __launch_bounds__(TPB) k_round(WalkArr m, const u64 *__restrict_
   }
   const int d = flg_impd(m.flg[j]);
   u64 f2 = 0;
-  if (!(p.semi && wt == 0.0 && d >= 1)) { f2 = 1ull; if (d == 0) f2 |= (1ull << 32); }
+  // reduce_my_walker drops zero weights outside the deterministic space (7222-7249), join_walker2 every zero weight (7071-7092)
+  const bool drop = p.semi ? (wt == 0.0 && d >= 1) : (wt == 0.0);
+  if (!drop) { f2 = 1ull; if (d == 0) f2 |= (1ull << 32); }
   flags2[j] = f2;
+}
+
+// join_walker2 (do_walk.f90:6990-7103), the non-semistochastic counterpart of the rounding: the
+// small walkers of one sign are joined along the list -- the pair's weight goes to one of the two
+// with probability proportional to its own weight, one draw per join -- until the running weight
+// exceeds min_wt; positive walkers first, then negative ones.  Which walkers end a chain depends on
+// the running sum, so the chain is followed by ONE lane; the 256 threads of the block only stream
+// the merged list through LDS in 1024-walker tiles (coalesced) ahead of it.  Draws: REPLAY = the
+// rannyu stream in join order, COUNTER = stream keyed by the merged index of the later walker.
+#define JOIN_TILE 1024
+__global__ void __launch_bounds__(TPB) k_join(WalkArr m, const u64 *__restrict__ flags, const u64 *__restrict__ pos, long long n_all, StepP p,
+                                              int mode, u64 seed, u64 step, DevScalars *sc) {
+  __shared__ double s_wt[JOIN_TILE]; __shared__ unsigned int s_rank[JOIN_TILE]; __shared__ unsigned char s_cand[JOIN_TILE];
+  u64 lcg = sc->lcg;
+  for (int pass = 0; pass < 2; pass++) {
+    bool ipair = false; long long j2 = 0; double w2 = 0.0;           // the walker currently carrying the chain and its weight (lane 0)
+    for (long long base = 0; base < n_all; base += JOIN_TILE) {
+      for (int k = threadIdx.x; k < JOIN_TILE; k += TPB) {
+        const long long j = base + k;
+        unsigned char cand = 0; double wt = 0.0; unsigned int rk = 0;
+        if (j < n_all && (flags[j] & 1ull)) {
+          wt = m.wt[j];
+          cand = ((pass == 0 ? wt > 0.0 : wt < 0.0) && fabs(wt) < p.min_wt && flg_init(m.flg[j]) < 3) ? 1 : 0;
+          rk = (unsigned int)(pos[j] & 0xFFFFFFFFull);
+        }
+        s_wt[k] = wt; s_rank[k] = rk; s_cand[k] = cand;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int lim = (n_all - base < JOIN_TILE) ? (int)(n_all - base) : JOIN_TILE;
+        for (int k = 0; k < lim; k++) {
+          if (!s_cand[k]) continue;
+          const long long j = base + k; const double wi = s_wt[k];
+          if (!ipair) { ipair = true; j2 = j; w2 = wi; continue; }
+          const double wttot = fabs(wi) + fabs(w2);
+          double r;
+          if (mode == 0) { lcg = (lcg * SQ_LCG_MULT) & SQ_MASK48; r = (double)lcg * 3.552713678800500929355621337890625e-15; }
+          else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, (u64)s_rank[k]); r = rng_draw(g); }
+          if (r > (fabs(wi) / wttot)) { w2 = copysign(wttot, w2); m.wt[j2] = w2; m.wt[j] = 0.0; }
+          else { m.wt[j2] = 0.0; w2 = copysign(wttot, wi); m.wt[j] = w2; j2 = j; }
+          if (wttot > p.min_wt) ipair = false;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0 && mode == 0) sc->lcg = lcg;
 }
 
 // C(T) lookup: open-addressed hash (linear probing, load <= 1/2) from the determinant's sort
@@ -491,7 +540,7 @@ __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64
     }
     w.up[o] = u; w.dn[o] = dd; w.wt[o] = wt; w.flg[o] = fj;
     w.me[o] = m.me[j]; w.en[o] = en; w.ed[o] = ed;
-    if (d == 0) loc_imp[ps >> 32] = (int)o;
+    if (d == 0 && p.semi) loc_imp[ps >> 32] = (int)o;
     s[0] += wt; s[1] += fabs(wt); s[8] += wt * wt;
     if (ini == 3) s[4] += wt * psg;
     if (d == 0 || (d == -2 && p.cti)) s[6] += fabs(wt);
@@ -1135,6 +1184,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long na
   device_excl_scan_u64(c->d_flags, c->d_pos, nall, &c->d_sc->tot1, sw[1], st);
   TEND(merge, st);
   TBEG(round, st);
+  if (!p.semi) hipLaunchKernelGGL(k_join, dim3(1), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, nall, p, mode, seed, step, c->d_sc);
   hipLaunchKernelGGL(k_round, dim3(nblk(nall)), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, c->d_flags2, nall, p, mode, seed, step, c->d_sc);
   device_excl_scan_u64(c->d_flags2, c->d_pos2, nall, &c->d_sc->tot2, sw[2], st);
   TEND(round, st);
@@ -1176,7 +1226,6 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   if (c->d_grow) return fail(SQMC_ERR_BAD_ARG, "context is configured for sharded steps: use sqmc_gpu_shard_begin/pack/finish");
   if (sp->semistochastic && (c->n_imp <= 0 || !c->d_prj_ptr)) return fail(SQMC_ERR_BAD_ARG, "semistochastic step without projector");
   if (!c->d_ct_up) return fail(SQMC_ERR_BAD_ARG, "C(T) table not set");
-  if (!sp->semistochastic) return fail(SQMC_ERR_UNSUPPORTED, "join_walker2 (non-semistochastic walk) is not implemented this round");
   hipStream_t st = c->st;
   StepP p; p.tau = sp->tau; p.e_trial = sp->e_trial; p.rfi = sp->reweight_factor_inv; p.r_init = sp->r_initiator; p.min_wt = sp->min_wt;
   p.cutoff = sp->always_spawn_cutoff_wt; p.ipow = sp->initiator_power; p.imind = sp->initiator_min_distance; p.cti = sp->c_t_initiator;
@@ -1320,7 +1369,6 @@ int sqmc_gpu_annihilate(sqmc_gpu_ctx *c, const sqmc_step_params *sp, int64_t n_s
   if (c->mwalk <= 0 || c->nwalk <= 0) return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0");
   if (c->d_grow) return fail(SQMC_ERR_BAD_ARG, "context is configured for sharded steps");
   if (!c->d_ct_up) return fail(SQMC_ERR_BAD_ARG, "C(T) table not set");
-  if (!sp->semistochastic) return fail(SQMC_ERR_UNSUPPORTED, "join_walker2 (non-semistochastic walk) is not implemented this round");
   const long long n0 = c->nwalk, nall = n0 + n_spawn;
   if (nall > c->mwalk) return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
   const u64 lim = c->htab.orb_mask;

@@ -644,7 +644,7 @@ def test_error_statuses_match_reference_stops(oracle, c2_walk, c2_setup):
     with pytest.raises(SqmcGpuError) as e:
         ctx(200000, walkers=broken)
     assert e.value.code == 5
-    # argument errors: unsorted walkers, no C(T) table, the walk variant that is not on the GPU
+    # argument errors: unsorted walkers, no C(T) table
     swapped = {k: v.copy() for k, v in main.items()}
     for k in swapped:
         swapped[k][[5, 6]] = swapped[k][[6, 5]]
@@ -655,12 +655,8 @@ def test_error_statuses_match_reference_stops(oracle, c2_walk, c2_setup):
     with pytest.raises(SqmcGpuError) as e:
         g.step(prm)
     assert e.value.code == -1
-    g.close()
-    g = ctx(200000)
-    with pytest.raises(SqmcGpuError) as e:
-        g.step(dict(prm, semistochastic=0))
-    assert e.value.code == -3
     # and the context is still usable after a refused call
+    g.set_ct_table(c2_setup.ct_up, c2_setup.ct_dn, c2_setup.ct_num, c2_setup.ct_den)
     out = g.step(prm)
     assert out[5] > 0
     g.close()
@@ -712,3 +708,42 @@ def test_hci_deck_conventions_across_curve(oracle, r):
     ou, od, ow_, oe, ohist = oracle.hci_variational(sysm, 2e-3, n_states=1)
     assert hist == ohist and abs(e[0] - oe[0]) < 1e-9
     assert np.array_equal(up, ou) and np.array_equal(dn, od)
+
+
+@pytest.mark.parametrize("rng_mode,nsteps", [(0, 50), (1, 120)])
+def test_non_semistochastic_walk_trajectory_bit_exact(oracle, c2_walk, c2_setup, rng_mode, nsteps):
+    """semistochastic = f: no deterministic space or projection, death/cloning on every walker,
+    and join_walker2 (do_walk.f90:6990-7103) instead of the stochastic rounding.  Same trajectory
+    as the oracle in both RNG disciplines."""
+    wk = oracle.initial_walkers(c2_setup, 100)
+    wk["imp_distance"] = np.where(wk["imp_distance"] == 0, 1, wk["imp_distance"]).astype(np.int8)   # a purely stochastic population
+    keep = ~((wk["wt"] == 0) & (wk["initiator"] < 3))
+    wk = {k: v[keep] for k, v in wk.items()}
+    g = gpu_ctx_from_oracle(c2_walk, rng_mode=rng_mode, seed=SEED, mwalk=400000)
+    g.set_ct_table(c2_setup.ct_up, c2_setup.ct_dn, c2_setup.ct_num, c2_setup.ct_den)
+    g.upload_walkers(wk)
+    ow = oracle.OracleWalk(c2_walk, c2_setup, wk, 400000, SEED, rng_mode=rng_mode)
+    pc = oracle.PopControl(c2_setup.tau, -75.72, 4000)
+    w_abs = np.abs(wk["wt"]).sum()
+    njoin = 0
+    for it in range(nsteps):
+        pc.pre_step(w_abs)
+        prm = pc.params(semistochastic=0)
+        st, out_c = ow.step(prm)
+        assert st == 0
+        out_g = g.step(prm)
+        for k in (5, 7, 15):
+            assert out_g[k] == out_c[k], (it, k, out_g[k], out_c[k])
+        assert np.allclose(out_g, out_c, rtol=1e-11, atol=1e-11), (it, out_g, out_c)
+        pc.post_step(out_c)
+        w_abs = out_c[1]
+    wg, wc = g.download_walkers(), ow.walkers()
+    if rng_mode == 0:
+        assert g.rng_state() == ow.rng_state()          # the single rannyu stream ends in the same state
+    g.close(); ow.close()
+    for k in ("up", "dn", "imp_distance", "initiator"):
+        assert np.array_equal(wg[k], wc[k]), k
+    assert np.array_equal(wg["wt"], wc["wt"])
+    assert len(wg["up"]) > 800
+    small = (np.abs(wg["wt"]) < 0.5 * pc.rfi * (1 - 1e-12)) & (wg["initiator"] < 3)
+    assert small.sum() <= 2                      # at most the unfinished last chain of each sign
