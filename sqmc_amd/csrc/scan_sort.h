@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) rs_scan_kernel(u32 *__restrict__ h
 // in 4 rounds of 64.  Rank among equal digits inside a round = popc(match & lanemask_lt) from
 // BITS ballots; per-wave digit counters live in LDS (private to the wave, in-order LDS queue),
 // then the four waves' counters are prefix-added once.  Only 4 sequential rounds per wave.
-template <int BITS>
+template <int BITS, bool VALS>
 __global__ void __launch_bounds__(256) rs_scatter_kernel(const u64 *__restrict__ kin, const u32 *__restrict__ vin,
                                                          u64 *__restrict__ kout, u32 *__restrict__ vout,
                                                          const u32 *__restrict__ hist, const u32 *__restrict__ rowtot,
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const u64 *__restrict__
   const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   u64 kreg[ROUNDS]; u32 vreg[ROUNDS], rnk[ROUNDS];
 #pragma unroll
-  for (int r = 0; r < ROUNDS; r++) { long long i = base + r * 64 + lane; kreg[r] = (i < n) ? kin[i] : 0; vreg[r] = (i < n) ? vin[i] : 0; }
+  for (int r = 0; r < ROUNDS; r++) { long long i = base + r * 64 + lane; kreg[r] = (i < n) ? kin[i] : 0; vreg[r] = (VALS && i < n) ? vin[i] : 0; }
 #pragma unroll
   for (int r = 0; r < ROUNDS; r++) {
     const long long i = base + r * 64 + lane;
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const u64 *__restrict__
     if (i < n) {
       const u32 dig = (u32)((kreg[r] >> shift) & (RS_RADIX - 1));
       const u32 dst = wcnt[wv][dig] + rnk[r];
-      kout[dst] = kreg[r]; vout[dst] = vreg[r];
+      kout[dst] = kreg[r]; if (VALS) vout[dst] = vreg[r];
     }
   }
 }
@@ -222,21 +222,25 @@ template <int BITS>
 static inline void radix_pass(u64 *ka, u32 *va, u64 *kb, u32 *vb, long long n, int ntiles, int shift, SortWork &w, hipStream_t st) {
   hipLaunchKernelGGL(rs_hist_kernel<BITS>, dim3(ntiles), dim3(256), 0, st, ka, w.hist, n, ntiles, shift);
   hipLaunchKernelGGL(rs_scan_kernel, dim3(1 << BITS), dim3(SCAN_BLOCK), 0, st, w.hist, w.rowtot, ntiles);
-  hipLaunchKernelGGL(rs_scatter_kernel<BITS>, dim3(ntiles), dim3(256), 0, st, ka, va, kb, vb, w.hist, w.rowtot, n, ntiles, shift);
+  if (va) hipLaunchKernelGGL((rs_scatter_kernel<BITS, true>), dim3(ntiles), dim3(256), 0, st, ka, va, kb, vb, w.hist, w.rowtot, n, ntiles, shift);
+  else hipLaunchKernelGGL((rs_scatter_kernel<BITS, false>), dim3(ntiles), dim3(256), 0, st, ka, va, kb, vb, w.hist, w.rowtot, n, ntiles, shift);
 }
 // digit width: the fewest passes of at most 10 bits, then the narrowest digit that still
-// covers the key in that many passes (28-bit C2 keys: 3 passes of 10 bits)
-static inline void device_radix_sort(u64 *&keys, u32 *&vals, long long n, int nbits, SortWork &w, hipStream_t st) {
+// covers the key in that many passes (28-bit C2 keys: 3 passes of 10 bits).  vals may be null
+// (keys only: the caller packed its payload into the bits below shift0, which are not sorted on
+// and ride along -- one scattered 8-byte write per element and pass instead of an 8- and a 4-byte
+// one).
+static inline void device_radix_sort(u64 *&keys, u32 *&vals, long long n, int nbits, SortWork &w, hipStream_t st, int shift0 = 0) {
   if (n <= 1) return;
   int ntiles = (int)((n + RS_TILE - 1) / RS_TILE);
-  u64 *ka = keys, *kb = w.k_alt; u32 *va = vals, *vb = w.v_alt;
+  u64 *ka = keys, *kb = w.k_alt; u32 *va = vals, *vb = vals ? w.v_alt : nullptr;
   const int npass = (nbits + 9) / 10;
   int bits = (nbits + npass - 1) / npass; if (bits < 8) bits = 8;
-  for (int pss = 0, shift = 0; pss < npass; pss++, shift += bits) {
+  for (int pss = 0, shift = shift0; pss < npass; pss++, shift += bits) {
     if (bits == 8) radix_pass<8>(ka, va, kb, vb, n, ntiles, shift, w, st);
     else if (bits == 9) radix_pass<9>(ka, va, kb, vb, n, ntiles, shift, w, st);
     else radix_pass<10>(ka, va, kb, vb, n, ntiles, shift, w, st);
     u64 *tk = ka; ka = kb; kb = tk; u32 *tv = va; va = vb; vb = tv;
   }
-  w.k_alt = kb; w.v_alt = vb; keys = ka; vals = va;
+  w.k_alt = kb; if (vals) { w.v_alt = vb; vals = va; } keys = ka;
 }

@@ -50,6 +50,17 @@ __host__ __device__ __forceinline__ u32 pack_flg(int impd, int init, int psign) 
 __host__ __device__ __forceinline__ int flg_impd(u32 f) { return (int)(int8_t)(f & 0xFF); }
 __host__ __device__ __forceinline__ int flg_init(u32 f) { return (int)(int8_t)((f >> 8) & 0xFF); }
 __host__ __device__ __forceinline__ int flg_psign(u32 f) { return (int)(int8_t)((f >> 16) & 0xFF); }
+// Sort records.  When the determinant key fits 32 bits (C2 cc-pVDZ: 28) the walker index rides in
+// the low half of the same 64-bit word, so every radix pass moves ONE word per element (the scatter
+// is one 8-byte write instead of an 8- and a 4-byte one to two places); otherwise keys and
+// indices are two arrays.
+__device__ __forceinline__ void put_key(u64 *__restrict__ keys, u32 *__restrict__ vals, long long k, u64 key, int pack) {
+  if (pack) keys[k] = (key << 32) | (u64)k; else { keys[k] = key; vals[k] = (u32)k; }
+}
+__device__ __forceinline__ u64 get_key(const u64 *__restrict__ skey, long long j, int pack) { return pack ? (skey[j] >> 32) : skey[j]; }
+__device__ __forceinline__ u32 get_perm(const u64 *__restrict__ skey, const u32 *__restrict__ perm, long long j, int pack) {
+  return pack ? (u32)skey[j] : perm[j];
+}
 static int alloc_walk(WalkArr &a, long long n) {
   HIPCHK(hipMalloc(&a.up, n * 8)); HIPCHK(hipMalloc(&a.dn, n * 8)); HIPCHK(hipMalloc(&a.wt, n * 8));
   HIPCHK(hipMalloc(&a.flg, n * 4));
@@ -105,7 +116,7 @@ struct sqmc_gpu_ctx {
   HostMail *h_mail, *d_mail; u64 mail_seq, cnt_seq;      // the same pinned words seen from host and device
   bool timers_pending;
   double *d_partials; int n_partial_blocks; double *d_wabs_part; u32 *d_done;
-  int key_bits; u64 invalid_key; u64 *d_binom;
+  int key_bits; int pack; u64 invalid_key; u64 *d_binom;
   // multi-rank sharding (owner = hash(det) mod shard_n)
   int shard_rank, shard_n; int *d_grow; long long n_imp_local; long long shard_n0, shard_nch;
   // in-library exchange over RCCL (sqmc_gpu_comm_init): communicator + device staging
@@ -121,11 +132,11 @@ struct sqmc_gpu_ctx {
 // gate + child count (COUNTER discipline).  do_walk.f90:3577-3589
 __global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, const double *__restrict__ wt,
                                               u64 *__restrict__ nchild, double *__restrict__ wchild, u64 *__restrict__ keys, u32 *__restrict__ vals,
-                                              long long n, StepP p, u64 seed, u64 step, DevScalars *sc) {
+                                              long long n, StepP p, u64 seed, u64 step, DevScalars *sc, int pack) {
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i == 0) { sc->n_invalid = 0; sc->tot1 = 0; sc->tot2 = 0; sc->err = 0; }   // every writer of these runs after this kernel
   if (i >= n) return;
-  keys[i] = det_key(dev, up[i], dn[i]); vals[i] = (u32)i;      // sort key of the walker itself
+  put_key(keys, vals, i, det_key(dev, up[i], dn[i]), pack);      // sort key of the walker itself
   double w = wt[i]; bool spawn, use_wt;
   if (fabs(w) < p.cutoff) {
     Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 0, (u64)i);
@@ -190,7 +201,7 @@ __global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict
 
 // a spawned walker (or the "no walker" marker) into slot n0 + c.  do_walk.f90:3700-3731
 __device__ __forceinline__ void spawn_emit(const ChemDev &dev, const WalkArr &w, u64 *__restrict__ keys, u32 *__restrict__ vals, long long n0, long long c,
-                                           u32 pf, u64 ju, u64 jd, double wj, const StepP &p, u64 invalid_key) {
+                                           u32 pf, u64 ju, u64 jd, double wj, const StepP &p, u64 invalid_key, int pack) {
   const long long k = n0 + c;
   if (wj != 0.0) {
     const int pd = flg_impd(pf), pi = flg_init(pf);
@@ -203,11 +214,10 @@ __device__ __forceinline__ void spawn_emit(const ChemDev &dev, const WalkArr &w,
     // matrix_elements / e_num / e_den of a spawn are the 1e51 sentinel (do_walk.f90:3728-3730):
     // not stored, k_merge supplies them for every slot >= n0
     w.up[k] = ju; w.dn[k] = jd; w.wt[k] = wj; w.flg[k] = pack_flg(d, ini, 0);
-    keys[k] = det_key(dev, ju, jd);
+    put_key(keys, vals, k, det_key(dev, ju, jd), pack);
   } else {
-    w.wt[k] = 0.0; keys[k] = invalid_key;     // sorts behind every real determinant
+    w.wt[k] = 0.0; put_key(keys, vals, k, invalid_key, pack);     // sorts behind every real determinant
   }
-  vals[k] = (u32)k;
 }
 
 #ifdef SPAWN_PROF
@@ -221,7 +231,7 @@ extern "C" int sqmc_gpu_debug_prof(unsigned long long *out) { return (int)hipMem
 __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
                                                const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
                                                long long n0, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc,
-                                               HostMail *mail, u64 cnt_seq) {
+                                               HostMail *mail, u64 cnt_seq, int pack) {
   // the grid covers the free capacity of the walker arrays; the number of children is read from
   // device memory so that the launch does not wait for the host to learn it
   PROF(0);
@@ -289,15 +299,15 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
       wj = proposal_weight(t, dev.integrals, p.tau, iu, id, ju, jd, level, prob);
       wj = wch * wj;
     }
-    spawn_emit(dev, w, keys, vals, n0, c, pflg, ju, jd, wj, p, invalid_key);
+    spawn_emit(dev, w, keys, vals, n0, c, pflg, ju, jd, wj, p, invalid_key, pack);
   }
   PROF(5);
 }
 
 __global__ void __launch_bounds__(TPB) k_main_keys(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, u64 *__restrict__ keys,
-                                                   u32 *__restrict__ vals, long long n) {
+                                                   u32 *__restrict__ vals, long long n, int pack) {
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
-  if (i < n) { keys[i] = det_key(dev, up[i], dn[i]); vals[i] = (u32)i; }
+  if (i < n) put_key(keys, vals, i, det_key(dev, up[i], dn[i]), pack);
 }
 
 // deterministic projection: x = w(loc); y = A x (rows summed in the reference's order);
@@ -350,7 +360,8 @@ __device__ __forceinline__ double ipow_d(int b, int e) { double r = 1.0; for (in
 // (stable sort), so the pairwise combination below is the reference's left-to-right scan.
 // do_walk.f90:5866-6083, check_initiator 6838-6872.
 __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *__restrict__ skey, const u32 *__restrict__ perm,
-                                               u64 *__restrict__ flags, double *__restrict__ wabs_part, long long n0, long long n_all, StepP p, u64 invalid_key) {
+                                               u64 *__restrict__ flags, double *__restrict__ wabs_part, long long n0, long long n_all, StepP p, u64 invalid_key,
+                                               int pack) {
   long long j = (long long)blockIdx.x * TPB + threadIdx.x;
   const long long n = n_all;
   // sum |w| and the number of real entries of the pre-merge list (my_w_abs_before_merge_cum,
@@ -358,10 +369,10 @@ __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *
   double wabs_j = 0.0, cnt_j = 0.0;
   bool head = false; u64 key = 0;
   if (j < n_all) {
-    key = skey[j];
+    key = get_key(skey, j, pack);
     wabs_j = fabs(w.wt[j]);
     if (key == invalid_key) flags[j] = 0;               // children that produced no walker sort last
-    else { cnt_j = 1.0; if (j > 0 && skey[j - 1] == key) flags[j] = 0; else head = true; }
+    else { cnt_j = 1.0; if (j > 0 && get_key(skey, j - 1, pack) == key) flags[j] = 0; else head = true; }
   }
   {
     __shared__ double red[2][TPB / 64];
@@ -372,15 +383,15 @@ __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *
     if (threadIdx.x == 0) { wabs_part[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3]; wabs_part[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3]; }
   }
   if (!head) return;
-  u32 t = perm[j];
+  u32 t = get_perm(skey, perm, j, pack);
   const bool t_spawn = (long long)t >= n0;
   double wt = w.wt[t], me = t_spawn ? 1e51 : w.me[t], en = t_spawn ? 1e51 : w.en[t], ed = t_spawn ? 1e51 : w.ed[t];
   const u32 ft = w.flg[t];
   int ini = flg_init(ft), d = flg_impd(ft), ps = flg_psign(ft);
   if (d == -1 && j > 0) d = 1;                 // 5985-5986 (the very first walker keeps -1 until the end)
   long long jj = j + 1;
-  for (; jj < n && skey[jj] == key; jj++) {
-    const u32 s = perm[jj];
+  for (; jj < n && get_key(skey, jj, pack) == key; jj++) {
+    const u32 s = get_perm(skey, perm, jj, pack);
     const double w2 = w.wt[s]; const u32 fs = w.flg[s]; const int i2 = flg_init(fs), d2 = flg_impd(fs);
     const bool same_sign = (w2 * wt > 0);
     // every later walker of a run is a spawn (walkers are unique): its cached values are the
@@ -404,7 +415,7 @@ __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *
     else if (ini < 2 && ((aw > thr && d >= 0) || ((aw > p.r_init || p.cti) && d == -2))) ini = ini + 1;
   }
   int dtest = d;
-  if (d == -1) { if (jj >= n || skey[jj] == invalid_key) dtest = 1; d = 1; }   // 6032-6036 then the last-det test at 6038
+  if (d == -1) { if (jj >= n || get_key(skey, jj, pack) == invalid_key) dtest = 1; d = 1; }   // 6032-6036 then the last-det test at 6038
   const bool discard = (((wt == 0.0 && (ini != 3 || p.r_init < 0)) || ini == 0) && dtest >= 1);
   m.up[j] = w.up[t]; m.dn[j] = w.dn[t]; m.wt[j] = wt; m.flg[j] = pack_flg(d, ini, ps);
   m.me[j] = me; m.en[j] = en; m.ed[j] = ed;
@@ -523,7 +534,7 @@ __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64
                                                  int *__restrict__ loc_imp, const u64 *__restrict__ skey, const u64 *__restrict__ hkey,
                                                  const u32 *__restrict__ hidx, u64 hmask,
                                                  const double *__restrict__ cnum, const double *__restrict__ cden,
-                                                 long long n_all, StepP p, double *__restrict__ partials) {
+                                                 long long n_all, StepP p, double *__restrict__ partials, int pack) {
   double s[NSTAT];
 #pragma unroll
   for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
@@ -535,7 +546,7 @@ __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64
     const u32 fj = m.flg[j]; const int d = flg_impd(fj), ini = flg_init(fj), psg = flg_psign(fj);
     double en = m.en[j], ed = m.ed[j];
     if (en > 1e50) {
-      long long q = ct_lookup(hkey, hidx, hmask, skey[j]);
+      long long q = ct_lookup(hkey, hidx, hmask, get_key(skey, j, pack));
       if (q < 0) { en = 0.0; ed = 0.0; } else { en = cnum[q]; ed = cden[q]; }
     }
     w.up[o] = u; w.dn[o] = dd; w.wt[o] = wt; w.flg[o] = fj;
@@ -872,7 +883,7 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
     if (tot >= 9.0e18L) { delete c; return fail(SQMC_ERR_UNSUPPORTED, "determinant space needs more than 63 key bits"); }
     u64 nd = (u64)(choose(cfg->norb, cfg->ndn) + 0.5L), total = (u64)(tot + 0.5L);
     int bits = 1; while (bits < 63 && ((1ull << bits) - 1ull) < total) bits++;
-    c->key_bits = bits; c->invalid_key = (1ull << bits) - 1ull;
+    c->key_bits = bits; c->invalid_key = (1ull << bits) - 1ull; c->pack = (bits <= 32) ? 1 : 0;
     HIPCHK(hipMalloc(&c->d_binom, bn.size() * 8));
     HIPCHK(hipMemcpy(c->d_binom, bn.data(), bn.size() * 8, hipMemcpyHostToDevice));
     c->dev.binom = c->d_binom; c->dev.n_dn_strings = nd;
@@ -1170,17 +1181,17 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long na
   // ---- sort
   TBEG(sort, st);
   if (mode == SQMC_RNG_REPLAY)
-    hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0);
+    hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0, c->pack);
   SortWork so; so.k_alt = c->d_keys_alt; so.v_alt = c->d_vals_alt; so.hist = c->d_hist; so.rowtot = c->d_rowtot; so.cap = M;
-  u64 *skey = c->d_keys; u32 *perm = c->d_vals;
-  device_radix_sort(skey, perm, nall, c->key_bits, so, st);
-  if (skey != c->d_keys) { c->d_keys_alt = c->d_keys; c->d_vals_alt = c->d_vals; c->d_keys = skey; c->d_vals = perm; }
+  u64 *skey = c->d_keys; u32 *perm = c->pack ? (u32 *)nullptr : c->d_vals;
+  device_radix_sort(skey, perm, nall, c->key_bits, so, st, c->pack ? 32 : 0);
+  if (skey != c->d_keys) { c->d_keys_alt = c->d_keys; c->d_keys = skey; if (!c->pack) { c->d_vals_alt = c->d_vals; c->d_vals = perm; } }
   TEND(sort, st);
   // ---- join: from here on weights are read
   if (join_side_stream) HIPCHK(hipStreamWaitEvent(st, c->e_join, 0));
   TBEG(merge, st);
   const int nbm = nblk(nall);
-  hipLaunchKernelGGL(k_merge, dim3(nbm), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, c->d_wabs_part, n0, nall, p, c->invalid_key);
+  hipLaunchKernelGGL(k_merge, dim3(nbm), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, c->d_wabs_part, n0, nall, p, c->invalid_key, c->pack);
   device_excl_scan_u64(c->d_flags, c->d_pos, nall, &c->d_sc->tot1, sw[1], st);
   TEND(merge, st);
   TBEG(round, st);
@@ -1191,7 +1202,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long na
   TBEG(estimate, st);
   const int nb = std::min(nblk(nall), 2048);
   hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, st, c->m, c->w, c->d_flags2, c->d_pos2, c->d_loc_imp, skey, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask,
-                     c->d_ct_num, c->d_ct_den, nall, p, c->d_partials);
+                     c->d_ct_num, c->d_ct_den, nall, p, c->d_partials, c->pack);
   const bool use_mail = (c->comm == nullptr);          // with a communicator the sums are all-reduced on the device first
   const u64 seq = ++c->mail_seq;
   hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials, nb, c->d_wabs_part, nbm, mode, c->d_sc, c->d_scan_state, c->d_scan_ticket,
@@ -1244,7 +1255,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
                        c->d_child_state, n0, M - n0, p, c->d_sc);
   } else {
     hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
-                       n0, p, seed, step, c->d_sc);
+                       n0, p, seed, step, c->d_sc, c->pack);
     device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw[0], st);
   }
   TEND(gate_scan, st);
@@ -1260,10 +1271,10 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   if (M > n0) {
     if (t_spawn >= 0)
       hipExtLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->ev0[t_spawn], c->ev1[t_spawn], 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq);
+                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack);
     else
       hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq);
+                         n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack);
   } else if (t_spawn >= 0) { hipEventRecord(c->ev0[t_spawn], st); hipEventRecord(c->ev1[t_spawn], st); }
   // ---- fork: death/clone and the deterministic projection only touch weights, which neither
   //      the spawn kernel (it uses the child weights of the gate) nor the sort reads
@@ -1351,11 +1362,11 @@ int sqmc_gpu_run(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats
 
 
 // keys of caller-supplied spawns (the "no walker" marker for weight 0, as k_spawn writes it)
-__global__ void __launch_bounds__(TPB) k_spawn_keys(ChemDev dev, WalkArr w, u64 *__restrict__ keys, u32 *__restrict__ vals, long long n0, long long nall, u64 invalid_key) {
+__global__ void __launch_bounds__(TPB) k_spawn_keys(ChemDev dev, WalkArr w, u64 *__restrict__ keys, u32 *__restrict__ vals, long long n0, long long nall, u64 invalid_key,
+                                                    int pack) {
   long long k = n0 + (long long)blockIdx.x * TPB + threadIdx.x;
   if (k >= nall) return;
-  keys[k] = (w.wt[k] != 0.0) ? det_key(dev, w.up[k], w.dn[k]) : invalid_key;
-  vals[k] = (u32)k;
+  put_key(keys, vals, k, (w.wt[k] != 0.0) ? det_key(dev, w.up[k], w.dn[k]) : invalid_key, pack);
 }
 
 // The second half of a step on its own: the caller's spawned walkers (creation order) are appended
@@ -1387,8 +1398,8 @@ int sqmc_gpu_annihilate(sqmc_gpu_ctx *c, const sqmc_step_params *sp, int64_t n_s
     HIPCHK(hipMemcpy(c->w.flg + n0, f.data(), n_spawn * 4, hipMemcpyHostToDevice));
   }
   HIPCHK(hipMemsetAsync(&c->d_sc->n_children, 0, 4 * sizeof(u64) + 2 * sizeof(int), st));
-  hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0);
-  if (n_spawn > 0) hipLaunchKernelGGL(k_spawn_keys, dim3(nblk(n_spawn)), dim3(TPB), 0, st, c->dev, c->w, c->d_keys, c->d_vals, n0, nall, c->invalid_key);
+  hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0, c->pack);
+  if (n_spawn > 0) hipLaunchKernelGGL(k_spawn_keys, dim3(nblk(n_spawn)), dim3(TPB), 0, st, c->dev, c->w, c->d_keys, c->d_vals, n0, nall, c->invalid_key, c->pack);
   return step_tail(c, p, n0, nall, false, out);
 }
 
@@ -1429,10 +1440,10 @@ __global__ void __launch_bounds__(TPB) k_prj_apply_rows(const int *__restrict__ 
 }
 // destination rank of every child (nranks = "no walker": weight 0), as an 8-bit sort key
 __global__ void __launch_bounds__(TPB) k_child_owner(const u64 *__restrict__ keys, u64 *__restrict__ okey, u32 *__restrict__ oval,
-                                                     long long n0, long long nch, u64 invalid_key, int nranks) {
+                                                     long long n0, long long nch, u64 invalid_key, int nranks, int pack) {
   long long c = (long long)blockIdx.x * TPB + threadIdx.x;
   if (c >= nch) return;
-  const u64 k = keys[n0 + c];
+  const u64 k = get_key(keys, n0 + c, pack);
   okey[c] = (k == invalid_key) ? (u64)nranks : (u64)det_owner(k, nranks);
   oval[c] = (u32)c;
 }
@@ -1445,13 +1456,13 @@ __global__ void __launch_bounds__(TPB) k_pack_send(WalkArr w, const u32 *__restr
   rec[4 * q] = w.up[k]; rec[4 * q + 1] = w.dn[k]; rec[4 * q + 2] = (u64)__double_as_longlong(w.wt[k]); rec[4 * q + 3] = (u64)w.flg[k];
 }
 __global__ void __launch_bounds__(TPB) k_unpack_recv(ChemDev dev, WalkArr w, const u64 *__restrict__ rec, u64 *__restrict__ keys, u32 *__restrict__ vals,
-                                                     long long n0, long long nrecv) {
+                                                     long long n0, long long nrecv, int pack) {
   long long q = (long long)blockIdx.x * TPB + threadIdx.x;
   if (q >= nrecv) return;
   const long long k = n0 + q;
   const u64 u = rec[4 * q], d = rec[4 * q + 1];
   w.up[k] = u; w.dn[k] = d; w.wt[k] = __longlong_as_double((long long)rec[4 * q + 2]); w.flg[k] = (u32)rec[4 * q + 3];
-  keys[k] = det_key(dev, u, d); vals[k] = (u32)k;
+  put_key(keys, vals, k, det_key(dev, u, d), pack);
 }
 
 int sqmc_gpu_det_owner(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, const uint64_t *dn, int32_t nranks, int32_t *owner) {
@@ -1501,12 +1512,12 @@ static int shard_begin_impl(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double 
   const u64 cseq = ++c->cnt_seq;
   if (n0 > 0) {
     hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
-                       n0, p, c->seed64, c->step_no, c->d_sc);
+                       n0, p, c->seed64, c->step_no, c->d_sc, c->pack);
     device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st);
     TBEG(spawn, st);
     if (M > n0)      // first: it posts the child count to the host mailbox as soon as it starts
       hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, c->rng_mode, c->seed64, c->step_no, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq);
+                         n0, M, p, c->rng_mode, c->seed64, c->step_no, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack);
     TEND(spawn, st);
     hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc);
     if (c->n_imp_local > 0)
@@ -1548,7 +1559,7 @@ static int shard_bucket(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const doubl
   *order = nullptr;
   if (nch > 0) {
     u64 *okey = c->d_flags, *okey_alt = c->d_pos; u32 *oval = (u32 *)c->d_flags2, *oval_alt = (u32 *)c->d_pos2;
-    hipLaunchKernelGGL(k_child_owner, dim3(nblk(nch)), dim3(TPB), 0, st, c->d_keys, okey, oval, n0, nch, c->invalid_key, P);
+    hipLaunchKernelGGL(k_child_owner, dim3(nblk(nch)), dim3(TPB), 0, st, c->d_keys, okey, oval, n0, nch, c->invalid_key, P, c->pack);
     SortWork so; so.k_alt = okey_alt; so.v_alt = oval_alt; so.hist = c->d_hist; so.rowtot = c->d_rowtot; so.cap = c->mwalk;
     u64 *sk = okey; u32 *sv = oval;
     device_radix_sort(sk, sv, nch, 8, so, st);               // one stable 8-bit pass; rowtot[d] = children per destination
@@ -1593,7 +1604,7 @@ int sqmc_gpu_shard_finish(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const uin
     return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
   }
   if (n_recv > 0)
-    hipLaunchKernelGGL(k_unpack_recv, dim3(nblk(n_recv)), dim3(TPB), 0, st, c->dev, c->w, (const u64 *)recv_dev, c->d_keys, c->d_vals, n0, (long long)n_recv);
+    hipLaunchKernelGGL(k_unpack_recv, dim3(nblk(n_recv)), dim3(TPB), 0, st, c->dev, c->w, (const u64 *)recv_dev, c->d_keys, c->d_vals, n0, (long long)n_recv, c->pack);
   if (n0 + n_recv == 0) {           // an empty shard stays empty this step
     for (int i = 0; i < 16; i++) out[i] = 0.0;
     hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
@@ -1846,7 +1857,7 @@ int sqmc_gpu_hci_connections(sqmc_gpu_ctx *c, int64_t n_ref, const uint64_t *ref
   HIPCHK(hipMalloc(&keys, T * 8)); HIPCHK(hipMalloc(&kalt, T * 8)); HIPCHK(hipMalloc(&vals, T * 4)); HIPCHK(hipMalloc(&valt, T * 4));
   long long ntiles = (T + RS_TILE - 1) / RS_TILE;
   HIPCHK(hipMalloc(&hist, ntiles * RS_MAX_RADIX * 4)); HIPCHK(hipMalloc(&rowtot, RS_MAX_RADIX * 4));
-  hipLaunchKernelGGL(k_main_keys, dim3(nblk(T)), dim3(TPB), 0, st, c->dev, du, dd, keys, vals, T);
+  hipLaunchKernelGGL(k_main_keys, dim3(nblk(T)), dim3(TPB), 0, st, c->dev, du, dd, keys, vals, T, 0);
   SortWork so; so.k_alt = kalt; so.v_alt = valt; so.hist = hist; so.rowtot = rowtot; so.cap = T;
   u64 *skey = keys; u32 *perm = vals;
   device_radix_sort(skey, perm, T, c->key_bits, so, st);
