@@ -39,7 +39,12 @@ static int fail(int code, const std::string &m) { g_err = m; return code; }
 static inline int nblk(long long n, int tpb = TPB) { return (int)((n + tpb - 1) / tpb); }
 
 // ------------------------------------------------------------------ walker SoA in HBM
+// A spawned walker as ONE 32-byte record (the wire record of the sharded exchange as well):
+// the annihilation kernel gathers spawns in sorted order, i.e. at random, and a record costs one
+// memory sector where four SoA fields cost four.  Resident walkers stay SoA (they are streamed).
+struct __attribute__((aligned(32))) SpawnRec { u64 up, dn; double wt; u64 flg; };
 struct WalkArr {
+  SpawnRec *sp;            // spawn c of the step lives in sp[c]; walker slots >= nwalk of the SoA arrays are unused during a step
   u64 *up, *dn; double *wt; u32 *flg; double *me, *en, *ed;
 };
 // imp_distance / initiator / perm_sign packed in one word: a gather through the sort
@@ -61,14 +66,16 @@ __device__ __forceinline__ u64 get_key(const u64 *__restrict__ skey, long long j
 __device__ __forceinline__ u32 get_perm(const u64 *__restrict__ skey, const u32 *__restrict__ perm, long long j, int pack) {
   return pack ? (u32)skey[j] : perm[j];
 }
-static int alloc_walk(WalkArr &a, long long n) {
+static int alloc_walk(WalkArr &a, long long n, bool with_spawn_records) {
+  a.sp = nullptr;
+  if (with_spawn_records) HIPCHK(hipMalloc(&a.sp, n * sizeof(SpawnRec)));
   HIPCHK(hipMalloc(&a.up, n * 8)); HIPCHK(hipMalloc(&a.dn, n * 8)); HIPCHK(hipMalloc(&a.wt, n * 8));
   HIPCHK(hipMalloc(&a.flg, n * 4));
   HIPCHK(hipMalloc(&a.me, n * 8)); HIPCHK(hipMalloc(&a.en, n * 8)); HIPCHK(hipMalloc(&a.ed, n * 8));
   return 0;
 }
 static void free_walk(WalkArr &a) {
-  hipFree(a.up); hipFree(a.dn); hipFree(a.wt); hipFree(a.flg);
+  hipFree(a.sp); hipFree(a.up); hipFree(a.dn); hipFree(a.wt); hipFree(a.flg);
   hipFree(a.me); hipFree(a.en); hipFree(a.ed);
 }
 
@@ -213,10 +220,11 @@ __device__ __forceinline__ void spawn_emit(const ChemDev &dev, const WalkArr &w,
     if (p.semi && pd == 0) ini = 1;
     // matrix_elements / e_num / e_den of a spawn are the 1e51 sentinel (do_walk.f90:3728-3730):
     // not stored, k_merge supplies them for every slot >= n0
-    w.up[k] = ju; w.dn[k] = jd; w.wt[k] = wj; w.flg[k] = pack_flg(d, ini, 0);
+    SpawnRec r; r.up = ju; r.dn = jd; r.wt = wj; r.flg = pack_flg(d, ini, 0);
+    w.sp[c] = r;
     put_key(keys, vals, k, det_key(dev, ju, jd), pack);
   } else {
-    w.wt[k] = 0.0; put_key(keys, vals, k, invalid_key, pack);     // sorts behind every real determinant
+    w.sp[c].wt = 0.0; put_key(keys, vals, k, invalid_key, pack);     // sorts behind every real determinant
   }
 }
 
@@ -370,7 +378,7 @@ __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *
   bool head = false; u64 key = 0;
   if (j < n_all) {
     key = get_key(skey, j, pack);
-    wabs_j = fabs(w.wt[j]);
+    wabs_j = fabs(j < n0 ? w.wt[j] : w.sp[j - n0].wt);
     if (key == invalid_key) flags[j] = 0;               // children that produced no walker sort last
     else { cnt_j = 1.0; if (j > 0 && get_key(skey, j - 1, pack) == key) flags[j] = 0; else head = true; }
   }
@@ -385,14 +393,18 @@ __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *
   if (!head) return;
   u32 t = get_perm(skey, perm, j, pack);
   const bool t_spawn = (long long)t >= n0;
-  double wt = w.wt[t], me = t_spawn ? 1e51 : w.me[t], en = t_spawn ? 1e51 : w.en[t], ed = t_spawn ? 1e51 : w.ed[t];
-  const u32 ft = w.flg[t];
+  // the head of a run is the resident walker if there is one (stable sort), else the first spawn
+  SpawnRec h;
+  if (t_spawn) h = w.sp[t - n0]; else { h.up = w.up[t]; h.dn = w.dn[t]; h.wt = w.wt[t]; h.flg = w.flg[t]; }
+  double wt = h.wt, me = t_spawn ? 1e51 : w.me[t], en = t_spawn ? 1e51 : w.en[t], ed = t_spawn ? 1e51 : w.ed[t];
+  const u32 ft = (u32)h.flg;
   int ini = flg_init(ft), d = flg_impd(ft), ps = flg_psign(ft);
   if (d == -1 && j > 0) d = 1;                 // 5985-5986 (the very first walker keeps -1 until the end)
   long long jj = j + 1;
   for (; jj < n && get_key(skey, jj, pack) == key; jj++) {
     const u32 s = get_perm(skey, perm, jj, pack);
-    const double w2 = w.wt[s]; const u32 fs = w.flg[s]; const int i2 = flg_init(fs), d2 = flg_impd(fs);
+    const SpawnRec r2 = w.sp[s - n0];                     // every later walker of a run is a spawn (walkers are unique)
+    const double w2 = r2.wt; const u32 fs = (u32)r2.flg; const int i2 = flg_init(fs), d2 = flg_impd(fs);
     const bool same_sign = (w2 * wt > 0);
     // every later walker of a run is a spawn (walkers are unique): its cached values are the
     // 1e51 sentinel, so the reference's min() merges leave me / en / ed unchanged
@@ -417,7 +429,7 @@ __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *
   int dtest = d;
   if (d == -1) { if (jj >= n || get_key(skey, jj, pack) == invalid_key) dtest = 1; d = 1; }   // 6032-6036 then the last-det test at 6038
   const bool discard = (((wt == 0.0 && (ini != 3 || p.r_init < 0)) || ini == 0) && dtest >= 1);
-  m.up[j] = w.up[t]; m.dn[j] = w.dn[t]; m.wt[j] = wt; m.flg[j] = pack_flg(d, ini, ps);
+  m.up[j] = h.up; m.dn[j] = h.dn; m.wt[j] = wt; m.flg[j] = pack_flg(d, ini, ps);
   m.me[j] = me; m.en[j] = en; m.ed[j] = ed;
   u64 f = 0;
   if (!discard) { f = 1ull; if (p.semi && d >= 1 && fabs(wt) < p.min_wt) f |= (1ull << 32); }
@@ -906,7 +918,7 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
   if (c->mwalk > 0) {
     const long long M = c->mwalk;
     if (M >= (1ll << 30)) { delete c; return fail(SQMC_ERR_UNSUPPORTED, "MWALK must be < 2^30"); }
-    if (alloc_walk(c->w, M) || alloc_walk(c->m, M)) return SQMC_ERR_HIP;
+    if (alloc_walk(c->w, M, true) || alloc_walk(c->m, M, false)) return SQMC_ERR_HIP;
     HIPCHK(hipMalloc(&c->d_nchild, (M + 1) * 8)); HIPCHK(hipMalloc(&c->d_child_off, (M + 1) * 8));
     HIPCHK(hipMalloc(&c->d_wchild, M * 8)); HIPCHK(hipMalloc(&c->d_child_state, M * 8));
     HIPCHK(hipMalloc(&c->d_keys, M * 8)); HIPCHK(hipMalloc(&c->d_keys_alt, M * 8));
@@ -1366,7 +1378,8 @@ __global__ void __launch_bounds__(TPB) k_spawn_keys(ChemDev dev, WalkArr w, u64 
                                                     int pack) {
   long long k = n0 + (long long)blockIdx.x * TPB + threadIdx.x;
   if (k >= nall) return;
-  put_key(keys, vals, k, (w.wt[k] != 0.0) ? det_key(dev, w.up[k], w.dn[k]) : invalid_key, pack);
+  const SpawnRec r = w.sp[k - n0];
+  put_key(keys, vals, k, (r.wt != 0.0) ? det_key(dev, r.up, r.dn) : invalid_key, pack);
 }
 
 // The second half of a step on its own: the caller's spawned walkers (creation order) are appended
@@ -1392,10 +1405,9 @@ int sqmc_gpu_annihilate(sqmc_gpu_ctx *c, const sqmc_step_params *sp, int64_t n_s
   c->nt = 0;
   HIPCHK(hipStreamSynchronize(st));
   if (n_spawn > 0) {
-    HIPCHK(hipMemcpy(c->w.up + n0, up, n_spawn * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.dn + n0, dn, n_spawn * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->w.wt + n0, wt, n_spawn * 8, hipMemcpyHostToDevice));
-    std::vector<u32> f(n_spawn); for (long long i = 0; i < n_spawn; i++) f[i] = pack_flg(impd[i], init[i], 0);
-    HIPCHK(hipMemcpy(c->w.flg + n0, f.data(), n_spawn * 4, hipMemcpyHostToDevice));
+    std::vector<SpawnRec> recs(n_spawn);
+    for (long long i = 0; i < n_spawn; i++) { recs[i].up = up[i]; recs[i].dn = dn[i]; recs[i].wt = wt[i]; recs[i].flg = pack_flg(impd[i], init[i], 0); }
+    HIPCHK(hipMemcpy(c->w.sp, recs.data(), n_spawn * sizeof(SpawnRec), hipMemcpyHostToDevice));
   }
   HIPCHK(hipMemsetAsync(&c->d_sc->n_children, 0, 4 * sizeof(u64) + 2 * sizeof(int), st));
   hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0, c->pack);
@@ -1453,7 +1465,8 @@ __global__ void __launch_bounds__(TPB) k_pack_send(WalkArr w, const u32 *__restr
   long long q = (long long)blockIdx.x * TPB + threadIdx.x;
   if (q >= nsend) return;
   const long long k = n0 + order[q];
-  rec[4 * q] = w.up[k]; rec[4 * q + 1] = w.dn[k]; rec[4 * q + 2] = (u64)__double_as_longlong(w.wt[k]); rec[4 * q + 3] = (u64)w.flg[k];
+  const SpawnRec r = w.sp[k - n0];
+  rec[4 * q] = r.up; rec[4 * q + 1] = r.dn; rec[4 * q + 2] = (u64)__double_as_longlong(r.wt); rec[4 * q + 3] = r.flg;
 }
 __global__ void __launch_bounds__(TPB) k_unpack_recv(ChemDev dev, WalkArr w, const u64 *__restrict__ rec, u64 *__restrict__ keys, u32 *__restrict__ vals,
                                                      long long n0, long long nrecv, int pack) {
@@ -1461,7 +1474,8 @@ __global__ void __launch_bounds__(TPB) k_unpack_recv(ChemDev dev, WalkArr w, con
   if (q >= nrecv) return;
   const long long k = n0 + q;
   const u64 u = rec[4 * q], d = rec[4 * q + 1];
-  w.up[k] = u; w.dn[k] = d; w.wt[k] = __longlong_as_double((long long)rec[4 * q + 2]); w.flg[k] = (u32)rec[4 * q + 3];
+  SpawnRec r; r.up = u; r.dn = d; r.wt = __longlong_as_double((long long)rec[4 * q + 2]); r.flg = rec[4 * q + 3] & 0xFFFFFFFFull;
+  w.sp[q] = r;
   put_key(keys, vals, k, det_key(dev, u, d), pack);
 }
 
