@@ -14,8 +14,10 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 #define SCAN_BLOCK 256
-#define SCAN_ITEMS 8                       // elements per thread
-#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
+#define SCAN_ITEMS_SMALL 8                 // elements per thread: small inputs want many tiles (latency) ...
+#define SCAN_ITEMS_LARGE 16                // ... large ones few (the look-back chain grows with the number of tiles)
+#define SCAN_LARGE_N (1ll << 19)
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS_SMALL)     // state words are provisioned for the small tile
 
 __device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, int lane) {
 #pragma unroll
@@ -52,17 +54,34 @@ __device__ __forceinline__ u64 block_excl_scan_u64(u64 v, u64 *total) {
 #define SCAN_ST_AGG (1ull << 62)
 #define SCAN_ST_INC (2ull << 62)
 #define SCAN_VAL_MASK ((1ull << 62) - 1ull)
+template <int SCAN_ITEMS>
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_lookback_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, long long n,
                                                                    u64 *__restrict__ state, u32 *__restrict__ ticket, u64 *__restrict__ total_out) {
+  constexpr int TILE_ELEMS = SCAN_BLOCK * SCAN_ITEMS;
   __shared__ u32 s_tile; __shared__ u64 s_excl;
   if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
   __syncthreads();
   const u32 tile = s_tile;
-  const long long base = (long long)tile * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
-  u64 v[SCAN_ITEMS], s = 0;
+  // Every wavefront owns a contiguous run of 64*ITEMS elements and reads it row by row (lane l takes
+  // element r*64 + l: 512 contiguous bytes per load instruction); rows are scanned with wave
+  // shuffles and chained through the row totals, waves through LDS.
+  __shared__ u64 s_wsum[SCAN_BLOCK / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long base = (long long)tile * TILE_ELEMS + (long long)wv * (64 * SCAN_ITEMS) + lane;
+  u64 v[SCAN_ITEMS], inc[SCAN_ITEMS], carry = 0;
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) { long long i = base + k; v[k] = (i < n) ? in[i] : 0; s += v[k]; }
-  u64 tot; u64 ex = block_excl_scan_u64(s, &tot);
+  for (int k = 0; k < SCAN_ITEMS; k++) { long long i = base + (long long)k * 64; v[k] = (i < n) ? in[i] : 0; }
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    const u64 x = wave_incl_scan_u64(v[k], lane);
+    inc[k] = x + carry;
+    carry += __shfl(x, 63, 64);
+  }
+  if (lane == 0) s_wsum[wv] = carry;
+  __syncthreads();
+  u64 ex = 0, tot = 0;
+#pragma unroll
+  for (int q = 0; q < SCAN_BLOCK / 64; q++) { if (q < wv) ex += s_wsum[q]; tot += s_wsum[q]; }
   if (threadIdx.x < 64) {                       // wave 0 publishes and looks back, 64 predecessors per poll
     const int lane = threadIdx.x;
     u64 excl = 0;
@@ -88,13 +107,13 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_lookback_kernel(const u64 *__
     }
     if (lane == 0) {
       s_excl = excl;
-      if (total_out && (long long)(tile + 1) * SCAN_TILE >= n) *total_out = excl + tot;
+      if (total_out && (long long)(tile + 1) * TILE_ELEMS >= n) *total_out = excl + tot;
     }
   }
   __syncthreads();
   ex += s_excl;
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) { long long i = base + k; if (i < n) out[i] = ex; ex += v[k]; }
+  for (int k = 0; k < SCAN_ITEMS; k++) { long long i = base + (long long)k * 64; if (i < n) out[i] = ex + inc[k] - v[k]; }
 }
 __global__ void scan_clear_kernel(u64 *state, u32 *ticket, int ntiles) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,9 +126,12 @@ struct ScanWork { u64 *state; u32 *ticket; long long cap_tiles; bool self_clear;
 // exclusive scan of n u64 values (< 2^62 in total); total (optional) is written on device
 static inline void device_excl_scan_u64(const u64 *in, u64 *out, long long n, u64 *total_out, ScanWork &w, hipStream_t st) {
   if (n <= 0) { if (total_out) hipMemsetAsync(total_out, 0, sizeof(u64), st); return; }
-  int ntiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+  const bool large = n >= SCAN_LARGE_N;
+  const long long tile = (long long)SCAN_BLOCK * (large ? SCAN_ITEMS_LARGE : SCAN_ITEMS_SMALL);
+  int ntiles = (int)((n + tile - 1) / tile);
   if (w.self_clear) hipLaunchKernelGGL(scan_clear_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, st, w.state, w.ticket, ntiles);
-  hipLaunchKernelGGL(scan_lookback_kernel, dim3(ntiles), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out);
+  if (large) hipLaunchKernelGGL(scan_lookback_kernel<SCAN_ITEMS_LARGE>, dim3(ntiles), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out);
+  else hipLaunchKernelGGL(scan_lookback_kernel<SCAN_ITEMS_SMALL>, dim3(ntiles), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out);
 }
 
 // ------------------------------------------------------------------------ radix sort
