@@ -136,6 +136,7 @@ static inline void device_excl_scan_u64(const u64 *in, u64 *out, long long n, u6
 
 // ------------------------------------------------------------------------ radix sort
 #define RS_MAX_RADIX 1024                   // 10-bit digits at most
+#define RS_LARGE_N (1ll << 20)
 #define RS_TILE 1024                        // keys per 256-thread block (4 waves x 4 rounds of 64)
 
 // histogram: hist[digit * ntiles + tile]; one 256-thread block (4 waves) per tile of 1024 keys
@@ -256,7 +257,11 @@ static inline void device_radix_sort(u64 *&keys, u32 *&vals, long long n, int nb
   if (n <= 1) return;
   int ntiles = (int)((n + RS_TILE - 1) / RS_TILE);
   u64 *ka = keys, *kb = w.k_alt; u32 *va = vals, *vb = vals ? w.v_alt : nullptr;
-  const int npass = (nbits + 9) / 10;
+  // Small inputs are launch bound: the fewest passes (10-bit digits).  Large ones are bound by the
+  // per-tile histogram matrix, whose column accesses cost a whole memory sector per 4-byte count
+  // and which grows with 2^bits: 8-bit digits there.
+  const int maxbits = (n >= RS_LARGE_N) ? 8 : 10;
+  const int npass = (nbits + maxbits - 1) / maxbits;
   int bits = (nbits + npass - 1) / npass; if (bits < 8) bits = 8;
   for (int pss = 0, shift = shift0; pss < npass; pss++, shift += bits) {
     if (bits == 8) radix_pass<8>(ka, va, kb, vb, n, ntiles, shift, w, st);
