@@ -178,33 +178,37 @@ def test_walk_counter_trajectory_bit_exact(oracle, c2_walk, c2_setup):
     assert len(wg["up"]) > 3000
 
 
-def test_walk_invariants_large(oracle, c2_walk, c2_setup):
-    """Size-independent properties at a population the oracle is not run at: walkers stay
-    sorted and unique, det-space walkers are all present, weights of stochastic walkers are
+@pytest.mark.parametrize("w_target,nsteps", [(200000, 120), (800000, 140)])
+def test_walk_invariants_large(oracle, c2_walk, c2_setup, w_target, nsteps):
+    """Size-independent properties at populations the oracle is not run at (the larger one is past
+    the switch to the large-input sort and scan variants: > 2^20 sorted elements per step): walkers
+    stay sorted and unique, det-space walkers are all present, weights of stochastic walkers are
     never below min_wt, sums reported by the step equal sums recomputed from the download."""
-    g = gpu_ctx_from_oracle(c2_walk, rng_mode=1, seed=SEED, mwalk=3_000_000)
+    g = gpu_ctx_from_oracle(c2_walk, rng_mode=1, seed=SEED, mwalk=8 * w_target + 100000)
     s = c2_setup
     g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
     g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
-    wk = oracle.initial_walkers(s, 1000)
+    wk = oracle.initial_walkers(s, 1000 if w_target <= 200000 else w_target)
     g.upload_walkers(wk)
-    pc = oracle.PopControl(s.tau, -75.72, 200000, n_equil_steps=10**9)
+    pc = oracle.PopControl(s.tau, -75.72, w_target, n_equil_steps=10**9)
     w_abs = np.abs(wk["wt"]).sum()
-    for it in range(120):
+    for it in range(nsteps):
         r = pc.pre_step(w_abs)
         if r != 1.0: g.scale_projector(r)
-        out = g.step(pc.params())
+        prm = pc.params()
+        out = g.step(prm)
         r = pc.post_step(out)
         if r != 1.0: g.scale_projector(r)
         w_abs = out[1]
     w = g.download_walkers()
     g.close()
+    rfi_used = prm["reweight_factor_inv"]                     # the factor of the step that produced these weights
     key = (w["up"].astype(object) << 26) | w["dn"].astype(object)
     assert all(key[i] < key[i + 1] for i in range(len(key) - 1))
     assert (w["imp_distance"] == 0).sum() == len(s.prj_counts)
     sto = w["imp_distance"] >= 1
-    assert np.all(np.abs(w["wt"][sto]) >= 0.5 * pc.rfi * (1 - 1e-12))
-    assert len(w["up"]) == int(out[5])
+    assert np.all(np.abs(w["wt"][sto]) >= 0.5 * rfi_used * (1 - 1e-12))
+    assert len(w["up"]) == int(out[5]) and int(out[7]) > (1 << 20 if w_target > 500000 else 0)
     assert np.isclose(np.abs(w["wt"]).sum(), out[1], rtol=1e-12)
     assert np.isclose(w["wt"].sum(), out[0], rtol=1e-10, atol=1e-8)
     assert np.isclose((w["e_num"] * w["wt"]).sum(), out[3], rtol=1e-10)
