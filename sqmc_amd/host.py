@@ -972,3 +972,47 @@ def dump_walk_deck(path, host, setup, walkers, w_target, e_trial, seed=(1346, 56
 
 def _np_f64(a):
     return np.ascontiguousarray(a, np.float64)
+
+
+# ------------------------------------------------------------- HCI wavefunction files
+def wf_filename(eps_var):
+    """hci.f90:195-197: write(fmt,'(es7.2e1)') eps_var ; filename = 'wf_eps_var=' // fmt"""
+    m, e = ("%.2e" % eps_var).split("e")
+    return "wf_eps_var=%sE%s%d" % (m, "-" if int(e) < 0 else "+", abs(int(e)))
+
+
+def _frecord(f, payload):
+    f.write(np.int32(len(payload)).tobytes()); f.write(payload); f.write(np.int32(len(payload)).tobytes())
+
+
+def write_wf_var(path, up, dn, wts, energy):
+    """The variational wavefunction dump of perform_hci (hci.f90:602-625; read back at :199-216):
+    Fortran sequential unformatted records  ndets (default integer) | dets_up(1:n) | dets_dn(1:n) |
+    wts(1:n,1:n_states) | energy(1:n_states), determinants as the reference's 128-bit integers
+    (little endian: low word, high word = 0 for norb <= 64), weights column-major."""
+    up, dn = np.ascontiguousarray(up, np.uint64), np.ascontiguousarray(dn, np.uint64)
+    wts = np.asarray(wts, np.float64).reshape(len(up), -1)
+    d128 = lambda a: np.stack([a, np.zeros_like(a)], axis=1).tobytes()
+    with open(path, "wb") as f:
+        _frecord(f, np.int32(len(up)).tobytes())
+        _frecord(f, d128(up)); _frecord(f, d128(dn))
+        _frecord(f, np.asfortranarray(wts).tobytes(order="F"))
+        _frecord(f, np.asarray(energy, np.float64).tobytes())
+
+
+def read_wf_var(path, n_states=1):
+    """-> (up, dn, wts[n, n_states], energy[n_states]) from a file written by the reference or by write_wf_var"""
+    raw = open(path, "rb").read()
+    recs, o = [], 0
+    while o < len(raw):
+        n = int(np.frombuffer(raw, np.int32, 1, o)[0])
+        recs.append(raw[o + 4:o + 4 + n])
+        if int(np.frombuffer(raw, np.int32, 1, o + 4 + n)[0]) != n:
+            raise ValueError("not a Fortran sequential unformatted file: " + path)
+        o += n + 8
+    nd = int(np.frombuffer(recs[0], np.int32)[0])
+    u = np.frombuffer(recs[1], np.uint64).reshape(nd, 2); d = np.frombuffer(recs[2], np.uint64).reshape(nd, 2)
+    if u[:, 1].any() or d[:, 1].any():
+        raise ValueError("determinants beyond 64 orbitals are not supported by this host")
+    wts = np.frombuffer(recs[3], np.float64).reshape(n_states, nd).T.copy()
+    return u[:, 0].copy(), d[:, 0].copy(), wts, np.frombuffer(recs[4], np.float64).copy()
