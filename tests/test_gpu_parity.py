@@ -751,3 +751,27 @@ def test_non_semistochastic_walk_trajectory_bit_exact(oracle, c2_walk, c2_setup,
     assert len(wg["up"]) > 800
     small = (np.abs(wg["wt"]) < 0.5 * pc.rfi * (1 - 1e-12)) & (wg["initiator"] < 3)
     assert small.sum() <= 2                      # at most the unfinished last chain of each sign
+
+
+def test_shipped_hci_deck_end_to_end(tmp_path):
+    """The reference's own input deck C2_v2z_curve/r1.24253/i_1sigma_g, unchanged, through
+    `python -m sqmc_amd.run`: deck grammar, hf_symmetry descent, two-state HCI, PT in the
+    determinant basis.  Every number the reference's run printed: 12776
+    determinants, E_var(1) = -75.719473642, PT(1) = -0.008762133, E_tot(1) = -75.728235774,
+    E_var(2) = -75.631097209, E_tot(2) = -75.638806440, 3.36 M / 3.24 M PT connections."""
+    import io, os
+    from conftest import FCIDUMP
+    from sqmc_amd import run as R
+    deck = R.parse_hci_deck(open(os.path.join(os.path.dirname(__file__), "golden", "C2_r1.24253_i_1sigma_g")).read())
+    assert deck["n_states"] == 2 and deck["eps_var_sched"] == [2e-3, 2e-3] and deck["hf_symmetry"] == 1 and deck["time_sym"]
+    buf = io.StringIO()
+    res = R.run_hci(deck, FCIDUMP, out=buf)
+    txt = buf.getvalue()
+    assert res["ndets"] == 12776
+    (e1, d1, n1), (e2, d2, n2) = res["states"]
+    assert abs(e1 - (-75.719473642)) < 2e-9 and abs(d1 - (-0.008762133)) < 2e-8 and abs(e1 + d1 - (-75.728235774)) < 2e-8
+    assert abs(e2 - (-75.631097209)) < 2e-9 and abs(e2 + d2 - (-75.638806440)) < 2e-8
+    assert abs(n1 - 3.36e6) < 1e4 and abs(n2 - 3.24e6) < 1e4
+    # the lines C2_v2z_curve/runall greps for
+    assert "Total energy(1)=" in txt and "Total energy(2)=" in txt and "Variational energy(1)=" in txt
+    assert "Iteration   5 eps1=1.0E-3 ndets=    12776" in txt
