@@ -775,3 +775,20 @@ def test_shipped_hci_deck_end_to_end(tmp_path):
     # the lines C2_v2z_curve/runall greps for
     assert "Total energy(1)=" in txt and "Total energy(2)=" in txt and "Variational energy(1)=" in txt
     assert "Iteration   5 eps1=1.0E-3 ndets=    12776" in txt
+
+
+def test_triplet_deck_matches_oracle(oracle):
+    """The other shipped deck of the same directory, i_3pi_u: time-reversal ANTIsymmetric states
+    (z = -1: determinants with up == dn drop out) of irrep 2.  No reference run is recorded for it,
+    so the GPU path is held against the oracle: same starting determinant, iteration history, E_var."""
+    import io, os
+    from conftest import FCIDUMP
+    from sqmc_amd import run as R
+    deck = R.parse_hci_deck(open(os.path.join(os.path.dirname(__file__), "golden", "C2_r1.24253_i_3pi_u")).read())
+    assert deck["z"] == -1 and deck["hf_symmetry"] == 2 and deck["n_states"] == 1
+    sysm = oracle.ChemSystem(FCIDUMP, 8, 4, "d2h", time_sym=True, z=-1, hf_mode=1, hf_symmetry=2)
+    ou, od, ow_, oe, ohist = oracle.hci_variational(sysm, deck["eps_var"], eps_sched=tuple(deck["eps_var_sched"]), n_states=1)
+    deck["eps_pt"] = 1e-5                                     # a lighter PT stage: it is checked elsewhere
+    res = R.run_hci(deck, FCIDUMP, out=io.StringIO())
+    assert res["ndets"] == len(ou) == ohist[-1]
+    assert abs(res["states"][0][0] - oe[0]) < 1e-9
