@@ -339,8 +339,8 @@ def test_hci_variational_matches_reference_run():
     """BASELINE.json configs[4]: HCI on C2 cc-pVDZ, eps1=1e-4 (schedule 2x2e-4), one state, the
     shipped deck's conventions (time_sym, z=+1, hf_symmetry=1), everything heavy on the GPU.
     The reference's own run recorded 694 -> 47038 -> 118626 -> 126386 -> 126708 determinants and
-    E_var = -75.727563003; the last two counts move by a few
-    determinants with the eigenvector's round-off at the selection threshold."""
+    E_var = -75.727563003; with the reference's Davidson iteration restated
+    on the host the counts agree exactly."""
     from conftest import FCIDUMP
     from sqmc_amd import host as H
     h = H.ChemHost(FCIDUMP, 8, 4, "d2h", time_sym=True, z=1, hf_symmetry=1)
@@ -348,8 +348,7 @@ def test_hci_variational_matches_reference_run():
     g.set_hb_tables(*h.hb_tables(g))
     up, dn, w, e, hist = H.hci_variational(h, g, 1e-4, eps_sched=(2e-4, 2e-4), n_states=1)
     g.close()
-    assert hist[:4] == [1, 694, 47038, 118626]
-    assert abs(hist[4] - 126386) <= 3 and abs(hist[5] - 126708) <= 3
+    assert hist == [1, 694, 47038, 118626, 126386, 126708]         # the reference's sequence, determinant for determinant
     assert abs(e[0] - (-75.727563003)) < 2e-9
     assert abs(np.dot(w[:, 0], w[:, 0]) - 1.0) < 1e-9
 
@@ -516,9 +515,9 @@ def test_hci_pt2_matches_oracle_and_reference_run(oracle, c2_hci):
     g.close()
     # the reference converts to the determinant basis before PT (hci.f90:648-659): 6.56 M connections there
     d, n = H.hci_pt2_determinant_basis(h, up, dn, w[:, 0], float(e[0]), 1e-6)
-    assert 6.4e6 < n < 6.8e6
-    assert abs(d - (-0.000979165)) < 2e-8
-    assert abs(e[0] + d - (-75.728542168)) < 2e-8
+    assert 6.55e6 < n < 6.57e6
+    assert abs(d - (-0.000979165)) < 2e-9
+    assert abs(e[0] + d - (-75.728542168)) < 2e-9
 
 
 def test_fortran_host_walk(tmp_path):
