@@ -217,6 +217,13 @@ int sqmc_gpu_spmv_prepare(int64_t n, const int64_t *row_counts, const int64_t *i
                           const double *values, sqmc_spmv_plan **plan);
 int sqmc_gpu_spmv_apply(sqmc_spmv_plan *plan, const double *x, double *y, int on_device);
 int sqmc_gpu_spmv_free(sqmc_spmv_plan *plan);
+/* generate_sparse_ham_chem_upper_triangular (chemistry.f90:7639-8010) and the plan of the Davidson
+ * matvec in one call, with the matrix never leaving the GPU: for a determinant list sorted by
+ * (up,dn) the Hamiltonian is built and expanded to the full symmetric CSR on the device; diag[n]
+ * (Davidson's preconditioner, more_tools.f90:2099-2110) and the number of stored upper-triangular
+ * nonzeros come back.  Use the plan with sqmc_gpu_spmv_apply / _free. */
+int sqmc_gpu_build_spmv_plan(sqmc_gpu_ctx *ctx, int64_t n, const uint64_t *up, const uint64_t *dn, sqmc_spmv_plan **plan, double *diag,
+                             int64_t *out_nnz);
 int sqmc_gpu_spmv_sym_upper(int64_t n, const int64_t *row_counts, const int64_t *indices,
                             const double *values, const double *x, double *y);
 

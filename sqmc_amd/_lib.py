@@ -17,7 +17,7 @@ EXPORTS = [
     "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_annihilate", "sqmc_gpu_det_owner", "sqmc_gpu_shard_config",
     "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init",
     "sqmc_gpu_shard_step", "sqmc_gpu_shard_run", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_spmv_prepare",
-    "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
+    "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_build_spmv_plan", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
     "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
 ]
 
@@ -360,6 +360,20 @@ class SpmvPlan:
         h = C.c_void_p()
         _chk(self.L.sqmc_gpu_spmv_prepare(self.n, _p(c), _p(i), _p(v), C.byref(h)))
         self.h = h
+
+    @classmethod
+    def from_dets(cls, g, up, dn):
+        """sqmc_gpu_build_spmv_plan: Hamiltonian of a sorted determinant list built and kept on the GPU.
+        Returns (plan, diagonal, stored upper-triangular nonzeros)."""
+        self = cls.__new__(cls)
+        self.L = g.L
+        u, d = _u64(up), _u64(dn)
+        self.n = len(u)
+        diag = np.zeros(self.n); nnz = C.c_int64(); h = C.c_void_p()
+        self.L.sqmc_gpu_build_spmv_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(self.L.sqmc_gpu_build_spmv_plan(g.h, self.n, _p(u), _p(d), C.byref(h), _p(diag), C.byref(nnz)))
+        self.h = h
+        return self, diag, nnz.value
 
     def apply(self, x):
         x = _f64(x); y = np.zeros(self.n)

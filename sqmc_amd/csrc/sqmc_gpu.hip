@@ -834,6 +834,49 @@ __global__ void __launch_bounds__(TPB) k_hci_dedup(const u64 *__restrict__ skey,
 // Symmetric matrix kept as FULL CSR (int32 columns) so that every row is owned by one
 // wavefront and no atomics are needed: 12 B per stored entry + 8 B gathered x.
 struct sqmc_spmv_plan { long long n, nnz_full; int *d_ptr, *d_col; double *d_val, *d_x, *d_y; hipStream_t st; };
+// ---- full CSR of the symmetric matrix on the device, from the upper-triangular storage that
+// k_build_ham leaves in HBM (row i: diagonal first, then columns j < i ascending).  Row j of the
+// full matrix = its stored part followed by the entries (i, j), i > j, in increasing i: the order
+// comes from a STABLE sort on the column index, never from atomics, so the matvec sums in the
+// same order run after run (the HCI selection thresholds see the same eigenvector bits).
+__global__ void __launch_bounds__(TPB) k_csr_keys(const u64 *__restrict__ cnt, const u64 *__restrict__ off, const long long *__restrict__ idx,
+                                                  u64 *__restrict__ keys, u32 *__restrict__ vals, u32 *__restrict__ rowof, u32 *__restrict__ colcount,
+                                                  long long n) {
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const long long b = (long long)off[i], c = (long long)cnt[i];
+  keys[b] = (u64)n; vals[b] = (u32)b; rowof[b] = (u32)i;                         // the diagonal sorts last and is not transposed
+  for (long long k = 1; k < c; k++) {
+    const long long j = idx[b + k] - 1;
+    keys[b + k] = (u64)j; vals[b + k] = (u32)(b + k); rowof[b + k] = (u32)i;
+    atomicAdd(&colcount[j], 1u);                                                   // a count: order-independent
+  }
+}
+__global__ void __launch_bounds__(TPB) k_csr_rowlen(const u64 *__restrict__ cnt, const u32 *__restrict__ colcount, u64 *__restrict__ rowlen, u64 *__restrict__ colc64, long long n) {
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) { rowlen[i] = cnt[i] + colcount[i]; colc64[i] = colcount[i]; }
+}
+__global__ void __launch_bounds__(TPB) k_csr_fill_stored(const u64 *__restrict__ cnt, const u64 *__restrict__ off, const long long *__restrict__ idx, const double *__restrict__ val,
+                                                         const u64 *__restrict__ ptr64, int *__restrict__ ptr, int *__restrict__ col, double *__restrict__ v,
+                                                         double *__restrict__ diag, long long n, long long nnz_full) {
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i > n) return;
+  if (i == n) { ptr[n] = (int)nnz_full; return; }
+  const long long b = (long long)off[i], c = (long long)cnt[i], d = (long long)ptr64[i];
+  ptr[i] = (int)d; diag[i] = val[b];
+  for (long long k = 0; k < c; k++) { col[d + k] = (int)(idx[b + k] - 1); v[d + k] = val[b + k]; }
+}
+__global__ void __launch_bounds__(TPB) k_csr_fill_transposed(const u64 *__restrict__ skeys, const u32 *__restrict__ sperm, const u32 *__restrict__ rowof,
+                                                             const double *__restrict__ val, const u64 *__restrict__ cnt, const u64 *__restrict__ ptr64,
+                                                             const u64 *__restrict__ colstart, int *__restrict__ col, double *__restrict__ v,
+                                                             long long n, long long n_strict) {
+  const long long q = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (q >= n_strict) return;
+  const long long j = (long long)skeys[q]; const u32 k = sperm[q];
+  const long long dst = (long long)ptr64[j] + (long long)cnt[j] + (q - (long long)colstart[j]);
+  col[dst] = (int)rowof[k]; v[dst] = val[k];
+}
+
 #define SPMV_ROWS_PER_BLOCK 4
 __global__ void __launch_bounds__(64 * SPMV_ROWS_PER_BLOCK) k_spmv_wave(const int *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val,
                                                                         const double *__restrict__ x, double *__restrict__ y, long long n) {
@@ -1818,6 +1861,63 @@ int sqmc_gpu_build_sparse_ham(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, co
   HIPCHK(hipMemcpy(vl, dval, total * 8, hipMemcpyDeviceToHost));
   *out_nnz = (int64_t)total; *out_row_counts = rc; *out_indices = ix; *out_values = vl;
   void *fr[] = {du, dd, dcnt, doff, dtot, dts, didx, dval};
+  for (void *q : fr) hipFree(q);
+  return SQMC_OK;
+}
+
+
+// The sparse Hamiltonian of a sorted determinant list built on the device AND left there as a
+// matvec plan: what generate_sparse_ham_chem_upper_triangular + davidson_sparse's matvec need,
+// without the matrix crossing PCIe twice or being expanded on the host.  diag[n] (the Davidson
+// preconditioner) and the number of stored (upper-triangular) nonzeros come back to the host.
+int sqmc_gpu_build_spmv_plan(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, const uint64_t *dn, sqmc_spmv_plan **plan, double *diag, int64_t *out_nnz) {
+  if (!c || !plan || !diag || !out_nnz || n <= 0) return fail(SQMC_ERR_BAD_ARG, "bad argument");
+  for (long long i = 1; i < n; i++)
+    if (!(up[i - 1] < up[i] || (up[i - 1] == up[i] && dn[i - 1] < dn[i]))) return fail(SQMC_ERR_BAD_ARG, "determinant list must be strictly sorted by (up,dn)");
+  hipStream_t st = c->st;
+  u64 *du, *dd, *dcnt, *doff, *dtot, *dts;
+  HIPCHK(hipMalloc(&du, n * 8)); HIPCHK(hipMalloc(&dd, n * 8)); HIPCHK(hipMalloc(&dcnt, n * 8)); HIPCHK(hipMalloc(&doff, n * 8)); HIPCHK(hipMalloc(&dtot, 16));
+  long long tiles = (n + SCAN_TILE - 1) / SCAN_TILE + 1;
+  HIPCHK(hipMalloc(&dts, (tiles + 1) * 8));
+  HIPCHK(hipMemcpy(du, up, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dd, dn, n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_build_ham, dim3(nblk(n)), dim3(TPB), 0, st, c->dev, du, dd, (long long)n, 0, dcnt, doff, (long long *)nullptr, (double *)nullptr);
+  ScanWork sw; sw.state = dts; sw.ticket = (u32 *)(dts + tiles); sw.cap_tiles = tiles; sw.self_clear = true;
+  device_excl_scan_u64(dcnt, doff, n, dtot, sw, st);
+  u64 total = 0;
+  HIPCHK(hipMemcpyAsync(&total, dtot, 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+  const long long n_strict = (long long)total - n, nnz_full = (long long)total + n_strict;
+  if (nnz_full >= (1ll << 31)) return fail(SQMC_ERR_UNSUPPORTED, "more than 2^31 expanded nonzeros");
+  long long *didx; double *dval;
+  HIPCHK(hipMalloc(&didx, (total + 1) * 8)); HIPCHK(hipMalloc(&dval, (total + 1) * 8));
+  hipLaunchKernelGGL(k_build_ham, dim3(nblk(n)), dim3(TPB), 0, st, c->dev, du, dd, (long long)n, 1, dcnt, doff, didx, dval);
+  // transpose bookkeeping
+  u64 *dkeys, *dkeys_alt, *drowlen, *dptr64, *dcolc, *dcolstart; u32 *dvals, *dvals_alt, *drowof, *dcolcount, *dhist, *drowtot;
+  const long long ntile_sort = (long long)((total + RS_TILE - 1) / RS_TILE);
+  HIPCHK(hipMalloc(&dkeys, total * 8)); HIPCHK(hipMalloc(&dkeys_alt, total * 8)); HIPCHK(hipMalloc(&dvals, total * 4)); HIPCHK(hipMalloc(&dvals_alt, total * 4));
+  HIPCHK(hipMalloc(&drowof, total * 4)); HIPCHK(hipMalloc(&dcolcount, (n + 1) * 4)); HIPCHK(hipMalloc(&drowlen, n * 8)); HIPCHK(hipMalloc(&dptr64, n * 8));
+  HIPCHK(hipMalloc(&dcolc, n * 8)); HIPCHK(hipMalloc(&dcolstart, n * 8));
+  HIPCHK(hipMalloc(&dhist, (size_t)RS_MAX_RADIX * (ntile_sort + 1) * 4)); HIPCHK(hipMalloc(&drowtot, RS_MAX_RADIX * 4));
+  HIPCHK(hipMemsetAsync(dcolcount, 0, (n + 1) * 4, st));
+  hipLaunchKernelGGL(k_csr_keys, dim3(nblk(n)), dim3(TPB), 0, st, dcnt, doff, didx, dkeys, dvals, drowof, dcolcount, (long long)n);
+  hipLaunchKernelGGL(k_csr_rowlen, dim3(nblk(n)), dim3(TPB), 0, st, dcnt, dcolcount, drowlen, dcolc, (long long)n);
+  device_excl_scan_u64(drowlen, dptr64, n, dtot, sw, st);
+  device_excl_scan_u64(dcolc, dcolstart, n, dtot + 1, sw, st);
+  int kb = 1; while ((1ll << kb) <= n) kb++;                      // keys are column indices 0..n (n = the diagonal marker)
+  SortWork so; so.k_alt = dkeys_alt; so.v_alt = dvals_alt; so.hist = dhist; so.rowtot = drowtot; so.cap = (long long)total;
+  u64 *sk = dkeys; u32 *sv = dvals;
+  device_radix_sort(sk, sv, (long long)total, kb, so, st);
+  sqmc_spmv_plan *p = new sqmc_spmv_plan(); p->n = n; p->nnz_full = nnz_full;
+  HIPCHK(hipStreamCreate(&p->st));
+  HIPCHK(hipMalloc(&p->d_ptr, (n + 1) * 4)); HIPCHK(hipMalloc(&p->d_col, (nnz_full + 1) * 4)); HIPCHK(hipMalloc(&p->d_val, (nnz_full + 1) * 8));
+  HIPCHK(hipMalloc(&p->d_x, n * 8)); HIPCHK(hipMalloc(&p->d_y, n * 8));
+  double *ddiag; HIPCHK(hipMalloc(&ddiag, n * 8));
+  hipLaunchKernelGGL(k_csr_fill_stored, dim3(nblk(n + 1)), dim3(TPB), 0, st, dcnt, doff, didx, dval, dptr64, p->d_ptr, p->d_col, p->d_val, ddiag, (long long)n, nnz_full);
+  if (n_strict > 0)
+    hipLaunchKernelGGL(k_csr_fill_transposed, dim3(nblk(n_strict)), dim3(TPB), 0, st, sk, sv, drowof, dval, dcnt, dptr64, dcolstart, p->d_col, p->d_val, (long long)n, n_strict);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(diag, ddiag, n * 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+  *out_nnz = (int64_t)total; *plan = p;
+  void *fr[] = {du, dd, dcnt, doff, dtot, dts, didx, dval, dkeys, dkeys_alt, dvals, dvals_alt, drowof, dcolcount, drowlen, dptr64, dcolc, dcolstart, dhist, drowtot, ddiag};
   for (void *q : fr) hipFree(q);
   return SQMC_OK;
 }

@@ -15,7 +15,7 @@ module sqmc_gpu_mod
   public :: sqmc_gpu_hamiltonian_batch, sqmc_gpu_hamiltonian_chem_batch, sqmc_gpu_build_sparse_ham, sqmc_gpu_propose_batch
   public :: sqmc_gpu_hci_connections, sqmc_gpu_free, sqmc_gpu_set_timing, sqmc_gpu_get_timing
   public :: sqmc_gpu_det_owner, sqmc_gpu_shard_config, sqmc_gpu_shard_begin, sqmc_gpu_shard_pack, sqmc_gpu_shard_finish
-  public :: sqmc_gpu_annihilate
+  public :: sqmc_gpu_annihilate, sqmc_gpu_build_spmv_plan
   public :: sqmc_gpu_comm_unique_id, sqmc_gpu_comm_init, sqmc_gpu_shard_step, sqmc_gpu_shard_run
   public :: sqmc_gpu_check
 
@@ -62,6 +62,10 @@ module sqmc_gpu_mod
     integer(c_int) function sqmc_gpu_run(ctx, pc, nsteps, stats, totals) bind(C, name='sqmc_gpu_run')
       import; type(c_ptr), value :: ctx; type(sqmc_popctl), intent(inout) :: pc; integer(c_int64_t), value :: nsteps
       type(c_ptr), value :: stats; real(c_double), intent(out) :: totals(16)
+    end function
+    integer(c_int) function sqmc_gpu_build_spmv_plan(ctx, n, up, dn, plan, diag, out_nnz) bind(C, name='sqmc_gpu_build_spmv_plan')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n; integer(c_int64_t), intent(in) :: up(*), dn(*)
+      type(c_ptr), intent(out) :: plan; real(c_double), intent(out) :: diag(*); integer(c_int64_t), intent(out) :: out_nnz
     end function
     integer(c_int) function sqmc_gpu_annihilate(ctx, p, n_spawn, up, dn, wt, imp_distance, initiator, out_stats) bind(C, name='sqmc_gpu_annihilate')
       import; type(c_ptr), value :: ctx; type(sqmc_step_params), intent(in) :: p; integer(c_int64_t), value :: n_spawn

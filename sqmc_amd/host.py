@@ -357,6 +357,21 @@ def sort_dets(up, dn):
     return np.lexsort((dn, up))
 
 
+def _dets_in(au, ad, bu, bd):
+    """mask over the determinants (au, ad): which of them occur in the list (bu, bd)"""
+    n = len(au)
+    u = np.concatenate((au, bu)); d = np.concatenate((ad, bd))
+    tag = np.concatenate((np.zeros(n, np.int8), np.ones(len(bu), np.int8)))
+    o = np.lexsort((tag, d, u))                      # equal determinants adjacent, the query (tag 0) first
+    us, ds, ts = u[o], d[o], tag[o]
+    hit = np.zeros(len(o), bool)
+    hit[:-1] = (us[:-1] == us[1:]) & (ds[:-1] == ds[1:]) & (ts[:-1] == 0) & (ts[1:] == 1)
+    out = np.zeros(n, bool)
+    q = o[hit]
+    out[q[q < n]] = True
+    return out
+
+
 def lowest_state(g, up, dn, k=1, v0=None):
     """Sparse H on the GPU (all-pairs builder) + Davidson with the GPU matvec."""
     counts, idx, val = g.build_sparse_ham(up, dn)
@@ -597,9 +612,7 @@ def hci_variational(host, g, eps_var, eps_sched=(), n_states=1, max_iters=50, lo
         coeffs = np.abs(wts).max(axis=1) if it > 1 else wts[:, 0].copy()
         cu, cd, _, _ = g.hci_connections(up, dn, coeffs, eps)              # sorted, unique, includes the old list
         # append the new determinants behind the old list in sorted order (hci.f90:979-991)
-        okey = np.stack((up, dn), axis=1); nkey = np.stack((cu, cd), axis=1)
-        old_set = set(map(tuple, okey.tolist()))
-        is_new = np.fromiter((tuple(k) not in old_set for k in nkey.tolist()), bool, len(nkey))
+        is_new = ~_dets_in(cu, cd, up, dn)
         n_old, n_new = len(up), len(up) + int(is_new.sum())
         if n_new == n_old:
             continue
@@ -610,18 +623,16 @@ def hci_variational(host, g, eps_var, eps_sched=(), n_states=1, max_iters=50, lo
         v0 = None
         if it > 1:
             v0 = np.zeros((n_new, n_states)); v0[np.argsort(order)[:n_old], :] = wts
-        counts, idx, val = g.build_sparse_ham(up[order], dn[order])
-        starts = np.concatenate(([0], np.cumsum(counts)))[:-1]
-        plan = SpmvPlan(counts, idx, val)
+        plan, diag, nnz = SpmvPlan.from_dets(g, up[order], dn[order])      # H built, expanded and kept on the GPU
         try:
-            w, X = davidson_lowest(plan, val[starts], k=n_states, v0=v0, tol=davidson_tol)
+            w, X = davidson_lowest(plan, diag, k=n_states, v0=v0, tol=davidson_tol)
         finally:
             plan.close()
         wts = np.zeros((n_new, n_states)); wts[order, :] = X
         energy = np.array(w)
         hist.append(n_new)
         if log:
-            log("Iteration %3d eps1=%.1e ndets=%9d nnz=%10d energy=%s" % (it, eps, n_new, len(val), " ".join("%.9f" % e for e in energy)))
+            log("Iteration %3d eps1=%.1e ndets=%9d nnz=%10d energy=%s" % (it, eps, n_new, nnz, " ".join("%.9f" % e for e in energy)))
         if np.max(np.abs(energy - old_energy)) < 1e-5 and eps == sched[-1]:
             break
         old_energy = energy.copy()
