@@ -8,6 +8,13 @@
   walk_c2_5steps.json    five semistochastic steps on C2 cc-pVDZ from the CPU oracle (the
                          reference holds no walk fixture; this one freezes the restatement).
   C2_r1.24253_FCIDUMP    copied data file of the reference (C2_v2z_curve/r1.24253/FCIDUMP).
+  curve/C2_r*_FCIDUMP    the integral files of the other eight geometries of the same directory
+                         (C2_v2z_curve/r*/FCIDUMP): input data of BASELINE.json configs[2].
+  C2_r1.24253_i_1sigma_g, C2_r1.24253_i_3pi_u
+                         the two input decks shipped next to that FCIDUMP (16 lines of run
+                         parameters each: input data, read by python -m sqmc_amd.run in the tests).
+
+Data files are copied byte for byte (cp); nothing here is reference source code.
 """
 import ctypes as C
 import json
