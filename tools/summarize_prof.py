@@ -31,6 +31,21 @@ def main(base, out):
             fl, wl = f[k][-30:], w.get(k, [0])[-30:]
             fa, wa = sum(fl) / len(fl), sum(wl) / len(wl)
             lines.append("%-50s %14.1f %14.1f %16.4e" % (k, fa, wa, (2 * fa + wa) * 1024))
+    def table(sub, title):
+        fs = glob.glob(base + '/%s/*/*counter_collection.csv' % sub)
+        if not fs:
+            return
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(fs[0])):
+            acc[r['Kernel_Name'][:48]][r['Counter_Name']].append(float(r['Counter_Value']))
+        names = sorted({c for k in acc for c in acc[k]})
+        lines.append("")
+        lines.append(title)
+        lines.append("%-50s" % "kernel" + "".join("%21s" % n for n in names))
+        for k in sorted(acc, key=lambda k: -sum(acc[k][names[0]][-30:]))[:16]:
+            lines.append("%-50s" % k + "".join("%21.2f" % (sum(acc[k][n][-30:]) / max(1, len(acc[k][n][-30:]))) for n in names))
+    table('occ', "# separate pass: rocprofv3 --pmc OccupancyPercent MeanOccupancyPerCU (averages over the last 30 launches; % of the chip's wave slots, waves per CU)")
+    table('sq', "# separate pass: rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE (per launch)")
     open(out, 'w').write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
