@@ -1,0 +1,279 @@
+!> A Fortran host for the variational stage of HCI on the GPU path (INTEGRATION.md, patch sketch 3):
+!> what perform_hci does per iteration (hci.f90:359-520) with the three heavy pieces behind
+!> sqmc_gpu_mod -- sqmc_gpu_hci_connections for find_doubly_excited + dedup (hci.f90:905-931),
+!> sqmc_gpu_build_spmv_plan for generate_sparse_ham_chem_upper_triangular, sqmc_gpu_spmv_apply for
+!> the matvec inside the Davidson iteration -- and the host logic (list bookkeeping, the small
+!> Krylov problem) written here.  Tables come from a deck written by sqmc_amd.host.dump_hci_deck.
+!>   usage: example_hci <deck>
+module hci_host_tools
+  use iso_c_binding
+  implicit none
+contains
+
+  !> permutation that sorts determinants by (up, dn); bottom-up merge sort on the index
+  subroutine argsort_dets(n, up, dn, order)
+    integer(c_int64_t), intent(in) :: n, up(n), dn(n)
+    integer(c_int64_t), intent(out) :: order(n)
+    integer(c_int64_t), allocatable :: tmp(:)
+    integer(c_int64_t) :: width, lo, mid, hi, a, b, k
+    allocate(tmp(n))
+    do k = 1, n
+      order(k) = k
+    enddo
+    width = 1
+    do while (width < n)
+      lo = 1
+      do while (lo <= n)
+        mid = min(lo + width, n + 1); hi = min(lo + 2*width, n + 1)
+        a = lo; b = mid; k = lo
+        do while (a < mid .and. b < hi)
+          if (up(order(b)) < up(order(a)) .or. (up(order(b)) == up(order(a)) .and. dn(order(b)) < dn(order(a)))) then
+            tmp(k) = order(b); b = b + 1
+          else
+            tmp(k) = order(a); a = a + 1
+          endif
+          k = k + 1
+        enddo
+        do while (a < mid); tmp(k) = order(a); a = a + 1; k = k + 1; enddo
+        do while (b < hi);  tmp(k) = order(b); b = b + 1; k = k + 1; enddo
+        lo = lo + 2*width
+      enddo
+      order = tmp
+      width = 2*width
+    enddo
+  end subroutine
+
+  !> is (u, d) in the list sorted through order?
+  logical function in_sorted(n, up, dn, order, u, d)
+    integer(c_int64_t), intent(in) :: n, up(n), dn(n), order(n), u, d
+    integer(c_int64_t) :: lo, hi, mid, m
+    lo = 1; hi = n; in_sorted = .false.
+    do while (lo <= hi)
+      mid = (lo + hi) / 2; m = order(mid)
+      if (up(m) == u .and. dn(m) == d) then
+        in_sorted = .true.; return
+      elseif (up(m) < u .or. (up(m) == u .and. dn(m) < d)) then
+        lo = mid + 1
+      else
+        hi = mid - 1
+      endif
+    enddo
+  end function
+
+  !> all eigenpairs of a small symmetric matrix by cyclic Jacobi rotations, eigenvalues ascending
+  subroutine jacobi_eig(m, a, w, v)
+    integer, intent(in) :: m
+    real(c_double), intent(inout) :: a(m, m)
+    real(c_double), intent(out) :: w(m), v(m, m)
+    integer :: sweep, p, q, i, k
+    real(c_double) :: off, theta, t, c, s, apq, tmp, x(m)
+    v = 0; do i = 1, m; v(i, i) = 1; enddo
+    do sweep = 1, 100
+      off = 0
+      do p = 1, m - 1; do q = p + 1, m; off = off + a(p, q)**2; enddo; enddo
+      if (off < 1.d-30) exit
+      do p = 1, m - 1
+        do q = p + 1, m
+          apq = a(p, q)
+          if (abs(apq) < 1.d-300) cycle
+          theta = (a(q, q) - a(p, p)) / (2 * apq)
+          t = sign(1.d0, theta) / (abs(theta) + sqrt(theta*theta + 1)); c = 1 / sqrt(t*t + 1); s = t * c
+          do k = 1, m
+            tmp = a(k, p); a(k, p) = c*tmp - s*a(k, q); a(k, q) = s*tmp + c*a(k, q)
+          enddo
+          do k = 1, m
+            tmp = a(p, k); a(p, k) = c*tmp - s*a(q, k); a(q, k) = s*tmp + c*a(q, k)
+          enddo
+          do k = 1, m
+            tmp = v(k, p); v(k, p) = c*tmp - s*v(k, q); v(k, q) = s*tmp + c*v(k, q)
+          enddo
+        enddo
+      enddo
+    enddo
+    do i = 1, m; w(i) = a(i, i); enddo
+    do i = 1, m - 1                                  ! selection sort, ascending
+      k = i
+      do p = i + 1, m; if (w(p) < w(k)) k = p; enddo
+      if (k /= i) then
+        tmp = w(i); w(i) = w(k); w(k) = tmp
+        x = v(:, i); v(:, i) = v(:, k); v(:, k) = x
+      endif
+    enddo
+  end subroutine
+end module
+
+program example_hci
+  use iso_c_binding
+  use sqmc_gpu_mod
+  use hci_host_tools
+  implicit none
+  character(len=512) :: deck
+  integer :: u, it, ns, nsched, i, j, k, itc, niter, iters, ist
+  integer(c_int64_t) :: hdr(18), n, n_old, n_new, n_conn, nnz, q
+  real(c_double) :: max_double, eps, tol
+  real(c_double), allocatable :: sched(:)
+  integer(c_int32_t), allocatable, target :: prod(:), osym(:), c2(:), hb_r(:), hb_s(:), pq_count(:)
+  integer(c_int64_t), allocatable :: pq_ind(:)
+  real(c_double), allocatable, target :: ints(:), hb_a(:)
+  integer(c_int64_t), allocatable :: up(:), dn(:), tu(:), td(:), order(:), us(:), ds(:)
+  real(c_double), allocatable :: wts(:,:), coeffs(:), energy(:), old_energy(:), diag(:), start(:,:)
+  real(c_double), allocatable :: v(:,:), hv(:,:), w(:,:), hw(:,:), hk(:,:), hwork(:,:), ev(:), y(:,:), low(:), low_prev(:), res(:), t(:), den(:)
+  integer(c_int64_t), pointer :: p_up(:), p_dn(:)
+  type(c_ptr) :: gpu, plan, c_up, c_dn, c_num, c_den
+  type(sqmc_chem_cfg) :: cfg
+  logical :: converged
+
+  if (command_argument_count() < 1) stop 'usage: example_hci <deck>'
+  call get_command_argument(1, deck)
+  open(newunit=u, file=trim(deck), access='stream', form='unformatted', status='old')
+  read(u) hdr
+  if (hdr(1) /= int(z'68636930', c_int64_t)) stop 'not an hci deck'
+  nsched = int(hdr(15)); ns = int(hdr(16))
+  allocate(sched(nsched), prod(hdr(10)), osym(hdr(11)), c2(hdr(12)), ints(hdr(9) + 1))
+  allocate(hb_r(hdr(13)), hb_s(hdr(13)), hb_a(hdr(13)), pq_ind(hdr(14)), pq_count(hdr(14)))
+  read(u) max_double, sched, prod, osym, c2, ints, hb_r, hb_s, hb_a, pq_ind, pq_count
+  close(u)
+  cfg%norb = int(hdr(2), c_int32_t); cfg%nup = int(hdr(3), c_int32_t); cfg%ndn = int(hdr(4), c_int32_t)
+  cfg%n_core_orb = int(hdr(5), c_int32_t); cfg%time_sym = int(hdr(6), c_int32_t); cfg%z = int(hdr(7), c_int32_t)
+  cfg%n_group = int(hdr(8), c_int32_t)
+  cfg%product_table = c_loc(prod); cfg%orbital_symmetries = c_loc(osym); cfg%combine_2 = c_loc(c2)
+  cfg%n_integrals = hdr(9); cfg%integrals = c_loc(ints)
+  cfg%rng_mode = SQMC_RNG_COUNTER; cfg%irand_seed = [1346, 5634, 6635, 4361]; cfg%mwalk = 0
+  call sqmc_gpu_check(sqmc_gpu_set_device(0_c_int), 'set_device')
+  call sqmc_gpu_check(sqmc_gpu_init_chem(cfg, gpu), 'init_chem')
+  call sqmc_gpu_check(sqmc_gpu_set_hb_tables(gpu, hdr(13), hb_r, hb_s, hb_a, int(hdr(14) - 1, c_int32_t), pq_ind, pq_count, max_double), 'set_hb_tables')
+
+  ! the list starts as the HF determinant (hci.f90:300-323)
+  n = 1
+  allocate(up(1), dn(1), wts(1, ns), energy(ns), old_energy(ns))
+  up(1) = hdr(17); dn(1) = hdr(18); wts = 0; wts(1, 1) = 1
+  energy = 0
+  call sqmc_gpu_check(sqmc_gpu_hamiltonian_batch(gpu, 1_c_int64_t, up, dn, up, dn, energy), 'hamiltonian')
+  old_energy = energy
+  write(6, '(''Iteration   0 eps1='',es7.1e1,'' ndets='',i9,'' energy='',10f16.9)') sched(1), n, energy
+  tol = 1.d-10
+  do it = 1, 50
+    eps = sched(min(it, nsched))
+    allocate(coeffs(n))
+    if (it > 1) then
+      coeffs = maxval(abs(wts), dim=2)
+    else
+      coeffs = wts(:, 1)
+    endif
+    ! connections above eps/|c|, sorted by (up,dn), unique, old determinants included
+    call sqmc_gpu_check(sqmc_gpu_hci_connections(gpu, n, up, dn, coeffs, eps, 0_c_int, n_conn, c_up, c_dn, c_num, c_den), 'hci_connections')
+    deallocate(coeffs)
+    call c_f_pointer(c_up, p_up, [n_conn]); call c_f_pointer(c_dn, p_dn, [n_conn])
+    ! append the new ones behind the old list, in sorted order (hci.f90:979-991)
+    allocate(order(n)); call argsort_dets(n, up, dn, order)
+    n_old = n; n_new = n
+    allocate(tu(n_conn), td(n_conn))
+    do q = 1, n_conn
+      if (.not. in_sorted(n_old, up, dn, order, p_up(q), p_dn(q))) then
+        n_new = n_new + 1; tu(n_new - n_old) = p_up(q); td(n_new - n_old) = p_dn(q)
+      endif
+    enddo
+    call sqmc_gpu_free(c_up); call sqmc_gpu_free(c_dn); call sqmc_gpu_free(c_num); call sqmc_gpu_free(c_den)
+    deallocate(order)
+    if (n_new == n_old) then
+      deallocate(tu, td); cycle
+    endif
+    if (n_new <= int(1.00001d0 * n_old, c_int64_t) .and. it >= nsched) then
+      deallocate(tu, td); exit
+    endif
+    allocate(us(n_new), ds(n_new))
+    us(1:n_old) = up; ds(1:n_old) = dn; us(n_old+1:n_new) = tu(1:n_new-n_old); ds(n_old+1:n_new) = td(1:n_new-n_old)
+    deallocate(up, dn, tu, td); call move_alloc(us, up); call move_alloc(ds, dn)
+    n = n_new
+    ! the builder wants sorted labels: permute in, permute the eigenvectors back out
+    allocate(order(n), us(n), ds(n), diag(n), start(n, ns))
+    call argsort_dets(n, up, dn, order)
+    us = up(order); ds = dn(order)
+    call sqmc_gpu_check(sqmc_gpu_build_spmv_plan(gpu, n, us, ds, plan, diag, nnz), 'build_spmv_plan')
+    start = 0
+    if (it == 1) then
+      do i = 1, min(ns, int(n)); start(i, i) = 1; enddo           ! list order = sorted order in iteration 1
+    else
+      do q = 1, n
+        if (order(q) <= n_old) start(q, :) = wts(order(q), :)
+      enddo
+    endif
+    ! ---- Davidson with diagonal preconditioner, the reference's scheme (more_tools.f90:2018-2244):
+    !      one correction vector per state and sweep, Krylov matrix diagonalised after every ns additions
+    iters = min(int(n), 50); niter = min(int(n), ns * iters)
+    allocate(v(n, ns*iters), hv(n, ns*iters), w(n, ns), hw(n, ns), hk(ns*iters, ns*iters), low(ns), low_prev(ns), res(ns), t(n), den(n))
+    v = 0; hv = 0; hk = 0
+    do i = 1, ns
+      v(:, i) = start(:, i) / sqrt(dot_product(start(:, i), start(:, i)))
+      do j = 1, i - 1
+        v(:, i) = v(:, i) - dot_product(v(:, i), v(:, j)) * v(:, j)
+      enddo
+      if (i > 1) v(:, i) = v(:, i) / sqrt(dot_product(v(:, i), v(:, i)))
+      call sqmc_gpu_check(sqmc_gpu_spmv_apply(plan, v(:, i), hv(:, i), 0_c_int), 'spmv_apply')
+    enddo
+    call seed_block()
+    w = v(:, 1:ns); hw = hv(:, 1:ns)
+    res = 1; low_prev = huge(1.d0); converged = .false.
+    ist = ns
+    do while (ist < niter * 10)
+      ist = ist + 1
+      itc = mod(ist - 1, niter) + 1
+      if (ist > niter .and. itc == 1) then
+        v(:, 1:ns) = w; hv(:, 1:ns) = hw
+        call seed_block()
+        cycle
+      endif
+      i = mod(itc - 1, ns) + 1
+      den = low(i) - diag
+      where (abs(den) < 1.d-8)
+        t = -1
+      elsewhere
+        t = (hw(:, i) - low(i) * w(:, i)) / den
+      end where
+      res(i) = dot_product(t, t)
+      if (sum(res) < 1.d-12) converged = .true.
+      do j = 1, itc - 1
+        t = t - dot_product(t, v(:, j)) * v(:, j)
+      enddo
+      t = t / sqrt(dot_product(t, t))
+      v(:, itc) = t
+      call sqmc_gpu_check(sqmc_gpu_spmv_apply(plan, v(:, itc), hv(:, itc), 0_c_int), 'spmv_apply')
+      do j = 1, itc
+        hk(j, itc) = dot_product(v(:, j), hv(:, itc)); hk(itc, j) = hk(j, itc)
+      enddo
+      if (mod(itc, ns) == 0) then
+        allocate(hwork(itc, itc), ev(itc), y(itc, itc))
+        hwork = hk(1:itc, 1:itc)
+        call jacobi_eig(itc, hwork, ev, y)
+        low = ev(1:ns)
+        w = matmul(v(:, 1:itc), y(:, 1:ns)); hw = matmul(hv(:, 1:itc), y(:, 1:ns))
+        deallocate(hwork, ev, y)
+        if (maxval(abs(low - low_prev)) < tol .or. converged) exit
+        low_prev = low
+      endif
+    enddo
+    call sqmc_gpu_check(sqmc_gpu_spmv_free(plan), 'spmv_free')
+    deallocate(wts); allocate(wts(n, ns))
+    do q = 1, n
+      wts(order(q), :) = w(q, :)
+    enddo
+    energy = low
+    deallocate(v, hv, w, hw, hk, low, low_prev, res, t, den, order, us, ds, diag, start)
+    write(6, '(''Iteration'',i4,'' eps1='',es7.1e1,'' ndets='',i9,'' nnz='',i11,'' energy='',10f16.9)') it, eps, n, nnz, energy
+    if (maxval(abs(energy - old_energy)) < 1.d-5 .and. it >= nsched) exit
+    old_energy = energy
+  enddo
+  write(6, '(a,i10,10es26.17)') 'fortran hci:', n, energy
+  call sqmc_gpu_check(sqmc_gpu_finalize(gpu), 'finalize')
+
+contains
+  subroutine seed_block()
+    integer :: a, b
+    do a = 1, ns
+      low(a) = dot_product(v(:, a), hv(:, a)); hk(a, a) = low(a)
+      do b = a + 1, ns
+        hk(a, b) = dot_product(v(:, a), hv(:, b)); hk(b, a) = hk(a, b)
+      enddo
+    enddo
+  end subroutine
+end program

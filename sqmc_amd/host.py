@@ -1027,3 +1027,19 @@ def read_wf_var(path, n_states=1):
         raise ValueError("determinants beyond 64 orbitals are not supported by this host")
     wts = np.frombuffer(recs[3], np.float64).reshape(n_states, nd).T.copy()
     return u[:, 0].copy(), d[:, 0].copy(), wts, np.frombuffer(recs[4], np.float64).copy()
+
+
+def dump_hci_deck(path, host, hb, eps_var, eps_sched=(), n_states=1):
+    """Tables + heat-bath lists + run parameters for a compiled HCI host (example_hci.f90), one
+    little-endian stream file: int64 header, float64 scalars, then the arrays in header order."""
+    prod, osym, c2 = (np.ascontiguousarray(a, np.int32).reshape(-1) for a in (host.prod, host.orbsym, host.combine_2))
+    ints = _np_f64(host.integrals)
+    hb_r, hb_s, hb_a, pq_ind, pq_count, max_double = hb
+    sched = np.array(list(eps_sched) + [eps_var], np.float64)
+    hdr = np.array([0x68636930, host.norb, host.nup, host.ndn, host.n_core_orb, int(host.time_sym), host.z, host.n_group, len(ints) - 1,
+                    len(prod), len(osym), len(c2), len(hb_r), len(pq_ind), len(sched), n_states, host.hf_up, host.hf_dn], np.int64)
+    assert len(pq_count) == len(pq_ind)
+    with open(path, "wb") as f:
+        for a in (hdr, np.array([max_double], np.float64), sched, prod, osym, c2, ints, np.ascontiguousarray(hb_r, np.int32),
+                  np.ascontiguousarray(hb_s, np.int32), _np_f64(hb_a), np.ascontiguousarray(pq_ind, np.int64), np.ascontiguousarray(pq_count, np.int32)):
+            f.write(a.tobytes())
