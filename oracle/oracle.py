@@ -236,7 +236,7 @@ def lowest_eigs(counts, idx, val, k=1, v0=None, tol=1e-12):
     return w[o], v[:, o]
 
 
-def davidson_sparse(counts, idx, val, n_states=1, initial_vectors=None, epsilon=1.0e-10):
+def davidson_sparse(counts, idx, val, n_states=1, initial_vectors=None, epsilon=1.0e-10, trace=None):
     """davidson_sparse, more_tools.f90:2018-2244 (and its one-state twin davidson_sparse_single,
     :3056-3230): diagonally preconditioned Davidson on the upper-triangular sparse storage.
     Start: the given vectors (Gram-Schmidt in order, :2066-2082) or unit vectors on the first
@@ -275,6 +275,8 @@ def davidson_sparse(counts, idx, val, n_states=1, initial_vectors=None, epsilon=
         for j in range(i + 1, n_states):
             hk[i, j] = hk[j, i] = np.dot(v[:, i], Hv[:, j])
     w, Hw = v[:, :n_states].copy(), Hv[:, :n_states].copy()
+    if trace is not None:
+        trace.append(low.copy())                   # 'Iteration, Eigenvalues=  1' (more_tools.f90:2128)
     res = np.ones(n_states)
     niter = min(n, n_states * iterations)
     low_prev = np.full(n_states, np.inf)
@@ -313,6 +315,8 @@ def davidson_sparse(counts, idx, val, n_states=1, initial_vectors=None, epsilon=
             if np.max(np.abs(low - low_prev)) < epsilon:
                 break
             low_prev = low.copy()
+            if trace is not None:
+                trace.append(low.copy())               # 'Iteration, Eigenvalues=' (more_tools.f90:2219)
             if converged:
                 break
     return low, w
@@ -667,6 +671,20 @@ class HegSystem:
         n = lib().orc_connected_heg(self.h, up, dn, _p(cu), _p(cd), _p(el) if with_elems else None, cap)
         assert n <= cap
         return cu[:n], cd[:n], el[:n]
+
+    def setup_hb(self):
+        pass
+
+    def important_connected(self, up, dn, eps, cap=400000):
+        """find_important_connected_dets_heg, heg.f90:2475-2727: the determinant itself, then every
+        momentum-conserving double excitation whose |H| exceeds eps.  The reference walks |H|-sorted
+        translation-invariant lists (dtm_hb_same_spin / dtm_hb_opposite_spin, heg.f90:243-640) and
+        stops at absH <= eps (:2608, :2629); the set is the same as screening all doubles."""
+        cu, cd, el = self.connected(up, dn, with_elems=True, cap=cap)
+        keep = np.abs(el) > eps
+        keep[0] = True
+        el = el.copy(); el[0] = 0.0
+        return cu[keep], cd[keep], el[keep]
 
     def build_sparse_ham(self, up, dn):
         up = np.ascontiguousarray(up, np.uint64); dn = np.ascontiguousarray(dn, np.uint64)
