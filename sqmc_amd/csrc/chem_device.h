@@ -32,6 +32,8 @@ struct ChemTab {
   int sys_type, n_dim;                 // 0 = 'chem', 1 = 'heg'
   double length_cell;
   double kvec[SQ_MAXORB + 1][3];       // 1-based
+  signed char krel[SQ_MAXORB + 1][3];  // the same in units of 2 pi / L (k_vectors_rel): exact momentum bookkeeping
+  int heg_nmax;                        // max |krel component|
   int c2_stride, c2_pad;               // combine_2 is stored packed: c2[i*c2_stride + j], 1-based
   unsigned short c2[(SQ_MAXORB + 2) * (SQ_MAXORB + 2)];   // only the first c2_stride^2 entries are used/staged
 };

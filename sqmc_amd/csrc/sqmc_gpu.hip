@@ -722,6 +722,7 @@ __global__ void __launch_bounds__(TPB) k_propose_batch(ChemDev dev, const u64 *u
   ju[i] = a; jd[i] = b; wj[i] = w; state_out[i] = g.x;
 }
 
+#define HEG_LUT_MAX 729            // (2*4+1)^3: plane-wave indices up to +-4 per direction
 // ================================================================ HCI connections
 // find_important_connected_dets_chem, chemistry.f90:6819-7159: one thread per reference
 // determinant; pass 0 counts, pass 1 writes at the scanned offsets.  Emits (up, dn,
@@ -731,7 +732,16 @@ __global__ void __launch_bounds__(TPB) k_hci_gen(ChemDev dev, const u64 *__restr
                                                  const u64 *__restrict__ offs, u64 *__restrict__ ou, u64 *__restrict__ od,
                                                  double *__restrict__ onum, double *__restrict__ oden) {
   __shared__ ChemTab t;
+  __shared__ unsigned char s_lut[HEG_LUT_MAX];        // plane wave (kx,ky,kz) -> orbital id, 0 = not in the basis (find_orb_id, heg.f90:752-771)
   stage_tab(&t, dev.tab, dev.tab_words);
+  if (t.sys_type == 1) {
+    const int W = 2 * t.heg_nmax + 1;
+    for (int k = threadIdx.x; k < W * W * W; k += TPB) s_lut[k] = 0;
+    __syncthreads();
+    for (int o = 1 + threadIdx.x; o <= t.norb; o += TPB)
+      s_lut[((t.krel[o][0] + t.heg_nmax) * W + (t.krel[o][1] + t.heg_nmax)) * W + (t.krel[o][2] + t.heg_nmax)] = (unsigned char)o;
+    __syncthreads();
+  }
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i >= n_ref) return;
   const double c = coef[i];
@@ -743,6 +753,42 @@ __global__ void __launch_bounds__(TPB) k_hci_gen(ChemDev dev, const u64 *__restr
   u64 cnt = 0; const u64 base = pass ? offs[i] : 0;
 #define EMIT(U, D, M, DEN) do { if (pass) { ou[base + cnt] = (U); od[base + cnt] = (D); onum[base + cnt] = (M) * c; oden[base + cnt] = (DEN); } cnt++; } while (0)
   { double hd = diag_mode ? h_any(t, dev.integrals, up, dn, up, dn) : 0.0; EMIT(up, dn, hd, c); }
+  if (t.sys_type == 1) {
+    // find_important_connected_dets_heg, heg.f90:2475-2727: no single excitations (momentum); every
+    // double p,q -> r,s with k_p + k_q = k_r + k_s whose |H| exceeds eps/|c|.  The reference walks
+    // |H|-sorted translation-invariant lists and stops at absH <= eps (:2608, :2629); here each
+    // candidate's element is evaluated and screened -- the same set, 91 pairs x norb holes for 14
+    // electrons.  Same-spin pairs take r < s (:2618).
+    const int nm = t.heg_nmax, W = 2 * nm + 1;
+    for (int cls = 0; cls < 3; cls++) {
+      const u64 A = (cls == 1) ? dn : up, B = (cls == 0) ? up : dn;     // strings of the first / second electron
+      for (u64 ea = A; ea; ea &= ea - 1) {
+        const int pa = ctz64(ea) + 1;
+        for (u64 eb = (cls == 2) ? B : (ea & (ea - 1)); eb; eb &= eb - 1) {
+          const int qb = ctz64(eb) + 1;
+          const int sx = t.krel[pa][0] + t.krel[qb][0], sy = t.krel[pa][1] + t.krel[qb][1], sz = t.krel[pa][2] + t.krel[qb][2];
+          for (u64 hr = t.orb_mask & ~A; hr; hr &= hr - 1) {
+            const int r = ctz64(hr) + 1;
+            const int kx = sx - t.krel[r][0], ky = sy - t.krel[r][1], kz = sz - t.krel[r][2];
+            if (kx < -nm || kx > nm || ky < -nm || ky > nm || kz < -nm || kz > nm) continue;
+            const int s_ = s_lut[((kx + nm) * W + (ky + nm)) * W + (kz + nm)];
+            if (!s_) continue;
+            if (cls != 2 && s_ <= r) continue;
+            if ((B >> (s_ - 1)) & 1) continue;
+            u64 nu = up, nd = dn;
+            if (cls == 0) nu = (up & ~bit64(pa - 1) & ~bit64(qb - 1)) | bit64(r - 1) | bit64(s_ - 1);
+            else if (cls == 1) nd = (dn & ~bit64(pa - 1) & ~bit64(qb - 1)) | bit64(r - 1) | bit64(s_ - 1);
+            else { nu = (up & ~bit64(pa - 1)) | bit64(r - 1); nd = (dn & ~bit64(qb - 1)) | bit64(s_ - 1); }
+            const double mel = h_heg(t, up, dn, nu, nd);
+            if (!(fabs(mel) > eps)) continue;
+            EMIT(nu, nd, mel, 0.0);
+          }
+        }
+      }
+    }
+    if (!pass) counts[i] = cnt;
+    return;
+  }
   // singles
   for (int sp = 0; sp < 2; sp++) {
     const u64 occ = sp ? dn : up;
@@ -1033,6 +1079,13 @@ int sqmc_gpu_init_heg(const sqmc_heg_cfg *cfg, sqmc_gpu_ctx **out) {
   t.orb_mask = (cfg->norb >= 64) ? ~0ull : ((1ull << cfg->norb) - 1ull);
   t.c2_stride = 0;
   for (int i = 1; i <= cfg->norb; i++) for (int j = 0; j < 3; j++) t.kvec[i][j] = (j < cfg->n_dim) ? cfg->k_vectors[(i - 1) * cfg->n_dim + j] : 0.0;
+  t.heg_nmax = 0;
+  for (int i = 1; i <= cfg->norb; i++) for (int j = 0; j < 3; j++) {
+    const long long kr = llround(t.kvec[i][j] * cfg->length_cell / (2.0 * 3.14159265358979323846264338327950288));
+    if (kr < -127 || kr > 127) { delete c; return fail(SQMC_ERR_UNSUPPORTED, "plane-wave index beyond +-127"); }
+    t.krel[i][j] = (signed char)kr;
+    if (llabs(kr) > t.heg_nmax) t.heg_nmax = (int)llabs(kr);
+  }
   return init_common(c, cfg->norb, cfg->nup, cfg->ndn, cfg->rng_mode, cfg->irand_seed, cfg->mwalk, out);
 }
 
@@ -1946,7 +1999,8 @@ int sqmc_gpu_propose_batch(sqmc_gpu_ctx *c, int64_t n, double tau, const uint64_
 int sqmc_gpu_hci_connections(sqmc_gpu_ctx *c, int64_t n_ref, const uint64_t *ref_up, const uint64_t *ref_dn, const double *coeffs, double eps,
                              int diag_mode, int64_t *out_n, uint64_t **out_up, uint64_t **out_dn, double **out_num, double **out_den) {
   if (!c || !out_n) return fail(SQMC_ERR_BAD_ARG, "null argument");
-  if (!c->dev.hb_r) return fail(SQMC_ERR_BAD_ARG, "heat-bath tables not set (sqmc_gpu_set_hb_tables)");
+  if (c->htab.sys_type == 0 && !c->dev.hb_r) return fail(SQMC_ERR_BAD_ARG, "heat-bath tables not set (sqmc_gpu_set_hb_tables)");
+  if (c->htab.sys_type == 1 && c->htab.heg_nmax > 4) return fail(SQMC_ERR_UNSUPPORTED, "HEG connections: plane-wave index beyond +-4");
   *out_n = 0;
   if (n_ref <= 0) return SQMC_OK;
   hipStream_t st = c->st;

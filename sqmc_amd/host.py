@@ -907,15 +907,7 @@ def hci_pt2(host, g, up, dn, coeffs, e_var, eps_pt):
     # membership in the variational space (binary_search at hci.f90:1159): merge of two sorted key lists
     order = sort_dets(up, dn)
     vu, vd = up[order], dn[order]
-    pos = np.searchsorted(vu, cu, side="left")          # first candidate with the same up string
-    in_v = np.zeros(len(cu), bool)
-    if host.norb <= 32:
-        kv = (vu << np.uint64(32)) | vd
-        kc = (cu << np.uint64(32)) | cd
-        in_v = np.isin(kc, kv, assume_unique=True)
-    else:
-        vset = set(zip(vu.tolist(), vd.tolist()))
-        in_v = np.fromiter(((a, b) in vset for a, b in zip(cu.tolist(), cd.tolist())), bool, len(cu))
+    in_v = _dets_in(cu, cd, vu, vd)
     out = ~in_v
     h_aa = g.hamiltonian_batch(cu[out], cd[out], cu[out], cd[out])
     delta = float(np.sum(num[out] ** 2 / (e_var - h_aa)))

@@ -846,3 +846,23 @@ def test_fortran_host_hci(tmp_path):
     assert abs(float(last[3]) - (-75.719473642)) < 2e-9 and abs(float(last[4]) - (-75.631097209)) < 2e-9
     its = [l for l in out.stdout.splitlines() if l.startswith("Iteration")]
     assert [int(l.split("ndets=")[1].split()[0]) for l in its] == [1, 650, 3767, 11787, 12705, 12776]
+
+
+def test_heg_hci_reproduces_reference_e2e_golden_output():
+    """The reference's own end-to-end fixture for the electron gas, src/e2e_tests/heg/o_det_ref (deck
+    i_det: 3D, 14 electrons, r_s = 0.5, cutoff 1.49, eps_var 1e-3, eps_pt 2e-7), on the GPU path:
+    1 -> 277 -> 9475 determinants (:226, :307, :379), E_var 58.282597 / 58.276906085 (:307, :434),
+    501881 connected determinants in the PT stage, lowering -0.000939196, total 58.275966889
+    (:431-437).  Connection generation (sqmc_gpu_hci_connections, HEG branch), Hamiltonian + matvec
+    plan, Davidson matvec and PT sums all come from the GPU."""
+    from sqmc_amd import host as H
+    hst = H.HegHost(3, 0.5, 14, 7, 1.49)
+    assert hst.norb == 19
+    g = hst.gpu()
+    up, dn, w, e, hist = H.hci_variational(hst, g, 1e-3, n_states=1)
+    assert hist == [1, 277, 9475]
+    assert abs(e[0] - 58.276906085) < 2e-9
+    d, n = H.hci_pt2(hst, g, up, dn, w[:, 0], float(e[0]), 2e-7)
+    g.close()
+    assert n == 501881
+    assert abs(d - (-0.000939196)) < 2e-9 and abs(e[0] + d - 58.275966889) < 2e-9
