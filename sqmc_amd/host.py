@@ -821,6 +821,35 @@ class HegHost:
     def gpu(self, **kw):
         return GpuChem.heg(self.n_dim, self.norb, self.nup, self.ndn, self.length_cell, self.k_vectors, **kw)
 
+    def madelung_energy(self):
+        """madelung_energy, heg.f90:2828-2906 (3D): Ewald self-interaction of the periodic images with
+        kappa = 10/L (the real-space erfc term is negligible), reciprocal sum over the cube of g-vectors
+        up to the first n_max whose term drops below 1e-10, times nelec/2.  Added to HCI totals as
+        'Total energy (includ. Madelung)'."""
+        import math
+        if self.n_dim != 3:
+            raise ValueError("Madelung energy is only implemented for 3d (heg.f90:2844)")
+        L, pi = self.length_cell, 4.0 * math.atan(1.0)
+        kappa = 10.0 / L
+        n_max = 1
+        while True:
+            g_max = 2 * pi * n_max / L
+            if 4 * pi / L ** 3 * math.exp(-(g_max / (2 * kappa)) ** 2) / g_max ** 2 < 1e-10:
+                break
+            n_max += 1
+        vals = [2 * pi / L * i for i in range(-n_max, n_max + 1)]
+        e = 0.0
+        for a in vals:
+            for b in vals:
+                for c_ in vals:
+                    g2 = sum_left((a * a, b * b, c_ * c_))
+                    if g2 < 1e-10:
+                        continue
+                    e = e + math.exp(-g2 / (2 * kappa) ** 2) / g2
+        e = e * 4 * pi / L ** 3
+        e = e - pi / L ** 3 / kappa ** 2 - 2 * kappa / pi ** 0.5
+        return e * self.nelec / 2.0
+
     def connected(self, up, dn):
         """the determinant + all momentum-conserving double excitations (unique, unsorted)"""
         n, kr = self.norb, self.k_rel

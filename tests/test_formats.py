@@ -39,3 +39,12 @@ def test_wf_file_roundtrip_through_fortran_io(tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
     u2, d2, w2, e2 = H.read_wf_var(b, 2)
     assert np.array_equal(u2, up) and np.array_equal(d2, dn) and np.array_equal(w2, wts) and np.array_equal(e2, e)
+
+
+def test_heg_madelung_energy_matches_reference_output():
+    """src/e2e_tests/heg/o_det_ref:75-76: 'Madelung energy =-10.224153', 'HF energy including Madelung
+    = 48.36852150' for 14 electrons at r_s = 0.5 (HF energy 58.592675, :226)."""
+    from sqmc_amd import host as H
+    h = H.HegHost(3, 0.5, 14, 7, 1.49)
+    m = h.madelung_energy()
+    assert abs(m - (-10.224153)) < 1e-6 and abs(58.592674968 + m - 48.36852150) < 1e-7

@@ -866,3 +866,4 @@ def test_heg_hci_reproduces_reference_e2e_golden_output():
     g.close()
     assert n == 501881
     assert abs(d - (-0.000939196)) < 2e-9 and abs(e[0] + d - 58.275966889) < 2e-9
+    assert abs(e[0] + d + hst.madelung_energy() - 48.051813420) < 2e-9          # 'Total energy (includ. Madelung)' :438
