@@ -863,7 +863,11 @@ def test_heg_hci_reproduces_reference_e2e_golden_output():
     assert hist == [1, 277, 9475]
     assert abs(e[0] - 58.276906085) < 2e-9
     d, n = H.hci_pt2(hst, g, up, dn, w[:, 0], float(e[0]), 2e-7)
+    # the deterministic piece of the semistochastic PT run of the same directory (deck i_st: eps_pt_big =
+    # 8.192e-4; o_st_ref:873 prints it as the first number in parentheses)
+    d_big, _ = H.hci_pt2(hst, g, up, dn, w[:, 0], float(e[0]), 8.1920e-4)
     g.close()
+    assert abs(d_big - (-0.000199339)) < 2e-9
     assert n == 501881
     assert abs(d - (-0.000939196)) < 2e-9 and abs(e[0] + d - 58.275966889) < 2e-9
     assert abs(e[0] + d + hst.madelung_energy() - 48.051813420) < 2e-9          # 'Total energy (includ. Madelung)' :438
