@@ -260,7 +260,10 @@ int sqmc_gpu_propose_batch(sqmc_gpu_ctx *ctx, int64_t n, double tau, const uint6
  * |H| >= eps/|c| (the reference det itself included), sorted by (up,dn), duplicates merged:
  * e_mix_num = sum_j H_ij c_j, e_mix_den = c_i on the reference determinants, else 0
  * (semistoch.f90:2039-2063).  diag_mode 0: the self slot carries H=0 (HCI, chemistry.f90:6896);
- * 1: it carries H_ii (find_connected_dets_chem, chemistry.f90:6574-6576, for C(T)).
+ * 1: it carries H_ii (find_connected_dets_chem, chemistry.f90:6574-6576, for C(T));
+ * 2: "raw" -- no sort, no merge: every generated connection in generation order with
+ *    e_mix_num = H_ki c_i and e_mix_den = i (0-based index of its reference determinant), what the
+ *    weighted sums of second_order_pt_alias (hci.f90:1314-1660: term1, term2) are formed from.
  * out arrays are allocated by the library, release each with sqmc_gpu_free. */
 int sqmc_gpu_hci_connections(sqmc_gpu_ctx *ctx, int64_t n_ref, const uint64_t *ref_up,
                              const uint64_t *ref_dn, const double *coeffs, double eps, int diag_mode,

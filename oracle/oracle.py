@@ -763,3 +763,75 @@ def hci_pt2(sysm, up, dn, coeffs, e_var, eps_pt):
     for (p, q), v in acc.items():
         delta += v * v / (e_var - sysm.ham(p, q, p, q))
     return delta, len(acc)
+
+
+# ------------------------------------------------------------------------------------
+# Semistochastic PT (second_order_pt_alias, hci.f90:1314-1660), oracle side
+# ------------------------------------------------------------------------------------
+def setup_alias(pdf):
+    """setup_alias, more_tools.f90:5603-5662: outcomes split in index order into 'smaller' (K p < 1) and
+    'larger', then paired from the END of both lists.  Returns 1-based J and q."""
+    K = len(pdf)
+    J = np.arange(1, K + 1); q = K * np.asarray(pdf, float)
+    smaller = [i + 1 for i in range(K) if q[i] < 1.0]
+    larger = [i + 1 for i in range(K) if not (q[i] < 1.0)]
+    while smaller and larger:
+        small, large = smaller[-1], larger[-1]
+        J[small - 1] = large
+        q[large - 1] = q[large - 1] + q[small - 1] - 1.0
+        if q[large - 1] < 1.0:
+            smaller[-1] = large; larger.pop()
+        else:
+            smaller.pop()
+    return J, q
+
+
+def second_order_pt_alias(sysm, up, dn, coeffs, e_var, eps_pt, eps_pt_big, n_mc, target_error, seed, max_samples=10**6):
+    """Per-sample values of the stochastic difference PT(eps_pt) - PT(eps_pt_big): alias draws with the
+    rannyu stream set from `seed` (sample_alias, more_tools.f90:5727-5752: one random_int, one rannyu),
+    repeats merged (tools.f90:1574-1602), term1/term2 sums over the connections of the sampled
+    determinants (hci.f90:1585-1600), Welford statistics (tools.f90:1761-1778).  Python loops: slow,
+    meant for a handful of samples."""
+    L = lib()
+    L.orc_rannyu.restype = C.c_double; L.orc_random_int.restype = C.c_int
+    order = sort_dets(up, dn)
+    up, dn, c = np.asarray(up)[order], np.asarray(dn)[order], np.asarray(coeffs, float)[order]
+    n = len(up)
+    prob = np.abs(c) / np.abs(c).sum()
+    J, q = setup_alias(prob)
+    rng = Rng()
+    L.orc_setrn(C.byref(rng), (C.c_int * 4)(*seed)); L.orc_rng_set_mode(C.byref(rng), 0)
+    vset = set(zip(up.tolist(), dn.tolist()))
+    vals, mean, s_acc, var = [], 0.0, 0.0, float("nan")
+    for sample in range(1, max_samples + 1):
+        draws = []
+        for _ in range(n_mc):
+            i = L.orc_random_int(C.byref(rng), n)
+            draws.append(i if L.orc_rannyu(C.byref(rng)) < q[i - 1] else int(J[i - 1]))
+        ids, counts = np.unique(draws, return_counts=True)
+        t1, t2, t1b, t2b = {}, {}, {}, {}
+        for i, cnt in zip(ids.tolist(), counts.tolist()):
+            ci, wop = c[i - 1], cnt / prob[i - 1]
+            cu, cd, el = sysm.important_connected(int(up[i - 1]), int(dn[i - 1]), eps_pt / abs(ci))
+            for a, b, hh in zip(cu[1:].tolist(), cd[1:].tolist(), el[1:].tolist()):
+                if (a, b) in vset:
+                    continue
+                x = hh * ci
+                t1[(a, b)] = t1.get((a, b), 0.0) + x * wop
+                t2[(a, b)] = t2.get((a, b), 0.0) + x * x * ((n_mc - 1) * wop - wop * wop)
+                if abs(hh) > eps_pt_big / abs(ci):
+                    t1b[(a, b)] = t1b.get((a, b), 0.0) + x * wop
+                    t2b[(a, b)] = t2b.get((a, b), 0.0) + x * x * ((n_mc - 1) * wop - wop * wop)
+        val = 0.0
+        for k in t1:
+            val += (t1[k] ** 2 + t2[k] - t1b.get(k, 0.0) ** 2 - t2b.get(k, 0.0)) / (e_var - sysm.ham(k[0], k[1], k[0], k[1]))
+        val /= n_mc * float(n_mc - 1)
+        vals.append(val)
+        old = mean
+        mean = mean + (val - mean) / sample
+        s_acc = s_acc + (val - mean) * (val - old)
+        if sample > 1:
+            var = s_acc / (sample - 1) / sample
+        if sample >= 10 and var < target_error ** 2:
+            break
+    return vals, mean, float(np.sqrt(var)) if sample > 1 else float("nan")

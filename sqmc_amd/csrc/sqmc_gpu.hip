@@ -751,8 +751,9 @@ __global__ void __launch_bounds__(TPB) k_hci_gen(ChemDev dev, const u64 *__restr
   const int n = t.norb;
   const double sqrt2 = sqrt(2.0), sqrt2inv = 1.0 / sqrt2;
   u64 cnt = 0; const u64 base = pass ? offs[i] : 0;
-#define EMIT(U, D, M, DEN) do { if (pass) { ou[base + cnt] = (U); od[base + cnt] = (D); onum[base + cnt] = (M) * c; oden[base + cnt] = (DEN); } cnt++; } while (0)
-  { double hd = diag_mode ? h_any(t, dev.integrals, up, dn, up, dn) : 0.0; EMIT(up, dn, hd, c); }
+  // diag_mode 2 ("raw", for the semistochastic PT): e_mix_den carries the index of the reference determinant instead
+#define EMIT(U, D, M, DEN) do { if (pass) { ou[base + cnt] = (U); od[base + cnt] = (D); onum[base + cnt] = (M) * c; oden[base + cnt] = (diag_mode == 2) ? (double)i : (DEN); } cnt++; } while (0)
+  { double hd = (diag_mode == 1) ? h_any(t, dev.integrals, up, dn, up, dn) : 0.0; EMIT(up, dn, hd, c); }
   if (t.sys_type == 1) {
     // find_important_connected_dets_heg, heg.f90:2475-2727: no single excitations (momentum); every
     // double p,q -> r,s with k_p + k_q = k_r + k_s whose |H| exceeds eps/|c|.  The reference walks
@@ -2022,6 +2023,21 @@ int sqmc_gpu_hci_connections(sqmc_gpu_ctx *c, int64_t n_ref, const uint64_t *ref
   u64 *du, *dd, *keys, *kalt, *flags, *pos, *ou, *od, *dts2, *dtot2; u32 *vals, *valt, *hist, *rowtot; double *dnum, *dden, *onum, *oden;
   HIPCHK(hipMalloc(&du, T * 8)); HIPCHK(hipMalloc(&dd, T * 8)); HIPCHK(hipMalloc(&dnum, T * 8)); HIPCHK(hipMalloc(&dden, T * 8));
   hipLaunchKernelGGL(k_hci_gen, dim3(nblk(n_ref)), dim3(TPB), 0, st, c->dev, dru, drd, dco, eps, diag_mode, (long long)n_ref, 1, dcnt, doff, du, dd, dnum, dden);
+  if (diag_mode == 2) {               // the unmerged list, in generation order
+    HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(st));
+    *out_n = T;
+    uint64_t *hu = (uint64_t *)malloc(T * 8 + 8), *hd = (uint64_t *)malloc(T * 8 + 8);
+    double *hn = (double *)malloc(T * 8 + 8), *hden = (double *)malloc(T * 8 + 8);
+    HIPCHK(hipMemcpy(hu, du, T * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hd, dd, T * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hn, dnum, T * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hden, dden, T * 8, hipMemcpyDeviceToHost));
+    if (out_up) *out_up = hu; else free(hu);
+    if (out_dn) *out_dn = hd; else free(hd);
+    if (out_num) *out_num = hn; else free(hn);
+    if (out_den) *out_den = hden; else free(hden);
+    void *fr0[] = {dru, drd, dco, dcnt, doff, dtot, dts, du, dd, dnum, dden};
+    for (void *q : fr0) hipFree(q);
+    return SQMC_OK;
+  }
   HIPCHK(hipMalloc(&keys, T * 8)); HIPCHK(hipMalloc(&kalt, T * 8)); HIPCHK(hipMalloc(&vals, T * 4)); HIPCHK(hipMalloc(&valt, T * 4));
   long long ntiles = (T + RS_TILE - 1) / RS_TILE;
   HIPCHK(hipMalloc(&hist, ntiles * RS_MAX_RADIX * 4)); HIPCHK(hipMalloc(&rowtot, RS_MAX_RADIX * 4));

@@ -358,18 +358,17 @@ def sort_dets(up, dn):
 
 
 def _dets_in(au, ad, bu, bd):
-    """mask over the determinants (au, ad): which of them occur in the list (bu, bd)"""
+    """mask over the determinants (au, ad): which of them occur in the list (bu, bd); repeats allowed on both sides"""
     n = len(au)
     u = np.concatenate((au, bu)); d = np.concatenate((ad, bd))
-    tag = np.concatenate((np.zeros(n, np.int8), np.ones(len(bu), np.int8)))
-    o = np.lexsort((tag, d, u))                      # equal determinants adjacent, the query (tag 0) first
-    us, ds, ts = u[o], d[o], tag[o]
-    hit = np.zeros(len(o), bool)
-    hit[:-1] = (us[:-1] == us[1:]) & (ds[:-1] == ds[1:]) & (ts[:-1] == 0) & (ts[1:] == 1)
-    out = np.zeros(n, bool)
-    q = o[hit]
-    out[q[q < n]] = True
-    return out
+    o = np.lexsort((d, u))
+    us, ds = u[o], d[o]
+    new = np.ones(len(o), bool)
+    new[1:] = (us[1:] != us[:-1]) | (ds[1:] != ds[:-1])
+    gid = np.empty(len(o), np.int64)
+    gid[o] = np.cumsum(new)                          # one integer per distinct determinant
+    return np.isin(gid[:n], gid[n:])
+
 
 
 def lowest_state(g, up, dn, k=1, v0=None):
@@ -1064,3 +1063,99 @@ def dump_hci_deck(path, host, hb, eps_var, eps_sched=(), n_states=1):
         for a in (hdr, np.array([max_double], np.float64), sched, prod, osym, c2, ints, np.ascontiguousarray(hb_r, np.int32),
                   np.ascontiguousarray(hb_s, np.int32), _np_f64(hb_a), np.ascontiguousarray(pq_ind, np.int64), np.ascontiguousarray(pq_count, np.int32)):
             f.write(a.tobytes())
+
+
+# --------------------------------------------------------------- semistochastic PT (hci.f90:1314-1660)
+class Rannyu:
+    """The host's copy of the reference's generator (rannyu.f90:11-87, tools.f90:129-147): 48-bit LCG
+    x <- x * 11^13 mod 2^48 seeded from four limbs (last one forced odd), r = x / 2^48,
+    random_int(n) = int(n r) + 1.  Stream 1 of the input line drives the alias sampling of the
+    stochastic PT (do_walk.f90:229-238)."""
+    M, MASK = 34522712143931, (1 << 48) - 1
+
+    def __init__(self, seed):
+        l = list(seed); l[3] = 2 * (l[3] // 2) + 1
+        self.x = (l[0] * (1 << 36) + l[1] * (1 << 24) + l[2] * (1 << 12) + l[3]) & self.MASK
+
+    def rannyu(self):
+        self.x = (self.x * self.M) & self.MASK
+        return self.x * 3.552713678800500929355621337890625e-15
+
+    def random_int(self, n):
+        return int(n * self.rannyu()) + 1
+
+
+def setup_alias(pdf):
+    """setup_alias, more_tools.f90:5603-5662 (Walker's alias tables; outcomes are split in index order
+    and paired from the END of the two lists, which fixes J and q to the last bit).  1-based J."""
+    K = len(pdf)
+    J = np.arange(1, K + 1); q = K * np.asarray(pdf, float)
+    smaller = [i + 1 for i in range(K) if q[i] < 1.0]
+    larger = [i + 1 for i in range(K) if not (q[i] < 1.0)]
+    while smaller and larger:
+        small, large = smaller[-1], larger[-1]
+        J[small - 1] = large
+        q[large - 1] = q[large - 1] + q[small - 1] - 1.0
+        if q[large - 1] < 1.0:
+            smaller[-1] = large; larger.pop()
+        else:
+            smaller.pop()
+    return J, q
+
+
+def hci_pt2_stochastic(host, g, up, dn, coeffs, e_var, eps_pt, eps_pt_big, n_mc, target_error, seed=(2726, 5165, 6543, 6524),
+                       max_samples=10**6, log=None):
+    """second_order_pt_alias, hci.f90:1314-1660 (one rank): the PT correction at eps_pt as the
+    deterministic correction at eps_pt_big (hci_pt2) plus a stochastic estimate of the difference.
+    Each sample draws n_mc variational determinants with probability |c_i| / sum|c| (alias method,
+    one random_int and one rannyu per draw), merges repeats (w_i copies), generates their connections
+    on the GPU and accumulates, for every connected determinant k outside the variational space,
+        term1 = sum_i H_ki c_i w_i/p_i        term2 = sum_i (H_ki c_i)^2 ((n_mc-1) w_i/p_i - (w_i/p_i)^2)
+    over the connections with |H_ki c_i| above eps_pt, and the same above eps_pt_big; the sample's value
+    is sum_k (term1^2 + term2 - term1_big^2 - term2_big) / (E_var - H_kk) / (n_mc (n_mc-1)).  Welford mean
+    and variance; stops after >= 10 samples once the error bar is below target_error.
+    The determinant list must be sorted by (up,dn) (hci.f90:1373-1380).
+    Returns dict(pt_big, pt_diff, pt_diff_std_dev, samples=[per-sample values], n_connected_big)."""
+    up, dn, c = np.ascontiguousarray(up, np.uint64), np.ascontiguousarray(dn, np.uint64), np.asarray(coeffs, float)
+    order = sort_dets(up, dn)
+    up, dn, c = up[order], dn[order], c[order]
+    n = len(up)
+    pt_big, n_big = hci_pt2(host, g, up, dn, c, e_var, eps_pt_big)
+    prob = np.abs(c) / np.abs(c).sum()
+    J, q = setup_alias(prob)
+    rng = Rannyu(seed)
+    mean = s_acc = var = 0.0
+    values = []
+    for sample in range(1, max_samples + 1):
+        draws = np.empty(n_mc, np.int64)
+        for k in range(n_mc):
+            i = rng.random_int(n)
+            draws[k] = i if rng.rannyu() < q[i - 1] else J[i - 1]
+        ids, counts = np.unique(draws, return_counts=True)                 # sort_and_merge_count_repeats, tools.f90:1574-1602
+        ci, wop = c[ids - 1], counts / prob[ids - 1]
+        cu, cd, x, src = g.hci_connections(up[ids - 1], dn[ids - 1], ci, eps_pt, diag_mode=2)
+        src = src.astype(np.int64)
+        own = (cu == up[ids - 1][src]) & (cd == dn[ids - 1][src])           # the self slot of every reference determinant
+        keep = ~own & ~_dets_in(cu, cd, up, dn)                             # connected determinants outside the variational space
+        cu, cd, x, src = cu[keep], cd[keep], x[keep], src[keep]
+        w1 = wop[src]
+        a1, a2 = x * w1, x * x * ((n_mc - 1) * w1 - w1 * w1)
+        big = np.abs(x) > eps_pt_big
+        o = np.lexsort((cd, cu))
+        cu, cd, a1, a2, big = cu[o], cd[o], a1[o], a2[o], big[o]
+        head = np.ones(len(cu), bool); head[1:] = (cu[1:] != cu[:-1]) | (cd[1:] != cd[:-1])
+        st = np.nonzero(head)[0]
+        t1, t2 = np.add.reduceat(a1, st), np.add.reduceat(a2, st)
+        t1b, t2b = np.add.reduceat(np.where(big, a1, 0.0), st), np.add.reduceat(np.where(big, a2, 0.0), st)
+        h_kk = g.hamiltonian_batch(cu[st], cd[st], cu[st], cd[st])
+        val = float(np.sum((t1 * t1 + t2 - t1b * t1b - t2b) / (e_var - h_kk))) / (n_mc * float(n_mc - 1))
+        values.append(val)
+        old = mean
+        mean = mean + (val - mean) / sample                                 # welford, tools.f90:1761-1778
+        s_acc = s_acc + (val - mean) * (val - old)
+        var = s_acc / (sample - 1) / sample if sample > 1 else float("nan")
+        if log:
+            log("Sample, E_2pt_now, E_2pt estimate, total energy=%6d%15.9f%12.8f%15.8f +-%12.8f" % (sample, val, mean, e_var + pt_big + mean, np.sqrt(var) if sample > 1 else float("nan")))
+        if sample >= 10 and var < target_error ** 2:
+            break
+    return dict(pt_big=pt_big, pt_diff=mean, pt_diff_std_dev=float(np.sqrt(var)), samples=values, n_connected_big=n_big)

@@ -5,7 +5,8 @@ Runs a reference input deck of run_type `hci` on the GPU path: the deck grammar 
 dump_wf_var, the chem Hamiltonian block of chemistry.f90:119-245, then the namelists
 &selected_ci and &hf_det) and the result lines of perform_hci (hci.f90:323, 487, 833-841), so the
 shipped decks (C2_v2z_curve/*/i_1sigma_g) run unchanged next to their FCIDUMP and the same
-`grep 'Total energy(1)'` post-processing applies.  Deterministic PT only (n_mc = 0).  Host-side
+`grep 'Total energy(1)'` post-processing applies.  PT: deterministic, or with `n_mc > 0` and
+`eps_pt_big` in &selected_ci the semistochastic scheme of second_order_pt_alias.  Host-side
 plumbing: every piece that scales with the number of determinants runs in libsqmc_gpu."""
 import argparse
 import os
@@ -84,6 +85,7 @@ def parse_hci_deck(text):
     sci = nl.get("selected_ci", {})
     deck["eps_var_sched"] = [float(v.lower().replace("d", "e")) for v in sci.get("eps_var_sched", [])]
     deck["n_mc"] = int(float(sci.get("n_mc", ["0"])[0]))
+    deck["eps_pt_big"] = float(sci["eps_pt_big"][0].lower().replace("d", "e")) if "eps_pt_big" in sci else 0.0
     hf = nl.get("hf_det", {})
     deck["hf_symmetry"] = int(hf["hf_symmetry"][0]) if "hf_symmetry" in hf else None
     if "irreps" in hf:
@@ -127,6 +129,27 @@ def run_hci(deck, fcidump="FCIDUMP", out=sys.stdout):
     t1 = time.perf_counter()
     results = []
     for i in range(n_states):
+        if deck["n_mc"] > 0 and deck["eps_pt_big"] > deck["eps_pt"]:
+            # semistochastic PT (second_order_pt_alias): deterministic at eps_pt_big + sampled difference; in the determinant basis
+            plain, du, dd, dc = h, up, dn, wts[:, i]
+            if h.time_sym:
+                import copy
+                plain = copy.copy(h); plain.time_sym = False
+                du, dd, dc = H.time_symmetrized_to_dets(up, dn, wts[:, i], h.z)
+            gp = plain.gpu()
+            gp.set_hb_tables(*plain.hb_tables(gp))
+            try:
+                r = H.hci_pt2_stochastic(plain, gp, du, dd, dc, float(energy[i]), deck["eps_pt"], deck["eps_pt_big"], deck["n_mc"], deck["target_error"],
+                                         seed=deck["irand_seed"][0], log=lambda m: p("\n" + m))
+            finally:
+                gp.close()
+            de, nconn = r["pt_big"] + r["pt_diff"], r["n_connected_big"]
+            p("\nState%4d:" % (i + 1))
+            p("Variational energy(%d)=%s%15.9f" % (i + 1, " " * 12, energy[i]))
+            p("2nd-order PT energy lowering(%d)=%s%15.9f +-%12.9f (%13.9f%13.9f)" % (i + 1, " " * 2, de, r["pt_diff_std_dev"], r["pt_big"], r["pt_diff"]))
+            p("Total energy(%d)=%s%15.9f +-%12.9f" % (i + 1, " " * 18, energy[i] + de, r["pt_diff_std_dev"]))
+            results.append((float(energy[i]), float(de), int(nconn)))
+            continue
         de, nconn = H.hci_pt2_determinant_basis(h, up, dn, wts[:, i], float(energy[i]), deck["eps_pt"])
         p("\nState%4d:" % (i + 1))
         p("Variational energy(%d)=%s%15.9f" % (i + 1, " " * 12, energy[i]))

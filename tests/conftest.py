@@ -61,6 +61,12 @@ def heg_setup(oracle, heg14):
     return oracle.setup_walk_heg(heg14, 250, 0.1)
 
 
+@pytest.fixture(scope="session")
+def heg14_hci(oracle, heg14):
+    """variational stage of the reference's e2e HEG deck (eps_var 1e-3, one state) in the oracle: ~60 s, shared"""
+    return oracle.hci_variational(heg14, 1e-3, n_states=1)
+
+
 def gpu_ctx_heg(hsys, **kw):
     import sqmc_amd
     return sqmc_amd.GpuChem.heg(hsys.n_dim, hsys.norb, hsys.nup, hsys.ndn, hsys.length_cell, hsys.k_vectors(), **kw)

@@ -871,3 +871,24 @@ def test_heg_hci_reproduces_reference_e2e_golden_output():
     assert n == 501881
     assert abs(d - (-0.000939196)) < 2e-9 and abs(e[0] + d - 58.275966889) < 2e-9
     assert abs(e[0] + d + hst.madelung_energy() - 48.051813420) < 2e-9          # 'Total energy (includ. Madelung)' :438
+
+
+def test_heg_semistochastic_pt_reproduces_reference_samples():
+    """The reference's second e2e fixture for the electron gas, src/e2e_tests/heg/o_st_ref (deck i_st =
+    i_det + `&selected_ci n_mc=200 eps_pt_big=8.1920e-4 /`): the semistochastic PT, sample by sample.
+    Same rannyu stream (seed 1 of the input line), alias tables, merging of repeats and estimator: the
+    first samples print -0.000628947, -0.000488905, -0.000786277, -0.000940695, -0.000707866 (:442-454),
+    the run stops after 143 samples (target error 1e-5) at -0.000729402 +- 0.000009966 on top of the
+    deterministic -0.000199339, total 58.275977344 (:868-874)."""
+    from sqmc_amd import host as H
+    hst = H.HegHost(3, 0.5, 14, 7, 1.49)
+    g = hst.gpu()
+    up, dn, w, e, hist = H.hci_variational(hst, g, 1e-3, n_states=1)
+    res = H.hci_pt2_stochastic(hst, g, up, dn, w[:, 0], float(e[0]), 2e-7, 8.1920e-4, 200, 1e-5, seed=(2726, 5165, 6543, 6524), max_samples=400)
+    g.close()
+    ref5 = [-0.000628947, -0.000488905, -0.000786277, -0.000940695, -0.000707866]
+    assert all(abs(a - b) < 1.5e-9 for a, b in zip(res["samples"][:5], ref5))
+    assert len(res["samples"]) == 143 and abs(res["samples"][-1] - (-0.000829319)) < 1.5e-9
+    assert abs(res["pt_big"] - (-0.000199339)) < 2e-9
+    assert abs(res["pt_diff"] - (-0.000729402)) < 2e-9 and abs(res["pt_diff_std_dev"] - 0.000009966) < 2e-9
+    assert abs(e[0] + res["pt_big"] + res["pt_diff"] - 58.275977344) < 3e-9
