@@ -48,3 +48,17 @@ def test_heg_madelung_energy_matches_reference_output():
     h = H.HegHost(3, 0.5, 14, 7, 1.49)
     m = h.madelung_energy()
     assert abs(m - (-10.224153)) < 1e-6 and abs(58.592674968 + m - 48.36852150) < 1e-7
+
+
+def test_heg_k_point_table_matches_reference_output():
+    """src/e2e_tests/heg/o_det_ref:53-72 prints the 19 plane waves inside cutoff 1.49 in the order the
+    reference's shell sort leaves them (which fixes every determinant label of the HEG runs); unit
+    2 pi / L = 3.2345 for 14 electrons at r_s = 0.5."""
+    from sqmc_amd import host as H
+    h = H.HegHost(3, 0.5, 14, 7, 1.49)
+    ref = [(0, 0, 0), (0, 0, 1), (0, 0, -1), (0, 1, 0), (-1, 0, 0), (0, -1, 0), (1, 0, 0), (1, -1, 0), (1, 0, -1), (0, 1, -1),
+           (-1, 0, 1), (0, -1, 1), (-1, 1, 0), (1, 0, 1), (-1, -1, 0), (1, 1, 0), (-1, 0, -1), (0, 1, 1), (0, -1, -1)]
+    unit = 2 * np.pi / h.length_cell
+    assert abs(unit - 3.2345) < 5e-5 and h.norb == 19
+    assert [tuple(int(x) for x in row) for row in np.round(np.asarray(h.k_vectors) / unit)] == ref
+    assert (h.hf_up, h.hf_dn) == (127, 127)                                  # 'HF det= 127 127' (:73)
