@@ -269,6 +269,13 @@ int sqmc_gpu_hci_connections(sqmc_gpu_ctx *ctx, int64_t n_ref, const uint64_t *r
                              const uint64_t *ref_dn, const double *coeffs, double eps, int diag_mode,
                              int64_t *out_n, uint64_t **out_up, uint64_t **out_dn,
                              double **out_e_mix_num, double **out_e_mix_den);
+/* The same restricted to slice `slice` of `n_slices` equal parts of the determinant-key range: every
+ * connection belongs to exactly one slice and its merged sums are exact within it, so a PT stage whose
+ * connected space does not fit one call (2^31 connections) is done slice by slice (the role of
+ * n_energy_batch, hci.f90:642).  slice 0 of 1 = sqmc_gpu_hci_connections. */
+int sqmc_gpu_hci_connections_slice(sqmc_gpu_ctx *ctx, int64_t n_ref, const uint64_t *ref_up, const uint64_t *ref_dn,
+                                   const double *coeffs, double eps, int diag_mode, int32_t slice, int32_t n_slices, int64_t *out_n,
+                                   uint64_t **out_up, uint64_t **out_dn, double **out_e_mix_num, double **out_e_mix_den);
 void sqmc_gpu_free(void *p);
 
 /* HIP-event timing on the library's streams.  level 0 off; 1 = only the k_spawn launch

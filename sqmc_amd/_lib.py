@@ -18,7 +18,7 @@ EXPORTS = [
     "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init",
     "sqmc_gpu_shard_step", "sqmc_gpu_shard_run", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_spmv_prepare",
     "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_build_spmv_plan", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
-    "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
+    "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_hci_connections_slice", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
 ]
 
 
@@ -337,12 +337,16 @@ class GpuChem:
         _chk(self.L.sqmc_gpu_propose_batch(self.h, n, float(tau), _p(u), _p(d), _p(s), _p(ju), _p(jd), _p(wj), _p(sa)))
         return ju, jd, wj, sa.reshape(n, 4)
 
-    def hci_connections(self, ref_up, ref_dn, coeffs, eps, diag_mode=0):
+    def hci_connections(self, ref_up, ref_dn, coeffs, eps, diag_mode=0, slice=0, n_slices=1):
         u, d, c = _u64(ref_up), _u64(ref_dn), _f64(coeffs)
         n = C.c_int64(); pu = C.c_void_p(); pd = C.c_void_p(); pn = C.c_void_p(); pe = C.c_void_p()
-        _chk(self.L.sqmc_gpu_hci_connections(self.h, len(u), _p(u), _p(d), _p(c), float(eps), int(diag_mode),
-                                             C.byref(n), C.byref(pu), C.byref(pd), C.byref(pn), C.byref(pe)))
+        self.L.sqmc_gpu_hci_connections_slice.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                                          C.c_int32, C.c_int32] + [C.c_void_p] * 5
+        _chk(self.L.sqmc_gpu_hci_connections_slice(self.h, len(u), _p(u), _p(d), _p(c), float(eps), int(diag_mode), int(slice), int(n_slices),
+                                                   C.byref(n), C.byref(pu), C.byref(pd), C.byref(pn), C.byref(pe)))
         k = n.value
+        if k == 0:
+            return np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0), np.zeros(0)
         def take(ptr, ct, dt):
             a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(max(k, 1),))[:k].astype(dt, copy=True)
             self.L.sqmc_gpu_free(ptr)

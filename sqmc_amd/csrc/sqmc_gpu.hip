@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(TPB) k_propose_batch(ChemDev dev, const u64 *u
 __global__ void __launch_bounds__(TPB) k_hci_gen(ChemDev dev, const u64 *__restrict__ rup, const u64 *__restrict__ rdn, const double *__restrict__ coef,
                                                  double eps_var, int diag_mode, long long n_ref, int pass, u64 *__restrict__ counts,
                                                  const u64 *__restrict__ offs, u64 *__restrict__ ou, u64 *__restrict__ od,
-                                                 double *__restrict__ onum, double *__restrict__ oden) {
+                                                 double *__restrict__ onum, double *__restrict__ oden, u64 key_lo, u64 key_hi) {
   __shared__ ChemTab t;
   __shared__ unsigned char s_lut[HEG_LUT_MAX];        // plane wave (kx,ky,kz) -> orbital id, 0 = not in the basis (find_orb_id, heg.f90:752-771)
   stage_tab(&t, dev.tab, dev.tab_words);
@@ -752,7 +752,12 @@ __global__ void __launch_bounds__(TPB) k_hci_gen(ChemDev dev, const u64 *__restr
   const double sqrt2 = sqrt(2.0), sqrt2inv = 1.0 / sqrt2;
   u64 cnt = 0; const u64 base = pass ? offs[i] : 0;
   // diag_mode 2 ("raw", for the semistochastic PT): e_mix_den carries the index of the reference determinant instead
-#define EMIT(U, D, M, DEN) do { if (pass) { ou[base + cnt] = (U); od[base + cnt] = (D); onum[base + cnt] = (M) * c; oden[base + cnt] = (diag_mode == 2) ? (double)i : (DEN); } cnt++; } while (0)
+  // [key_lo, key_hi): only connections whose determinant key falls in this slice are kept -- the PT stage
+  // of a large space is done in slices of the connected space, each with exact sums (the role of
+  // n_energy_batch, hci.f90:642); the full range keeps everything without computing keys
+  const bool sliced = !(key_lo == 0 && key_hi == ~0ull);
+#define EMIT(U, D, M, DEN) do { bool in_ = true; if (sliced) { const u64 kk_ = det_key(dev, (U), (D)); in_ = (kk_ >= key_lo && kk_ < key_hi); } \
+    if (in_) { if (pass) { ou[base + cnt] = (U); od[base + cnt] = (D); onum[base + cnt] = (M) * c; oden[base + cnt] = (diag_mode == 2) ? (double)i : (DEN); } cnt++; } } while (0)
   { double hd = (diag_mode == 1) ? h_any(t, dev.integrals, up, dn, up, dn) : 0.0; EMIT(up, dn, hd, c); }
   if (t.sys_type == 1) {
     // find_important_connected_dets_heg, heg.f90:2475-2727: no single excitations (momentum); every
@@ -1999,7 +2004,19 @@ int sqmc_gpu_propose_batch(sqmc_gpu_ctx *c, int64_t n, double tau, const uint64_
 
 int sqmc_gpu_hci_connections(sqmc_gpu_ctx *c, int64_t n_ref, const uint64_t *ref_up, const uint64_t *ref_dn, const double *coeffs, double eps,
                              int diag_mode, int64_t *out_n, uint64_t **out_up, uint64_t **out_dn, double **out_num, double **out_den) {
+  return sqmc_gpu_hci_connections_slice(c, n_ref, ref_up, ref_dn, coeffs, eps, diag_mode, 0, 1, out_n, out_up, out_dn, out_num, out_den);
+}
+
+int sqmc_gpu_hci_connections_slice(sqmc_gpu_ctx *c, int64_t n_ref, const uint64_t *ref_up, const uint64_t *ref_dn, const double *coeffs, double eps,
+                                   int diag_mode, int32_t slice, int32_t n_slices, int64_t *out_n, uint64_t **out_up, uint64_t **out_dn,
+                                   double **out_num, double **out_den) {
   if (!c || !out_n) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  if (n_slices < 1 || slice < 0 || slice >= n_slices) return fail(SQMC_ERR_BAD_ARG, "slice out of range");
+  u64 key_lo = 0, key_hi = ~0ull;
+  if (n_slices > 1) {                 // equal parts of the key range [0, invalid_key]
+    const long double span = ((long double)c->invalid_key + 1.0L) / (long double)n_slices;
+    key_lo = (u64)(span * slice); key_hi = (slice == n_slices - 1) ? (~0ull - 1ull) : (u64)(span * (slice + 1));
+  }
   if (c->htab.sys_type == 0 && !c->dev.hb_r) return fail(SQMC_ERR_BAD_ARG, "heat-bath tables not set (sqmc_gpu_set_hb_tables)");
   if (c->htab.sys_type == 1 && c->htab.heg_nmax > 4) return fail(SQMC_ERR_UNSUPPORTED, "HEG connections: plane-wave index beyond +-4");
   *out_n = 0;
@@ -2013,16 +2030,17 @@ int sqmc_gpu_hci_connections(sqmc_gpu_ctx *c, int64_t n_ref, const uint64_t *ref
   HIPCHK(hipMemcpy(dru, ref_up, n_ref * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(drd, ref_dn, n_ref * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dco, coeffs, n_ref * 8, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_hci_gen, dim3(nblk(n_ref)), dim3(TPB), 0, st, c->dev, dru, drd, dco, eps, diag_mode, (long long)n_ref, 0, dcnt, doff,
-                     (u64 *)nullptr, (u64 *)nullptr, (double *)nullptr, (double *)nullptr);
+                     (u64 *)nullptr, (u64 *)nullptr, (double *)nullptr, (double *)nullptr, key_lo, key_hi);
   ScanWork sw; sw.state = dts; sw.ticket = (u32 *)(dts + tiles); sw.cap_tiles = tiles; sw.self_clear = true;
   device_excl_scan_u64(dcnt, doff, n_ref, dtot, sw, st);
   u64 total = 0;
   HIPCHK(hipMemcpyAsync(&total, dtot, 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
-  if (total >= (1ull << 31)) return fail(SQMC_ERR_UNSUPPORTED, "more than 2^31 connections in one call: batch the reference list");
+  if (total >= (1ull << 31)) return fail(SQMC_ERR_UNSUPPORTED, "more than 2^31 connections in one call: use more slices (sqmc_gpu_hci_connections_slice)");
+  if (total == 0) { void *fz[] = {dru, drd, dco, dcnt, doff, dtot, dts}; for (void *q : fz) hipFree(q); return SQMC_OK; }
   const long long T = (long long)total;
   u64 *du, *dd, *keys, *kalt, *flags, *pos, *ou, *od, *dts2, *dtot2; u32 *vals, *valt, *hist, *rowtot; double *dnum, *dden, *onum, *oden;
   HIPCHK(hipMalloc(&du, T * 8)); HIPCHK(hipMalloc(&dd, T * 8)); HIPCHK(hipMalloc(&dnum, T * 8)); HIPCHK(hipMalloc(&dden, T * 8));
-  hipLaunchKernelGGL(k_hci_gen, dim3(nblk(n_ref)), dim3(TPB), 0, st, c->dev, dru, drd, dco, eps, diag_mode, (long long)n_ref, 1, dcnt, doff, du, dd, dnum, dden);
+  hipLaunchKernelGGL(k_hci_gen, dim3(nblk(n_ref)), dim3(TPB), 0, st, c->dev, dru, drd, dco, eps, diag_mode, (long long)n_ref, 1, dcnt, doff, du, dd, dnum, dden, key_lo, key_hi);
   if (diag_mode == 2) {               // the unmerged list, in generation order
     HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(st));
     *out_n = T;

@@ -15,7 +15,7 @@ module sqmc_gpu_mod
   public :: sqmc_gpu_hamiltonian_batch, sqmc_gpu_hamiltonian_chem_batch, sqmc_gpu_build_sparse_ham, sqmc_gpu_propose_batch
   public :: sqmc_gpu_hci_connections, sqmc_gpu_free, sqmc_gpu_set_timing, sqmc_gpu_get_timing
   public :: sqmc_gpu_det_owner, sqmc_gpu_shard_config, sqmc_gpu_shard_begin, sqmc_gpu_shard_pack, sqmc_gpu_shard_finish
-  public :: sqmc_gpu_annihilate, sqmc_gpu_build_spmv_plan
+  public :: sqmc_gpu_annihilate, sqmc_gpu_build_spmv_plan, sqmc_gpu_hci_connections_slice
   public :: sqmc_gpu_comm_unique_id, sqmc_gpu_comm_init, sqmc_gpu_shard_step, sqmc_gpu_shard_run
   public :: sqmc_gpu_check
 
@@ -196,6 +196,13 @@ module sqmc_gpu_mod
         bind(C, name='sqmc_gpu_hci_connections')
       import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n_ref; integer(c_int64_t), intent(in) :: ref_up(*), ref_dn(*)
       real(c_double), intent(in) :: coeffs(*); real(c_double), value :: eps; integer(c_int), value :: diag_mode
+      integer(c_int64_t), intent(out) :: out_n; type(c_ptr), intent(out) :: out_up, out_dn, out_num, out_den
+    end function
+    integer(c_int) function sqmc_gpu_hci_connections_slice(ctx, n_ref, ref_up, ref_dn, coeffs, eps, diag_mode, slice, n_slices, out_n, out_up, out_dn, &
+        out_num, out_den) bind(C, name='sqmc_gpu_hci_connections_slice')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n_ref; integer(c_int64_t), intent(in) :: ref_up(*), ref_dn(*)
+      real(c_double), intent(in) :: coeffs(*); real(c_double), value :: eps; integer(c_int), value :: diag_mode
+      integer(c_int32_t), value :: slice, n_slices
       integer(c_int64_t), intent(out) :: out_n; type(c_ptr), intent(out) :: out_up, out_dn, out_num, out_den
     end function
     subroutine sqmc_gpu_free(p) bind(C, name='sqmc_gpu_free')

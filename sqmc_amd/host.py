@@ -924,22 +924,25 @@ def sum_left(it):
     return t
 
 
-def hci_pt2(host, g, up, dn, coeffs, e_var, eps_pt):
+def hci_pt2(host, g, up, dn, coeffs, e_var, eps_pt, n_slices=1):
     """Deterministic Epstein-Nesbet second-order correction, second_order_pt (hci.f90:1100-1182):
     delta_E = sum over determinants a outside the variational space of
     (sum_i H_ai c_i)^2 / (E_var - H_aa), the inner sum screened by |H_ai c_i| >= eps_pt.
-    Connections, their dedup-sum and the diagonal elements all come from the GPU.
+    Connections, their dedup-sum and the diagonal elements all come from the GPU.  n_slices > 1
+    does the connected space in that many slices of the determinant-key range (exact: every
+    connected determinant lives in one slice), for spaces whose connections do not fit one call.
     Returns (delta_E, number of connected determinants)."""
     up, dn = np.ascontiguousarray(up, np.uint64), np.ascontiguousarray(dn, np.uint64)
-    cu, cd, num, den = g.hci_connections(up, dn, coeffs, eps_pt)
-    # membership in the variational space (binary_search at hci.f90:1159): merge of two sorted key lists
-    order = sort_dets(up, dn)
-    vu, vd = up[order], dn[order]
-    in_v = _dets_in(cu, cd, vu, vd)
-    out = ~in_v
-    h_aa = g.hamiltonian_batch(cu[out], cd[out], cu[out], cd[out])
-    delta = float(np.sum(num[out] ** 2 / (e_var - h_aa)))
-    return delta, len(cu)
+    delta, n_conn = 0.0, 0
+    for sl in range(n_slices):
+        cu, cd, num, den = g.hci_connections(up, dn, coeffs, eps_pt, slice=sl, n_slices=n_slices)
+        if len(cu) == 0:
+            continue
+        out = ~_dets_in(cu, cd, up, dn)        # membership in the variational space (binary_search at hci.f90:1159)
+        h_aa = g.hamiltonian_batch(cu[out], cd[out], cu[out], cd[out])
+        delta += float(np.sum(num[out] ** 2 / (e_var - h_aa)))
+        n_conn += len(cu)
+    return delta, n_conn
 
 
 def time_symmetrized_to_dets(up, dn, coeffs, z=1):

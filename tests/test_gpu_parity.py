@@ -511,6 +511,9 @@ def test_hci_pt2_matches_oracle_and_reference_run(oracle, c2_hci):
     d_cpu, n_cpu = oracle.hci_pt2(c2_hci, up, dn, w[:, 0], float(e[0]), 2e-5)
     assert n_gpu - len(up) == n_cpu
     assert abs(d_gpu - d_cpu) < 1e-12 and -0.05 < d_gpu < -0.005
+    # the connected space in 7 slices of the key range: same determinants, same sums
+    d_sl, n_sl = H.hci_pt2(h, g, up, dn, w[:, 0], float(e[0]), 2e-5, n_slices=7)
+    assert n_sl == n_gpu and abs(d_sl - d_gpu) < 1e-14
     up, dn, w, e, hist = H.hci_variational(h, g, 1e-4, eps_sched=(2e-4, 2e-4), n_states=1)
     g.close()
     # the reference converts to the determinant basis before PT (hci.f90:648-659): 6.56 M connections there
@@ -866,6 +869,8 @@ def test_heg_hci_reproduces_reference_e2e_golden_output():
     # the deterministic piece of the semistochastic PT run of the same directory (deck i_st: eps_pt_big =
     # 8.192e-4; o_st_ref:873 prints it as the first number in parentheses)
     d_big, _ = H.hci_pt2(hst, g, up, dn, w[:, 0], float(e[0]), 8.1920e-4)
+    d_sl, n_sl = H.hci_pt2(hst, g, up, dn, w[:, 0], float(e[0]), 2e-7, n_slices=4)       # sliced connected space: identical
+    assert n_sl == n and abs(d_sl - d) < 1e-15
     g.close()
     assert abs(d_big - (-0.000199339)) < 2e-9
     assert n == 501881
