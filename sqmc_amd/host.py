@@ -959,7 +959,7 @@ def time_symmetrized_to_dets(up, dn, coeffs, z=1):
     return ou[order], od[order], oc[order]
 
 
-def hci_pt2_determinant_basis(host, up, dn, coeffs, e_var, eps_pt):
+def hci_pt2_determinant_basis(host, up, dn, coeffs, e_var, eps_pt, n_slices=1):
     """do_pt as the reference runs it for a time-symmetric variational stage: back to the
     determinant basis, time_sym off from then on (hci.f90:648-659), then second_order_pt."""
     import copy
@@ -967,7 +967,7 @@ def hci_pt2_determinant_basis(host, up, dn, coeffs, e_var, eps_pt):
         g = host.gpu()
         g.set_hb_tables(*host.hb_tables(g))
         try:
-            return hci_pt2(host, g, up, dn, coeffs, e_var, eps_pt)
+            return hci_pt2(host, g, up, dn, coeffs, e_var, eps_pt, n_slices)
         finally:
             g.close()
     plain = copy.copy(host)
@@ -976,7 +976,7 @@ def hci_pt2_determinant_basis(host, up, dn, coeffs, e_var, eps_pt):
     g = plain.gpu()
     try:
         g.set_hb_tables(*plain.hb_tables(g))
-        return hci_pt2(plain, g, du, dd, dc, e_var, eps_pt)
+        return hci_pt2(plain, g, du, dd, dc, e_var, eps_pt, n_slices)
     finally:
         g.close()
 

@@ -9,15 +9,21 @@ import torch            # before the HIP library: both must share one libamdhip6
 import sqmc_amd
 from sqmc_amd import host as H
 
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--eps-var", type=float, default=1e-4)
+ap.add_argument("--eps-pt", type=float, default=1e-6)
+ap.add_argument("--pt-slices", type=int, default=1, help="slices of the connected space in the PT stage")
+args = ap.parse_args()
 FCIDUMP = os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP")
 t0 = time.perf_counter()
 h = H.ChemHost(FCIDUMP, 8, 4, "d2h", time_sym=True, z=1, hf_symmetry=1)
 g = h.gpu()
 g.set_hb_tables(*h.hb_tables(g))
 t1 = time.perf_counter()
-up, dn, w, e, hist = H.hci_variational(h, g, 1e-4, eps_sched=(2e-4, 2e-4))
+up, dn, w, e, hist = H.hci_variational(h, g, args.eps_var, eps_sched=(2 * args.eps_var, 2 * args.eps_var))
 t2 = time.perf_counter()
-de_pt, n_conn = H.hci_pt2_determinant_basis(h, up, dn, w[:, 0], float(e[0]), 1e-6)
+de_pt, n_conn = H.hci_pt2_determinant_basis(h, up, dn, w[:, 0], float(e[0]), args.eps_pt, n_slices=args.pt_slices)
 t2b = time.perf_counter()
 order = H.sort_dets(up, dn)
 ta = time.perf_counter(); counts, idx, val = g.build_sparse_ham(up[order], dn[order]); tb = time.perf_counter()
@@ -36,7 +42,7 @@ for _ in range(reps):
 torch.cuda.synchronize(); t4 = time.perf_counter()
 ms = (t4 - t3) / reps * 1e3
 alg = 20.0 * nnz + 20.0 * n            # 20 B per stored nonzero + 20 B per row
-print(json.dumps({"hci_variational_s": t2 - t1, "setup_s": t1 - t0, "ndets_history": hist, "e_var": float(e[0]), "pt2_eps": 1e-6, "pt2_delta_e": de_pt, "pt2_connected_dets": n_conn, "pt2_s": t2b - t2, "e_total": float(e[0]) + de_pt,
+print(json.dumps({"hci_variational_s": t2 - t1, "setup_s": t1 - t0, "ndets_history": hist, "e_var": float(e[0]), "eps_var": args.eps_var, "pt2_eps": args.eps_pt, "pt2_slices": args.pt_slices, "pt2_delta_e": de_pt, "pt2_connected_dets": n_conn, "pt2_s": t2b - t2, "e_total": float(e[0]) + de_pt,
                   "build_sparse_ham_s": tb - ta, "n": n, "nnz_upper": nnz, "spmv_ms": ms,
                   "spmv_algorithmic_GBs": alg / (ms * 1e-3) / 1e9, "spmv_frac_of_8TBs": alg / (ms * 1e-3) / 1e9 / 8000.0,
                   "spmv_moved_GBs_full_csr": (12.0 * nnz_full + 8.0 * nnz_full + 20.0 * n) / (ms * 1e-3) / 1e9}))
