@@ -63,6 +63,11 @@ def _namelists(text):
 def parse_hci_deck(text):
     lines = [l for l in text.splitlines() if l.strip() and not l.lstrip().startswith("!")]
     deck = {}
+    # The decks of src/e2e_tests were written for the grammar in which the walk parameters (six lines:
+    # nstep..., w_abs_gen..., tau..., reweight..., population control..., proposal_method...) come before
+    # run_type, and semistoch/use_exp_proj after dump_wf_var: recognise it by the position of 'hci'.
+    if lines[1].split()[0].strip("'\"").lower() != "hci" and len(lines) > 7 and lines[7].split()[0].strip("'\"").lower() == "hci":
+        lines = [lines[0]] + lines[7:10] + lines[11:]
     s = re.sub(r"\s+", " ", lines[0].strip())
     digits = "".join(ch for ch in lines[0][:33] if ch.isdigit())           # '(4i4,x,4i4)'
     deck["irand_seed"] = [[int(digits[4 * i:4 * i + 4]) for i in range(4)], [int(digits[16 + 4 * i:20 + 4 * i]) for i in range(4)]]
@@ -74,6 +79,16 @@ def parse_hci_deck(text):
     deck["dump_wf_var"] = _logical(lines[3].split()[0])
     toks = lines[4].replace(",", " ").split()
     deck["hamiltonian_type"], deck["ipr"] = toks[0].strip("'\"").lower(), int(float(toks[1]))
+    nl = _namelists("\n".join(lines[5:]))
+    sci = nl.get("selected_ci", {})
+    deck["eps_var_sched"] = [float(v.lower().replace("d", "e")) for v in sci.get("eps_var_sched", [])]
+    deck["n_mc"] = int(float(sci.get("n_mc", ["0"])[0]))
+    deck["eps_pt_big"] = float(sci["eps_pt_big"][0].lower().replace("d", "e")) if "eps_pt_big" in sci else 0.0
+    if deck["hamiltonian_type"] == "heg":              # read_heg, heg.f90:102-170
+        deck["n_dim"] = int(_numbers(lines[5], 1)[0]); deck["r_s"] = _numbers(lines[6], 1)[0]
+        ne, nu = _numbers(lines[7], 2)
+        deck.update(nelec=int(ne), nup=int(nu), cutoff_radius=_numbers(lines[8], 1)[0])
+        return deck
     if deck["hamiltonian_type"] != "chem":
         raise SystemExit("sqmc_amd.run: hamiltonian_type %r decks are not handled here" % deck["hamiltonian_type"])
     ne, nu = _numbers(lines[5], 2)
@@ -81,11 +96,6 @@ def parse_hci_deck(text):
     deck["z"] = int(_numbers(lines[8], 1)[0])
     deck["norb"] = int(_numbers(lines[9], 1)[0])
     deck["orbital_symmetries"] = [int(x) for x in _numbers(lines[10], deck["norb"])]
-    nl = _namelists("\n".join(lines[11:]))
-    sci = nl.get("selected_ci", {})
-    deck["eps_var_sched"] = [float(v.lower().replace("d", "e")) for v in sci.get("eps_var_sched", [])]
-    deck["n_mc"] = int(float(sci.get("n_mc", ["0"])[0]))
-    deck["eps_pt_big"] = float(sci["eps_pt_big"][0].lower().replace("d", "e")) if "eps_pt_big" in sci else 0.0
     hf = nl.get("hf_det", {})
     deck["hf_symmetry"] = int(hf["hf_symmetry"][0]) if "hf_symmetry" in hf else None
     if "irreps" in hf:
@@ -93,7 +103,54 @@ def parse_hci_deck(text):
     return deck
 
 
+def run_hci_heg(deck, out=sys.stdout):
+    """HEG decks: no integral file; result lines as hci.f90 prints them for 'heg' (no state index in the
+    older output format the e2e fixtures were produced with; Madelung total, correlation energy)."""
+    import torch            # noqa: F401
+    import sqmc_amd
+    from . import host as H
+    p = lambda *a: (print(*a, file=out), out.flush())
+    sqmc_amd.set_device(0)
+    h = H.HegHost(deck["n_dim"], deck["r_s"], deck["nelec"], deck["nup"], deck["cutoff_radius"])
+    p("Within cutoff_radius =%10.5f number of spatial orbitals =%4d" % (deck["cutoff_radius"], h.norb))
+    g = h.gpu()
+    e_hf = g.hamiltonian_batch([h.hf_up], [h.hf_dn], [h.hf_up], [h.hf_dn])[0]
+    mad = h.madelung_energy() if deck["n_dim"] == 3 else 0.0
+    p("Madelung energy =%10.6f" % mad)
+    p("Iteration   0 %8d =%9.2E dets, energy=%16.6f" % (1, 1.0, e_hf))
+
+    def log(msg):
+        m = re.match(r"Iteration\s+(\d+) eps1=(\S+) ndets=\s*(\d+).*energy=(.*)", msg)
+        p("Iteration%4d %8d =%9.2E dets, energy=%s" % (int(m.group(1)), int(m.group(3)), float(m.group(3)), "".join("%16.6f" % float(x) for x in m.group(4).split())))
+    up, dn, wts, energy, hist = H.hci_variational(h, g, deck["eps_var"], eps_sched=tuple(deck["eps_var_sched"]), n_states=deck["n_states"], log=log)
+    res = {"ndets": len(up), "hist": hist, "e_hf": float(e_hf), "madelung": mad}
+    e0 = float(energy[0])
+    if deck["n_mc"] > 0 and deck["eps_pt_big"] > deck["eps_pt"]:
+        r = H.hci_pt2_stochastic(h, g, up, dn, wts[:, 0], e0, deck["eps_pt"], deck["eps_pt_big"], deck["n_mc"], deck["target_error"],
+                                 seed=deck["irand_seed"][0], log=lambda m: p("\n" + m))
+        de, err = r["pt_big"] + r["pt_diff"], r["pt_diff_std_dev"]
+        p("\nVariational energy=%s%15.9f" % (" " * 16, e0))
+        p("Second-order PT energy lowering=%s%15.9f +-%12.9f (%13.9f%13.9f)" % (" " * 3, de, err, r["pt_big"], r["pt_diff"]))
+        p("Total energy=%s%15.9f +-%12.9f" % (" " * 22, e0 + de, err))
+        p("Total energy (includ. Madelung)=%s%15.9f +-%12.9f" % (" " * 3, e0 + de + mad, err))
+        res.update(pt=de, pt_err=err, pt_big=r["pt_big"], pt_diff=r["pt_diff"], n_samples=len(r["samples"]))
+    else:
+        de, nconn = H.hci_pt2(h, g, up, dn, wts[:, 0], e0, deck["eps_pt"])
+        p("\nPT_correction, eps_pt, ndets_connected for fully deterministic run=%15.9f%12.4E%12d" % (de, deck["eps_pt"], nconn))
+        p("\nVariational energy=%s%15.9f" % (" " * 16, e0))
+        p("Second-order PT energy lowering=%s%15.9f" % (" " * 3, de))
+        p("Total energy=%s%15.9f" % (" " * 22, e0 + de))
+        p("Total energy (includ. Madelung)=%s%15.9f" % (" " * 3, e0 + de + mad))
+        res.update(pt=de, n_connected=nconn)
+    p("Correlation energy =%s%15.9f" % (" " * 16, e0 + de - e_hf))
+    g.close()
+    res.update(e_var=e0, e_total=e0 + de)
+    return res
+
+
 def run_hci(deck, fcidump="FCIDUMP", out=sys.stdout):
+    if deck["hamiltonian_type"] == "heg":
+        return run_hci_heg(deck, out)
     import torch            # noqa: F401  one libamdhip64 per process
     import sqmc_amd
     from . import host as H

@@ -14,6 +14,12 @@
                          the two input decks shipped next to that FCIDUMP (16 lines of run
                          parameters each: input data, read by python -m sqmc_amd.run in the tests).
 
+  heg_e2e_i_det, heg_e2e_i_st
+                         the two input decks of the reference's end-to-end test directory
+                         (src/e2e_tests/heg/i_det, i_st: run parameters, 21 and 25 lines); the numbers
+                         of the golden outputs next to them (o_det_ref, o_st_ref) are transcribed into
+                         the tests with their line numbers.
+
 Data files are copied byte for byte (cp); nothing here is reference source code.
 """
 import ctypes as C

@@ -897,3 +897,27 @@ def test_heg_semistochastic_pt_reproduces_reference_samples():
     assert abs(res["pt_big"] - (-0.000199339)) < 2e-9
     assert abs(res["pt_diff"] - (-0.000729402)) < 2e-9 and abs(res["pt_diff_std_dev"] - 0.000009966) < 2e-9
     assert abs(e[0] + res["pt_big"] + res["pt_diff"] - 58.275977344) < 3e-9
+
+
+@pytest.mark.parametrize("deckname", ["heg_e2e_i_det", "heg_e2e_i_st"])
+def test_reference_e2e_heg_decks_run_unchanged(deckname):
+    """The two input decks of the reference's own end-to-end test directory (src/e2e_tests/heg/i_det,
+    i_st; copied as data), unchanged, through `python -m sqmc_amd.run`, against the golden outputs that
+    sit next to them (o_det_ref, o_st_ref): the numbers e2e_check.py extracts (variational energy, PT
+    lowering, its error bar) and the totals, to the printed digits instead of its 0.01 / 0.05 tolerances."""
+    import io, os
+    from sqmc_amd import run as R
+    deck = R.parse_hci_deck(open(os.path.join(os.path.dirname(__file__), "golden", deckname)).read())
+    buf = io.StringIO()
+    res = R.run_hci(deck, out=buf)
+    txt = buf.getvalue()
+    assert res["hist"] == [1, 277, 9475] and abs(res["e_var"] - 58.276906085) < 2e-9
+    assert "Variational energy=" in txt and "Second-order PT energy lowering=" in txt      # what e2e_check.py greps for
+    if deckname.endswith("i_det"):
+        assert res["n_connected"] == 501881
+        assert abs(res["pt"] - (-0.000939196)) < 2e-9 and abs(res["e_total"] - 58.275966889) < 2e-9
+        assert abs(res["e_total"] + res["madelung"] - 48.051813420) < 2e-9
+    else:
+        assert res["n_samples"] == 143
+        assert abs(res["pt"] - (-0.000928741)) < 2e-9 and abs(res["pt_err"] - 0.000009966) < 2e-9
+        assert abs(res["e_total"] - 58.275977344) < 3e-9 and abs(res["e_total"] + res["madelung"] - 48.051823875) < 3e-9
