@@ -921,3 +921,29 @@ def test_reference_e2e_heg_decks_run_unchanged(deckname):
         assert res["n_samples"] == 143
         assert abs(res["pt"] - (-0.000928741)) < 2e-9 and abs(res["pt_err"] - 0.000009966) < 2e-9
         assert abs(res["e_total"] - 58.275977344) < 3e-9 and abs(res["e_total"] + res["madelung"] - 48.051823875) < 3e-9
+
+
+def test_semistochastic_pt_chem_agrees_with_deterministic():
+    """No reference fixture exists for the chemistry variant of the semistochastic PT, so it is held
+    against the deterministic PT of the same space (C2, eps_var 2e-3, determinant basis after
+    time_symmetrized_to_dets): the estimate of PT(eps_pt) must agree within its own error bar (4 sigma)
+    and the deterministic piece must equal hci_pt2 at eps_pt_big."""
+    import copy
+    from conftest import FCIDUMP
+    from sqmc_amd import host as H
+    h = H.ChemHost(FCIDUMP, 8, 4, "d2h", time_sym=True, z=1, hf_symmetry=1)
+    g = h.gpu()
+    g.set_hb_tables(*h.hb_tables(g))
+    up, dn, w, e, hist = H.hci_variational(h, g, 2e-3, n_states=1)
+    g.close()
+    plain = copy.copy(h); plain.time_sym = False
+    du, dd, dc = H.time_symmetrized_to_dets(up, dn, w[:, 0], h.z)
+    gp = plain.gpu()
+    gp.set_hb_tables(*plain.hb_tables(gp))
+    det, _ = H.hci_pt2(plain, gp, du, dd, dc, float(e[0]), 1e-6)
+    big, _ = H.hci_pt2(plain, gp, du, dd, dc, float(e[0]), 2e-4)
+    r = H.hci_pt2_stochastic(plain, gp, du, dd, dc, float(e[0]), 1e-6, 2e-4, 300, 1e-4, max_samples=2000)
+    gp.close()
+    assert abs(r["pt_big"] - big) < 1e-14
+    assert r["pt_diff_std_dev"] <= 1e-4 * 1.0001 and len(r["samples"]) >= 10
+    assert abs(r["pt_big"] + r["pt_diff"] - det) < 4 * r["pt_diff_std_dev"]
