@@ -51,7 +51,10 @@ def main():
     import sqmc_amd
     from sqmc_amd import host as H
     dist = None
-    if world > 1:
+    multi = world > 1 or bool(os.environ.get("SQMC_BENCH_FORCE_SHARDED"))     # rehearsal of the N>1 code path with one rank
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         torch.cuda.set_device(local)
         backend = os.environ.get("SQMC_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 path on a one-GPU box
@@ -59,7 +62,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    comm_dev = "cuda" if (world > 1 and backend == "nccl") else "cpu"
+    comm_dev = "cuda" if (multi and backend == "nccl") else "cpu"
     sqmc_amd.set_device(local)
 
     if args.system == "heg":
@@ -71,13 +74,13 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
     parallelism = "single GPU"
     walk = None
-    if world > 1:
+    if multi:
         # weak scaling: the global target grows with the number of GPUs, determinants are sharded by
         # hash ownership and spawns cross ranks through one RCCL all-to-all per step
         try:
@@ -111,7 +114,7 @@ def main():
     if walk is None:
         kw = dict(w_begin=min(args.target, 1e4), n_truncate_trial_wf=1, size_deterministic=500) if args.system == "heg" else {}
         walk = H.GpuWalk(hst, args.target, seed=H.rank_seed((1346, 5634, 6635, 4361), rank), **kw)
-        if world > 1:
+        if multi:
             parallelism = "replicas x%d (sharded path unavailable)" % world
     sharded = isinstance(walk, H.ShardedWalk)
 
@@ -150,7 +153,7 @@ def main():
         walk.run(20, keep_stats=False)
         stage_ms = dict(walk.g.timing())
     tot = torch.tensor([nwalk_sum, spawn_sum, dt], dtype=torch.float64, device=comm_dev)
-    if world > 1:
+    if multi:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot)
         dt = float(mx[2])
@@ -184,7 +187,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(walk, hst, n_avg)
         print(json.dumps(line), flush=True)
     walk.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
