@@ -127,7 +127,8 @@ struct sqmc_gpu_ctx {
   // multi-rank sharding (owner = hash(det) mod shard_n)
   int shard_rank, shard_n; int *d_grow; long long n_imp_local; long long shard_n0, shard_nch;
   // in-library exchange over RCCL (sqmc_gpu_comm_init): communicator + device staging
-  ncclComm_t comm; double *d_xg; u64 *d_send, *d_recv; long long xch_cap; u32 *d_cnt_mine, *d_cnt_all; u32 *h_cnt_all;
+  ncclComm_t comm, comm2; double *d_xg; u64 *d_send, *d_recv; long long xch_cap; u32 *d_cnt_mine, *d_cnt_all; u32 *h_cnt_all, *d_cnt_mail;
+  u64 cntall_seq;      // comm2: second communicator (ncclCommSplit) for the all-reduce that runs on the side stream
   // timing
   int timing; hipEvent_t ev0[NTIMERS], ev1[NTIMERS]; const char *tname[NTIMERS]; int nt; float tms[NTIMERS];
   double tsum[NTIMERS]; long long tsteps;         // accumulated over the steps since sqmc_gpu_set_timing
@@ -1608,7 +1609,7 @@ int sqmc_gpu_shard_config(sqmc_gpu_ctx *c, int32_t rank, int32_t nranks, int64_t
 // phase 1 of a sharded step: gate, child offsets, death/clone, spawn (into local slots), and the
 // owned entries of the deterministic-space weight vector written into x_global (device pointer,
 // n_imp doubles, zeroed here) for the caller's all-reduce (do_walk.f90:2259-2260).
-static int shard_begin_impl(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double *x_global_dev, int64_t *n_children, bool full_sync) {
+static int shard_begin_impl(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double *x_global_dev, int64_t *n_children, bool full_sync, bool side = false) {
   if (!c || !sp || !n_children) return fail(SQMC_ERR_BAD_ARG, "null argument");
   if (c->shard_n < 1 || !c->d_grow) return fail(SQMC_ERR_BAD_ARG, "sqmc_gpu_shard_config not called");
   if (c->rng_mode != SQMC_RNG_COUNTER) return fail(SQMC_ERR_UNSUPPORTED, "sharded steps need the COUNTER RNG discipline");
@@ -1623,21 +1624,34 @@ static int shard_begin_impl(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double 
   collect_timers(c);
   c->nt = 0;
   if (n0 == 0) HIPCHK(hipMemsetAsync(&c->d_sc->n_children, 0, 4 * sizeof(u64) + 2 * sizeof(int), st));   // otherwise k_gate clears them
-  if (x_global_dev && c->n_imp > 0) HIPCHK(hipMemsetAsync(x_global_dev, 0, c->n_imp * 8, st));
+  // side = the in-library step with a second communicator: death/clone, the gather of the owned
+  // deterministic weights (and later their all-reduce and the projection) run on the side stream
+  // beside k_spawn, the bucketing of the spawns and their exchange
+  hipStream_t sx = side ? c->st2 : st;
+  if (!side && x_global_dev && c->n_imp > 0) HIPCHK(hipMemsetAsync(x_global_dev, 0, c->n_imp * 8, st));
   const bool mail = (n0 > 0 && M > n0);
   const u64 cseq = ++c->cnt_seq;
   if (n0 > 0) {
     hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
                        n0, p, c->seed64, c->step_no, c->d_sc, c->pack);
     device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st);
+  }
+  if (side) HIPCHK(hipEventRecord(c->e_fork, st));
+  if (n0 > 0) {
     TBEG(spawn, st);
     if (M > n0)      // first: it posts the child count to the host mailbox as soon as it starts
       hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
                          n0, M, p, c->rng_mode, c->seed64, c->step_no, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack);
     TEND(spawn, st);
-    hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc);
+  }
+  if (side) {
+    HIPCHK(hipStreamWaitEvent(sx, c->e_fork, 0));
+    if (x_global_dev && c->n_imp > 0) HIPCHK(hipMemsetAsync(x_global_dev, 0, c->n_imp * 8, sx));
+  }
+  if (n0 > 0) {
+    hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, sx, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc);
     if (c->n_imp_local > 0)
-      hipLaunchKernelGGL(k_prj_gather_rows, dim3(nblk(c->n_imp_local)), dim3(TPB), 0, st, c->w.wt, c->d_loc_imp, c->d_grow, x_global_dev, c->n_imp_local);
+      hipLaunchKernelGGL(k_prj_gather_rows, dim3(nblk(c->n_imp_local)), dim3(TPB), 0, sx, c->w.wt, c->d_loc_imp, c->d_grow, x_global_dev, c->n_imp_local);
   }
   HIPCHK(hipGetLastError());
   long long nch = 0;
@@ -1666,10 +1680,10 @@ int sqmc_gpu_shard_begin(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double *x_
 // device part of phase 2; leaves the per-destination counts in d_rowtot[0..P) (valid when nch > 0)
 // and the permutation of the children by destination in *order.  Children that produced no
 // walker sort behind the last rank.
-static int shard_bucket(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const double *x_global_dev, u32 **order) {
+static int shard_bucket(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const double *x_global_dev, u32 **order, bool apply_rows = true) {
   hipStream_t st = c->st;
   const long long n0 = c->shard_n0, nch = c->shard_nch; const int P = c->shard_n;
-  if (c->n_imp_local > 0)
+  if (apply_rows && c->n_imp_local > 0)
     hipLaunchKernelGGL(k_prj_apply_rows, dim3(nblk(c->n_imp_local, TPB / 64)), dim3(TPB), 0, st, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, x_global_dev,
                        c->d_loc_imp, c->d_grow, c->w.wt, c->n_imp_local, sp->e_trial, sp->tau);
   *order = nullptr;
@@ -1708,7 +1722,7 @@ int sqmc_gpu_shard_pack(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const doubl
 
 // phase 3: the records received from all ranks (rank order, creation order inside a rank) become
 // the spawned walkers behind the occupied slots; then the usual sort / merge / round / estimate.
-int sqmc_gpu_shard_finish(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const uint64_t *recv_dev, int64_t n_recv, double out[16]) {
+static int shard_finish_impl(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const uint64_t *recv_dev, int64_t n_recv, double out[16], bool join) {
   if (!c || !sp || !out || n_recv < 0) return fail(SQMC_ERR_BAD_ARG, "bad argument");
   hipStream_t st = c->st;
   StepP p; p.tau = sp->tau; p.e_trial = sp->e_trial; p.rfi = sp->reweight_factor_inv; p.r_init = sp->r_initiator; p.min_wt = sp->min_wt;
@@ -1722,6 +1736,7 @@ int sqmc_gpu_shard_finish(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const uin
   if (n_recv > 0)
     hipLaunchKernelGGL(k_unpack_recv, dim3(nblk(n_recv)), dim3(TPB), 0, st, c->dev, c->w, (const u64 *)recv_dev, c->d_keys, c->d_vals, n0, (long long)n_recv, c->pack);
   if (n0 + n_recv == 0) {           // an empty shard stays empty this step
+    if (join) HIPCHK(hipStreamWaitEvent(st, c->e_join, 0));
     for (int i = 0; i < 16; i++) out[i] = 0.0;
     hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
     c->step_no++;
@@ -1735,9 +1750,12 @@ int sqmc_gpu_shard_finish(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const uin
     }
     return SQMC_OK;
   }
-  int r = step_tail(c, p, n0, n0 + n_recv, false, out);
+  int r = step_tail(c, p, n0, n0 + n_recv, join, out);
   if (r == SQMC_ERR_NO_WALKERS) r = SQMC_OK;      // a shard may legitimately own nothing
   return r;
+}
+int sqmc_gpu_shard_finish(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const uint64_t *recv_dev, int64_t n_recv, double out[16]) {
+  return shard_finish_impl(c, sp, recv_dev, n_recv, out, false);
 }
 
 
@@ -1753,6 +1771,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *);
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
   ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, ncclConfig_t *);     // optional (NCCL >= 2.18)
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
@@ -1772,14 +1791,16 @@ static int rccl_bind() {
   BIND(GetUniqueId); BIND(CommInitRank); BIND(CommDestroy); BIND(AllReduce); BIND(AllGather); BIND(Send); BIND(Recv); BIND(GroupStart); BIND(GroupEnd);
   BIND(GetErrorString);
 #undef BIND
+  *(void **)(&g_rccl.CommSplit) = dlsym(h, "ncclCommSplit");
   g_rccl.lib = h;
   return SQMC_OK;
 }
 #define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail(SQMC_ERR_HIP, std::string(#x) + ": " + g_rccl.GetErrorString(r_)); } while (0)
 
 static void comm_release(sqmc_gpu_ctx *c) {
+  if (c->comm2 && g_rccl.lib) g_rccl.CommDestroy(c->comm2);
   if (c->comm && g_rccl.lib) g_rccl.CommDestroy(c->comm);
-  c->comm = nullptr;
+  c->comm = nullptr; c->comm2 = nullptr;
   hipFree(c->d_xg); hipFree(c->d_send); hipFree(c->d_recv); hipFree(c->d_cnt_mine); hipFree(c->d_cnt_all);
   if (c->h_cnt_all) hipHostFree(c->h_cnt_all);
   c->d_xg = nullptr; c->d_send = c->d_recv = nullptr; c->d_cnt_mine = c->d_cnt_all = nullptr; c->h_cnt_all = nullptr;
@@ -1812,8 +1833,26 @@ int sqmc_gpu_comm_init(sqmc_gpu_ctx *c, const uint8_t id[SQMC_COMM_ID_BYTES]) {
   HIPCHK(hipMalloc(&c->d_xg, (c->n_imp + 1) * 8));
   HIPCHK(hipMalloc(&c->d_send, c->xch_cap * 32)); HIPCHK(hipMalloc(&c->d_recv, c->xch_cap * 32));
   HIPCHK(hipMalloc(&c->d_cnt_mine, P * 4)); HIPCHK(hipMalloc(&c->d_cnt_all, (size_t)P * P * 4));
-  HIPCHK(hipHostMalloc(&c->h_cnt_all, (size_t)P * P * 4 + P * 4));
+  const size_t cnt_bytes = ((size_t)P * P + 32) * 4 + 16;
+  HIPCHK(hipHostMalloc(&c->h_cnt_all, cnt_bytes, hipHostMallocMapped));     // the P x P send counts + a sequence word: written by the GPU
+  memset(c->h_cnt_all, 0, cnt_bytes);
+  HIPCHK(hipHostGetDevicePointer((void **)&c->d_cnt_mail, c->h_cnt_all, 0));
+  c->cntall_seq = 0;
+  // a second communicator for the all-reduce of the deterministic weights, so that it can run on the side
+  // stream beside the spawn path (SQMC_SHARD_OVERLAP=0 keeps everything on one stream and one communicator)
+  c->comm2 = nullptr;
+  const char *ov = getenv("SQMC_SHARD_OVERLAP");
+  if (g_rccl.CommSplit && !(ov && ov[0] == '0')) {
+    if (g_rccl.CommSplit(c->comm, 0, c->shard_rank, &c->comm2, nullptr) != ncclSuccess) c->comm2 = nullptr;
+  }
   return SQMC_OK;
+}
+
+// the P x P counts of the all-gather, posted to pinned host memory (counts, system fence, sequence word)
+__global__ void k_post_counts(const u32 *__restrict__ cnt, int n, u32 *mail, u64 seq) {
+  for (int k = threadIdx.x; k < n; k += blockDim.x) mail[k] = cnt[k];
+  __syncthreads();
+  if (threadIdx.x == 0) { __threadfence_system(); *(volatile u64 *)(mail + ((n + 15) / 16) * 16) = seq; }
 }
 
 // One sharded MC step with the exchanges inside: out[0..6] are the global sums, out[7..15] local.
@@ -1823,14 +1862,24 @@ int sqmc_gpu_shard_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[
   hipStream_t st = c->st;
   const int P = c->shard_n, me = c->shard_rank;
   int64_t nch = 0;
-  int r = shard_begin_impl(c, sp, c->d_xg, &nch, false);
+  const bool side = (c->comm2 != nullptr);
+  int r = shard_begin_impl(c, sp, c->d_xg, &nch, false, side);
   if (r) return r;
-  if (c->n_imp > 0) NCCLCHK(g_rccl.AllReduce(c->d_xg, c->d_xg, (size_t)c->n_imp, ncclDouble, ncclSum, c->comm, st));
+  {   // deterministic projection: all-reduce of the weights, then the rows this rank owns
+    hipStream_t sx = side ? c->st2 : st;
+    if (c->n_imp > 0) NCCLCHK(g_rccl.AllReduce(c->d_xg, c->d_xg, (size_t)c->n_imp, ncclDouble, ncclSum, side ? c->comm2 : c->comm, sx));
+    if (side) {
+      if (c->n_imp_local > 0)
+        hipLaunchKernelGGL(k_prj_apply_rows, dim3(nblk(c->n_imp_local, TPB / 64)), dim3(TPB), 0, sx, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, c->d_xg,
+                           c->d_loc_imp, c->d_grow, c->w.wt, c->n_imp_local, sp->e_trial, sp->tau);
+      HIPCHK(hipEventRecord(c->e_join, sx));
+    }
+  }
   // bucket + pack without a host round trip: every child is packed in destination order (the
   // ones that made no walker sort last and are never sent), the counts stay on the device and go
   // straight into the all-gather that tells every rank who sends how much to whom
   u32 *order;
-  r = shard_bucket(c, sp, c->d_xg, &order); if (r) return r;
+  r = shard_bucket(c, sp, c->d_xg, &order, !side); if (r) return r;
   const long long nch_l = c->shard_nch;
   if (nch_l > c->xch_cap) return fail(SQMC_ERR_SPAWN_OVERFLOW, "send buffer too small for this step's spawns");
   if (nch_l > 0) {
@@ -1838,8 +1887,15 @@ int sqmc_gpu_shard_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[
     HIPCHK(hipMemcpyAsync(c->d_cnt_mine, c->d_rowtot, P * 4, hipMemcpyDeviceToDevice, st));
   } else HIPCHK(hipMemsetAsync(c->d_cnt_mine, 0, P * 4, st));
   NCCLCHK(g_rccl.AllGather(c->d_cnt_mine, c->d_cnt_all, (size_t)P, ncclUint32, c->comm, st));
-  HIPCHK(hipMemcpyAsync(c->h_cnt_all, c->d_cnt_all, (size_t)P * P * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  {
+    const u64 qs = ++c->cntall_seq;
+    hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(256), 0, st, (const u32 *)c->d_cnt_all, P * P, c->d_cnt_mail, qs);
+    HIPCHK(hipGetLastError());
+    volatile u64 *flag = (volatile u64 *)(c->h_cnt_all + ((P * P + 15) / 16) * 16);
+    int wr = wait_mail(flag, qs, st);
+    if (wr > 0) return fail(SQMC_ERR_HIP, std::string("step failed on the device: ") + hipGetErrorString((hipError_t)wr));
+    if (wr < 0) HIPCHK(hipMemcpy(c->h_cnt_all, c->d_cnt_all, (size_t)P * P * 4, hipMemcpyDeviceToHost));
+  }
   long long scnt[256];
   for (int q = 0; q < P; q++) scnt[q] = c->h_cnt_all[(size_t)me * P + q];
   long long soff[257], roff[257]; soff[0] = roff[0] = 0;
@@ -1857,7 +1913,7 @@ int sqmc_gpu_shard_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[
   }
   NCCLCHK(g_rccl.GroupEnd());
   if (scnt[me] > 0) HIPCHK(hipMemcpyAsync(c->d_recv + 4 * roff[me], c->d_send + 4 * soff[me], (size_t)scnt[me] * 32, hipMemcpyDeviceToDevice, st));
-  return sqmc_gpu_shard_finish(c, sp, (const uint64_t *)c->d_recv, n_recv, out);
+  return shard_finish_impl(c, sp, (const uint64_t *)c->d_recv, n_recv, out, side);
 }
 
 int sqmc_gpu_shard_run(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats, double totals[16]) {
