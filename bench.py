@@ -37,8 +37,10 @@ def main():
     ap.add_argument("--target", type=float, default=1e5, help="w_abs_gen_target")
     ap.add_argument("--equil", type=int, default=400, help="untimed equilibration steps before warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--system", default="c2", choices=["c2", "heg"], help="c2 = BASELINE.json configs[1] (the metric's config, default); "
-                    "heg = the 14-electron 3D electron gas of configs[3] (auxiliary; no CPU baseline leg)")
+    ap.add_argument("--system", default="c2", choices=["c2", "heg", "hubbard"], help="c2 = BASELINE.json configs[1] (the metric's config, default); "
+                    "heg = the 14-electron 3D electron gas of configs[3]; hubbard = real-space Hubbard U/t=4 at half filling "
+                    "(configs[0] lattice by default) -- both auxiliary, no CPU baseline leg")
+    ap.add_argument("--hubbard-lattice", default="4x4", help="l_x x l_y (periodic), e.g. 4x4 (configs[0]) or 6x4")
     ap.add_argument("--heg-rs", type=float, default=1.0)
     ap.add_argument("--heg-cutoff", type=float, default=2.3, help="plane-wave cutoff radius (2.3 -> 57 orbitals; the GPU path holds at most 64)")
     args = ap.parse_args()
@@ -68,6 +70,10 @@ def main():
     if args.system == "heg":
         hst = H.HegHost(3, args.heg_rs, 14, 7, args.heg_cutoff)
         workload = "3D HEG r_s=%g, 14 electrons in %d plane waves, semistochastic walk" % (args.heg_rs, hst.norb)
+    elif args.system == "hubbard":
+        lx, ly = (int(v) for v in args.hubbard_lattice.lower().split("x"))
+        hst = H.HubbardHost(lx, ly, True, lx * ly // 2, lx * ly // 2, 1.0, 4.0)
+        workload = "%dx%d Hubbard U/t=4 half filling (periodic), real space (hubbard2), semistochastic walk" % (lx, ly)
     else:
         hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
         workload = "C2 cc-pVDZ r=1.24253 (8e,26o, D2h) semistochastic walk, uniform2 proposal"
@@ -85,6 +91,8 @@ def main():
         # hash ownership and spawns cross ranks through one RCCL all-to-all per step
         try:
             skw = dict(w_begin=min(args.target * world, 1e4), n_truncate_trial_wf=1, size_deterministic=500) if args.system == "heg" else {}
+            if args.system == "hubbard":
+                skw = dict(w_begin=min(args.target * world, 1e4), n_truncate_trial_wf=20, size_deterministic=500, tau_multiplier=0.5)
             walk = H.ShardedWalk(hst, args.target * world, rank, world, device_index=local, seed=(1346, 5634, 6635, 4361), **skw)
             ok = torch.ones(1, device=comm_dev)
         except Exception as exc:                      # keep the scaling run alive: independent replicas
@@ -113,6 +121,8 @@ def main():
                     walk = H.ShardedWalk(hst, args.target * world, rank, world, device_index=local, seed=(1346, 5634, 6635, 4361), **skw)
     if walk is None:
         kw = dict(w_begin=min(args.target, 1e4), n_truncate_trial_wf=1, size_deterministic=500) if args.system == "heg" else {}
+        if args.system == "hubbard":
+            kw = dict(w_begin=min(args.target, 1e4), n_truncate_trial_wf=20, size_deterministic=500, tau_multiplier=0.5)
         walk = H.GpuWalk(hst, args.target, seed=H.rank_seed((1346, 5634, 6635, 4361), rank), **kw)
         if multi:
             parallelism = "replicas x%d (sharded path unavailable)" % world
@@ -173,8 +183,10 @@ def main():
             "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload + ", w_abs_gen_target=%g, size_deterministic=1000, Psi_T 100 dets, min_wt 0.5, r_initiator 1, "
-                                   "tau_multiplier 0.1" % (args.target * (world if sharded else 1)),
+            "config": {"workload": workload + ", w_abs_gen_target=%g, %s, min_wt 0.5, r_initiator 1" % (
+                                   args.target * (world if sharded else 1),
+                                   {"c2": "size_deterministic=1000, Psi_T 100 dets, tau_multiplier 0.1", "heg": "size_deterministic=500, Psi_T 1 det, tau_multiplier 0.1",
+                                    "hubbard": "size_deterministic=500, Psi_T 20 dets, tau_multiplier 0.5"}[args.system]),
                        "occupied_dets_per_step": n_avg, "spawns_per_step": s_avg, "spawns_per_s": spawn_all / dt,
                        "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": parallelism},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

@@ -86,6 +86,24 @@ typedef struct {
   int64_t mwalk;
 } sqmc_heg_cfg;
 int sqmc_gpu_init_heg(const sqmc_heg_cfg *cfg, sqmc_gpu_ctx **out);
+/* Real-space Hubbard model on an l_x by l_y square lattice (hamiltonian_type 'hubbard2'): the
+ * scalars read_hubbard takes from the deck (hubbard.f90:138-382: l_x, l_y, pbc, t, U, nup, ndn).
+ * Site s (1-based) sits at x = mod(s-1, l_x)+1, y = (s-1)/l_x+1 and bit s-1 of a determinant
+ * word; neighbours follow get_nbr (more_tools.f90:223-355).  The walk then uses
+ * off_diagonal_move_hubbard (hubbard.f90:2992-3120) and hamiltonian_hubbard (1536-1644) as the
+ * operator pair.  The energy estimator is the library's usual one over a determinant-list trial
+ * wavefunction (the 'else' branch of energy_pieces_hubbard, 4514-4527, as a C(T) table); the
+ * Gutzwiller/Slater trial functions of hubbard.f90 are host-side code outside this path.
+ * A periodic direction of length 2 is refused: the reference's connected list counts that bond
+ * twice while hamiltonian_hubbard counts it once. */
+typedef struct {
+  int32_t l_x, l_y, pbc, nup, ndn;
+  double t, U;
+  int32_t rng_mode;
+  int32_t irand_seed[4];
+  int64_t mwalk;
+} sqmc_hubbard_cfg;
+int sqmc_gpu_init_hubbard(const sqmc_hubbard_cfg *cfg, sqmc_gpu_ctx **out);
 int sqmc_gpu_finalize(sqmc_gpu_ctx *ctx);
 const char *sqmc_gpu_last_error(void);
 

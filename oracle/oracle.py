@@ -553,7 +553,8 @@ class OracleWalk:
     def step(self, params):
         out = np.zeros(16)
         p = StepParams(**params)
-        fn = self.L.orc_walk_step_heg if isinstance(self.sysm, HegSystem) else self.L.orc_walk_step
+        fn = (self.L.orc_walk_step_heg if isinstance(self.sysm, HegSystem) else
+              self.L.orc_walk_step_hubbard if isinstance(self.sysm, HubbardSystem) else self.L.orc_walk_step)
         st = fn(self.sysm.h, self.h, C.byref(p), _p(out))
         return st, out
 
@@ -736,6 +737,136 @@ def setup_walk_heg(hsys, size_deterministic=500, tau_multiplier=0.1, n_truncate_
     psi_index = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(s.psi_up, s.psi_dn))}
     for j in range(n_t):
         xu, xd, el = hsys.connected(int(s.psi_up[j]), int(s.psi_dn[j]), with_elems=True, cap=100000)
+        for a, b, h in zip(xu.tolist(), xd.tolist(), el.tolist()):
+            acc[(a, b)] = acc.get((a, b), 0.0) + h * s.psi_c[j]
+    keys = sorted(acc)
+    s.ct_up = np.array([k[0] for k in keys], np.uint64); s.ct_dn = np.array([k[1] for k in keys], np.uint64)
+    s.ct_num = np.array([acc[k] for k in keys])
+    s.ct_den = np.array([s.psi_c[psi_index[k]] if k in psi_index else 0.0 for k in keys])
+    s.e_trial0 = float(math.fsum(a * b for a, b in zip(s.ct_num, s.ct_den)) / math.fsum(b * b for b in s.ct_den))
+    return s
+
+
+class Hub(C.Structure):
+    _fields_ = [("l_x", C.c_int), ("l_y", C.c_int), ("pbc", C.c_int), ("nsites", C.c_int), ("nup", C.c_int), ("ndn", C.c_int),
+                ("t", C.c_double), ("U", C.c_double)]
+
+
+def hubbard_start_det(l_x, l_y, nup, ndn):
+    """Starting determinant of the harness (not a reference rule: the reference starts hubbard2 walks
+    from its Gutzwiller machinery): up electrons on the sites with x+y even first, dn electrons on
+    the sites with x+y odd first -- the Neel state at half filling."""
+    sites = list(range(l_x * l_y))
+    even = [s for s in sites if ((s % l_x) + (s // l_x)) % 2 == 0]
+    odd = [s for s in sites if ((s % l_x) + (s // l_x)) % 2 == 1]
+    up = sum(1 << s for s in (even + odd)[:nup])
+    dn = sum(1 << s for s in (odd + even)[:ndn])
+    return up, dn
+
+
+class HubbardSystem:
+    """orc_hub handle: real-space Hubbard model on an l_x by l_y square lattice (hubbard.f90, 'hubbard2')."""
+
+    def __init__(self, l_x, l_y, pbc, nup, ndn, t=1.0, U=4.0):
+        L = lib()
+        L.orc_hub_new.restype = C.c_void_p
+        L.orc_hub_new.argtypes = [C.c_int] * 5 + [C.c_double] * 2
+        L.orc_hub_free.argtypes = [C.c_void_p]
+        L.orc_get_nbr.argtypes = [C.c_int] * 5
+        L.orc_fermionic_phase.argtypes = [C.c_uint64, C.c_int, C.c_int]
+        for f in (L.orc_hamiltonian_hubbard, L.orc_hamiltonian_hubbard_checked):
+            f.restype = C.c_double
+            f.argtypes = [C.c_void_p] + [C.c_uint64] * 4
+        L.orc_off_diagonal_move_hubbard.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_uint64, C.c_uint64] + [C.c_void_p] * 4
+        L.orc_connected_hubbard.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_build_sparse_ham_hubbard.restype = C.c_int64
+        L.orc_build_sparse_ham_hubbard.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+        L.orc_walk_step_hubbard.argtypes = [C.c_void_p] * 4
+        self.h = L.orc_hub_new(l_x, l_y, int(bool(pbc)), nup, ndn, t, U)
+        if not self.h:
+            raise RuntimeError("orc_hub_new failed")
+        self.l_x, self.l_y, self.pbc, self.nup, self.ndn, self.t, self.U = l_x, l_y, bool(pbc), nup, ndn, float(t), float(U)
+        self.norb, self.nelec = l_x * l_y, nup + ndn
+        self.hf_up, self.hf_dn = hubbard_start_det(l_x, l_y, nup, ndn)
+
+    def close(self):
+        if self.h:
+            lib().orc_hub_free(self.h)
+            self.h = None
+
+    def ham(self, iu, id_, ju, jd):
+        return lib().orc_hamiltonian_hubbard_checked(self.h, iu, id_, ju, jd)
+
+    def ham_unchecked(self, iu, id_, ju, jd):
+        return lib().orc_hamiltonian_hubbard(self.h, iu, id_, ju, jd)
+
+    def connected(self, up, dn, with_elems=True, cap=4 * 128 + 1):
+        cu = np.zeros(cap, np.uint64); cd = np.zeros(cap, np.uint64); el = np.zeros(cap)
+        n = lib().orc_connected_hubbard(self.h, up, dn, _p(cu), _p(cd), _p(el) if with_elems else None, cap)
+        assert n <= cap
+        return cu[:n], cd[:n], el[:n]
+
+    def build_sparse_ham(self, up, dn):
+        up = np.ascontiguousarray(up, np.uint64); dn = np.ascontiguousarray(dn, np.uint64)
+        n = len(up)
+        rc = C.c_void_p(); ix = C.c_void_p(); vl = C.c_void_p()
+        nnz = lib().orc_build_sparse_ham_hubbard(self.h, n, _p(up), _p(dn), C.byref(rc), C.byref(ix), C.byref(vl))
+        counts = np.ctypeslib.as_array(C.cast(rc, C.POINTER(C.c_int64)), shape=(n,)).copy()
+        idx = np.ctypeslib.as_array(C.cast(ix, C.POINTER(C.c_int64)), shape=(nnz,)).copy()
+        val = np.ctypeslib.as_array(C.cast(vl, C.POINTER(C.c_double)), shape=(nnz,)).copy()
+        for q in (rc, ix, vl):
+            lib().orc_free(q)
+        return counts, idx, val
+
+    def spectral_range_bound(self):
+        """U * (largest - smallest possible number of doubly occupied sites) + 4 t per electron:
+        an upper bound on the spread of the spectrum; tau = tau_multiplier / this."""
+        ns = self.norb
+        return self.U * (min(self.nup, self.ndn) - max(0, self.nelec - ns)) + 4.0 * abs(self.t) * self.nelec
+
+    def first_order_space(self, n_levels=2):
+        """the start determinant and everything within n_levels hops of it, sorted by (up, dn)"""
+        seen = {(self.hf_up, self.hf_dn)}
+        frontier = [(self.hf_up, self.hf_dn)]
+        for _ in range(n_levels):
+            nxt = []
+            for (a, b) in frontier:
+                cu, cd, _e = self.connected(a, b, with_elems=False)
+                for k in zip(cu.tolist(), cd.tolist()):
+                    if k not in seen:
+                        seen.add(k); nxt.append(k)
+            frontier = nxt
+        keys = sorted(seen)
+        return np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint64)
+
+
+def setup_walk_hubbard(hsys, size_deterministic=500, tau_multiplier=0.5, n_truncate_trial_wf=20, n_levels=2):
+    """hubbard2 walk set-up with a determinant-list trial wavefunction (energy_pieces_hubbard's
+    last branch, hubbard.f90:4514-4527): ground state of H in {start det + n_levels hops};
+    Psi_T = its n_truncate_trial_wf largest determinants, deterministic space = the
+    size_deterministic largest, C(T) = the connections of Psi_T with sum_j H_ij c_j."""
+    import math
+    s = WalkSetup()
+    up, dn = hsys.first_order_space(n_levels)
+    counts, idx, val = hsys.build_sparse_ham(up, dn)
+    w, v = davidson_sparse(counts, idx, val, 1)
+    c = v[:, 0]
+    if c[np.argmax(np.abs(c))] < 0:
+        c = -c
+    by = np.argsort(-np.abs(c), kind="stable")
+    up_s, dn_s, c_s = up[by], dn[by], c[by]
+    n_t, n_i = _truncate_at_csf(c_s, n_truncate_trial_wf), _truncate_at_csf(c_s, size_deterministic)
+    norm = 1.0 / math.sqrt(math.fsum(float(x) * float(x) for x in c_s[:n_t]))
+    s.psi_up, s.psi_dn, s.psi_c = up_s[:n_t].copy(), dn_s[:n_t].copy(), c_s[:n_t] * norm
+    o = sort_dets(up_s[:n_i], dn_s[:n_i])
+    s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
+    s.tau, s.e_var = tau_multiplier / hsys.spectral_range_bound(), float(w[0])
+    pc, pi, pv = hsys.build_sparse_ham(s.imp_up, s.imp_dn)
+    s.prj_counts, s.prj_indices, s.prj_values = pc, pi, -s.tau * pv
+    acc = {}
+    psi_index = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(s.psi_up, s.psi_dn))}
+    for j in range(n_t):
+        xu, xd, el = hsys.connected(int(s.psi_up[j]), int(s.psi_dn[j]), with_elems=True)
         for a, b, h in zip(xu.tolist(), xd.tolist(), el.tolist()):
             acc[(a, b)] = acc.get((a, b), 0.0) + h * s.psi_c[j]
     keys = sorted(acc)

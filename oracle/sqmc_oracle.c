@@ -922,12 +922,14 @@ int64_t orc_join_walker2(orc_walk *w, int64_t n, const orc_step_params *p) {
 }
 
 /* system dispatch of the walk: 'chem' or 'heg' (do_walk.f90:3599-3633, 3745-3769) */
-typedef struct { const orc_chem *chem; const orc_heg *heg; } orc_sys;
+typedef struct { const orc_chem *chem; const orc_heg *heg; const orc_hub *hub; } orc_sys;
 static double sys_diag(const orc_sys *y, det_t u, det_t d) {
+  if (y->hub) return orc_hamiltonian_hubbard(y->hub, u, d, u, d);
   return y->chem ? orc_hamiltonian(y->chem, u, d, u, d) : orc_hamiltonian_heg(y->heg, u, d, u, d);
 }
 static void sys_move(const orc_sys *y, orc_rng *g, double tau, det_t u, det_t d, det_t *ju, det_t *jd, double *wj, int *nd) {
-  if (y->chem) orc_off_diagonal_move_chem(y->chem, g, tau, u, d, ju, jd, wj, nd);
+  if (y->hub) orc_off_diagonal_move_hubbard(y->hub, g, tau, u, d, ju, jd, wj, nd);
+  else if (y->chem) orc_off_diagonal_move_chem(y->chem, g, tau, u, d, ju, jd, wj, nd);
   else orc_off_diagonal_move_heg(y->heg, g, tau, u, d, ju, jd, wj, nd);
 }
 
@@ -999,11 +1001,15 @@ static void search_list_and_update(orc_walk *w, int64_t n, double acc[7]) {
  * run_type 'none'.  Population control (2880-2901) stays with the caller. */
 static int walk_step_sys(const orc_sys *s, orc_walk *w, const orc_step_params *p, double out[16]);
 int orc_walk_step(const orc_chem *c, orc_walk *w, const orc_step_params *p, double out[16]) {
-  orc_sys y = {c, NULL};
+  orc_sys y = {c, NULL, NULL};
+  return walk_step_sys(&y, w, p, out);
+}
+int orc_walk_step_hubbard(const orc_hub *h, orc_walk *w, const orc_step_params *p, double out[16]) {
+  orc_sys y = {NULL, NULL, h};
   return walk_step_sys(&y, w, p, out);
 }
 int orc_walk_step_heg(const orc_heg *h, orc_walk *w, const orc_step_params *p, double out[16]) {
-  orc_sys y = {NULL, h};
+  orc_sys y = {NULL, h, NULL};
   return walk_step_sys(&y, w, p, out);
 }
 static int walk_step_sys(const orc_sys *s, orc_walk *w, const orc_step_params *p, double out[16]) {
@@ -1224,6 +1230,154 @@ int64_t orc_build_sparse_ham_heg(const orc_heg *h, int64_t n, const det_t *up, c
     for (int64_t j = 0; j < i; j++) {
       if (popcnt(up[i] ^ up[j]) + popcnt(dn[i] ^ dn[j]) != 4) continue;
       double v = orc_hamiltonian_heg(h, up[i], dn[i], up[j], dn[j]);
+      if (v == 0.0) continue;
+      idx[nnz] = j + 1; val[nnz] = v; nnz++; rc[i]++;
+    }
+  }
+  *row_counts = rc; *indices = idx; *values = val;
+  return nnz;
+}
+
+
+/* ==================================================================== real-space Hubbard */
+orc_hub *orc_hub_new(int l_x, int l_y, int pbc, int nup, int ndn, double t, double U) {
+  if (l_x < 1 || l_y < 1 || l_x * l_y > ORC_MAXORB || nup < 0 || ndn < 0 || nup > l_x * l_y || ndn > l_x * l_y || nup + ndn < 1) return NULL;
+  orc_hub *h = calloc(1, sizeof(orc_hub));
+  h->l_x = l_x; h->l_y = l_y; h->pbc = pbc; h->nsites = l_x * l_y; h->nup = nup; h->ndn = ndn; h->t = t; h->U = U;
+  return h;
+}
+void orc_hub_free(orc_hub *h) { free(h); }
+
+/* more_tools.f90:223-355 */
+int orc_get_nbr(int l_x, int l_y, int pbc, int site, int nbr_type) {
+  int y_1 = ((site - 1) / l_x) + 1, x_1 = site - ((y_1 - 1) * l_x);
+  int allowed = 1, y_2 = y_1, x_2 = x_1;
+  if (nbr_type == 1) {                                   /* LEFT */
+    x_2 = x_1 - 1; y_2 = y_1;
+    if (!pbc) allowed = (x_2 > 0);
+    else { if (x_2 == 0) x_2 = l_x; if (x_2 == x_1) allowed = 0; }
+  }
+  if (nbr_type == 2) {                                   /* RIGHT */
+    x_2 = x_1 + 1; y_2 = y_1;
+    if (!pbc) allowed = (x_2 <= l_x);
+    else { if (x_2 == l_x + 1) x_2 = 1; if (x_2 == x_1) allowed = 0; }
+  }
+  if (nbr_type == 3) {                                   /* UP */
+    x_2 = x_1; y_2 = y_1 + 1;
+    if (!pbc) allowed = (y_2 <= l_y);
+    else { if (y_2 == l_y + 1) y_2 = 1; if (y_2 == y_1) allowed = 0; }
+  }
+  if (nbr_type == 4) {                                   /* DOWN */
+    x_2 = x_1; y_2 = y_1 - 1;
+    if (!pbc) allowed = (y_2 > 0);
+    else { if (y_2 == 0) y_2 = l_y; if (y_2 == y_1) allowed = 0; }
+  }
+  return allowed ? ((y_2 - 1) * l_x) + x_2 : -1;
+}
+
+/* more_tools.f90:140-176: parity of the occupied sites strictly between the two positions */
+int orc_fermionic_phase(det_t config, int site_1, int site_2) {
+  int lo = site_1 < site_2 ? site_1 : site_2, hi = site_1 < site_2 ? site_2 : site_1, num_betn = 0;
+  for (int i = lo + 1; i <= hi - 1; i++) if (btest(config, i - 1)) num_betn++;
+  return (num_betn % 2 == 0) ? 1 : -1;
+}
+
+/* hubbard.f90:1536-1644 */
+double orc_hamiltonian_hubbard(const orc_hub *h, det_t iu, det_t id, det_t ju, det_t jd) {
+  int ns = h->nsites;
+  if (iu == ju && id == jd) {
+    det_t both = iu & id; int docc = 0;
+    for (int i = 1; i <= ns; i++) if (btest(both, i - 1)) docc++;
+    return h->U * docc;
+  }
+  det_t c1 = 0, c2 = 0, cfg = 0; int flag = 0;
+  if (iu == ju) { c1 = id & ~jd; c2 = ~id & jd; cfg = id; flag = 1; }
+  if (id == jd) { c1 = iu & ~ju; c2 = ~iu & ju; cfg = iu; flag = 1; }
+  if (!flag) return 0.0;
+  int pos_1 = 0, pos_2 = 0, num_ones = 0;
+  for (int i = 1; i <= ns; i++) if (btest(c1, i - 1)) { num_ones++; if (num_ones == 1) pos_1 = i; else return 0.0; }
+  if (num_ones == 0) return 0.0;
+  num_ones = 0;
+  for (int i = 1; i <= ns; i++) if (btest(c2, i - 1)) { num_ones++; if (num_ones == 1) pos_2 = i; else return 0.0; }
+  if (num_ones == 0) return 0.0;
+  return -h->t * orc_fermionic_phase(cfg, pos_1 < pos_2 ? pos_1 : pos_2, pos_1 < pos_2 ? pos_2 : pos_1);
+}
+
+double orc_hamiltonian_hubbard_checked(const orc_hub *h, det_t iu, det_t id, det_t ju, det_t jd) {
+  if (iu == ju && id == jd) return orc_hamiltonian_hubbard(h, iu, id, ju, jd);
+  det_t a, b;
+  if (iu == ju) { a = id & ~jd; b = jd & ~id; } else if (id == jd) { a = iu & ~ju; b = ju & ~iu; } else return 0.0;
+  if (popcnt(a) != 1 || popcnt(b) != 1) return 0.0;
+  int p1 = trailz(a) + 1, p2 = trailz(b) + 1, bond = 0;
+  for (int k = 1; k <= 4; k++) if (orc_get_nbr(h->l_x, h->l_y, h->pbc, p1, k) == p2) bond = 1;
+  return bond ? orc_hamiltonian_hubbard(h, iu, id, ju, jd) : 0.0;
+}
+
+/* hubbard.f90:2992-3120 with choose_random_electron 1024-1058 (vmc off) */
+void orc_off_diagonal_move_hubbard(const orc_hub *h, orc_rng *g, double tau, det_t iu, det_t id,
+                                   det_t *ju, det_t *jd, double *weight_j, int *n_draws) {
+  int draws = 0;
+  *weight_j = 0; *ju = iu; *jd = id;
+  int chosen_site, chosen_spin;
+  for (;;) {
+    chosen_site = orc_random_int(g, 2 * h->l_x * h->l_y); draws++;
+    if (chosen_site % 2 == 0) { chosen_spin = 0; chosen_site = chosen_site / 2; if (btest(id, chosen_site - 1)) break; }
+    else { chosen_spin = 1; chosen_site = (chosen_site + 1) / 2; if (btest(iu, chosen_site - 1)) break; }
+  }
+  det_t det = chosen_spin ? iu : id;
+  int ctr = 0, allowed_nbrs[4];
+  for (int k = 1; k <= 4; k++) {
+    int nbr = orc_get_nbr(h->l_x, h->l_y, h->pbc, chosen_site, k);
+    if (nbr > 0 && !btest(det, nbr - 1)) allowed_nbrs[ctr++] = nbr;
+  }
+  if (ctr == 0) { if (n_draws) *n_draws = draws; return; }
+  int target_k = orc_random_int(g, ctr); draws++;
+  int target_site = allowed_nbrs[target_k - 1];
+  det = (det | BIT(target_site - 1)) & ~BIT(chosen_site - 1);
+  if (chosen_spin == 0) *jd = det; else *ju = det;
+  double me = orc_hamiltonian_hubbard(h, iu, id, *ju, *jd);
+  double proposal_prob_inv = (double)((h->nup + h->ndn) * ctr);
+  double acceptance_prob = fabs(me) * tau * proposal_prob_inv;
+  *weight_j = acceptance_prob * copysign(1.0, -me);
+  if (n_draws) *n_draws = draws;
+}
+
+/* hubbard.f90:5306-5457 */
+int orc_connected_hubbard(const orc_hub *h, det_t up, det_t dn, det_t *cu, det_t *cd, double *el, int cap) {
+  int n = 0, num_e = 0, docc = 0, nel = h->nup + h->ndn;
+  for (int i_ctr = 1; i_ctr <= 2 * h->nsites; i_ctr++) {
+    if (num_e == nel) break;
+    int i = (i_ctr + 1) / 2, is_up = (i_ctr % 2 != 0);
+    det_t config = is_up ? up : dn, other = is_up ? dn : up;
+    if (!btest(config, i - 1)) continue;
+    num_e++;
+    if (is_up && btest(other, i - 1)) docc++;
+    for (int j = 1; j <= 4; j++) {
+      int nbr = orc_get_nbr(h->l_x, h->l_y, h->pbc, i, j);
+      if (nbr > 0 && !btest(config, nbr - 1)) {
+        det_t nc = (config & ~BIT(i - 1)) | BIT(nbr - 1);
+        if (n < cap) { cu[n] = is_up ? nc : up; cd[n] = is_up ? dn : nc; if (el) el[n] = -h->t * (double)orc_fermionic_phase(config, i, nbr); }
+        n++;
+      }
+    }
+  }
+  /* the diagonal entry U*doubly_occupied: doubly occupied sites are only counted while electrons
+   * are being enumerated (the loop exits once all are found), which covers every up electron */
+  if (n < cap) { cu[n] = up; cd[n] = dn; if (el) el[n] = h->U * docc; }
+  n++;
+  return n;
+}
+
+int64_t orc_build_sparse_ham_hubbard(const orc_hub *h, int64_t n, const det_t *up, const det_t *dn,
+                                     int64_t **row_counts, int64_t **indices, double **values) {
+  int64_t cap = n * 16 + 1024, nnz = 0;
+  int64_t *rc = calloc(n, sizeof(int64_t)), *idx = malloc(cap * sizeof(int64_t)); double *val = malloc(cap * sizeof(double));
+  for (int64_t i = 0; i < n; i++) {
+    if (nnz + i + 2 > cap) { cap = 2 * cap + i; idx = realloc(idx, cap * sizeof(int64_t)); val = realloc(val, cap * sizeof(double)); }
+    idx[nnz] = i + 1; val[nnz] = orc_hamiltonian_hubbard(h, up[i], dn[i], up[i], dn[i]); nnz++; rc[i] = 1;
+    for (int64_t j = 0; j < i; j++) {
+      if (popcnt(up[i] ^ up[j]) + popcnt(dn[i] ^ dn[j]) != 2) continue;
+      double v = orc_hamiltonian_hubbard_checked(h, up[i], dn[i], up[j], dn[j]);
       if (v == 0.0) continue;
       idx[nnz] = j + 1; val[nnz] = v; nnz++; rc[i]++;
     }

@@ -160,3 +160,33 @@ int64_t orc_build_sparse_ham_heg(const orc_heg *h, int64_t n, const det_t *up, c
 /* one MC step with the HEG as the system (same step logic as orc_walk_step) */
 int  orc_walk_step_heg(const orc_heg *h, orc_walk *w, const orc_step_params *p, double out[16]);
 #endif
+
+/* ---- real-space Hubbard model on a square lattice: hubbard.f90 (read_hubbard 138-382,
+ * choose_random_electron 1024-1058, hamiltonian_hubbard 1536-1644, off_diagonal_move_hubbard
+ * 2992-3120, find_connected_dets_hubbard 5306-5457), more_tools.f90 (fermionic_phase 140-176,
+ * get_nbr 223-355).  PARITY UNPINNED: the reference holds no fixture for this model and
+ * hubbard.f90 does not compile unmodified with the flang of this image; the restatement follows
+ * the source text line by line. ---- */
+#ifndef SQMC_ORACLE_HUB_H
+#define SQMC_ORACLE_HUB_H
+typedef struct {
+  int l_x, l_y, pbc, nsites, nup, ndn;
+  double t, U;
+} orc_hub;
+orc_hub *orc_hub_new(int l_x, int l_y, int pbc, int nup, int ndn, double t, double U);
+void   orc_hub_free(orc_hub *h);
+/* get_nbr: nbr_type 1 LEFT, 2 RIGHT, 3 UP, 4 DOWN; returns the neighbour (1-based) or -1 if not allowed */
+int    orc_get_nbr(int l_x, int l_y, int pbc, int site, int nbr_type);
+int    orc_fermionic_phase(det_t config, int site_1, int site_2);
+/* hamiltonian_hubbard as written: "NOT checking for neighbors, assumes inherent connectedness" */
+double orc_hamiltonian_hubbard(const orc_hub *h, det_t iu, det_t id, det_t ju, det_t jd);
+/* the same with the lattice-bond test of is_connected_hubbard (5876-5977) in front: what a matrix builder may call on any pair */
+double orc_hamiltonian_hubbard_checked(const orc_hub *h, det_t iu, det_t id, det_t ju, det_t jd);
+void   orc_off_diagonal_move_hubbard(const orc_hub *h, orc_rng *g, double tau, det_t iu, det_t id,
+                                     det_t *ju, det_t *jd, double *weight_j, int *n_draws);
+/* find_connected_dets_hubbard: the hops in the reference's order (electron by electron, L R U D), the determinant itself LAST */
+int    orc_connected_hubbard(const orc_hub *h, det_t up, det_t dn, det_t *cu, det_t *cd, double *elems, int cap);
+int64_t orc_build_sparse_ham_hubbard(const orc_hub *h, int64_t n, const det_t *up, const det_t *dn,
+                                     int64_t **row_counts, int64_t **indices, double **values);
+int  orc_walk_step_hubbard(const orc_hub *h, orc_walk *w, const orc_step_params *p, double out[16]);
+#endif

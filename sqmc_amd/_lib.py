@@ -12,7 +12,7 @@ RNG_REPLAY, RNG_COUNTER = 0, 1
 _LIB = None
 
 EXPORTS = [
-    "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_init_heg", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_projector",
+    "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_init_heg", "sqmc_gpu_init_hubbard", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_projector",
     "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
     "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_annihilate", "sqmc_gpu_det_owner", "sqmc_gpu_shard_config",
     "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init",
@@ -51,6 +51,11 @@ class ChemCfg(C.Structure):
 class HegCfg(C.Structure):
     _fields_ = [("n_dim", C.c_int32), ("norb", C.c_int32), ("nup", C.c_int32), ("ndn", C.c_int32), ("length_cell", C.c_double),
                 ("k_vectors", C.c_void_p), ("rng_mode", C.c_int32), ("irand_seed", C.c_int32 * 4), ("mwalk", C.c_int64)]
+
+
+class HubbardCfg(C.Structure):
+    _fields_ = [("l_x", C.c_int32), ("l_y", C.c_int32), ("pbc", C.c_int32), ("nup", C.c_int32), ("ndn", C.c_int32),
+                ("t", C.c_double), ("U", C.c_double), ("rng_mode", C.c_int32), ("irand_seed", C.c_int32 * 4), ("mwalk", C.c_int64)]
 
 
 class StepParams(C.Structure):
@@ -172,6 +177,22 @@ class GpuChem:
         h = C.c_void_p()
         _chk(L.sqmc_gpu_init_heg(C.byref(cfg), C.byref(h)))
         self.h, self.norb, self.mwalk = h, norb, mwalk
+        return self
+
+    @classmethod
+    def hubbard(cls, l_x, l_y, pbc, nup, ndn, t, U, rng_mode=RNG_COUNTER, seed=(1346, 5634, 6635, 4361), mwalk=0):
+        """context for the real-space Hubbard model on an l_x by l_y lattice ('hubbard2')"""
+        self = cls.__new__(cls)
+        self.L = L = load_library()
+        self._tabs = []
+        cfg = HubbardCfg()
+        cfg.l_x, cfg.l_y, cfg.pbc, cfg.nup, cfg.ndn, cfg.t, cfg.U = l_x, l_y, int(bool(pbc)), nup, ndn, float(t), float(U)
+        cfg.rng_mode, cfg.mwalk = rng_mode, mwalk
+        for i in range(4):
+            cfg.irand_seed[i] = seed[i]
+        h = C.c_void_p()
+        _chk(L.sqmc_gpu_init_hubbard(C.byref(cfg), C.byref(h)))
+        self.h, self.norb, self.mwalk = h, l_x * l_y, mwalk
         return self
 
     def close(self):

@@ -29,9 +29,13 @@ struct ChemTab {
   unsigned char orbsym[SQ_MAXORB + 1]; // 1-based
   double nuclear;
   // homogeneous electron gas (sys_type 1): plane-wave orbitals k_vectors(:, i), heg.f90:643-749
-  int sys_type, n_dim;                 // 0 = 'chem', 1 = 'heg'
+  int sys_type, n_dim;                 // 0 = 'chem', 1 = 'heg', 2 = 'hubbard2' (real-space Hubbard, hubbard.f90)
   double length_cell;
-  double kvec[SQ_MAXORB + 1][3];       // 1-based
+  double hub_t, hub_U;                 // hubbard2: hopping and on-site repulsion
+  union {
+    double kvec[SQ_MAXORB + 1][3];     // heg, 1-based
+    unsigned char hub_nbr[SQ_MAXORB + 1][4];   // hubbard2: get_nbr(site, LEFT/RIGHT/UP/DOWN), 0 = not allowed (more_tools.f90:223-355)
+  };
   signed char krel[SQ_MAXORB + 1][3];  // the same in units of 2 pi / L (k_vectors_rel): exact momentum bookkeeping
   int heg_nmax;                        // max |krel component|
   int c2_stride, c2_pad;               // combine_2 is stored packed: c2[i*c2_stride + j], 1-based
@@ -302,8 +306,26 @@ __device__ inline double h_heg(const ChemTab &t, u64 iu, u64 id, u64 ju, u64 jd)
   return pot / (L * L * L);
 }
 
+// ---- real-space Hubbard, hamiltonian_hubbard (hubbard.f90:1536-1644) with the Jordan-Wigner
+// phase of fermionic_phase (more_tools.f90:140-176).  The reference "assumes inherent
+// connectedness" of the pair it is given; here the hop must also be a lattice bond
+// (is_connected_hubbard), so that the all-pairs matrix builder can call it on anything.
+__device__ __forceinline__ double h_hubbard(const ChemTab &t, u64 iu, u64 id, u64 ju, u64 jd) {
+  if (iu == ju && id == jd) return t.hub_U * popc64(iu & id);
+  u64 cfg, cj;
+  if (iu == ju) { cfg = id; cj = jd; } else if (id == jd) { cfg = iu; cj = ju; } else return 0.0;
+  const u64 a = cfg & ~cj, b = cj & ~cfg;
+  if (popc64(a) != 1 || popc64(b) != 1) return 0.0;
+  const int p1 = ctz64(a) + 1, p2 = ctz64(b) + 1;
+  if (t.hub_nbr[p1][0] != p2 && t.hub_nbr[p1][1] != p2 && t.hub_nbr[p1][2] != p2 && t.hub_nbr[p1][3] != p2) return 0.0;
+  const int lo = p1 < p2 ? p1 : p2, hi = p1 < p2 ? p2 : p1;         // sites strictly between: 0-based bits lo .. hi-2
+  const int phase = (popc64(cfg & maskr64(hi - 1) & ~maskr64(lo)) & 1) ? -1 : 1;
+  return -t.hub_t * phase;
+}
+
 __device__ inline double h_any(const ChemTab &t, const double *__restrict__ ints, u64 iu, u64 id, u64 ju, u64 jd) {
   if (t.sys_type == 1) return h_heg(t, iu, id, ju, jd);
+  if (t.sys_type == 2) return h_hubbard(t, iu, id, ju, jd);
   if (t.time_sym) return h_time_sym(t, ints, iu, id, ju, jd);
   int lev = excitation_level(iu, id, ju, jd);
   return lev < 0 ? 0.0 : h_level(t, ints, iu, id, ju, jd, lev);
@@ -453,6 +475,11 @@ __device__ inline double proposal_weight(const ChemTab &t, const double *__restr
     const double acc = tau * fabs(me) / prob;
     return acc * copysign(1.0, -me);
   }
+  if (t.sys_type == 2) {                 // hubbard.f90:3111-3116; prob holds proposal_prob_inv = nelec * ctr
+    const double me = h_hubbard(t, iu, id, ju, jd);
+    const double acc = fabs(me) * tau * prob;
+    return acc * copysign(1.0, -me);
+  }
   if (!t.time_sym) return -tau * h_level(t, ints, iu, id, ju, jd, level) / prob;
   const double sqrt2 = sqrt(2.0);
   const double norm_i = (iu == id) ? sqrt2 : 1.0;
@@ -519,7 +546,38 @@ __device__ inline int propose_heg(const ChemTab &t, Rng &g, u64 iu, u64 id, u64 
   }
   return 0;
 }
+// off_diagonal_move_hubbard, hubbard.f90:2992-3120 (vmc off): an electron by rejection over the
+// 2*nsites spin-sites (choose_random_electron, 1024-1058), then one of its empty lattice
+// neighbours (LEFT, RIGHT, UP, DOWN order).  Returns 1 with prob = the INVERSE proposal
+// probability real((nup+ndn)*ctr) the reference multiplies with, or 0 (no empty neighbour).
+#define SQ_HUB_MAX_TRIES 4096            // the rejection loop ends with probability 1; the bound keeps a wave from spinning on a corrupt (empty) determinant
+__device__ inline int propose_hubbard(const ChemTab &t, Rng &g, u64 iu, u64 id, u64 &ju, u64 &jd, double &prob) {
+  ju = iu; jd = id;
+  const int ns2 = 2 * t.norb;
+  int site = 0, spin = 0; bool found = false;
+  for (int it = 0; it < SQ_HUB_MAX_TRIES && !found; it++) {
+    const int cs = rng_int(g, ns2);
+    if ((cs & 1) == 0) { spin = 0; site = cs / 2; found = (id >> (site - 1)) & 1; }
+    else { spin = 1; site = (cs + 1) / 2; found = (iu >> (site - 1)) & 1; }
+  }
+  if (!found) return 0;
+  const u64 det = spin ? iu : id;
+  int ctr = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int nb = t.hub_nbr[site][k]; if (nb && !((det >> (nb - 1)) & 1)) ctr++; }
+  if (ctr == 0) return 0;
+  const int tk = rng_int(g, ctr);
+  int target = 0, seen = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int nb = t.hub_nbr[site][k]; if (nb && !((det >> (nb - 1)) & 1)) { seen++; if (seen == tk) target = nb; } }
+  const u64 dj = (det | bit64(target - 1)) & ~bit64(site - 1);
+  if (spin) ju = dj; else jd = dj;
+  prob = (double)(t.nelec * ctr);
+  return 1;
+}
 // proposal of the system at hand (the procedure pointer `move`, do_walk.f90:126-134, 3599-3633)
 __device__ __forceinline__ int propose_any(const ChemTab &t, Rng &g, u64 iu, u64 id, u64 &ju, u64 &jd, double &prob) {
-  return (t.sys_type == 1) ? propose_heg(t, g, iu, id, ju, jd, prob) : propose_uniform(t, g, iu, id, ju, jd, prob);
+  if (t.sys_type == 1) return propose_heg(t, g, iu, id, ju, jd, prob);
+  if (t.sys_type == 2) return propose_hubbard(t, g, iu, id, ju, jd, prob);
+  return propose_uniform(t, g, iu, id, ju, jd, prob);
 }

@@ -1096,6 +1096,39 @@ int sqmc_gpu_init_heg(const sqmc_heg_cfg *cfg, sqmc_gpu_ctx **out) {
   return init_common(c, cfg->norb, cfg->nup, cfg->ndn, cfg->rng_mode, cfg->irand_seed, cfg->mwalk, out);
 }
 
+// get_nbr, more_tools.f90:223-355: neighbour `type` (0 LEFT, 1 RIGHT, 2 UP, 3 DOWN) of a 1-based site, 0 if not allowed
+static int hubbard_nbr(int lx, int ly, int pbc, int site, int type) {
+  const int y1 = (site - 1) / lx + 1, x1 = site - (y1 - 1) * lx;
+  int x2 = x1, y2 = y1; bool ok = true;
+  if (type == 0) { x2 = x1 - 1; if (!pbc) ok = x2 > 0; else { if (x2 == 0) x2 = lx; if (x2 == x1) ok = false; } }
+  if (type == 1) { x2 = x1 + 1; if (!pbc) ok = x2 <= lx; else { if (x2 == lx + 1) x2 = 1; if (x2 == x1) ok = false; } }
+  if (type == 2) { y2 = y1 + 1; if (!pbc) ok = y2 <= ly; else { if (y2 == ly + 1) y2 = 1; if (y2 == y1) ok = false; } }
+  if (type == 3) { y2 = y1 - 1; if (!pbc) ok = y2 > 0; else { if (y2 == 0) y2 = ly; if (y2 == y1) ok = false; } }
+  return ok ? (y2 - 1) * lx + x2 : 0;
+}
+
+int sqmc_gpu_init_hubbard(const sqmc_hubbard_cfg *cfg, sqmc_gpu_ctx **out) {
+  if (!cfg || !out) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  if (cfg->l_x < 1 || cfg->l_y < 1) return fail(SQMC_ERR_BAD_ARG, "l_x and l_y must be positive");
+  const long long ns = (long long)cfg->l_x * cfg->l_y;
+  if (ns > SQ_MAXORB) return fail(SQMC_ERR_UNSUPPORTED, "l_x*l_y must be <= 64 (one 64-bit word per spin)");
+  if (cfg->nup < 0 || cfg->ndn < 0 || cfg->nup > ns || cfg->ndn > ns || cfg->nup + cfg->ndn < 1) return fail(SQMC_ERR_BAD_ARG, "nup / ndn out of range");
+  if (cfg->pbc && (cfg->l_x == 2 || cfg->l_y == 2))
+    return fail(SQMC_ERR_UNSUPPORTED, "a periodic direction of length 2 doubles a bond in the reference's connected list but not in hamiltonian_hubbard");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SQMC_ERR_HIP, "no HIP device: libsqmc_gpu has no CPU fallback");
+  sqmc_gpu_ctx *c = new sqmc_gpu_ctx();
+  memset((void *)c, 0, sizeof(*c));
+  HIPCHK(hipStreamCreate(&c->st));
+  ChemTab &t = c->htab;
+  t.sys_type = 2; t.n_dim = 2; t.hub_t = cfg->t; t.hub_U = cfg->U;
+  t.norb = (int)ns; t.nup = cfg->nup; t.ndn = cfg->ndn; t.ncore = 0; t.nelec = cfg->nup + cfg->ndn; t.time_sym = 0; t.z = 1; t.ngroup = 1;
+  t.orb_mask = (ns >= 64) ? ~0ull : ((1ull << ns) - 1ull);
+  t.c2_stride = 0;
+  for (int s = 1; s <= (int)ns; s++) for (int k = 0; k < 4; k++) t.hub_nbr[s][k] = (unsigned char)hubbard_nbr(cfg->l_x, cfg->l_y, cfg->pbc, s, k);
+  return init_common(c, (int)ns, cfg->nup, cfg->ndn, cfg->rng_mode, cfg->irand_seed, cfg->mwalk, out);
+}
+
 static void comm_release(sqmc_gpu_ctx *c);
 int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   if (!c) return SQMC_OK;
@@ -2074,6 +2107,7 @@ int sqmc_gpu_hci_connections_slice(sqmc_gpu_ctx *c, int64_t n_ref, const uint64_
     key_lo = (u64)(span * slice); key_hi = (slice == n_slices - 1) ? (~0ull - 1ull) : (u64)(span * (slice + 1));
   }
   if (c->htab.sys_type == 0 && !c->dev.hb_r) return fail(SQMC_ERR_BAD_ARG, "heat-bath tables not set (sqmc_gpu_set_hb_tables)");
+  if (c->htab.sys_type == 2) return fail(SQMC_ERR_UNSUPPORTED, "connection generation for hubbard2 is the host's 4*nelec neighbour list (find_connected_dets_hubbard); no heat-bath screening applies");
   if (c->htab.sys_type == 1 && c->htab.heg_nmax > 4) return fail(SQMC_ERR_UNSUPPORTED, "HEG connections: plane-wave index beyond +-4");
   *out_n = 0;
   if (n_ref <= 0) return SQMC_OK;

@@ -7,7 +7,7 @@ module sqmc_gpu_mod
   use iso_c_binding
   implicit none
   private
-  public :: sqmc_chem_cfg, sqmc_heg_cfg, sqmc_gpu_init_heg, sqmc_step_params, sqmc_popctl, sqmc_gpu_run
+  public :: sqmc_chem_cfg, sqmc_heg_cfg, sqmc_gpu_init_heg, sqmc_hubbard_cfg, sqmc_gpu_init_hubbard, sqmc_step_params, sqmc_popctl, sqmc_gpu_run
   public :: sqmc_gpu_set_device, sqmc_gpu_init_chem, sqmc_gpu_finalize, sqmc_gpu_last_error, sqmc_gpu_set_hb_tables
   public :: sqmc_gpu_set_projector, sqmc_gpu_scale_projector, sqmc_gpu_set_ct_table, sqmc_gpu_upload_walkers
   public :: sqmc_gpu_num_walkers, sqmc_gpu_download_walkers, sqmc_gpu_step, sqmc_gpu_get_rng, sqmc_gpu_set_rng
@@ -39,6 +39,14 @@ module sqmc_gpu_mod
     integer(c_int32_t) :: n_dim, norb, nup, ndn
     real(c_double) :: length_cell
     type(c_ptr) :: k_vectors           ! real(c_double) k_vectors(n_dim, norb), as in module heg
+    integer(c_int32_t) :: rng_mode
+    integer(c_int32_t) :: irand_seed(4)
+    integer(c_int64_t) :: mwalk
+  end type
+
+  type, bind(C) :: sqmc_hubbard_cfg    ! hamiltonian_type 'hubbard2': the scalars of read_hubbard
+    integer(c_int32_t) :: l_x, l_y, pbc, nup, ndn
+    real(c_double) :: t, U
     integer(c_int32_t) :: rng_mode
     integer(c_int32_t) :: irand_seed(4)
     integer(c_int64_t) :: mwalk
@@ -113,6 +121,9 @@ module sqmc_gpu_mod
     end function
     integer(c_int) function sqmc_gpu_init_heg(cfg, ctx) bind(C, name='sqmc_gpu_init_heg')
       import; type(sqmc_heg_cfg), intent(in) :: cfg; type(c_ptr), intent(out) :: ctx
+    end function
+    integer(c_int) function sqmc_gpu_init_hubbard(cfg, ctx) bind(C, name='sqmc_gpu_init_hubbard')
+      import; type(sqmc_hubbard_cfg), intent(in) :: cfg; type(c_ptr), intent(out) :: ctx
     end function
     integer(c_int) function sqmc_gpu_finalize(ctx) bind(C, name='sqmc_gpu_finalize')
       import; type(c_ptr), value :: ctx

@@ -916,6 +916,112 @@ class HegHost:
         return s
 
 
+class HubbardHost:
+    """Real-space Hubbard model on an l_x by l_y square lattice (hamiltonian_type 'hubbard2'): the
+    scalars of read_hubbard (hubbard.f90:138-382) and the walk set-up on the GPU path with a
+    determinant-list trial wavefunction (the last branch of energy_pieces_hubbard, 4514-4527); the
+    Gutzwiller / Slater trial functions of hubbard.f90 are outside this path."""
+
+    def __init__(self, l_x, l_y, pbc, nup, ndn, t=1.0, U=4.0):
+        self.l_x, self.l_y, self.pbc, self.nup, self.ndn, self.t, self.U = l_x, l_y, bool(pbc), nup, ndn, float(t), float(U)
+        self.norb, self.nelec = l_x * l_y, nup + ndn
+        sites = list(range(self.norb))
+        even = [q for q in sites if ((q % l_x) + (q // l_x)) % 2 == 0]
+        odd = [q for q in sites if ((q % l_x) + (q // l_x)) % 2 == 1]
+        # start determinant of the harness: the Neel state at half filling (up on x+y even first, dn on x+y odd first)
+        self.hf_up = sum(1 << q for q in (even + odd)[:nup])
+        self.hf_dn = sum(1 << q for q in (odd + even)[:ndn])
+        self.nbr = [[self._get_nbr(site, k) for k in (1, 2, 3, 4)] for site in range(1, self.norb + 1)]
+
+    def _get_nbr(self, site, nbr_type):
+        """get_nbr, more_tools.f90:223-355 (1 LEFT, 2 RIGHT, 3 UP, 4 DOWN); 0 when not allowed"""
+        lx, ly = self.l_x, self.l_y
+        y1 = (site - 1) // lx + 1
+        x1 = site - (y1 - 1) * lx
+        x2, y2, ok = x1, y1, True
+        if nbr_type in (1, 2):
+            x2 = x1 - 1 if nbr_type == 1 else x1 + 1
+            if not self.pbc:
+                ok = 0 < x2 <= lx
+            else:
+                x2 = lx if x2 == 0 else (1 if x2 == lx + 1 else x2)
+                ok = x2 != x1
+        else:
+            y2 = y1 + 1 if nbr_type == 3 else y1 - 1
+            if not self.pbc:
+                ok = 0 < y2 <= ly
+            else:
+                y2 = ly if y2 == 0 else (1 if y2 == ly + 1 else y2)
+                ok = y2 != y1
+        return (y2 - 1) * lx + x2 if ok else 0
+
+    def gpu(self, **kw):
+        return GpuChem.hubbard(self.l_x, self.l_y, self.pbc, self.nup, self.ndn, self.t, self.U, **kw)
+
+    def connected(self, up, dn):
+        """the determinant and its nearest-neighbour hops (find_connected_dets_hubbard, hubbard.f90:5306-5457), unique, sorted"""
+        out = {(up, dn)}
+        for site in range(1, self.norb + 1):
+            for is_up in (True, False):
+                cfg = up if is_up else dn
+                if not (cfg >> (site - 1)) & 1:
+                    continue
+                for nb in self.nbr[site - 1]:
+                    if nb and not (cfg >> (nb - 1)) & 1:
+                        nc = (cfg & ~(1 << (site - 1))) | (1 << (nb - 1))
+                        out.add((nc, dn) if is_up else (up, nc))
+        keys = sorted(out)
+        return np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint64)
+
+    def spectral_range_bound(self):
+        return self.U * (min(self.nup, self.ndn) - max(0, self.nelec - self.norb)) + 4.0 * abs(self.t) * self.nelec
+
+    def first_order_space(self, n_levels=2):
+        seen = {(self.hf_up, self.hf_dn)}
+        frontier = [(self.hf_up, self.hf_dn)]
+        for _ in range(n_levels):
+            nxt = []
+            for (a, b) in frontier:
+                cu, cd = self.connected(a, b)
+                for k in zip(cu.tolist(), cd.tolist()):
+                    if k not in seen:
+                        seen.add(k); nxt.append(k)
+            frontier = nxt
+        keys = sorted(seen)
+        return np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint64)
+
+    def setup_walk(self, g, n_truncate_trial_wf=20, size_deterministic=500, tau_multiplier=0.5, n_levels=2):
+        s = WalkSetup()
+        up, dn = self.first_order_space(n_levels)
+        w, X, _ = lowest_state(g, up, dn)
+        c = X[:, 0]
+        if c[np.argmax(np.abs(c))] < 0:
+            c = -c
+        by = np.argsort(-np.abs(c), kind="stable")
+        up_s, dn_s, c_s = up[by], dn[by], c[by]
+        n_t, n_i = _truncate_at_csf(c_s, n_truncate_trial_wf), _truncate_at_csf(c_s, size_deterministic)
+        s.psi_up, s.psi_dn = up_s[:n_t].copy(), dn_s[:n_t].copy()
+        s.psi_c = c_s[:n_t] / np.sqrt(np.dot(c_s[:n_t], c_s[:n_t]))
+        o = sort_dets(up_s[:n_i], dn_s[:n_i])
+        s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
+        s.tau, s.e_var = tau_multiplier / self.spectral_range_bound(), float(w[0])
+        pc, pi_, pv = g.build_sparse_ham(s.imp_up, s.imp_dn)
+        s.prj_counts, s.prj_indices, s.prj_values = pc, pi_, -s.tau * pv
+        acc = {}
+        psi_index = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(s.psi_up, s.psi_dn))}
+        for j in range(n_t):
+            cu, cd = self.connected(int(s.psi_up[j]), int(s.psi_dn[j]))
+            h = g.hamiltonian_batch(cu, cd, np.full(len(cu), s.psi_up[j]), np.full(len(cu), s.psi_dn[j]))
+            for a, b, v in zip(cu.tolist(), cd.tolist(), h.tolist()):
+                acc[(a, b)] = acc.get((a, b), 0.0) + v * s.psi_c[j]
+        keys = sorted(acc)
+        s.ct_up = np.array([k[0] for k in keys], np.uint64); s.ct_dn = np.array([k[1] for k in keys], np.uint64)
+        s.ct_num = np.array([acc[k] for k in keys])
+        s.ct_den = np.array([s.psi_c[psi_index[k]] if k in psi_index else 0.0 for k in keys])
+        s.e_trial0 = float(np.dot(s.ct_num, s.ct_den) / np.dot(s.ct_den, s.ct_den))
+        return s
+
+
 def sum_left(it):
     """left-to-right floating sum (Fortran SUM over a tiny array)"""
     t = 0.0

@@ -67,6 +67,22 @@ def heg14_hci(oracle, heg14):
     return oracle.hci_variational(heg14, 1e-3, n_states=1)
 
 
+@pytest.fixture(scope="session")
+def hub44(oracle):
+    """BASELINE.json configs[0]: 4x4 Hubbard, U/t = 4, half filling, periodic"""
+    return oracle.HubbardSystem(4, 4, True, 8, 8, 1.0, 4.0)
+
+
+@pytest.fixture(scope="session")
+def hub_setup(oracle, hub44):
+    return oracle.setup_walk_hubbard(hub44, 500, 0.5, 20)
+
+
+def gpu_ctx_hub(hsys, **kw):
+    import sqmc_amd
+    return sqmc_amd.GpuChem.hubbard(hsys.l_x, hsys.l_y, hsys.pbc, hsys.nup, hsys.ndn, hsys.t, hsys.U, **kw)
+
+
 def gpu_ctx_heg(hsys, **kw):
     import sqmc_amd
     return sqmc_amd.GpuChem.heg(hsys.n_dim, hsys.norb, hsys.nup, hsys.ndn, hsys.length_cell, hsys.k_vectors(), **kw)

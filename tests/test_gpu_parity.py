@@ -496,6 +496,114 @@ def test_heg_host_setup_matches_oracle(oracle, heg14, heg_setup):
     assert 58.26 < e < 58.29          # the reference's HCI total energy for this system: 58.27597 (o_det_ref:436)
 
 
+def test_hubbard_matrix_elements_and_proposals_bit_exact(oracle, hub44):
+    """hamiltonian_hubbard / off_diagonal_move_hubbard (real-space Hubbard,
+    BASELINE.json configs[0] lattice) on the GPU against the oracle: values, determinants and the
+    rannyu state after the (rejection-sampled, variable-length) draw sequence."""
+    from conftest import gpu_ctx_hub
+    L = oracle.lib()
+    g = gpu_ctx_hub(hub44)
+    rng = np.random.default_rng(77)
+    n = 6000
+    up, dn = _random_dets(rng, 16, 8, n), _random_dets(rng, 16, 8, n)
+    # pairs: each determinant with itself, with one of its hops, with an unrelated determinant, with a non-bond single hop
+    ju, jd = up.copy(), dn.copy()
+    for i in range(n):
+        if i % 4 == 1:
+            cu, cd, _ = hub44.connected(int(up[i]), int(dn[i]), with_elems=False)
+            k = int(rng.integers(0, len(cu))); ju[i], jd[i] = cu[k], cd[k]
+        elif i % 4 == 2:
+            ju[i], jd[i] = _random_dets(rng, 16, 8, 1)[0], dn[i]
+        elif i % 4 == 3:
+            ju[i], jd[i] = _random_dets(rng, 16, 8, 1)[0], _random_dets(rng, 16, 8, 1)[0]
+    h_gpu = g.hamiltonian_batch(up, dn, ju, jd)
+    h_cpu = np.array([hub44.ham(int(a), int(b), int(c), int(d)) for a, b, c, d in zip(up, dn, ju, jd)])
+    assert np.array_equal(h_gpu, h_cpu) and np.count_nonzero(h_cpu) > n // 3
+    for i in range(1, n, 4):      # on lattice bonds the bond test changes nothing: the reference's own routine agrees
+        assert hub44.ham_unchecked(int(up[i]), int(dn[i]), int(ju[i]), int(jd[i])) == h_cpu[i]
+    seeds = rng.integers(0, 4096, size=(n, 4)).astype(np.int32); seeds[:, 3] |= 1
+    tau = 0.0052
+    pju, pjd, wj, sa = g.propose_batch(tau, up, dn, seeds)
+    g.close()
+    r = oracle.Rng(); a, b, w, nd = C.c_uint64(), C.c_uint64(), C.c_double(), C.c_int()
+    nz, long_draws = 0, 0
+    for i in range(n):
+        L.orc_setrn(C.byref(r), (C.c_int * 4)(*seeds[i]))
+        L.orc_off_diagonal_move_hubbard(hub44.h, C.byref(r), tau, int(up[i]), int(dn[i]), C.byref(a), C.byref(b), C.byref(w), C.byref(nd))
+        assert w.value == wj[i], (i, w.value, wj[i])
+        assert [r.l[k] for k in range(4)] == list(sa[i])
+        long_draws += nd.value > 3
+        if w.value != 0.0:
+            nz += 1
+            assert (a.value, b.value) == (int(pju[i]), int(pjd[i]))
+    assert nz > n // 2 and long_draws > n // 10       # the rejection loop of choose_random_electron was exercised
+
+
+@pytest.mark.parametrize("rng_mode,semi,nsteps", [(0, 1, 60), (1, 1, 120), (0, 0, 50)])
+def test_hubbard_walk_trajectory_bit_exact(oracle, hub44, hub_setup, rng_mode, semi, nsteps):
+    """BASELINE.json configs[0] (4x4 Hubbard, U/t = 4, half filling): the step pipeline with
+    off_diagonal_move_hubbard / hamiltonian_hubbard as the operator pair, semistochastic and plain
+    (join_walker2) variants, against the oracle walker for walker."""
+    from conftest import gpu_ctx_hub
+    s = hub_setup
+    g = gpu_ctx_hub(hub44, rng_mode=rng_mode, seed=SEED, mwalk=400000)
+    if semi:
+        g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
+    g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
+    wk = oracle.initial_walkers(s, 50)
+    if not semi:                                   # a purely stochastic population
+        wk["imp_distance"] = np.where(wk["imp_distance"] == 0, 1, wk["imp_distance"]).astype(np.int8)
+        keep = ~((wk["wt"] == 0) & (wk["initiator"] < 3))
+        wk = {k: v[keep] for k, v in wk.items()}
+    g.upload_walkers(wk)
+    ow = oracle.OracleWalk(hub44, s, wk, 400000, SEED, rng_mode=rng_mode)
+    pc = oracle.PopControl(s.tau, s.e_trial0, 4000)
+    w_abs = float(np.abs(wk["wt"]).sum())
+    for it in range(nsteps):
+        r = pc.pre_step(w_abs)
+        if r != 1.0 and semi:
+            ow.scale_projector(r); g.scale_projector(r)
+        st, oc = ow.step(pc.params(semistochastic=semi))
+        og = g.step(pc.params(semistochastic=semi))
+        assert st == 0 and og[5] == oc[5] and og[7] == oc[7] and og[15] == oc[15], (it, og, oc)
+        assert np.allclose(og, oc, rtol=1e-11, atol=1e-11)
+        r = pc.post_step(oc)
+        if r != 1.0 and semi:
+            ow.scale_projector(r); g.scale_projector(r)
+        w_abs = oc[1]
+    wg, wc = g.download_walkers(), ow.walkers()
+    if rng_mode == 0:
+        assert g.rng_state() == ow.rng_state()
+    g.close(); ow.close()
+    for k in ("up", "dn", "imp_distance", "initiator"):
+        assert np.array_equal(wg[k], wc[k]), k
+    assert np.array_equal(wg["wt"], wc["wt"])
+    assert len(wg["up"]) > 300
+
+
+def test_hubbard_host_setup_matches_oracle_and_walk_runs(oracle, hub44, hub_setup):
+    """sqmc_amd.host.HubbardHost: same lattice, same connected lists, equivalent walk set-up; a
+    short walk at 1e4 target (configs[0]'s population) lands below the variational energy of the
+    small set-up space and above the exact ground state (-13.6219 t for 4x4, U/t = 4)."""
+    from sqmc_amd import host as H
+    hh = H.HubbardHost(4, 4, True, 8, 8, 1.0, 4.0)
+    assert (hh.hf_up, hh.hf_dn) == (hub44.hf_up, hub44.hf_dn)
+    for site in range(1, 17):
+        assert hh.nbr[site - 1] == [max(oracle.lib().orc_get_nbr(4, 4, 1, site, k), 0) for k in (1, 2, 3, 4)]
+    cu, cd, _ = hub44.connected(hub44.hf_up, hub44.hf_dn, with_elems=False)
+    pu, pd = hh.connected(hh.hf_up, hh.hf_dn)
+    assert sorted(zip(cu.tolist(), cd.tolist())) == list(zip(pu.tolist(), pd.tolist()))
+    w = H.GpuWalk(hh, 10000, w_begin=200, size_deterministic=500, n_truncate_trial_wf=20, tau_multiplier=0.5)
+    s = w.setup
+    assert abs(s.e_var - hub_setup.e_var) < 1e-9 and s.tau == hub_setup.tau and len(s.ct_up) == len(hub_setup.ct_up)
+    assert np.array_equal(s.imp_up, hub_setup.imp_up) and np.allclose(s.ct_num, hub_setup.ct_num, atol=1e-9)
+    stats, tot = w.run(1500)
+    e = (stats[700:, 3] * np.sign(stats[700:, 2])).sum() / np.abs(stats[700:, 2]).sum()
+    w.close()
+    print("4x4 Hubbard projected energy", e, "population", stats[-1, 1], "dets", stats[-1, 5])
+    assert -14.5 < e < s.e_var
+
+
 def test_hci_pt2_matches_oracle_and_reference_run(oracle, c2_hci):
     """Epstein-Nesbet PT2 on the GPU path: against the oracle on a ~4k-determinant space, and
     against the reference's own run at eps1=1e-4 / eps2=1e-6 (dE_PT = -0.000979165,

@@ -25,6 +25,10 @@ def _worker(rank, world, port, outdir, system="c2"):
     if system == "heg":       # 14 electrons, 19 plane waves: the reference's e2e HEG system (BASELINE.json configs[3] is its big brother)
         hst = H.HegHost(3, 0.5, 14, 7, 1.49)
         w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000, n_truncate_trial_wf=1, size_deterministic=250)
+    elif system == "hub":     # BASELINE.json configs[0]: 4x4 Hubbard, U/t = 4, half filling
+        hst = H.HubbardHost(4, 4, True, 8, 8, 1.0, 4.0)
+        w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000, n_truncate_trial_wf=20, size_deterministic=500,
+                          tau_multiplier=0.5)
     else:
         hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
         w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
@@ -176,4 +180,26 @@ def test_sharded_heg_walk_invariants(tmp_path):
     assert np.isclose(sum(float(np.abs(r["wt"]).sum()) for r in res), out[1], rtol=1e-12)
     e = res[0]["outs"][10:, 3].sum() / res[0]["outs"][10:, 2].sum()
     assert 58.0 < e < 58.7                  # HF energy 58.592675 (heg.f90 e2e reference), correlation lowers it
+    assert out[1] > 1.5 * W_BEGIN
+
+
+def test_sharded_hubbard_walk_invariants(tmp_path):
+    """BASELINE.json configs[0] lattice (4x4 Hubbard, U/t = 4, half filling) sharded over two ranks:
+    off_diagonal_move_hubbard / hamiltonian_hubbard under the same ownership and exchange rules."""
+    res = _run(2, tmp_path, 29591, system="hub")
+    for r in res[1:]:
+        assert np.array_equal(r["outs"][:, :7], res[0]["outs"][:, :7])
+    keys, n_imp = [], 0
+    for rank, r in enumerate(res):
+        assert np.all(r["owner"] == rank)
+        k = [(int(a), int(b)) for a, b in zip(r["up"], r["dn"])]
+        assert k == sorted(set(k))
+        keys += k
+        n_imp += int((r["imp_distance"] == 0).sum())
+    assert len(keys) == len(set(keys)) and n_imp == int(res[0]["n_imp_global"])
+    out = res[0]["outs"][-1]
+    assert int(out[5]) == len(keys)
+    assert np.isclose(sum(float(np.abs(r["wt"]).sum()) for r in res), out[1], rtol=1e-12)
+    e = res[0]["outs"][10:, 3].sum() / res[0]["outs"][10:, 2].sum()
+    assert -14.5 < e < -8.0                 # between the exact ground state (-13.62) and the Neel determinant's neighbourhood
     assert out[1] > 1.5 * W_BEGIN
