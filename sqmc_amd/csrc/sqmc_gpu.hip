@@ -361,6 +361,7 @@ __global__ void __launch_bounds__(TPB) k_scale(double *__restrict__ v, long long
   if (i < n) v[i] = v[i] * r;
 }
 
+#define MERGE_SHORT 4
 // integer ** integer of the reference (0**0 = 1)
 __device__ __forceinline__ double ipow_d(int b, int e) { double r = 1.0; for (int i = 0; i < e; i++) r *= (double)b; return r; }
 
@@ -391,34 +392,95 @@ __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *
     __syncthreads();
     if (threadIdx.x == 0) { wabs_part[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3]; wabs_part[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3]; }
   }
-  if (!head) return;
-  u32 t = get_perm(skey, perm, j, pack);
-  const bool t_spawn = (long long)t >= n0;
-  // the head of a run is the resident walker if there is one (stable sort), else the first spawn
-  SpawnRec h;
-  if (t_spawn) h = w.sp[t - n0]; else { h.up = w.up[t]; h.dn = w.dn[t]; h.wt = w.wt[t]; h.flg = w.flg[t]; }
-  double wt = h.wt, me = t_spawn ? 1e51 : w.me[t], en = t_spawn ? 1e51 : w.en[t], ed = t_spawn ? 1e51 : w.ed[t];
-  const u32 ft = (u32)h.flg;
-  int ini = flg_init(ft), d = flg_impd(ft), ps = flg_psign(ft);
-  if (d == -1 && j > 0) d = 1;                 // 5985-5986 (the very first walker keeps -1 until the end)
+  // Heads combine their run left to right.  The first MERGE_SHORT followers are read by the
+  // head's own lane (most runs end there); what is left of a long run (a heavy determinant whose
+  // children land on a few neighbours: hundreds of equal keys) is fetched by the whole wavefront,
+  // 64 records per round trip, parked in LDS and folded in by the head in storage order -- the
+  // same sequence of operations, without one dependent HBM access per record.
+  __shared__ double s_w2[TPB / 64][64];
+  __shared__ u32 s_f2[TPB / 64][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  SpawnRec h; h.up = 0; h.dn = 0; h.wt = 0.0; h.flg = 0;
+  double wt = 0.0, me = 1e51, en = 1e51, ed = 1e51;
+  int ini = 0, d = 0, ps = 0;
   long long jj = j + 1;
-  for (; jj < n && get_key(skey, jj, pack) == key; jj++) {
-    const u32 s = get_perm(skey, perm, jj, pack);
-    const SpawnRec r2 = w.sp[s - n0];                     // every later walker of a run is a spawn (walkers are unique)
-    const double w2 = r2.wt; const u32 fs = (u32)r2.flg; const int i2 = flg_init(fs), d2 = flg_impd(fs);
-    const bool same_sign = (w2 * wt > 0);
+  bool pending = false;
+#define MERGE_FOLD(W2, FS) do {                                                                     \
+    const double w2_ = (W2); const u32 fs_ = (FS); const int i2 = flg_init(fs_), d2 = flg_impd(fs_); \
+    const bool same_sign = (w2_ * wt > 0);                                                          \
+    if (same_sign) { if (i2 > ini) ini = i2; }                                                      \
+    if (d == -2) { if (d2 == 0) d = 0; }                                                            \
+    else if (d2 == -2) { if (d != 0) d = -2; }                                                      \
+    else if (d != 0 && d != -2) { int a_ = d2 < 0 ? -d2 : d2; if (a_ < d) d = a_; }                 \
+    if (!same_sign) {                                                                               \
+      if (fabs(wt) < fabs(w2_)) { if (ini != 3 || p.r_init == -1.0) ini = i2; }                     \
+      else if (fabs(wt) == fabs(w2_)) { if (ini != 3 || p.r_init == -1.0) ini = 0; }                \
+    }                                                                                               \
+    if (!(d == 0 && d2 == -1)) wt = wt + w2_;                                                       \
+  } while (0)
+  if (head) {
+    const u32 t = get_perm(skey, perm, j, pack);
+    const bool t_spawn = (long long)t >= n0;
+    // the head of a run is the resident walker if there is one (stable sort), else the first spawn
+    if (t_spawn) h = w.sp[t - n0]; else { h.up = w.up[t]; h.dn = w.dn[t]; h.wt = w.wt[t]; h.flg = w.flg[t]; }
+    wt = h.wt;
+    if (!t_spawn) { me = w.me[t]; en = w.en[t]; ed = w.ed[t]; }
+    const u32 ft = (u32)h.flg;
+    ini = flg_init(ft); d = flg_impd(ft); ps = flg_psign(ft);
+    if (d == -1 && j > 0) d = 1;                 // 5985-5986 (the very first walker keeps -1 until the end)
     // every later walker of a run is a spawn (walkers are unique): its cached values are the
     // 1e51 sentinel, so the reference's min() merges leave me / en / ed unchanged
-    if (same_sign) { if (i2 > ini) ini = i2; }
-    if (d == -2) { if (d2 == 0) d = 0; }
-    else if (d2 == -2) { if (d != 0) d = -2; }
-    else if (d != 0 && d != -2) { int a = d2 < 0 ? -d2 : d2; if (a < d) d = a; }
-    if (!same_sign) {
-      if (fabs(wt) < fabs(w2)) { if (ini != 3 || p.r_init == -1.0) ini = i2; }
-      else if (fabs(wt) == fabs(w2)) { if (ini != 3 || p.r_init == -1.0) ini = 0; }
+    int k = 0;
+    for (; k < MERGE_SHORT && jj < n && get_key(skey, jj, pack) == key; jj++, k++) {
+      const u32 s = get_perm(skey, perm, jj, pack);
+      const SpawnRec r2 = w.sp[s - n0];
+      MERGE_FOLD(r2.wt, (u32)r2.flg);
     }
-    if (!(d == 0 && d2 == -1)) wt = wt + w2;
+    pending = (k == MERGE_SHORT) && jj < n && get_key(skey, jj, pack) == key;
   }
+  for (u64 pend = __ballot(pending); pend; pend &= pend - 1) {
+    const int leader = __ffsll((long long)pend) - 1;
+    long long base = __shfl(jj, leader, 64);
+    const u64 lkey = __shfl(key, leader, 64);
+    for (;;) {
+      const long long idx = base + lane;
+      const bool valid = idx < n && get_key(skey, idx, pack) == lkey;
+      double w2 = 0.0; u32 f2 = 0;
+      if (valid) { const u32 s = get_perm(skey, perm, idx, pack); const SpawnRec r2 = w.sp[s - n0]; w2 = r2.wt; f2 = (u32)r2.flg; }
+      const u64 vb = __ballot(valid);                     // equal keys are contiguous: the valid lanes are a prefix
+      const int cnt = (vb == ~0ull) ? 64 : __ffsll((long long)~vb) - 1;
+      // A chunk whose weights all carry the sign of the running sum (the usual case: children of one
+      // parent) needs no sign logic: the initiator flag is a maximum, imp_distance a minimum, and only
+      // the additions stay in order (skipped terms become -0.0, which leaves a non-zero sum unchanged).
+      const double wt_l = __shfl(wt, leader, 64); const int d_l = __shfl(d, leader, 64);
+      const int i2 = flg_init(f2), d2 = flg_impd(f2);
+      const bool plain = !valid || (((w2 > 0) == (wt_l > 0)) && fabs(w2) > 1e-150 && d2 != 0 && d2 != -2);
+      if (fabs(wt_l) > 1e-150 && __ballot(plain) == ~0ull) {
+        int im = valid ? i2 : 0, dm = valid ? (d2 < 0 ? -d2 : d2) : 1 << 20;
+        for (int o = 32; o > 0; o >>= 1) { const int a = __shfl_xor(im, o, 64), b = __shfl_xor(dm, o, 64); im = a > im ? a : im; dm = b < dm ? b : dm; }
+        s_w2[wv][lane] = (valid && !(d_l == 0 && d2 == -1)) ? w2 : -0.0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == leader) {
+          if (im > ini) ini = im;
+          if (d >= 1 && dm < d) d = dm;
+          if (cnt == 64) {
+#pragma unroll
+            for (int l = 0; l < 64; l++) wt = wt + s_w2[wv][l];
+          } else for (int l = 0; l < cnt; l++) wt = wt + s_w2[wv][l];
+          jj += cnt;
+        }
+      } else {
+        s_w2[wv][lane] = w2; s_f2[wv][lane] = f2;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == leader) { for (int l = 0; l < cnt; l++) MERGE_FOLD(s_w2[wv][l], s_f2[wv][l]); jj += cnt; }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (cnt < 64) break;
+      base += 64;
+    }
+  }
+#undef MERGE_FOLD
+  if (!head) return;
   // check_initiator
   {
     const int dd = d - p.imind > 0 ? d - p.imind : 0;
