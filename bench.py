@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--system", default="c2", choices=["c2", "heg", "hubbard"], help="c2 = BASELINE.json configs[1] (the metric's config, default); "
                     "heg = the 14-electron 3D electron gas of configs[3]; hubbard = real-space Hubbard U/t=4 at half filling "
                     "(configs[0] lattice by default) -- both auxiliary, no CPU baseline leg")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak (default, the driver's contract): --target is the population per GPU; "
+                    "strong: --target is the global population, split over the ranks by determinant ownership")
     ap.add_argument("--hubbard-lattice", default="4x4", help="l_x x l_y (periodic), e.g. 4x4 (configs[0]) or 6x4")
     ap.add_argument("--heg-rs", type=float, default=1.0)
     ap.add_argument("--heg-cutoff", type=float, default=2.3, help="plane-wave cutoff radius (2.3 -> 57 orbitals; the GPU path holds at most 64)")
@@ -78,6 +80,8 @@ def main():
         hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
         workload = "C2 cc-pVDZ r=1.24253 (8e,26o, D2h) semistochastic walk, uniform2 proposal"
 
+    g_target = args.target * world if args.scaling == "weak" else args.target      # global population of the sharded walk
+
     def fence():
         torch.cuda.synchronize()
         if multi:
@@ -90,10 +94,10 @@ def main():
         # weak scaling: the global target grows with the number of GPUs, determinants are sharded by
         # hash ownership and spawns cross ranks through one RCCL all-to-all per step
         try:
-            skw = dict(w_begin=min(args.target * world, 1e4), n_truncate_trial_wf=1, size_deterministic=500) if args.system == "heg" else {}
+            skw = dict(w_begin=min(g_target, 1e4), n_truncate_trial_wf=1, size_deterministic=500) if args.system == "heg" else {}
             if args.system == "hubbard":
-                skw = dict(w_begin=min(args.target * world, 1e4), n_truncate_trial_wf=20, size_deterministic=500, tau_multiplier=0.5)
-            walk = H.ShardedWalk(hst, args.target * world, rank, world, device_index=local, seed=(1346, 5634, 6635, 4361), **skw)
+                skw = dict(w_begin=min(g_target, 1e4), n_truncate_trial_wf=20, size_deterministic=500, tau_multiplier=0.5)
+            walk = H.ShardedWalk(hst, g_target, rank, world, device_index=local, seed=(1346, 5634, 6635, 4361), **skw)
             ok = torch.ones(1, device=comm_dev)
         except Exception as exc:                      # keep the scaling run alive: independent replicas
             sys.stderr.write("rank %d: sharded set-up failed (%r); falling back to replicas\n" % (rank, exc))
@@ -118,7 +122,7 @@ def main():
                     parallelism = "sharded x%d (hash-owned determinants), in-library RCCL: all-reduce + all-to-all of spawns + all-reduce per step" % world
                 else:                                     # same walk, exchanges from Python
                     walk.close()
-                    walk = H.ShardedWalk(hst, args.target * world, rank, world, device_index=local, seed=(1346, 5634, 6635, 4361), **skw)
+                    walk = H.ShardedWalk(hst, g_target, rank, world, device_index=local, seed=(1346, 5634, 6635, 4361), **skw)
     if walk is None:
         kw = dict(w_begin=min(args.target, 1e4), n_truncate_trial_wf=1, size_deterministic=500) if args.system == "heg" else {}
         if args.system == "hubbard":
@@ -181,10 +185,10 @@ def main():
         step_bytes = 68.0 * n_avg + 84.0 * s_avg
         line = {
             "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if sharded else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload + ", w_abs_gen_target=%g, %s, min_wt 0.5, r_initiator 1" % (
-                                   args.target * (world if sharded else 1),
+                                   g_target if sharded else args.target,
                                    {"c2": "size_deterministic=1000, Psi_T 100 dets, tau_multiplier 0.1", "heg": "size_deterministic=500, Psi_T 1 det, tau_multiplier 0.1",
                                     "hubbard": "size_deterministic=500, Psi_T 20 dets, tau_multiplier 0.5"}[args.system]),
                        "occupied_dets_per_step": n_avg, "spawns_per_step": s_avg, "spawns_per_s": spawn_all / dt,

@@ -54,6 +54,32 @@ __device__ __forceinline__ u64 block_excl_scan_u64(u64 v, u64 *total) {
 #define SCAN_ST_AGG (1ull << 62)
 #define SCAN_ST_INC (2ull << 62)
 #define SCAN_VAL_MASK ((1ull << 62) - 1ull)
+// Called by the 64 lanes of ONE wavefront of the block that owns `tile`: publishes the tile's
+// aggregate, sums the aggregates of all earlier tiles (64 predecessors per poll, stopping at the
+// first one that already carries an inclusive value), publishes the tile's inclusive value and
+// returns the exclusive prefix in every lane.
+__device__ __forceinline__ u64 lookback_exclusive(u64 *__restrict__ state, u32 tile, u64 tot, int lane) {
+  u64 excl = 0;
+  if (tile == 0) { if (lane == 0) atomicExch((unsigned long long *)&state[0], SCAN_ST_INC | tot); return 0; }
+  if (lane == 0) atomicExch((unsigned long long *)&state[tile], SCAN_ST_AGG | tot);
+  long long p = (long long)tile - 1;
+  while (true) {
+    const long long idx = p - lane;
+    const u64 w = (idx >= 0) ? atomicAdd((unsigned long long *)&state[idx], 0ull) : SCAN_ST_INC;
+    const u64 st = w >> 62;
+    const u64 inc_mask = __ballot(st == 2), zero_mask = __ballot(st == 0);
+    const int first_inc = inc_mask ? __builtin_ctzll(inc_mask) : 64;
+    const u64 need = (first_inc >= 63) ? ~0ull : ((2ull << first_inc) - 1ull);
+    if (zero_mask & need) continue;           // some needed predecessor has not published yet
+    u64 val = (lane <= first_inc) ? (w & SCAN_VAL_MASK) : 0;
+    for (int o = 32; o > 0; o >>= 1) val += __shfl_down(val, o, 64);
+    excl += __shfl(val, 0, 64);
+    if (first_inc < 64) break;
+    p -= 64;
+  }
+  if (lane == 0) atomicExch((unsigned long long *)&state[tile], SCAN_ST_INC | (excl + tot));
+  return excl;
+}
 template <int SCAN_ITEMS>
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_lookback_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, long long n,
                                                                    u64 *__restrict__ state, u32 *__restrict__ ticket, u64 *__restrict__ total_out) {
@@ -83,29 +109,8 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_lookback_kernel(const u64 *__
 #pragma unroll
   for (int q = 0; q < SCAN_BLOCK / 64; q++) { if (q < wv) ex += s_wsum[q]; tot += s_wsum[q]; }
   if (threadIdx.x < 64) {                       // wave 0 publishes and looks back, 64 predecessors per poll
-    const int lane = threadIdx.x;
-    u64 excl = 0;
-    if (tile == 0) { if (lane == 0) atomicExch((unsigned long long *)&state[0], SCAN_ST_INC | tot); }
-    else {
-      if (lane == 0) atomicExch((unsigned long long *)&state[tile], SCAN_ST_AGG | tot);
-      long long p = (long long)tile - 1;
-      while (true) {
-        const long long idx = p - lane;
-        const u64 w = (idx >= 0) ? atomicAdd((unsigned long long *)&state[idx], 0ull) : SCAN_ST_INC;
-        const u64 st = w >> 62;
-        const u64 inc_mask = __ballot(st == 2), zero_mask = __ballot(st == 0);
-        const int first_inc = inc_mask ? __builtin_ctzll(inc_mask) : 64;
-        const u64 need = (first_inc >= 63) ? ~0ull : ((2ull << first_inc) - 1ull);
-        if (zero_mask & need) continue;           // some needed predecessor has not published yet
-        u64 val = (lane <= first_inc) ? (w & SCAN_VAL_MASK) : 0;
-        for (int o = 32; o > 0; o >>= 1) val += __shfl_down(val, o, 64);
-        excl += __shfl(val, 0, 64);
-        if (first_inc < 64) break;
-        p -= 64;
-      }
-      if (lane == 0) atomicExch((unsigned long long *)&state[tile], SCAN_ST_INC | (excl + tot));
-    }
-    if (lane == 0) {
+    const u64 excl = lookback_exclusive(state, tile, tot, threadIdx.x);
+    if (threadIdx.x == 0) {
       s_excl = excl;
       if (total_out && (long long)(tile + 1) * TILE_ELEMS >= n) *total_out = excl + tot;
     }

@@ -114,6 +114,7 @@ struct sqmc_gpu_ctx {
   u64 *d_nchild; u64 *d_child_off; double *d_wchild; u64 *d_child_state;
   u64 *d_keys, *d_keys_alt; u32 *d_vals, *d_vals_alt; u32 *d_hist, *d_rowtot;
   u64 *d_flags, *d_pos, *d_flags2, *d_pos2; u64 *d_scan_state; u32 *d_scan_ticket; long long cap_tiles;   // 3 look-back scans per step
+  u64 *d_fstate; u32 *d_fticket; long long cap_ftiles;          // k_anneal: two look-backs over 256-slot tiles
   // projector (full CSR, rows in the reference's accumulation order)
   long long n_imp, prj_nnz; int *d_prj_ptr, *d_prj_col; double *d_prj_val; int *d_loc_imp, *d_loc_imp_new; double *d_prj_x;
   // C(T)
@@ -361,7 +362,6 @@ __global__ void __launch_bounds__(TPB) k_scale(double *__restrict__ v, long long
   if (i < n) v[i] = v[i] * r;
 }
 
-#define MERGE_SHORT 4
 // integer ** integer of the reference (0**0 = 1)
 __device__ __forceinline__ double ipow_d(int b, int e) { double r = 1.0; for (int i = 0; i < e; i++) r *= (double)b; return r; }
 
@@ -369,42 +369,67 @@ __device__ __forceinline__ double ipow_d(int b, int e) { double r = 1.0; for (in
 // order.  Within a run the original walker comes first and spawns keep creation order
 // (stable sort), so the pairwise combination below is the reference's left-to-right scan.
 // do_walk.f90:5866-6083, check_initiator 6838-6872.
-__global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *__restrict__ skey, const u32 *__restrict__ perm,
-                                               u64 *__restrict__ flags, double *__restrict__ wabs_part, long long n0, long long n_all, StepP p, u64 invalid_key,
-                                               int pack) {
-  long long j = (long long)blockIdx.x * TPB + threadIdx.x;
+struct MergedRec { u64 up, dn; double wt, me, en, ed; u32 flg; int d; u64 f; };   // f: bit 0 = kept after the merge, bit 32 = small weight, to be rounded
+// block sum of the two pre-merge partials into row `tile` (all 256 threads)
+__device__ __forceinline__ void store_wabs(double *__restrict__ wabs_part, long long tile, double wabs, double cnt) {
+  __shared__ double red[2][TPB / 64];
+  double v = wabs, q = cnt;
+  for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); q += __shfl_down(q, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = v; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) { wabs_part[2 * tile] = red[0][0] + red[0][1] + red[0][2] + red[0][3]; wabs_part[2 * tile + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3]; }
+}
+// The merged walker of sorted slot j (f = 0 for slots that are not the head of a run or are
+// discarded).  The 64 lanes of a wavefront call it together on 64 CONSECUTIVE slots (lane l: slot
+// j0 + l).  Every lane fetches the record of its own slot -- one gather for the whole row, no
+// dependent chain per follower -- and parks weight and flags in LDS; the head of a run then folds
+// its followers in storage order out of LDS (the reference's left-to-right scan).  Only a run
+// that leaves the row needs more loads: the wavefront fetches it 64 records per round trip.
+// load_slot also adds the slot's share of the sums over the pre-merge list
+// (my_w_abs_before_merge_cum, nwalk_before_merge; do_walk.f90:2347-2349) to wabs / cnt.
+struct SlotIn { u64 key; SpawnRec h; double me, en, ed; bool head, real; };
+// all global loads of one slot (independent of every other slot: a thread issues those of its ITEMS slots together)
+__device__ __forceinline__ SlotIn load_slot(const WalkArr &w, const u64 *__restrict__ skey, const u32 *__restrict__ perm,
+                                            long long j, long long n0, long long n_all, u64 invalid_key, int pack, double &wabs, double &cnt) {
+  SlotIn in; in.key = invalid_key; in.h.up = 0; in.h.dn = 0; in.h.wt = 0.0; in.h.flg = 0; in.me = 1e51; in.en = 1e51; in.ed = 1e51;
+  const int lane = threadIdx.x & 63;
+  const bool valid = j < n_all;
+  u32 t = 0;
+  if (valid) { in.key = get_key(skey, j, pack); t = get_perm(skey, perm, j, pack); }
+  u64 kprev = __shfl_up(in.key, 1, 64);                  // key of the slot before: the neighbouring lane has it
+  if (lane == 0) kprev = (valid && j > 0) ? get_key(skey, j - 1, pack) : invalid_key;
+  in.real = valid && in.key != invalid_key;              // children that produced no walker sort last
+  in.head = in.real && !(j > 0 && kprev == in.key);
+  // the head of a run is the resident walker if there is one (stable sort), else the first spawn;
+  // every later walker of a run is a spawn (walkers are unique): its cached values are the 1e51
+  // sentinel, so the reference's min() merges leave me / en / ed unchanged
+  if (in.real) {
+    if ((long long)t >= n0) in.h = w.sp[t - n0];
+    else { in.h.up = w.up[t]; in.h.dn = w.dn[t]; in.h.wt = w.wt[t]; in.h.flg = w.flg[t]; in.me = w.me[t]; in.en = w.en[t]; in.ed = w.ed[t]; }
+    wabs += fabs(in.h.wt); cnt += 1.0;
+  }
+  return in;
+}
+#define SLOT_STOP 0x80000000u     // in the staged flag word: this slot starts a run or holds no walker
+// stage weight and flags of a slot at its place in the tile (LDS); the block synchronises before folding
+__device__ __forceinline__ void stage_slot(const SlotIn &in, double *__restrict__ s_w, u32 *__restrict__ s_f, int idx) {
+  s_w[idx] = in.h.wt; s_f[idx] = (u32)in.h.flg | ((in.head || !in.real) ? SLOT_STOP : 0u);
+}
+// fold the run that starts at in-tile slot idx (if `in` is a head) out of the staged tile; a run that
+// leaves the tile is continued from HBM by the head's wavefront, 64 records per round trip
+__device__ __forceinline__ MergedRec fold_slot(const SlotIn &in, const double *__restrict__ s_w, const u32 *__restrict__ s_f, int idx, int tile_slots,
+                                               const WalkArr &w, const u64 *__restrict__ skey, const u32 *__restrict__ perm,
+                                               long long j, long long n0, long long n_all, const StepP &p, u64 invalid_key, int pack) {
   const long long n = n_all;
-  // sum |w| and the number of real entries of the pre-merge list (my_w_abs_before_merge_cum,
-  // nwalk_before_merge; do_walk.f90:2347-2349): any order will do, so slot j itself is read
-  double wabs_j = 0.0, cnt_j = 0.0;
-  bool head = false; u64 key = 0;
-  if (j < n_all) {
-    key = get_key(skey, j, pack);
-    wabs_j = fabs(j < n0 ? w.wt[j] : w.sp[j - n0].wt);
-    if (key == invalid_key) flags[j] = 0;               // children that produced no walker sort last
-    else { cnt_j = 1.0; if (j > 0 && get_key(skey, j - 1, pack) == key) flags[j] = 0; else head = true; }
-  }
-  {
-    __shared__ double red[2][TPB / 64];
-    double v = wabs_j, q = cnt_j;
-    for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); q += __shfl_down(q, o, 64); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = v; red[1][threadIdx.x >> 6] = q; }
-    __syncthreads();
-    if (threadIdx.x == 0) { wabs_part[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3]; wabs_part[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3]; }
-  }
-  // Heads combine their run left to right.  The first MERGE_SHORT followers are read by the
-  // head's own lane (most runs end there); what is left of a long run (a heavy determinant whose
-  // children land on a few neighbours: hundreds of equal keys) is fetched by the whole wavefront,
-  // 64 records per round trip, parked in LDS and folded in by the head in storage order -- the
-  // same sequence of operations, without one dependent HBM access per record.
+  MergedRec out; out.up = 0; out.dn = 0; out.wt = 0.0; out.me = 1e51; out.en = 1e51; out.ed = 1e51; out.flg = 0; out.d = 0; out.f = 0;
   __shared__ double s_w2[TPB / 64][64];
   __shared__ u32 s_f2[TPB / 64][64];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  SpawnRec h; h.up = 0; h.dn = 0; h.wt = 0.0; h.flg = 0;
-  double wt = 0.0, me = 1e51, en = 1e51, ed = 1e51;
+  const u64 key = in.key; const bool head = in.head;
+  const SpawnRec h = in.h; const double me = in.me, en = in.en, ed = in.ed;
+  double wt = h.wt;
   int ini = 0, d = 0, ps = 0;
   long long jj = j + 1;
-  bool pending = false;
 #define MERGE_FOLD(W2, FS) do {                                                                     \
     const double w2_ = (W2); const u32 fs_ = (FS); const int i2 = flg_init(fs_), d2 = flg_impd(fs_); \
     const bool same_sign = (w2_ * wt > 0);                                                          \
@@ -418,26 +443,19 @@ __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *
     }                                                                                               \
     if (!(d == 0 && d2 == -1)) wt = wt + w2_;                                                       \
   } while (0)
+  bool reached_end = false;
   if (head) {
-    const u32 t = get_perm(skey, perm, j, pack);
-    const bool t_spawn = (long long)t >= n0;
-    // the head of a run is the resident walker if there is one (stable sort), else the first spawn
-    if (t_spawn) h = w.sp[t - n0]; else { h.up = w.up[t]; h.dn = w.dn[t]; h.wt = w.wt[t]; h.flg = w.flg[t]; }
-    wt = h.wt;
-    if (!t_spawn) { me = w.me[t]; en = w.en[t]; ed = w.ed[t]; }
     const u32 ft = (u32)h.flg;
     ini = flg_init(ft); d = flg_impd(ft); ps = flg_psign(ft);
     if (d == -1 && j > 0) d = 1;                 // 5985-5986 (the very first walker keeps -1 until the end)
-    // every later walker of a run is a spawn (walkers are unique): its cached values are the
-    // 1e51 sentinel, so the reference's min() merges leave me / en / ed unchanged
-    int k = 0;
-    for (; k < MERGE_SHORT && jj < n && get_key(skey, jj, pack) == key; jj++, k++) {
-      const u32 s = get_perm(skey, perm, jj, pack);
-      const SpawnRec r2 = w.sp[s - n0];
-      MERGE_FOLD(r2.wt, (u32)r2.flg);
-    }
-    pending = (k == MERGE_SHORT) && jj < n && get_key(skey, jj, pack) == key;
+    int l = idx + 1;
+    for (; l < tile_slots; l++) { const u32 fl = s_f[l]; if (fl & SLOT_STOP) break; MERGE_FOLD(s_w[l], fl); }
+    jj = j + (l - idx);
+    reached_end = (l == tile_slots);
   }
+  // the last run of the tile may go on in the next tile
+  const long long jn = (j - idx) + tile_slots;
+  const bool pending = head && reached_end && jn < n && get_key(skey, jn, pack) == key;
   for (u64 pend = __ballot(pending); pend; pend &= pend - 1) {
     const int leader = __ffsll((long long)pend) - 1;
     long long base = __shfl(jj, leader, 64);
@@ -480,7 +498,7 @@ __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *
     }
   }
 #undef MERGE_FOLD
-  if (!head) return;
+  if (!head) return out;
   // check_initiator
   {
     const int dd = d - p.imind > 0 ? d - p.imind : 0;
@@ -492,11 +510,27 @@ __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *
   int dtest = d;
   if (d == -1) { if (jj >= n || get_key(skey, jj, pack) == invalid_key) dtest = 1; d = 1; }   // 6032-6036 then the last-det test at 6038
   const bool discard = (((wt == 0.0 && (ini != 3 || p.r_init < 0)) || ini == 0) && dtest >= 1);
-  m.up[j] = h.up; m.dn[j] = h.dn; m.wt[j] = wt; m.flg[j] = pack_flg(d, ini, ps);
-  m.me[j] = me; m.en[j] = en; m.ed[j] = ed;
-  u64 f = 0;
-  if (!discard) { f = 1ull; if (p.semi && d >= 1 && fabs(wt) < p.min_wt) f |= (1ull << 32); }
-  flags[j] = f;
+  out.up = h.up; out.dn = h.dn; out.wt = wt; out.flg = pack_flg(d, ini, ps); out.d = d;
+  out.me = me; out.en = en; out.ed = ed;
+  if (!discard) { out.f = 1ull; if (p.semi && d >= 1 && fabs(wt) < p.min_wt) out.f |= (1ull << 32); }
+  return out;
+}
+__global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *__restrict__ skey, const u32 *__restrict__ perm,
+                                               u64 *__restrict__ flags, double *__restrict__ wabs_part, long long n0, long long n_all, StepP p, u64 invalid_key,
+                                               int pack) {
+  const long long j = (long long)blockIdx.x * TPB + threadIdx.x;
+  double wabs = 0.0, cnt = 0.0;
+  __shared__ double s_w[TPB]; __shared__ u32 s_f[TPB];
+  const SlotIn in = load_slot(w, skey, perm, j, n0, n_all, invalid_key, pack, wabs, cnt);
+  stage_slot(in, s_w, s_f, threadIdx.x);
+  __syncthreads();
+  const MergedRec r = fold_slot(in, s_w, s_f, threadIdx.x, TPB, w, skey, perm, j, n0, n_all, p, invalid_key, pack);
+  store_wabs(wabs_part, blockIdx.x, wabs, cnt);
+  if (j >= n_all) return;
+  flags[j] = r.f;
+  if (!(r.f & 1ull)) return;                   // not the head of a run, or discarded: nothing to store
+  m.up[j] = r.up; m.dn[j] = r.dn; m.wt[j] = r.wt; m.flg[j] = r.flg;
+  m.me[j] = r.me; m.en[j] = r.en; m.ed[j] = r.ed;
 }
 
 // stochastic rounding of small weights (reduce_my_walker, do_walk.f90:7196-7254); RNG draws
@@ -653,6 +687,148 @@ __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64
     partials[(long long)blockIdx.x * NSTAT + threadIdx.x] = v;
   }
 }
+// The whole annihilation tail of a semistochastic step in ONE kernel: merge of the sorted list
+// (merge_slot), rank among the kept walkers by a decoupled look-back across tiles, stochastic
+// rounding (reduce_my_walker, do_walk.f90:7196-7254; draws exactly as k_round takes them), rank
+// among the survivors by a second look-back, then compaction into the OTHER walker buffer with the
+// reweighting, the C(T) lookup of first-visit determinants and the per-tile estimator sums
+// (k_compact).  The merged walkers never leave the registers: the intermediate arrays, the two
+// flag/position arrays and four launches of the unfused path (k_merge, scan, k_round, scan,
+// k_compact) are gone.  Tiles are handed out by an atomic ticket (forward progress without
+// co-residency assumptions, as in scan_lookback_kernel); both look-backs use the same tile order.
+#ifdef ANNEAL_PROF
+__device__ unsigned long long g_aprof[8 * 16384];
+#define APROF(K) do { if (threadIdx.x == 0 && tile < 16384) g_aprof[tile * 8 + (K)] = wall_clock64(); } while (0)
+extern "C" int sqmc_gpu_debug_aprof(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_aprof), sizeof(g_aprof)); }
+#else
+#define APROF(K)
+#endif
+template <int ITEMS>
+__global__ void __launch_bounds__(TPB) k_anneal(WalkArr w, WalkArr o, const u64 *__restrict__ skey, const u32 *__restrict__ perm, int *__restrict__ loc_imp,
+                                                const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 hmask,
+                                                const double *__restrict__ cnum, const double *__restrict__ cden,
+                                                double *__restrict__ partials, double *__restrict__ wabs_part, long long n0, long long n_all, StepP p,
+                                                u64 invalid_key, int pack, int mode, u64 seed, u64 step, DevScalars *sc,
+                                                u64 *__restrict__ state1, u64 *__restrict__ state2, u32 *__restrict__ ticket) {
+  constexpr int TILE = TPB * ITEMS;
+  __shared__ u32 s_tile; __shared__ u64 s_ex[2]; __shared__ u64 s_wsum[2][TPB / 64];
+  __shared__ double s_w[TILE]; __shared__ u32 s_f[TILE];          // weight and flags of every slot of the tile
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const u32 tile = s_tile;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // every wavefront owns 64*ITEMS consecutive slots and takes them row by row (lane l: slot r*64 + l)
+  const long long base = (long long)tile * TILE + (long long)wv * (64 * ITEMS) + lane;
+  const bool last_tile = (long long)(tile + 1) * TILE >= n_all;
+  APROF(0);
+  u64 key[ITEMS]; double wabs = 0.0, cnt = 0.0;
+  MergedRec r[ITEMS];
+  {
+    SlotIn in[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) { in[k] = load_slot(w, skey, perm, base + (long long)k * 64, n0, n_all, invalid_key, pack, wabs, cnt); key[k] = in[k].key; }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) stage_slot(in[k], s_w, s_f, wv * (64 * ITEMS) + k * 64 + lane);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) r[k] = fold_slot(in[k], s_w, s_f, wv * (64 * ITEMS) + k * 64 + lane, TILE, w, skey, perm, base + (long long)k * 64, n0, n_all, p, invalid_key, pack);
+  }
+  APROF(1);
+  store_wabs(wabs_part, tile, wabs, cnt);
+  APROF(2);
+  // ---- rank among the kept walkers (lo) and among the rounding draws (hi)
+  u64 inc[ITEMS], carry = 0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) { const u64 x = wave_incl_scan_u64(r[k].f, lane); inc[k] = x + carry; carry += __shfl(x, 63, 64); }
+  if (lane == 0) s_wsum[0][wv] = carry;
+  __syncthreads();
+  u64 ex = 0, tot = 0;
+#pragma unroll
+  for (int q = 0; q < TPB / 64; q++) { if (q < wv) ex += s_wsum[0][q]; tot += s_wsum[0][q]; }
+  if (threadIdx.x < 64) {
+    const u64 e = lookback_exclusive(state1, tile, tot, threadIdx.x);
+    if (threadIdx.x == 0) { s_ex[0] = e; if (last_tile) sc->tot1 = e + tot; }
+  }
+  __syncthreads();
+  ex += s_ex[0];
+  APROF(3);
+  u64 f2[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    f2[k] = 0;
+    if (r[k].f & 1ull) {
+      if (r[k].f >> 32) {
+        const u64 ex1 = ex + inc[k] - r[k].f;
+        double rr;
+        if (mode == 0) rr = (double)lcg_skip(sc->lcg, (ex1 >> 32) + 1) * 3.552713678800500929355621337890625e-15;
+        else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, ex1 & 0xFFFFFFFFull); rr = rng_draw(g); }
+        if (rr < (fabs(r[k].wt) / p.min_wt)) r[k].wt = copysign(p.min_wt, r[k].wt); else r[k].wt = 0.0;
+      }
+      // reduce_my_walker drops zero weights outside the deterministic space (7222-7249)
+      const bool drop = p.semi ? (r[k].wt == 0.0 && r[k].d >= 1) : (r[k].wt == 0.0);
+      if (!drop) { f2[k] = 1ull; if (r[k].d == 0) f2[k] |= (1ull << 32); }
+    }
+  }
+  // ---- final position (lo) and rank among the deterministic-space walkers (hi)
+  carry = 0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) { const u64 x = wave_incl_scan_u64(f2[k], lane); inc[k] = x + carry; carry += __shfl(x, 63, 64); }
+  if (lane == 0) s_wsum[1][wv] = carry;
+  __syncthreads();
+  ex = 0; tot = 0;
+#pragma unroll
+  for (int q = 0; q < TPB / 64; q++) { if (q < wv) ex += s_wsum[1][q]; tot += s_wsum[1][q]; }
+  if (threadIdx.x < 64) {
+    const u64 e = lookback_exclusive(state2, tile, tot, threadIdx.x);
+    if (threadIdx.x == 0) { s_ex[1] = e; if (last_tile) sc->tot2 = e + tot; }
+  }
+  __syncthreads();
+  ex += s_ex[1];
+  APROF(4);
+  // ---- compaction, reweighting (2487), estimator pieces (2573-2684, more_tools.f90:4041-4098)
+  double s[NSTAT];
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    if (!(f2[k] & 1ull)) continue;
+    const u64 ex2 = ex + inc[k] - f2[k];
+    const long long q0 = (long long)(ex2 & 0xFFFFFFFFull);
+    const double wt = r[k].wt * p.rfi;
+    const int d = r[k].d, ini = flg_init(r[k].flg), psg = flg_psign(r[k].flg);
+    double en = r[k].en, ed = r[k].ed;
+    if (en > 1e50) {
+      const long long q = ct_lookup(hkey, hidx, hmask, key[k]);
+      if (q < 0) { en = 0.0; ed = 0.0; } else { en = cnum[q]; ed = cden[q]; }
+    }
+    o.up[q0] = r[k].up; o.dn[q0] = r[k].dn; o.wt[q0] = wt; o.flg[q0] = r[k].flg;
+    o.me[q0] = r[k].me; o.en[q0] = en; o.ed[q0] = ed;
+    if (d == 0 && p.semi) loc_imp[ex2 >> 32] = (int)q0;
+    s[0] += wt; s[1] += fabs(wt); s[8] += wt * wt;
+    if (ini == 3) s[4] += wt * psg;
+    if (d == 0 || (d == -2 && p.cti)) s[6] += fabs(wt);
+    double e_num = en * wt, e_den = ed * wt;
+    if (e_num != 0.0) {
+      if (fabs(e_den) < 1e-22) e_den = fabs(e_den);
+      s[2] += e_den; s[3] += e_num; s[9] += e_num * e_num; s[10] += e_den * e_den;
+      s[11] += e_num * copysign(1.0, e_den); s[12] += fabs(e_den); s[5] += e_num * e_den;
+    }
+  }
+  __shared__ double red[TPB / 64][NSTAT];
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) {
+    double v = s[k];
+    for (int q = 32; q > 0; q >>= 1) v += __shfl_down(v, q, 64);
+    if (lane == 0) red[wv][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NSTAT) {
+    double v = 0.0;
+    for (int q = 0; q < TPB / 64; q++) v += red[q][threadIdx.x];
+    partials[(long long)tile * NSTAT + threadIdx.x] = v;
+  }
+  APROF(5);
+}
 // posts the (all-reduced) scalars of a sharded step to the host mailbox
 __global__ void k_post_mail(const DevScalars *sc, HostMail *mail, u64 seq) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -665,7 +841,10 @@ __global__ void k_post_mail(const DevScalars *sc, HostMail *mail, u64 seq) {
 // k_compact needs an agent-scope release in every block and cost more than this launch.
 __global__ void __launch_bounds__(TPB) k_finish(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
                                                 int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words,
-                                                HostMail *mail, u64 seq) {
+                                                HostMail *mail, u64 seq, u64 *__restrict__ fstate, u32 *__restrict__ fticket, long long cap_ftiles, int n_ftiles) {
+  // the look-back words k_anneal used this step (two arrays, n_ftiles words each) are zero again for the next one
+  for (int i = threadIdx.x; i < n_ftiles; i += TPB) { fstate[i] = 0; fstate[cap_ftiles + i] = 0; }
+  if (threadIdx.x == 0 && n_ftiles > 0) *fticket = 0;
   finish_step(partials, nblocks, wabs_part, nwabs, mode, sc, scan_state, scan_ticket, n_scan_words);
   if (mail && threadIdx.x == 0) {
     for (int i = 0; i < 16; i++) mail->stats[i] = sc->stats[i];
@@ -1088,6 +1267,9 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
     c->cap_tiles = (M + SCAN_TILE - 1) / SCAN_TILE + 1;
     HIPCHK(hipMalloc(&c->d_scan_state, 3 * c->cap_tiles * 8)); HIPCHK(hipMalloc(&c->d_scan_ticket, 3 * 4));
     HIPCHK(hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8)); HIPCHK(hipMemset(c->d_scan_ticket, 0, 3 * 4));
+    c->cap_ftiles = nblk(M) + 1;
+    HIPCHK(hipMalloc(&c->d_fstate, 2 * c->cap_ftiles * 8)); HIPCHK(hipMalloc(&c->d_fticket, 4));
+    HIPCHK(hipMemset(c->d_fstate, 0, 2 * c->cap_ftiles * 8)); HIPCHK(hipMemset(c->d_fticket, 0, 4));
     c->n_partial_blocks = nblk(M);
     HIPCHK(hipMalloc(&c->d_partials, ((long long)c->n_partial_blocks * NSTAT + 128) * 8));
     HIPCHK(hipMalloc(&c->d_wabs_part, ((long long)c->n_partial_blocks * 2 + 2) * 8));
@@ -1199,7 +1381,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
     free_walk(c->w); free_walk(c->m);
     hipFree(c->d_nchild); hipFree(c->d_child_off); hipFree(c->d_wchild); hipFree(c->d_child_state);
     hipFree(c->d_keys); hipFree(c->d_keys_alt); hipFree(c->d_vals); hipFree(c->d_vals_alt); hipFree(c->d_hist); hipFree(c->d_rowtot);
-    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done);
+    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done);
   }
   hipFree(c->d_binom); hipFree(c->d_grow);
   comm_release(c);
@@ -1399,24 +1581,43 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long na
   TEND(sort, st);
   // ---- join: from here on weights are read
   if (join_side_stream) HIPCHK(hipStreamWaitEvent(st, c->e_join, 0));
-  TBEG(merge, st);
   const int nbm = nblk(nall);
-  hipLaunchKernelGGL(k_merge, dim3(nbm), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, c->d_wabs_part, n0, nall, p, c->invalid_key, c->pack);
-  device_excl_scan_u64(c->d_flags, c->d_pos, nall, &c->d_sc->tot1, sw[1], st);
-  TEND(merge, st);
-  TBEG(round, st);
-  if (!p.semi) hipLaunchKernelGGL(k_join, dim3(1), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, nall, p, mode, seed, step, c->d_sc);
-  hipLaunchKernelGGL(k_round, dim3(nblk(nall)), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, c->d_flags2, nall, p, mode, seed, step, c->d_sc);
-  device_excl_scan_u64(c->d_flags2, c->d_pos2, nall, &c->d_sc->tot2, sw[2], st);
-  TEND(round, st);
-  TBEG(estimate, st);
-  const int nb = std::min(nblk(nall), 2048);
-  hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, st, c->m, c->w, c->d_flags2, c->d_pos2, c->d_loc_imp, skey, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask,
-                     c->d_ct_num, c->d_ct_den, nall, p, c->d_partials, c->pack);
   const bool use_mail = (c->comm == nullptr);          // with a communicator the sums are all-reduced on the device first
   const u64 seq = ++c->mail_seq;
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials, nb, c->d_wabs_part, nbm, mode, c->d_sc, c->d_scan_state, c->d_scan_ticket,
-                     (int)(3 * c->cap_tiles), use_mail ? c->d_mail : (HostMail *)nullptr, seq);
+  int nb, n_ft = 0;
+  if (p.semi) {
+    // one kernel from the sorted list to the new walker arrays; the buffers swap roles afterwards
+    TBEG(anneal, st);
+    static const int items_env = getenv("SQMC_ANNEAL_ITEMS") ? atoi(getenv("SQMC_ANNEAL_ITEMS")) : 0;
+    const int items = items_env ? items_env : (nall < (1ll << 20) ? 2 : 4);     // small lists want many tiles, large ones short look-back chains
+    nb = n_ft = (int)((nall + (long long)TPB * items - 1) / ((long long)TPB * items));
+#define ANNEAL_LAUNCH(I) hipLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, \
+                       c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, n0, nall, p, c->invalid_key, c->pack, mode, seed, step, c->d_sc,          \
+                       c->d_fstate, c->d_fstate + c->cap_ftiles, c->d_fticket)
+    if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 8) ANNEAL_LAUNCH(8); else ANNEAL_LAUNCH(4);
+#undef ANNEAL_LAUNCH
+    std::swap(c->w.up, c->m.up); std::swap(c->w.dn, c->m.dn); std::swap(c->w.wt, c->m.wt); std::swap(c->w.flg, c->m.flg);
+    std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed);
+    TEND(anneal, st);
+  } else {
+    TBEG(merge, st);
+    hipLaunchKernelGGL(k_merge, dim3(nbm), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, c->d_wabs_part, n0, nall, p, c->invalid_key, c->pack);
+    device_excl_scan_u64(c->d_flags, c->d_pos, nall, &c->d_sc->tot1, sw[1], st);
+    TEND(merge, st);
+    TBEG(round, st);
+    hipLaunchKernelGGL(k_join, dim3(1), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, nall, p, mode, seed, step, c->d_sc);
+    hipLaunchKernelGGL(k_round, dim3(nblk(nall)), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, c->d_flags2, nall, p, mode, seed, step, c->d_sc);
+    device_excl_scan_u64(c->d_flags2, c->d_pos2, nall, &c->d_sc->tot2, sw[2], st);
+    TEND(round, st);
+    nb = std::min(nblk(nall), 2048);
+    TBEG(compact, st);
+    hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, st, c->m, c->w, c->d_flags2, c->d_pos2, c->d_loc_imp, skey, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask,
+                       c->d_ct_num, c->d_ct_den, nall, p, c->d_partials, c->pack);
+    TEND(compact, st);
+  }
+  TBEG(estimate, st);
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials, nb, c->d_wabs_part, p.semi ? nb : nbm, mode, c->d_sc, c->d_scan_state, c->d_scan_ticket,
+                     (int)(3 * c->cap_tiles), use_mail ? c->d_mail : (HostMail *)nullptr, seq, c->d_fstate, c->d_fticket, c->cap_ftiles, n_ft);
   TEND(estimate, st);
   HIPCHK(hipGetLastError());
   if (!use_mail) {
