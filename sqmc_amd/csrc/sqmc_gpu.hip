@@ -410,6 +410,8 @@ __device__ __forceinline__ SlotIn load_slot(const WalkArr &w, const u64 *__restr
   }
   return in;
 }
+#define MERGE_AHEAD 4
+#define MERGE_SELF 8
 #define SLOT_STOP 0x80000000u     // in the staged flag word: this slot starts a run or holds no walker
 // stage weight and flags of a slot at its place in the tile (LDS); the block synchronises before folding
 __device__ __forceinline__ void stage_slot(const SlotIn &in, double *__restrict__ s_w, u32 *__restrict__ s_f, int idx) {
@@ -443,58 +445,87 @@ __device__ __forceinline__ MergedRec fold_slot(const SlotIn &in, const double *_
     }                                                                                               \
     if (!(d == 0 && d2 == -1)) wt = wt + w2_;                                                       \
   } while (0)
-  bool reached_end = false;
+  // A head folds the first MERGE_SELF followers of its run itself (most runs end there).  What is
+  // left of a long run (a heavy determinant whose children land on a few neighbours: hundreds of
+  // equal keys) is folded by the whole wavefront, 64 records at a time: out of the staged tile as
+  // far as it reaches, then out of HBM.
+  int lt = idx + 1;                              // next in-tile slot of this lane's run
+  bool pending = false;
   if (head) {
     const u32 ft = (u32)h.flg;
     ini = flg_init(ft); d = flg_impd(ft); ps = flg_psign(ft);
     if (d == -1 && j > 0) d = 1;                 // 5985-5986 (the very first walker keeps -1 until the end)
-    int l = idx + 1;
-    for (; l < tile_slots; l++) { const u32 fl = s_f[l]; if (fl & SLOT_STOP) break; MERGE_FOLD(s_w[l], fl); }
-    jj = j + (l - idx);
-    reached_end = (l == tile_slots);
+    bool open = true;
+    for (int k = 0; k < MERGE_SELF && lt < tile_slots; k++, lt++) { const u32 fl = s_f[lt]; if (fl & SLOT_STOP) { open = false; break; } MERGE_FOLD(s_w[lt], fl); }
+    jj = j + (lt - idx);
+    pending = open && (lt < tile_slots ? !(s_f[lt] & SLOT_STOP) : (j - idx + tile_slots < n && get_key(skey, j - idx + tile_slots, pack) == key));
   }
-  // the last run of the tile may go on in the next tile
-  const long long jn = (j - idx) + tile_slots;
-  const bool pending = head && reached_end && jn < n && get_key(skey, jn, pack) == key;
+  // one chunk of up to 64 followers held one per lane (valid lanes form a prefix); returns its length
+  auto fold_chunk = [&](bool valid, double w2, u32 f2, int leader) -> int {
+    const u64 vb = __ballot(valid);
+    const int cnt = (vb == ~0ull) ? 64 : __ffsll((long long)~vb) - 1;
+    // A chunk whose weights all carry the sign of the running sum (the usual case: children of one
+    // parent) needs no sign logic: the initiator flag is a maximum, imp_distance a minimum, and only
+    // the additions stay in order (skipped terms become -0.0, which leaves a non-zero sum unchanged).
+    const double wt_l = __shfl(wt, leader, 64); const int d_l = __shfl(d, leader, 64);
+    const bool use = valid && lane < cnt;
+    const int i2 = flg_init(f2), d2 = flg_impd(f2);
+    const bool plain = !use || (((w2 > 0) == (wt_l > 0)) && fabs(w2) > 1e-150 && d2 != 0 && d2 != -2);
+    if (fabs(wt_l) > 1e-150 && __ballot(plain) == ~0ull) {
+      int im = use ? i2 : 0, dm = use ? (d2 < 0 ? -d2 : d2) : 1 << 20;
+      for (int o = 32; o > 0; o >>= 1) { const int a = __shfl_xor(im, o, 64), b = __shfl_xor(dm, o, 64); im = a > im ? a : im; dm = b < dm ? b : dm; }
+      s_w2[wv][lane] = (use && !(d_l == 0 && d2 == -1)) ? w2 : -0.0;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == leader) {
+        if (im > ini) ini = im;
+        if (d >= 1 && dm < d) d = dm;
+        if (cnt == 64) {
+#pragma unroll
+          for (int l = 0; l < 64; l++) wt = wt + s_w2[wv][l];
+        } else for (int l = 0; l < cnt; l++) wt = wt + s_w2[wv][l];
+        jj += cnt;
+      }
+    } else {
+      s_w2[wv][lane] = w2; s_f2[wv][lane] = f2;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == leader) { for (int l = 0; l < cnt; l++) MERGE_FOLD(s_w2[wv][l], s_f2[wv][l]); jj += cnt; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return cnt;
+  };
+  const long long jn = (j - idx) + tile_slots;   // first slot after the tile
   for (u64 pend = __ballot(pending); pend; pend &= pend - 1) {
     const int leader = __ffsll((long long)pend) - 1;
-    long long base = __shfl(jj, leader, 64);
+    int ltl = __shfl(lt, leader, 64);
     const u64 lkey = __shfl(key, leader, 64);
-    for (;;) {
-      const long long idx = base + lane;
-      const bool valid = idx < n && get_key(skey, idx, pack) == lkey;
-      double w2 = 0.0; u32 f2 = 0;
-      if (valid) { const u32 s = get_perm(skey, perm, idx, pack); const SpawnRec r2 = w.sp[s - n0]; w2 = r2.wt; f2 = (u32)r2.flg; }
-      const u64 vb = __ballot(valid);                     // equal keys are contiguous: the valid lanes are a prefix
-      const int cnt = (vb == ~0ull) ? 64 : __ffsll((long long)~vb) - 1;
-      // A chunk whose weights all carry the sign of the running sum (the usual case: children of one
-      // parent) needs no sign logic: the initiator flag is a maximum, imp_distance a minimum, and only
-      // the additions stay in order (skipped terms become -0.0, which leaves a non-zero sum unchanged).
-      const double wt_l = __shfl(wt, leader, 64); const int d_l = __shfl(d, leader, 64);
-      const int i2 = flg_init(f2), d2 = flg_impd(f2);
-      const bool plain = !valid || (((w2 > 0) == (wt_l > 0)) && fabs(w2) > 1e-150 && d2 != 0 && d2 != -2);
-      if (fabs(wt_l) > 1e-150 && __ballot(plain) == ~0ull) {
-        int im = valid ? i2 : 0, dm = valid ? (d2 < 0 ? -d2 : d2) : 1 << 20;
-        for (int o = 32; o > 0; o >>= 1) { const int a = __shfl_xor(im, o, 64), b = __shfl_xor(dm, o, 64); im = a > im ? a : im; dm = b < dm ? b : dm; }
-        s_w2[wv][lane] = (valid && !(d_l == 0 && d2 == -1)) ? w2 : -0.0;
-        __builtin_amdgcn_wave_barrier();
-        if (lane == leader) {
-          if (im > ini) ini = im;
-          if (d >= 1 && dm < d) d = dm;
-          if (cnt == 64) {
-#pragma unroll
-            for (int l = 0; l < 64; l++) wt = wt + s_w2[wv][l];
-          } else for (int l = 0; l < cnt; l++) wt = wt + s_w2[wv][l];
-          jj += cnt;
-        }
-      } else {
-        s_w2[wv][lane] = w2; s_f2[wv][lane] = f2;
-        __builtin_amdgcn_wave_barrier();
-        if (lane == leader) { for (int l = 0; l < cnt; l++) MERGE_FOLD(s_w2[wv][l], s_f2[wv][l]); jj += cnt; }
-      }
-      __builtin_amdgcn_wave_barrier();
+    // ---- the part of the run that lies in the staged tile
+    while (ltl < tile_slots) {
+      const int li = ltl + lane;
+      const u32 fl = (li < tile_slots) ? s_f[li] : SLOT_STOP;
+      const bool valid = !(fl & SLOT_STOP);
+      const int cnt = fold_chunk(valid, valid ? s_w[li] : 0.0, fl, leader);
+      ltl += cnt;
       if (cnt < 64) break;
-      base += 64;
+    }
+    if (ltl < tile_slots) continue;              // the run ended inside the tile
+    // ---- the run reaches the end of the tile: the rest, if any, comes from HBM
+    long long base = jn;
+    for (bool more = true; more;) {
+      // MERGE_AHEAD rows of 64 records are requested together (one latency for 256 records), then folded row by row
+      double w2q[MERGE_AHEAD]; u32 f2q[MERGE_AHEAD]; bool vq[MERGE_AHEAD];
+#pragma unroll
+      for (int q = 0; q < MERGE_AHEAD; q++) {
+        const long long ix = base + (long long)q * 64 + lane;
+        vq[q] = ix < n && get_key(skey, ix, pack) == lkey;
+        w2q[q] = 0.0; f2q[q] = 0;
+        if (vq[q]) { const u32 sx = get_perm(skey, perm, ix, pack); const SpawnRec r2 = w.sp[sx - n0]; w2q[q] = r2.wt; f2q[q] = (u32)r2.flg; }
+      }
+#pragma unroll
+      for (int q = 0; q < MERGE_AHEAD; q++) {
+        if (!more) break;
+        if (fold_chunk(vq[q], w2q[q], f2q[q], leader) < 64) more = false;
+      }
+      base += 64 * MERGE_AHEAD;
     }
   }
 #undef MERGE_FOLD
