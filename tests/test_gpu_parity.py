@@ -658,19 +658,21 @@ def test_fortran_host_walk(tmp_path):
     walk.close()
 
 
-@pytest.mark.parametrize("rng_mode,rfi", [(0, 1.0), (1, 1.0), (1, 0.93)])
-def test_annihilate_door_matches_oracle_merge(oracle, c2_walk, c2_setup, rng_mode, rfi):
+@pytest.mark.parametrize("rng_mode,rfi,heavy", [(0, 1.0, False), (1, 1.0, False), (1, 0.93, False), (0, 1.0, True), (1, 0.93, True)])
+def test_annihilate_door_matches_oracle_merge(oracle, c2_walk, c2_setup, rng_mode, rfi, heavy):
     """sqmc_gpu_annihilate against merge_sort2_up_dn + merge_original_with_spawned2 +
     reduce_my_walker of the oracle on a collision-heavy hand-made spawn list: many spawns per
     determinant in both signs, exact cancellations, spawns onto deterministic-space and onto the
     permanent-initiator determinant, spawns from the deterministic space (imp_distance -1),
-    non-initiator spawns onto empty determinants, zero-weight proposals."""
+    non-initiator spawns onto empty determinants, zero-weight proposals.  `heavy`: a few determinants
+    collect thousands of spawns each (the runs of equal keys span several tiles of the annihilation
+    kernel: wavefront-cooperative folds, in mixed signs and -- one determinant -- in one sign)."""
     rs = np.random.RandomState(1234 + rng_mode)
     main = oracle.initial_walkers(c2_setup, 300)
     n0 = len(main["up"])
-    pool = rs.choice(len(c2_setup.ct_up), 80, replace=False)
-    ns = 4000
-    from_main = rs.rand(ns) < 0.4
+    pool = rs.choice(len(c2_setup.ct_up), 6 if heavy else 80, replace=False)
+    ns = 14000 if heavy else 4000
+    from_main = rs.rand(ns) < (0.03 if heavy else 0.4)
     im, ip = rs.randint(0, n0, ns), pool[rs.randint(0, len(pool), ns)]
     up = np.where(from_main, main["up"][im], c2_setup.ct_up[ip]).astype(np.uint64)
     dn = np.where(from_main, main["dn"][im], c2_setup.ct_dn[ip]).astype(np.uint64)
@@ -678,6 +680,13 @@ def test_annihilate_door_matches_oracle_merge(oracle, c2_walk, c2_setup, rng_mod
     wt[rs.rand(ns) < 0.05] = 0.0
     impd = rs.choice([-1, 1, 2, 3, 5], ns).astype(np.int8)
     init = np.where(impd == -1, 1, rs.randint(0, 2, ns)).astype(np.int8)
+    if heavy:      # the children of one parent: thousands of equal same-sign weights onto one determinant (and a second one in the deterministic space)
+        one = (~from_main) & (ip == pool[0])
+        wt[one] = 0.3; impd[one] = 2; init[one] = 0
+        imp_dets = np.nonzero(main["imp_distance"] == 0)[0]
+        sel = rs.rand(ns) < 0.12
+        up[sel], dn[sel] = main["up"][imp_dets[5]], main["dn"][imp_dets[5]]
+        wt[sel] = -0.2; impd[sel] = np.where(rs.rand(int(sel.sum())) < 0.5, -1, 2); init[sel] = 1
     prm = dict(tau=c2_setup.tau, e_trial=-75.7, reweight_factor_inv=rfi, r_initiator=1.0, min_wt=0.5, always_spawn_cutoff_wt=0.5,
                initiator_power=0, initiator_min_distance=0, c_t_initiator=0, semistochastic=1, reached_w_abs_gen=2)
     # ---- oracle: the three routines in the order of do_walk.f90:2335-2473, then the reweighting of :2487
@@ -710,6 +719,8 @@ def test_annihilate_door_matches_oracle_merge(oracle, c2_walk, c2_setup, rng_mod
         assert np.array_equal(got[k], ref[k]), k
     assert int(out[7]) == n0 + len(nz)                      # nwalk_before_merge: zero-weight proposals are no walkers
     assert n < n0 + len(nz) - 1000                          # the list really collided
+    if heavy:
+        assert n < n0 + 400
 
 
 def test_error_statuses_match_reference_stops(oracle, c2_walk, c2_setup):
