@@ -1,6 +1,7 @@
 """python -m sqmc_amd.run -i <deck>   (or  < deck)
 
-Runs a reference input deck of run_type `hci` on the GPU path: the deck grammar of read_input
+Runs a reference input deck on the GPU path.  run_type `none`: a projector Monte Carlo walk, see
+walk_run.py.  run_type `hci`: the deck grammar of read_input
 (do_walk.f90:406-574 for hci decks: seeds, run_type, `eps_var eps_pt target_error n_states`,
 dump_wf_var, the chem Hamiltonian block of chemistry.f90:119-245, then the namelists
 &selected_ci and &hf_det) and the result lines of perform_hci (hci.f90:323, 487, 833-841), so the
@@ -229,8 +230,14 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m sqmc_amd.run", description=__doc__.split("\n\n")[0])
     ap.add_argument("-i", "--input", default=None, help="deck file (default: stdin)")
     ap.add_argument("--fcidump", default="FCIDUMP", help="integral file (the reference reads ./FCIDUMP)")
+    ap.add_argument("--walkalize", default=None, help="walk decks: write the per-step record of unit 1 (step, 1/rew_fac_inv, w_abs_gen, e_gen, nwalk) to this file")
     a = ap.parse_args(argv)
     text = open(a.input).read() if a.input else sys.stdin.read()
+    lines = [l for l in text.splitlines() if l.strip() and not l.lstrip().startswith("!")]
+    run_type = lines[1].split()[0].strip("'\"").lower() if len(lines) > 1 else ""
+    if run_type in ("none", "no_fixed_node"):          # a projector walk: the grammar of read_input for run_type /= hci
+        from .walk_run import parse_walk_deck, run_walk
+        return run_walk(parse_walk_deck(text), a.fcidump, walkalize=a.walkalize)
     deck = parse_hci_deck(text)
     return run_hci(deck, a.fcidump)
 

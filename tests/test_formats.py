@@ -62,3 +62,37 @@ def test_heg_k_point_table_matches_reference_output():
     assert abs(unit - 3.2345) < 5e-5 and h.norb == 19
     assert [tuple(int(x) for x in row) for row in np.round(np.asarray(h.k_vectors) / unit)] == ref
     assert (h.hf_up, h.hf_dn) == (127, 127)                                  # 'HF det= 127 127' (:73)
+
+
+def test_walk_deck_grammar_and_estimators():
+    """run_type `none` decks (read_input, do_walk.f90:222-404 + read_chem, chemistry.f90:119-245): the
+    fixture deck parses to the parameters of BASELINE.md's walk smoke test; decks outside the GPU path
+    stop with a message; the generation / block estimators (do_walk.f90:2792-2843, 2986-3040) reduce
+    to the textbook ratio-of-means error for uncorrelated data."""
+    import os
+    import numpy as np
+    import pytest
+    from sqmc_amd.walk_run import parse_walk_deck, WalkStats
+    text = open(os.path.join(os.path.dirname(__file__), "golden", "C2_r1.24253_i_walk")).read()
+    d = parse_walk_deck(text)
+    assert (d["nstep"], d["nblk"], d["nblk_eq"], d["ipr"]) == (100, 4, 2, 0)
+    assert (d["w_abs_gen_begin"], d["w_abs_gen_target"], d["mwalk"]) == (100, 10000, 0)
+    assert d["proposal_method"] == "uniform2" and d["semistochastic"] and d["size_deterministic"] == 1000
+    assert d["irand_seed"][1] == [1346, 5634, 6635, 4361] and d["n_truncate_trial_wf"] == [100] and len(d["orbital_symmetries"]) == 26
+    with pytest.raises(SystemExit, match="proposal_method"):
+        parse_walk_deck(text.replace("uniform2 0", "fast_heatbath 0"))
+    with pytest.raises(SystemExit, match="hf_to_psit"):
+        parse_walk_deck(text.replace("f f 0.5 ", "t f 0.5 "))
+    with pytest.raises(SystemExit, match="run_type"):
+        parse_walk_deck(text.replace("none  ", "vmc   "))
+    rs = np.random.RandomState(7)
+    st = WalkStats()
+    num = -75.7 * 100 * (1 + 0.01 * rs.randn(4000)); den = 100 * (1 + 0.02 * rs.randn(4000))
+    for b in range(40):
+        for i in range(100):
+            st.generation(num[b * 100 + i], den[b * 100 + i])
+        st.block(num[b * 100:(b + 1) * 100].sum(), den[b * 100:(b + 1) * 100].sum())
+    expect = 75.7 * np.sqrt(0.01 ** 2 + 0.02 ** 2) / np.sqrt(4000)
+    assert abs(st.e_genabs_err / expect - 1) < 0.05 and abs(st.e_blkabs_err / expect - 1) < 0.35
+    assert abs(st.e_genabs_ave + 75.7) < 4 * expect and abs(st.e_blkabs_ave + 75.7) < 4 * expect
+    assert 0.4 < st.t_corr < 2.5                       # uncorrelated generations: block and generation errors agree

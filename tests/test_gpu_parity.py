@@ -496,6 +496,30 @@ def test_heg_host_setup_matches_oracle(oracle, heg14, heg_setup):
     assert 58.26 < e < 58.29          # the reference's HCI total energy for this system: 58.27597 (o_det_ref:436)
 
 
+def test_walk_deck_end_to_end(tmp_path):
+    """A run_type `none` deck in the reference's grammar (tests/golden/C2_r1.24253_i_walk: the walk
+    smoke test of BASELINE.md -- C2 cc-pVDZ, uniform2, semistochastic, size_deterministic 1000, Psi_T
+    100 dets, target 1e4, 100-step blocks) through `python -m sqmc_amd.run`'s walk runner: set-up
+    figures of the reference run (1002 deterministic dets, tau 0.005314, ~16,400 occupied and ~32,500
+    pre-merge determinants), the reference's block-wise equilibration and output lines, and an energy
+    that agrees with the near-FCI HCI total energy of this geometry (-75.7285) within the error bar."""
+    import io, os
+    from conftest import FCIDUMP
+    from sqmc_amd.walk_run import parse_walk_deck, run_walk
+    deck = parse_walk_deck(open(os.path.join(os.path.dirname(__file__), "golden", "C2_r1.24253_i_walk")).read())
+    buf = io.StringIO()
+    wal = str(tmp_path / "walkalize")
+    r = run_walk(deck, FCIDUMP, out=buf, walkalize=wal)
+    txt = buf.getvalue()
+    assert r["n_imp"] == 1002 and abs(r["tau"] - 0.005314) < 1e-6
+    assert 15800 < r["nwalk_av"] < 17000
+    assert "Equilibration of everything achieved" in txt and "Energy=" in txt and "w_abs_gen_target=    10000 reached" in txt
+    assert txt.count("iblk, w_perm_initiator, nwalk, w_abs, w_abs_imp=") == r["n_blocks_total"] == r["n_equil_sets"] * 2 + 4
+    assert abs(r["energy"] - (-75.7285)) < max(5 * r["energy_err"], 3e-3), (r["energy"], r["energy_err"])
+    rec = open(wal).read().splitlines()
+    assert len(rec) == 100 * r["n_blocks_total"] + 1 and rec[-1].endswith("nstep, nblk, w_abs_gen_target, e_trial, tau")
+
+
 def test_hubbard_matrix_elements_and_proposals_bit_exact(oracle, hub44):
     """hamiltonian_hubbard / off_diagonal_move_hubbard (real-space Hubbard,
     BASELINE.json configs[0] lattice) on the GPU against the oracle: values, determinants and the
