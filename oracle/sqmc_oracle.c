@@ -867,7 +867,9 @@ int64_t orc_merge_original_with_spawned2(orc_walk *w, int64_t nwalk, const orc_s
 int64_t orc_reduce_my_walker(orc_walk *w, int64_t n, const orc_step_params *p) {
   for (int64_t i = 0; i < n; i++)
     if (w->imp_distance[i] >= 1 && fabs(w->wt[i]) < p->min_wt) {
-      orc_rng_seek(&w->rng, 2, (uint64_t)i);
+      /* COUNTER discipline: the draw is keyed by the determinant itself, so that no rank among the
+       * merged walkers is needed to find it (REPLAY takes the next number of the one stream) */
+      orc_rng_seek(&w->rng, 2, (uint64_t)w->up[i] * 0x9E3779B97F4A7C15ull + (uint64_t)w->dn[i]);
       if (orc_rannyu(&w->rng) < (fabs(w->wt[i]) / p->min_wt)) w->wt[i] = copysign(p->min_wt, w->wt[i]);
       else w->wt[i] = 0.0;
     }

@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(TPB) k_round(WalkArr m, const u64 *__restrict_
     const u64 ps = pos[j];
     double r;
     if (mode == 0) r = (double)lcg_skip(sc->lcg, (ps >> 32) + 1) * 3.552713678800500929355621337890625e-15;
-    else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, ps & 0xFFFFFFFFull); r = rng_draw(g); }
+    else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, m.up[j] * SQ_GOLDEN + m.dn[j]); r = rng_draw(g); }   // keyed by the determinant
     if (r < (fabs(wt) / p.min_wt)) wt = copysign(p.min_wt, wt); else wt = 0.0;
     m.wt[j] = wt;
   }
@@ -735,7 +735,7 @@ extern "C" int sqmc_gpu_debug_aprof(unsigned long long *out) { return (int)hipMe
 #define APROF(K)
 #endif
 template <int ITEMS>
-__global__ void __launch_bounds__(TPB) k_anneal(WalkArr w, WalkArr o, const u64 *__restrict__ skey, const u32 *__restrict__ perm, int *__restrict__ loc_imp,
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) k_anneal(WalkArr w, WalkArr o, const u64 *__restrict__ skey, const u32 *__restrict__ perm, int *__restrict__ loc_imp,
                                                 const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 hmask,
                                                 const double *__restrict__ cnum, const double *__restrict__ cden,
                                                 double *__restrict__ partials, double *__restrict__ wabs_part, long long n0, long long n_all, StepP p,
@@ -767,21 +767,24 @@ __global__ void __launch_bounds__(TPB) k_anneal(WalkArr w, WalkArr o, const u64 
   APROF(1);
   store_wabs(wabs_part, tile, wabs, cnt);
   APROF(2);
-  // ---- rank among the kept walkers (lo) and among the rounding draws (hi)
-  u64 inc[ITEMS], carry = 0;
+  // ---- REPLAY discipline only: rank among the rounding draws of the one rannyu stream (hi word;
+  //      lo = rank among the kept walkers).  The COUNTER discipline keys a draw by its determinant,
+  //      needs no rank, and so spares every tile the wait for the slowest earlier tile.
+  u64 inc[ITEMS], carry = 0, ex = 0, tot = 0;
+  if (mode == 0) {
 #pragma unroll
-  for (int k = 0; k < ITEMS; k++) { const u64 x = wave_incl_scan_u64(r[k].f, lane); inc[k] = x + carry; carry += __shfl(x, 63, 64); }
-  if (lane == 0) s_wsum[0][wv] = carry;
-  __syncthreads();
-  u64 ex = 0, tot = 0;
+    for (int k = 0; k < ITEMS; k++) { const u64 x = wave_incl_scan_u64(r[k].f, lane); inc[k] = x + carry; carry += __shfl(x, 63, 64); }
+    if (lane == 0) s_wsum[0][wv] = carry;
+    __syncthreads();
 #pragma unroll
-  for (int q = 0; q < TPB / 64; q++) { if (q < wv) ex += s_wsum[0][q]; tot += s_wsum[0][q]; }
-  if (threadIdx.x < 64) {
-    const u64 e = lookback_exclusive(state1, tile, tot, threadIdx.x);
-    if (threadIdx.x == 0) { s_ex[0] = e; if (last_tile) sc->tot1 = e + tot; }
+    for (int q = 0; q < TPB / 64; q++) { if (q < wv) ex += s_wsum[0][q]; tot += s_wsum[0][q]; }
+    if (threadIdx.x < 64) {
+      const u64 e = lookback_exclusive(state1, tile, tot, threadIdx.x);
+      if (threadIdx.x == 0) { s_ex[0] = e; if (last_tile) sc->tot1 = e + tot; }
+    }
+    __syncthreads();
+    ex += s_ex[0];
   }
-  __syncthreads();
-  ex += s_ex[0];
   APROF(3);
   u64 f2[ITEMS];
 #pragma unroll
@@ -789,10 +792,9 @@ __global__ void __launch_bounds__(TPB) k_anneal(WalkArr w, WalkArr o, const u64 
     f2[k] = 0;
     if (r[k].f & 1ull) {
       if (r[k].f >> 32) {
-        const u64 ex1 = ex + inc[k] - r[k].f;
         double rr;
-        if (mode == 0) rr = (double)lcg_skip(sc->lcg, (ex1 >> 32) + 1) * 3.552713678800500929355621337890625e-15;
-        else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, ex1 & 0xFFFFFFFFull); rr = rng_draw(g); }
+        if (mode == 0) { const u64 ex1 = ex + inc[k] - r[k].f; rr = (double)lcg_skip(sc->lcg, (ex1 >> 32) + 1) * 3.552713678800500929355621337890625e-15; }
+        else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, r[k].up * SQ_GOLDEN + r[k].dn); rr = rng_draw(g); }
         if (rr < (fabs(r[k].wt) / p.min_wt)) r[k].wt = copysign(p.min_wt, r[k].wt); else r[k].wt = 0.0;
       }
       // reduce_my_walker drops zero weights outside the deterministic space (7222-7249)
