@@ -1158,6 +1158,100 @@ def read_wf_var(path, n_states=1):
     return u[:, 0].copy(), d[:, 0].copy(), wts, np.frombuffer(recs[4], np.float64).copy()
 
 
+def _orbs(det, n_core_orb=0):
+    """1-based occupied orbitals above the core, renumbered from the first non-core orbital"""
+    d, out = int(det) >> n_core_orb, []
+    while d:
+        low = d & -d
+        out.append(low.bit_length())
+        d ^= low
+    return out
+
+
+def _det_from_orbs(orbs, n_core_orb=0):
+    d = (1 << n_core_orb) - 1
+    for o in orbs:
+        d |= 1 << (int(o) + n_core_orb - 1)
+    return d
+
+
+def _f(x, w, dec):
+    """Fortran fw.d (a leading zero before the point may be dropped when the field is full)"""
+    t = "%*.*f" % (w, dec, x)
+    if len(t) > w and t.lstrip("-").startswith("0."):
+        t = t.replace("0.", ".", 1)
+    return t if len(t) <= w else "*" * w
+
+
+def write_psit_connections(path, psi_up, ct_up, ct_dn, ct_num, ct_den, nup, ndn, norb, n_core_orb=0):
+    """psit_con_out_file, semistoch.f90:86-126: C(T) as text -- header `(i8,i12,2i4,i6,i3,f15.8,...)`,
+    a title line, then per determinant with |e_loc_num| > 1e-10 the occupied orbitals (core removed)
+    `(i3, (nel-1)i4)` and `f22.15, f19.15` numerator and denominator.  A reference run with
+    use_psit_con_in reads it back (do_walk.f90:702-741)."""
+    keep = np.abs(ct_num) > 1e-10
+    with open(path, "w") as f:
+        f.write("%8d%12d%4d%4d%6d%3d%s ndet_psi_t, ndet_connections_nonzero, nup-n_core_orb, ndn-n_core_orb, norb, 0, E_T\n"
+                % (len(psi_up), int(keep.sum()), nup - n_core_orb, ndn - n_core_orb, norb, 0, _f(ct_num[0] / ct_den[0] if ct_den[0] != 0 else 0.0, 15, 8)))
+        f.write("orb_up          orb_dn           e_loc_num            e_loc_den\n")
+        for u, d_, a, b in zip(ct_up[keep].tolist(), ct_dn[keep].tolist(), ct_num[keep].tolist(), ct_den[keep].tolist()):
+            o = _orbs(u, n_core_orb) + _orbs(d_, n_core_orb)
+            f.write("%3d" % o[0] + "".join("%4d" % v for v in o[1:]) + _f(a, 22, 15) + _f(b, 19, 15) + "\n")
+
+
+def read_psit_connections(path, nup, ndn, n_core_orb=0):
+    """the reader of do_walk.f90:702-741 (list-directed): returns (ct_up, ct_dn, ct_num, ct_den), sorted by (up, dn);
+    the determinants with |e_loc_den| > 1e-12 are Psi_T with that coefficient"""
+    with open(path) as f:
+        head = f.readline().split()
+        n_con = int(head[1])
+        f.readline()
+        rows = [f.readline().replace(",", " ").split() for _ in range(n_con)]
+    nu, nd = nup - n_core_orb, ndn - n_core_orb
+    up = np.array([_det_from_orbs(r[:nu], n_core_orb) for r in rows], np.uint64)
+    dn = np.array([_det_from_orbs(r[nu:nu + nd], n_core_orb) for r in rows], np.uint64)
+    num = np.array([float(r[nu + nd].lower().replace("d", "e")) for r in rows])
+    den = np.array([float(r[nu + nd + 1].lower().replace("d", "e")) for r in rows])
+    o = sort_dets(up, dn)
+    return up[o], dn[o], num[o], den[o]
+
+
+def write_dtm_elems(path, imp_up, imp_dn, counts, indices, h_values, dtm_energy, n_core_orb=0):
+    """dtm_elems_out_file, do_walk.f90:970-1010: the deterministic space and its Hamiltonian (NOT yet
+    multiplied by -tau) in the upper-triangular row format of the projector: `n_imp nnz energy`,
+    the row counts, one line `i orbitals...` per determinant, one line `index value` per stored element."""
+    with open(path, "w") as f:
+        f.write(" %d %d %s number of deterministic dets, number of nonzero deterministic Hamiltonian elements, ground state energy within deterministic space\n"
+                % (len(imp_up), len(h_values), repr(float(dtm_energy))))
+        f.write("".join("%8d" % c for c in counts) + "\n")
+        for i, (u, d_) in enumerate(zip(np.asarray(imp_up).tolist(), np.asarray(imp_dn).tolist())):
+            f.write(" %d " % (i + 1) + " ".join("%d" % v for v in _orbs(u, n_core_orb) + _orbs(d_, n_core_orb)) + "\n")
+        for ix, v in zip(np.asarray(indices).tolist(), np.asarray(h_values).tolist()):
+            f.write(" %d %s\n" % (ix, repr(float(v))))
+
+
+def read_dtm_elems(path, nup, ndn, n_core_orb=0):
+    """the reader of do_walk.f90:898-940: (imp_up, imp_dn, counts, indices, H values, energy); multiply the
+    values by -tau for sqmc_gpu_set_projector as the reference does at :943"""
+    body = open(path).read().replace(",", " ").split()
+    n_imp, nnz, e = int(body[0]), int(body[1]), float(body[2].lower().replace("d", "e"))
+    pos = 3
+    while not body[pos].lstrip("-").isdigit():       # the describing text of the first record (a compiler may wrap it over two lines)
+        pos += 1
+    body = body[pos:]
+    counts = np.array(body[:n_imp], np.int64)
+    pos = n_imp
+    nu, nd = nup - n_core_orb, ndn - n_core_orb
+    up, dn = np.zeros(n_imp, np.uint64), np.zeros(n_imp, np.uint64)
+    for _ in range(n_imp):
+        ind = int(body[pos]) - 1
+        up[ind] = _det_from_orbs(body[pos + 1:pos + 1 + nu], n_core_orb)
+        dn[ind] = _det_from_orbs(body[pos + 1 + nu:pos + 1 + nu + nd], n_core_orb)
+        pos += 1 + nu + nd
+    idx = np.array(body[pos:pos + 2 * nnz:2], np.int64)
+    val = np.array([float(t.lower().replace("d", "e")) for t in body[pos + 1:pos + 2 * nnz:2]])
+    return up, dn, counts, idx, val, e
+
+
 def dump_hci_deck(path, host, hb, eps_var, eps_sched=(), n_states=1):
     """Tables + heat-bath lists + run parameters for a compiled HCI host (example_hci.f90), one
     little-endian stream file: int64 header, float64 scalars, then the arrays in header order."""

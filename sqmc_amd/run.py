@@ -231,13 +231,18 @@ def main(argv=None):
     ap.add_argument("-i", "--input", default=None, help="deck file (default: stdin)")
     ap.add_argument("--fcidump", default="FCIDUMP", help="integral file (the reference reads ./FCIDUMP)")
     ap.add_argument("--walkalize", default=None, help="walk decks: write the per-step record of unit 1 (step, 1/rew_fac_inv, w_abs_gen, e_gen, nwalk) to this file")
+    for name, what in (("psit-con", "C(T): Psi_T connections with local-energy pieces (psit_con_in/out_file, semistoch.f90:86-126)"),
+                       ("dtm-elems", "the deterministic space and its Hamiltonian (dtm_elems_in/out_file, do_walk.f90:898-1010)")):
+        ap.add_argument("--%s-in" % name, default=None, help="walk decks: read %s from this file instead of building it" % what)
+        ap.add_argument("--%s-out" % name, default=None, help="walk decks: write %s to this file" % what)
     a = ap.parse_args(argv)
     text = open(a.input).read() if a.input else sys.stdin.read()
     lines = [l for l in text.splitlines() if l.strip() and not l.lstrip().startswith("!")]
     run_type = lines[1].split()[0].strip("'\"").lower() if len(lines) > 1 else ""
     if run_type in ("none", "no_fixed_node"):          # a projector walk: the grammar of read_input for run_type /= hci
         from .walk_run import parse_walk_deck, run_walk
-        return run_walk(parse_walk_deck(text), a.fcidump, walkalize=a.walkalize)
+        return run_walk(parse_walk_deck(text), a.fcidump, walkalize=a.walkalize, psit_con_in=a.psit_con_in, psit_con_out=a.psit_con_out,
+                        dtm_elems_in=a.dtm_elems_in, dtm_elems_out=a.dtm_elems_out)
     deck = parse_hci_deck(text)
     return run_hci(deck, a.fcidump)
 

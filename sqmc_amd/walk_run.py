@@ -182,7 +182,8 @@ def _nint(x):
     return int(math.floor(x + 0.5)) if x >= 0 else -int(math.floor(-x + 0.5))
 
 
-def run_walk(deck, fcidump="FCIDUMP", out=sys.stdout, walkalize=None, max_equil_sets=50):
+def run_walk(deck, fcidump="FCIDUMP", out=sys.stdout, walkalize=None, max_equil_sets=50, psit_con_in=None, psit_con_out=None,
+             dtm_elems_in=None, dtm_elems_out=None):
     import torch            # noqa: F401  one libamdhip64 per process
     import sqmc_amd
     from . import host as H
@@ -216,6 +217,25 @@ def run_walk(deck, fcidump="FCIDUMP", out=sys.stdout, walkalize=None, max_equil_
     s = hst.setup_walk(g, **skw)
     if d["tau"] != 0:                                         # an explicit tau overrides tau_multiplier (do_walk.f90:1396-1412)
         s.prj_values = s.prj_values * (d["tau"] / s.tau); s.tau = d["tau"]
+    n_core = d.get("n_core_orb", 0)
+    # the reference's restart files (use_psit_con_in/out, use_elems_in/out; hamiltonian_mod.f90:1340-1400): C(T) and the
+    # deterministic space can come from, or go to, the text files a reference run writes and reads
+    if psit_con_in:
+        p(" Reading in the local energies from the file " + psit_con_in)
+        s.ct_up, s.ct_dn, s.ct_num, s.ct_den = H.read_psit_connections(psit_con_in, hst.nup, hst.ndn, n_core)
+        in_t = np.abs(s.ct_den) > 1e-12
+        s.psi_up, s.psi_dn, s.psi_c = s.ct_up[in_t], s.ct_dn[in_t], s.ct_den[in_t]
+        s.e_trial0 = float(np.dot(s.ct_num, s.ct_den) / np.dot(s.ct_den, s.ct_den))
+    if dtm_elems_in and semi:
+        p(" Reading in the matrix elements from the file " + dtm_elems_in)
+        s.imp_up, s.imp_dn, s.prj_counts, s.prj_indices, hv, s.e_var = H.read_dtm_elems(dtm_elems_in, hst.nup, hst.ndn, n_core)
+        s.prj_values = -s.tau * hv
+    if psit_con_out:
+        p(" Dumping the local energies into file " + psit_con_out)
+        H.write_psit_connections(psit_con_out, s.psi_up, s.ct_up, s.ct_dn, s.ct_num, s.ct_den, hst.nup, hst.ndn, hst.norb, n_core)
+    if dtm_elems_out and semi:
+        p(" Dumping the deterministic matrix elements into file " + dtm_elems_out)
+        H.write_dtm_elems(dtm_elems_out, s.imp_up, s.imp_dn, s.prj_counts, s.prj_indices, s.prj_values / (-s.tau), s.e_var, n_core)
     p("ndet_psi_t, ndet_psi_t_connected, n_imp=%8d%10d%8d" % (len(s.psi_up), len(s.ct_up), len(s.imp_up)))
     p("tau=%12.8f  variational energy of the set-up space=%16.8f" % (s.tau, s.e_var))
     if semi:

@@ -96,3 +96,52 @@ def test_walk_deck_grammar_and_estimators():
     assert abs(st.e_genabs_err / expect - 1) < 0.05 and abs(st.e_blkabs_err / expect - 1) < 0.35
     assert abs(st.e_genabs_ave + 75.7) < 4 * expect and abs(st.e_blkabs_ave + 75.7) < 4 * expect
     assert 0.4 < st.t_corr < 2.5                       # uncorrelated generations: block and generation errors agree
+
+
+def test_walk_input_files_roundtrip_through_fortran_io(tmp_path):
+    """psit_connections / deterministic-matrix-element files: written by
+    sqmc_amd.host, read by a Fortran program with the reference's read statements
+    (do_walk.f90:702-741, 898-940: list-directed) and rewritten with the reference's write
+    statements (semistoch.f90:86-126, do_walk.f90:970-1010); the rewritten files read back to the
+    same data, and the psit file is byte-identical (it is fully format-controlled)."""
+    from sqmc_amd import host as H
+    exe = os.path.join(ROOT, "sqmc_amd", "fortran", "walk_io_check")
+    if not os.path.exists(exe):
+        if not os.path.exists(FLANG):
+            pytest.skip("flang absent")
+        subprocess.check_call([FLANG, "-O2", os.path.join(ROOT, "sqmc_amd", "fortran", "walk_io_check.f90"), "-o", exe])
+    rs = np.random.RandomState(5)
+    nup = ndn = 4; norb = 26; n = 3000
+
+    def dets(k):
+        out = set()
+        while len(out) < k:
+            out.add((sum(1 << int(o) for o in rs.choice(norb, nup, replace=False)), sum(1 << int(o) for o in rs.choice(norb, ndn, replace=False))))
+        a = sorted(out)
+        return np.array([x[0] for x in a], np.uint64), np.array([x[1] for x in a], np.uint64)
+    cu, cd = dets(n)
+    num = rs.randn(n) * 10 ** rs.uniform(-6, 2, n); den = np.where(rs.rand(n) < 0.05, rs.randn(n), 0.0)
+    num[0], den[0] = -75.5 * 0.9, 0.9
+    num[7] = 1e-12                                            # below the 1e-10 print threshold: dropped
+    a, b = str(tmp_path / "psit_connections.out"), str(tmp_path / "psit_back")
+    H.write_psit_connections(a, cu[:40], cu, cd, num, den, nup, ndn, norb)
+    out = subprocess.run([exe, "psit", a, b, str(nup), str(ndn), str(norb)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert open(a).read() == open(b).read()
+    ru, rd, rn, rden = H.read_psit_connections(b, nup, ndn)
+    keep = np.abs(num) > 1e-10
+    assert keep.sum() == n - 1 and np.array_equal(ru, cu[keep]) and np.array_equal(rd, cd[keep])
+    assert np.allclose(rn, num[keep], rtol=3e-16, atol=6e-16) and np.allclose(rden, den[keep], rtol=3e-16, atol=6e-16)   # f22.15 / f19.15: 15 decimals
+    # deterministic space: 500 determinants, random upper-triangular rows
+    iu, idn = dets(500)
+    counts = rs.randint(1, 30, 500); counts = np.minimum(counts, np.arange(1, 501))
+    idx = np.concatenate([[i + 1] + sorted(rs.choice(i, c - 1, replace=False) + 1) if c > 1 else [i + 1] for i, c in enumerate(counts)]).astype(np.int64)
+    val = rs.randn(len(idx)) * 10 ** rs.uniform(-8, 1, len(idx))
+    a, b = str(tmp_path / "dtm_projector.out"), str(tmp_path / "dtm_back")
+    H.write_dtm_elems(a, iu, idn, counts, idx, val, -75.66376534)
+    out = subprocess.run([exe, "dtm", a, b, str(nup), str(ndn)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr + out.stdout
+    for path in (a, b):                                      # our file, and the one Fortran wrote with the reference's statements
+        u2, d2, c2, i2, v2, e2 = H.read_dtm_elems(path, nup, ndn)
+        assert np.array_equal(u2, iu) and np.array_equal(d2, idn) and np.array_equal(c2, counts) and np.array_equal(i2, idx)
+        assert np.array_equal(v2, val) and e2 == -75.66376534

@@ -518,6 +518,14 @@ def test_walk_deck_end_to_end(tmp_path):
     assert abs(r["energy"] - (-75.7285)) < max(5 * r["energy_err"], 3e-3), (r["energy"], r["energy_err"])
     rec = open(wal).read().splitlines()
     assert len(rec) == 100 * r["n_blocks_total"] + 1 and rec[-1].endswith("nstep, nblk, w_abs_gen_target, e_trial, tau")
+    # restart files of the reference: dump C(T) and the deterministic space, start a second run from them
+    pc, de = str(tmp_path / "psit_connections.out"), str(tmp_path / "dtm_projector.out")
+    r1 = run_walk(deck, FCIDUMP, out=io.StringIO(), psit_con_out=pc, dtm_elems_out=de)
+    buf2 = io.StringIO()
+    r2 = run_walk(deck, FCIDUMP, out=buf2, psit_con_in=pc, dtm_elems_in=de)
+    assert "Reading in the local energies" in buf2.getvalue() and "Reading in the matrix elements" in buf2.getvalue()
+    assert r2["n_imp"] == 1002 and r2["tau"] == r1["tau"] and 0 < r1["n_ct"] - r2["n_ct"] < 0.2 * r1["n_ct"]     # entries with |e_num| <= 1e-10 are not written
+    assert abs(r2["energy"] - r1["energy"]) < 5 * (r1["energy_err"] + r2["energy_err"]) + 1e-3
 
 
 def test_hubbard_matrix_elements_and_proposals_bit_exact(oracle, hub44):
