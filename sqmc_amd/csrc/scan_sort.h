@@ -81,9 +81,13 @@ __device__ __forceinline__ u64 lookback_exclusive(u64 *__restrict__ state, u32 t
   return excl;
 }
 template <int SCAN_ITEMS>
-__global__ void __launch_bounds__(SCAN_BLOCK) scan_lookback_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, long long n,
-                                                                   u64 *__restrict__ state, u32 *__restrict__ ticket, u64 *__restrict__ total_out) {
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_lookback_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, long long n_arg,
+                                                                   u64 *__restrict__ state, u32 *__restrict__ ticket, u64 *__restrict__ total_out,
+                                                                   const u64 *__restrict__ n_dev) {
   constexpr int TILE_ELEMS = SCAN_BLOCK * SCAN_ITEMS;
+  // n_dev: the length lives in device memory (the launch was sized for an upper bound n_arg by a host
+  // that does not know it yet); tiles past the end scan zeros and repeat the total
+  const long long n = n_dev ? (long long)(*n_dev & 0xFFFFFFFFull) : n_arg;
   __shared__ u32 s_tile; __shared__ u64 s_excl;
   if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
   __syncthreads();
@@ -129,14 +133,14 @@ __global__ void scan_clear_kernel(u64 *state, u32 *ticket, int ntiles) {
 struct ScanWork { u64 *state; u32 *ticket; long long cap_tiles; bool self_clear; };
 
 // exclusive scan of n u64 values (< 2^62 in total); total (optional) is written on device
-static inline void device_excl_scan_u64(const u64 *in, u64 *out, long long n, u64 *total_out, ScanWork &w, hipStream_t st) {
+static inline void device_excl_scan_u64(const u64 *in, u64 *out, long long n, u64 *total_out, ScanWork &w, hipStream_t st, const u64 *n_dev = nullptr) {
   if (n <= 0) { if (total_out) hipMemsetAsync(total_out, 0, sizeof(u64), st); return; }
   const bool large = n >= SCAN_LARGE_N;
   const long long tile = (long long)SCAN_BLOCK * (large ? SCAN_ITEMS_LARGE : SCAN_ITEMS_SMALL);
   int ntiles = (int)((n + tile - 1) / tile);
   if (w.self_clear) hipLaunchKernelGGL(scan_clear_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, st, w.state, w.ticket, ntiles);
-  if (large) hipLaunchKernelGGL(scan_lookback_kernel<SCAN_ITEMS_LARGE>, dim3(ntiles), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out);
-  else hipLaunchKernelGGL(scan_lookback_kernel<SCAN_ITEMS_SMALL>, dim3(ntiles), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out);
+  if (large) hipLaunchKernelGGL(scan_lookback_kernel<SCAN_ITEMS_LARGE>, dim3(ntiles), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out, n_dev);
+  else hipLaunchKernelGGL(scan_lookback_kernel<SCAN_ITEMS_SMALL>, dim3(ntiles), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out, n_dev);
 }
 
 // ------------------------------------------------------------------------ radix sort

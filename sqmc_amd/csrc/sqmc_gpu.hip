@@ -91,6 +91,7 @@ struct DevScalars {
   u64 n_invalid;           // children that produced no walker (weight 0)
   u64 tot1;                // packed scan total 1: lo = kept after merge, hi = rounding draws
   u64 tot2;                // packed scan total 2: lo = final walkers, hi = det-space walkers
+  u64 nwalk;               // walkers after the last finished step (k_finish); the next step's head kernels read it when the host does not know it yet
   int err;                 // SQMC_ERR_* raised on device
   int pad;
   double stats[16];
@@ -134,6 +135,9 @@ struct sqmc_gpu_ctx {
   int timing; hipEvent_t ev0[NTIMERS], ev1[NTIMERS]; const char *tname[NTIMERS]; int nt; float tms[NTIMERS];
   double tsum[NTIMERS]; long long tsteps;         // accumulated over the steps since sqmc_gpu_set_timing
   hipStream_t st2; hipEvent_t e_fork, e_join, e_cnt;    // second stream: death + deterministic projection beside spawn + sort
+  // pipelined head (sqmc_gpu_run, COUNTER discipline, target population reached): gate + scan + spawn of step n+1 are
+  // enqueued right behind k_finish of step n, before the host has read step n's sums
+  bool pipeline_next, head_ready; StepP head_p; u64 head_cseq; hipEvent_t hev[4];
 };
 
 // ===================================================================== step kernels
@@ -141,8 +145,9 @@ struct sqmc_gpu_ctx {
 // gate + child count (COUNTER discipline).  do_walk.f90:3577-3589
 __global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, const double *__restrict__ wt,
                                               u64 *__restrict__ nchild, double *__restrict__ wchild, u64 *__restrict__ keys, u32 *__restrict__ vals,
-                                              long long n, StepP p, u64 seed, u64 step, DevScalars *sc, int pack) {
+                                              long long n_arg, StepP p, u64 seed, u64 step, DevScalars *sc, int pack, int n_on_device) {
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  const long long n = n_on_device ? (long long)sc->nwalk : n_arg;      // pipelined head: the grid covers an upper bound
   if (i == 0) { sc->n_invalid = 0; sc->tot1 = 0; sc->tot2 = 0; sc->err = 0; }   // every writer of these runs after this kernel
   if (i >= n) return;
   put_key(keys, vals, i, det_key(dev, up[i], dn[i]), pack);      // sort key of the walker itself
@@ -240,8 +245,9 @@ extern "C" int sqmc_gpu_debug_prof(unsigned long long *out) { return (int)hipMem
 // one thread per child proposal; parent found by binary search in the child offsets
 __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
                                                const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
-                                               long long n0, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc,
-                                               HostMail *mail, u64 cnt_seq, int pack) {
+                                               long long n0_arg, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc,
+                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device) {
+  const long long n0 = n_on_device ? (long long)sc->nwalk : n0_arg;     // pipelined head: launched before the host learnt the walker count
   // the grid covers the free capacity of the walker arrays; the number of children is read from
   // device memory so that the launch does not wait for the host to learn it
   PROF(0);
@@ -922,6 +928,7 @@ __device__ void finish_step(const double *__restrict__ partials, int nblocks, co
     double *o = sc->stats;
     o[0] = tot[0]; o[1] = tot[1]; o[2] = tot[2]; o[3] = tot[3]; o[4] = tot[4];
     o[5] = (double)(sc->tot2 & 0xFFFFFFFFull); o[6] = tot[6];
+    sc->nwalk = sc->tot2 & 0xFFFFFFFFull;
     o[7] = tot[NSTAT + 1]; o[8] = tot[8]; o[9] = tot[9]; o[10] = tot[10];
     o[11] = tot[11]; o[12] = tot[12]; o[13] = tot[5]; o[14] = tot[NSTAT]; o[15] = (double)sc->n_children;
     if (mode == 0) sc->lcg = lcg_skip(sc->lcg, sc->tot1 >> 32);
@@ -1312,6 +1319,7 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
   HIPCHK(hipStreamCreate(&c->st2));
   HIPCHK(hipEventCreateWithFlags(&c->e_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->e_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->e_cnt, hipEventDisableTiming));
+  for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->hev[i]));
   *out = c;
   return SQMC_OK;
 }
@@ -1424,6 +1432,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   hipFree(c->d_sc); hipHostFree(c->h_sc); if (c->h_mail) hipHostFree((void *)c->h_mail);
   for (int i = 0; i < NTIMERS; i++) { hipEventDestroy(c->ev0[i]); hipEventDestroy(c->ev1[i]); }
   hipEventDestroy(c->e_fork); hipEventDestroy(c->e_join); hipEventDestroy(c->e_cnt);
+  for (int i = 0; i < 4; i++) hipEventDestroy(c->hev[i]);
   hipStreamDestroy(c->st2); hipStreamDestroy(c->st);
   delete c;
   return SQMC_OK;
@@ -1595,6 +1604,46 @@ static void collect_timers(sqmc_gpu_ctx *c) {
   }
   c->tsteps++;
 }
+// The head of a step: spawn gate + child offsets + k_spawn (COUNTER discipline).  With dev_n the
+// walker count is read on the device (sc->nwalk, written by k_finish of the step before) and n0 is
+// only an upper bound that sizes the grids: the pipelined launch behind k_finish of the previous
+// step, before the host has read that step's sums.  g0/g1 and s0/s1 (may be null) time gate+scan
+// and k_spawn; the child count goes to the host mailbox under sequence number *cseq.
+static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0, bool dev_n, hipEvent_t g0, hipEvent_t g1, hipEvent_t s0, hipEvent_t s1, u64 *cseq) {
+  hipStream_t st = c->st;
+  const long long M = c->mwalk;
+  ScanWork sw0; sw0.state = c->d_scan_state; sw0.ticket = c->d_scan_ticket; sw0.cap_tiles = c->cap_tiles; sw0.self_clear = false;
+  if (g0) hipEventRecord(g0, st);
+  hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
+                     n0, p, c->seed64, step, c->d_sc, c->pack, dev_n ? 1 : 0);
+  device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st, dev_n ? &c->d_sc->nwalk : nullptr);
+  if (g1) hipEventRecord(g1, st);
+  // ---- spawn goes out first: the host is the slower side at the start of a step, and k_spawn
+  //      is on the critical path (exactly one k_spawn launch inside this timer: the per-launch time
+  //      bench.py reports, taken from the kernel's own start/stop timestamps).  It is launched
+  //      over the whole free capacity with a device-side child count and posts that count to the
+  //      host mailbox as soon as it starts.
+  HIPCHK(hipEventRecord(c->e_fork, st));
+  *cseq = ++c->cnt_seq;
+  const long long nfree = dev_n ? M : M - n0;          // dev_n: nothing is known about the count but that it is >= 0
+  if (nfree > 0) {
+    if (s0)
+      hipExtLaunchKernelGGL(k_spawn, dim3(nblk(nfree)), dim3(TPB), 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
+                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0);
+    else
+      hipLaunchKernelGGL(k_spawn, dim3(nblk(nfree)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0);
+  } else if (s0) { hipEventRecord(s0, st); hipEventRecord(s1, st); }
+  HIPCHK(hipGetLastError());
+  return SQMC_OK;
+}
+// a pipelined head whose step will not run (the step before it failed): drain it and reset what it touched
+static void drop_head(sqmc_gpu_ctx *c) {
+  if (!c->head_ready) return;
+  c->head_ready = false;
+  hipStreamSynchronize(c->st);
+  hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
+}
 // sort -> merge -> round -> compact/estimate -> readback; shared by the single-rank step and
 // the sharded step (where the spawns behind slot n0 arrived from other ranks)
 static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long nall, bool join_side_stream, double out[16]) {
@@ -1653,6 +1702,15 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long na
                      (int)(3 * c->cap_tiles), use_mail ? c->d_mail : (HostMail *)nullptr, seq, c->d_fstate, c->d_fticket, c->cap_ftiles, n_ft);
   TEND(estimate, st);
   HIPCHK(hipGetLastError());
+  if (c->pipeline_next) {
+    // the next step's gate + scan + spawn go out now, behind k_finish: the GPU runs on while the host
+    // reads this step's sums and does its population control.  nall bounds the new walker count.
+    c->pipeline_next = false;
+    int rh = enqueue_head(c, p, step + 1, nall, true, c->timing >= 2 ? c->hev[0] : nullptr, c->timing >= 2 ? c->hev[1] : nullptr,
+                          c->timing >= 1 ? c->hev[2] : nullptr, c->timing >= 1 ? c->hev[3] : nullptr, &c->head_cseq);
+    if (rh) return rh;
+    c->head_ready = true; c->head_p = p;
+  }
   if (!use_mail) {
     int rr = comm_allreduce_stats(c); if (rr) return rr;      // do_walk.f90:2778-2790: the sums every rank needs
     hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(64), 0, st, (const DevScalars *)c->d_sc, c->d_mail, seq);
@@ -1666,12 +1724,12 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long na
   }
   c->timers_pending = (c->timing != 0);
   c->step_no++;
-  if (c->h_sc->err) return fail(c->h_sc->err, "diagonal_factor<0 after target population has been reached");
+  if (c->h_sc->err) { drop_head(c); return fail(c->h_sc->err, "diagonal_factor<0 after target population has been reached"); }
   const long long nfinal = (long long)(c->h_sc->tot2 & 0xFFFFFFFFull), nimp = (long long)(c->h_sc->tot2 >> 32);
   c->nwalk = nfinal;
   for (int i = 0; i < 16; i++) out[i] = c->h_sc->stats[i];
-  if (nfinal == 0) return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0");
-  if (p.semi && nimp != (c->shard_n > 1 || c->d_grow ? c->n_imp_local : c->n_imp)) return fail(SQMC_ERR_IMP_BROKEN, "locations of my imp broken");
+  if (nfinal == 0) { drop_head(c); return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0"); }
+  if (p.semi && nimp != (c->shard_n > 1 || c->d_grow ? c->n_imp_local : c->n_imp)) { drop_head(c); return fail(SQMC_ERR_IMP_BROKEN, "locations of my imp broken"); }
   return SQMC_OK;
 }
 
@@ -1687,39 +1745,46 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   p.semi = sp->semistochastic; p.reached = sp->reached_w_abs_gen;
   const long long n0 = c->nwalk, M = c->mwalk;
   const int mode = c->rng_mode; const u64 seed = c->seed64, step = c->step_no;
-  ScanWork sw[3];      // one look-back state per scan of the step; k_finish re-zeroes them for the next step
-  for (int q = 0; q < 3; q++) { sw[q].state = c->d_scan_state + q * c->cap_tiles; sw[q].ticket = c->d_scan_ticket + q; sw[q].cap_tiles = c->cap_tiles; sw[q].self_clear = false; }
   collect_timers(c);
   c->nt = 0;
   hipStream_t st2 = c->st2;
-  // ---- gate / child offsets (the gate kernel also clears the step's device scalars)
-  TBEG(gate_scan, st);
-  if (mode == SQMC_RNG_REPLAY) {
+  int t_gate_scan = -1, t_spawn = -1;
+  if (c->timing >= 2 && c->nt < NTIMERS) { t_gate_scan = c->nt++; c->tname[t_gate_scan] = "gate_scan"; }
+  if (c->timing >= 1 && c->nt < NTIMERS) { t_spawn = c->nt++; c->tname[t_spawn] = "spawn"; }
+  u64 cseq;
+  if (c->head_ready) {
+    // gate + scan + spawn of this step already run behind k_finish of the last one (pipelined head):
+    // they only depend on parameters that are constant once the target population has been reached
+    c->head_ready = false;
+    const StepP &h = c->head_p;
+    if (h.tau != p.tau || h.cutoff != p.cutoff || h.semi != p.semi || h.cti != p.cti || mode == SQMC_RNG_REPLAY) {
+      hipStreamSynchronize(st);
+      return fail(SQMC_ERR_BAD_ARG, "internal: the pipelined head of this step was launched with other parameters");
+    }
+    cseq = c->head_cseq;
+    if (t_gate_scan >= 0) { std::swap(c->ev0[t_gate_scan], c->hev[0]); std::swap(c->ev1[t_gate_scan], c->hev[1]); }
+    if (t_spawn >= 0) { std::swap(c->ev0[t_spawn], c->hev[2]); std::swap(c->ev1[t_spawn], c->hev[3]); }
+  } else if (mode == SQMC_RNG_REPLAY) {
+    // ---- gate / child offsets (the gate kernel also clears the step's device scalars)
+    if (t_gate_scan >= 0) hipEventRecord(c->ev0[t_gate_scan], st);
     hipLaunchKernelGGL(k_replay_prepass, dim3(1), dim3(64), 0, st, c->d_tab, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_child_off,
                        c->d_child_state, n0, M - n0, p, c->d_sc);
+    if (t_gate_scan >= 0) hipEventRecord(c->ev1[t_gate_scan], st);
+    HIPCHK(hipEventRecord(c->e_fork, st));
+    cseq = ++c->cnt_seq;
+    if (M > n0) {
+      if (t_spawn >= 0)
+        hipExtLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->ev0[t_spawn], c->ev1[t_spawn], 0, c->dev, c->w, c->d_child_off, c->d_wchild,
+                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0);
+      else
+        hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0);
+    } else if (t_spawn >= 0) { hipEventRecord(c->ev0[t_spawn], st); hipEventRecord(c->ev1[t_spawn], st); }
   } else {
-    hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
-                       n0, p, seed, step, c->d_sc, c->pack);
-    device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw[0], st);
+    int r = enqueue_head(c, p, step, n0, false, t_gate_scan >= 0 ? c->ev0[t_gate_scan] : nullptr, t_gate_scan >= 0 ? c->ev1[t_gate_scan] : nullptr,
+                         t_spawn >= 0 ? c->ev0[t_spawn] : nullptr, t_spawn >= 0 ? c->ev1[t_spawn] : nullptr, &cseq);
+    if (r) return r;
   }
-  TEND(gate_scan, st);
-  // ---- spawn goes out first: the host is the slower side at the start of a step, and k_spawn
-  //      is on the critical path (exactly one k_spawn launch inside this timer: the per-launch time
-  //      bench.py reports, taken from the kernel's own start/stop timestamps).  It is launched
-  //      over the whole free capacity with a device-side child count and posts that count to the
-  //      host mailbox as soon as it starts.
-  HIPCHK(hipEventRecord(c->e_fork, st));
-  const u64 cseq = ++c->cnt_seq;
-  int t_spawn = -1;
-  if (c->timing >= 1 && c->nt < NTIMERS) { t_spawn = c->nt++; c->tname[t_spawn] = "spawn"; }
-  if (M > n0) {
-    if (t_spawn >= 0)
-      hipExtLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->ev0[t_spawn], c->ev1[t_spawn], 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack);
-    else
-      hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack);
-  } else if (t_spawn >= 0) { hipEventRecord(c->ev0[t_spawn], st); hipEventRecord(c->ev1[t_spawn], st); }
   // ---- fork: death/clone and the deterministic projection only touch weights, which neither
   //      the spawn kernel (it uses the child weights of the gate) nor the sort reads
   HIPCHK(hipStreamWaitEvent(st2, c->e_fork, 0));
@@ -1770,9 +1835,14 @@ static int run_steps(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *s
     sp.min_wt = pc->min_wt; sp.always_spawn_cutoff_wt = pc->always_spawn_cutoff_wt; sp.initiator_power = pc->initiator_power;
     sp.initiator_min_distance = pc->initiator_min_distance; sp.c_t_initiator = pc->c_t_initiator; sp.semistochastic = pc->semistochastic;
     sp.reached_w_abs_gen = pc->reached_w_abs_gen; sp.reserved = 0;
+    // pipelined head: once the target population has been reached tau and r_initiator stay put, and the head of a step
+    // (gate, scan, spawn) depends on nothing else that this step's sums could change
+    c->pipeline_next = (one_step == (step_fn)sqmc_gpu_step && it + 1 < nsteps && pc->reached_w_abs_gen == 2 && c->rng_mode != SQMC_RNG_REPLAY &&
+                        !getenv("SQMC_NO_PIPELINE"));
     double out[16];
     int r = one_step(c, &sp, out);
-    if (r) return r;
+    c->pipeline_next = false;
+    if (r) { drop_head(c); return r; }
     if (stats) memcpy(stats + it * 16, out, sizeof(out));
     for (int k = 0; k < 16; k++) totals[k] += out[k];
     // do_walk.f90:2880-2923
@@ -1962,7 +2032,7 @@ static int shard_begin_impl(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double 
   const u64 cseq = ++c->cnt_seq;
   if (n0 > 0) {
     hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
-                       n0, p, c->seed64, c->step_no, c->d_sc, c->pack);
+                       n0, p, c->seed64, c->step_no, c->d_sc, c->pack, 0);
     device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st);
   }
   if (side) HIPCHK(hipEventRecord(c->e_fork, st));
@@ -1970,7 +2040,7 @@ static int shard_begin_impl(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double 
     TBEG(spawn, st);
     if (M > n0)      // first: it posts the child count to the host mailbox as soon as it starts
       hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, c->rng_mode, c->seed64, c->step_no, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack);
+                         n0, M, p, c->rng_mode, c->seed64, c->step_no, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0);
     TEND(spawn, st);
   }
   if (side) {
