@@ -142,12 +142,20 @@ struct sqmc_gpu_ctx {
 
 // ===================================================================== step kernels
 
+// Everything k_finish does, as arguments: in the pipelined head the first block of the NEXT step's gate
+// kernel does it (one launch less on the critical path).
+struct FinArgs {
+  const double *partials; int nblocks; const double *wabs_part; int nwabs; int mode; u64 *scan_state; u32 *scan_ticket; int n_scan_words;
+  HostMail *mail; u64 seq; u64 *fstate; u32 *fticket; long long cap_ftiles; int n_ftiles; int on;
+};
+__device__ void finish_all(const FinArgs &f, DevScalars *sc);
 // gate + child count (COUNTER discipline).  do_walk.f90:3577-3589
 __global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, const double *__restrict__ wt,
                                               u64 *__restrict__ nchild, double *__restrict__ wchild, u64 *__restrict__ keys, u32 *__restrict__ vals,
-                                              long long n_arg, StepP p, u64 seed, u64 step, DevScalars *sc, int pack, int n_on_device) {
+                                              long long n_arg, StepP p, u64 seed, u64 step, DevScalars *sc, int pack, int n_on_device, FinArgs fin) {
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   const long long n = n_on_device ? (long long)sc->nwalk : n_arg;      // pipelined head: the grid covers an upper bound
+  if (fin.on && blockIdx.x == 0) finish_all(fin, sc);                  // the last step's final sums and mail, before this step clears the scalars
   if (i == 0) { sc->n_invalid = 0; sc->tot1 = 0; sc->tot2 = 0; sc->err = 0; }   // every writer of these runs after this kernel
   if (i >= n) return;
   put_key(keys, vals, i, det_key(dev, up[i], dn[i]), pack);      // sort key of the walker itself
@@ -819,7 +827,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
   for (int q = 0; q < TPB / 64; q++) { if (q < wv) ex += s_wsum[1][q]; tot += s_wsum[1][q]; }
   if (threadIdx.x < 64) {
     const u64 e = lookback_exclusive(state2, tile, tot, threadIdx.x);
-    if (threadIdx.x == 0) { s_ex[1] = e; if (last_tile) sc->tot2 = e + tot; }
+    if (threadIdx.x == 0) { s_ex[1] = e; if (last_tile) { sc->tot2 = e + tot; sc->nwalk = (e + tot) & 0xFFFFFFFFull; } }
   }
   __syncthreads();
   ex += s_ex[1];
@@ -878,19 +886,19 @@ __global__ void k_post_mail(const DevScalars *sc, HostMail *mail, u64 seq) {
 }
 // The final reduction stays a kernel of its own: folding it into the last-arriving block of
 // k_compact needs an agent-scope release in every block and cost more than this launch.
-__global__ void __launch_bounds__(TPB) k_finish(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
-                                                int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words,
-                                                HostMail *mail, u64 seq, u64 *__restrict__ fstate, u32 *__restrict__ fticket, long long cap_ftiles, int n_ftiles) {
+__global__ void __launch_bounds__(TPB) k_finish(FinArgs f, DevScalars *sc) { finish_all(f, sc); }
+__device__ void finish_all(const FinArgs &f, DevScalars *sc) {
   // the look-back words k_anneal used this step (two arrays, n_ftiles words each) are zero again for the next one
-  for (int i = threadIdx.x; i < n_ftiles; i += TPB) { fstate[i] = 0; fstate[cap_ftiles + i] = 0; }
-  if (threadIdx.x == 0 && n_ftiles > 0) *fticket = 0;
-  finish_step(partials, nblocks, wabs_part, nwabs, mode, sc, scan_state, scan_ticket, n_scan_words);
-  if (mail && threadIdx.x == 0) {
-    for (int i = 0; i < 16; i++) mail->stats[i] = sc->stats[i];
-    mail->tot2 = sc->tot2; mail->err = sc->err;
+  for (int i = threadIdx.x; i < f.n_ftiles; i += TPB) { f.fstate[i] = 0; f.fstate[f.cap_ftiles + i] = 0; }
+  if (threadIdx.x == 0 && f.n_ftiles > 0) *f.fticket = 0;
+  finish_step(f.partials, f.nblocks, f.wabs_part, f.nwabs, f.mode, sc, f.scan_state, f.scan_ticket, f.n_scan_words);
+  if (f.mail && threadIdx.x == 0) {
+    for (int i = 0; i < 16; i++) f.mail->stats[i] = sc->stats[i];
+    f.mail->tot2 = sc->tot2; f.mail->err = sc->err;
     __threadfence_system();
-    mail->seq = seq;
+    f.mail->seq = f.seq;
   }
+  __syncthreads();
 }
 
 // final reduction: sums block partials
@@ -1609,13 +1617,15 @@ static void collect_timers(sqmc_gpu_ctx *c) {
 // only an upper bound that sizes the grids: the pipelined launch behind k_finish of the previous
 // step, before the host has read that step's sums.  g0/g1 and s0/s1 (may be null) time gate+scan
 // and k_spawn; the child count goes to the host mailbox under sequence number *cseq.
-static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0, bool dev_n, hipEvent_t g0, hipEvent_t g1, hipEvent_t s0, hipEvent_t s1, u64 *cseq) {
+static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0, bool dev_n, hipEvent_t g0, hipEvent_t g1, hipEvent_t s0, hipEvent_t s1, u64 *cseq,
+                        const FinArgs *fin = nullptr) {
   hipStream_t st = c->st;
   const long long M = c->mwalk;
   ScanWork sw0; sw0.state = c->d_scan_state; sw0.ticket = c->d_scan_ticket; sw0.cap_tiles = c->cap_tiles; sw0.self_clear = false;
+  FinArgs fa; memset(&fa, 0, sizeof(fa)); if (fin) fa = *fin;
   if (g0) hipEventRecord(g0, st);
   hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
-                     n0, p, c->seed64, step, c->d_sc, c->pack, dev_n ? 1 : 0);
+                     n0, p, c->seed64, step, c->d_sc, c->pack, dev_n ? 1 : 0, fa);
   device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st, dev_n ? &c->d_sc->nwalk : nullptr);
   if (g1) hipEventRecord(g1, st);
   // ---- spawn goes out first: the host is the slower side at the start of a step, and k_spawn
@@ -1697,9 +1707,14 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long na
                        c->d_ct_num, c->d_ct_den, nall, p, c->d_partials, c->pack);
     TEND(compact, st);
   }
+  FinArgs fa;
+  fa.partials = c->d_partials; fa.nblocks = nb; fa.wabs_part = c->d_wabs_part; fa.nwabs = p.semi ? nb : nbm; fa.mode = mode;
+  fa.scan_state = c->d_scan_state; fa.scan_ticket = c->d_scan_ticket; fa.n_scan_words = (int)(3 * c->cap_tiles);
+  fa.mail = use_mail ? c->d_mail : (HostMail *)nullptr; fa.seq = seq; fa.fstate = c->d_fstate; fa.fticket = c->d_fticket; fa.cap_ftiles = c->cap_ftiles;
+  fa.n_ftiles = n_ft; fa.on = 1;
+  const bool fin_in_gate = c->pipeline_next && p.semi && use_mail;     // the next step's gate kernel does the final sums in its first block
   TBEG(estimate, st);
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, c->d_partials, nb, c->d_wabs_part, p.semi ? nb : nbm, mode, c->d_sc, c->d_scan_state, c->d_scan_ticket,
-                     (int)(3 * c->cap_tiles), use_mail ? c->d_mail : (HostMail *)nullptr, seq, c->d_fstate, c->d_fticket, c->cap_ftiles, n_ft);
+  if (!fin_in_gate) hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, fa, c->d_sc);
   TEND(estimate, st);
   HIPCHK(hipGetLastError());
   if (c->pipeline_next) {
@@ -1707,7 +1722,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long na
     // reads this step's sums and does its population control.  nall bounds the new walker count.
     c->pipeline_next = false;
     int rh = enqueue_head(c, p, step + 1, nall, true, c->timing >= 2 ? c->hev[0] : nullptr, c->timing >= 2 ? c->hev[1] : nullptr,
-                          c->timing >= 1 ? c->hev[2] : nullptr, c->timing >= 1 ? c->hev[3] : nullptr, &c->head_cseq);
+                          c->timing >= 1 ? c->hev[2] : nullptr, c->timing >= 1 ? c->hev[3] : nullptr, &c->head_cseq, fin_in_gate ? &fa : nullptr);
     if (rh) return rh;
     c->head_ready = true; c->head_p = p;
   }
@@ -2032,7 +2047,7 @@ static int shard_begin_impl(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double 
   const u64 cseq = ++c->cnt_seq;
   if (n0 > 0) {
     hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
-                       n0, p, c->seed64, c->step_no, c->d_sc, c->pack, 0);
+                       n0, p, c->seed64, c->step_no, c->d_sc, c->pack, 0, FinArgs{});
     device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st);
   }
   if (side) HIPCHK(hipEventRecord(c->e_fork, st));
