@@ -528,6 +528,21 @@ def test_walk_deck_end_to_end(tmp_path):
     assert abs(r2["energy"] - r1["energy"]) < 5 * (r1["energy_err"] + r2["energy_err"]) + 1e-3
 
 
+@pytest.mark.parametrize("deckname,lo,hi", [("heg14_i_walk", 58.270, 58.280), ("hubbard4x4_i_walk", -12.5, -10.0)])
+def test_walk_decks_of_the_other_systems(deckname, lo, hi):
+    """Walk decks for the electron gas (the system of the reference's e2e fixtures, whose HCI total
+    energy is 58.27597) and for the real-space Hubbard lattice of BASELINE.json configs[0] (exact
+    ground state -13.62 t; at 1e4 walkers the initiator approximation sits well above it)."""
+    import io, os
+    from sqmc_amd.walk_run import parse_walk_deck, run_walk
+    deck = parse_walk_deck(open(os.path.join(os.path.dirname(__file__), "golden", deckname)).read())
+    buf = io.StringIO()
+    r = run_walk(deck, out=buf)
+    assert "Equilibration of everything achieved" in buf.getvalue() and "Energy=" in buf.getvalue()
+    assert lo < r["energy"] < hi, r
+    assert r["nwalk_av"] > 5000 and r["energy_err"] < 0.05
+
+
 def test_hubbard_matrix_elements_and_proposals_bit_exact(oracle, hub44):
     """hamiltonian_hubbard / off_diagonal_move_hubbard (real-space Hubbard,
     BASELINE.json configs[0] lattice) on the GPU against the oracle: values, determinants and the
