@@ -24,9 +24,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 FCIDUMP = os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# HBM bytes per k_spawn launch from the PMC passes in profiles/ (FETCH_SIZE doubled as the guide
-# prescribes for gfx950, + WRITE_SIZE, KiB -> bytes); None until measured for the current kernel.
-TRAFFIC_K_SPAWN = 1.97e7      # profiles/r01_bench_1e5_rocprof_summary.txt: (2*6466.8 + 6328.9) KiB
+# HBM bytes per launch from the PMC passes in profiles/ (FETCH_SIZE doubled as the guide prescribes for
+# gfx950, + WRITE_SIZE, KiB -> bytes), default configuration only
+TRAFFIC_K_ANNEAL = 3.32e7     # profiles/r01_bench_1e5_rocprof_summary.txt: (2*12534.5 + 7311.8) KiB
+TRAFFIC_K_SPAWN = 1.97e7      # same file: (2*6505.5 + 6252.1) KiB
 
 
 def main():
@@ -145,7 +146,8 @@ def main():
         # out[5] (nwalk) is already the all-reduced global count; spawns (out[15]) are rank-local
         nwalk_sum, spawn_sum = float(stats[:, 5].sum()) / world, float(stats[:, 15].sum())
         e_num, e_den = float((stats[:, 3] * np.sign(stats[:, 2])).sum()), float(np.abs(stats[:, 2]).sum())
-        spawn_ms = dict(walk.g.timing()).get("spawn", float("nan"))
+        timers_timed = walk.g.timing()
+        spawn_ms = dict(timers_timed).get("spawn", float("nan"))
         walk.g.set_timing(2)
         for _ in range(10):
             walk.step()
@@ -162,7 +164,8 @@ def main():
         dt = time.perf_counter() - t0
         nwalk_sum, spawn_sum = float(totals[5]) / (world if sharded else 1), float(totals[15])      # sharded: nwalk is the global count
         e_num, e_den = float((stats[:, 3] * np.sign(stats[:, 2])).sum()), float(np.abs(stats[:, 2]).sum())
-        spawn_ms = dict(walk.g.timing())["spawn"]          # mean ms per k_spawn launch over the K timed steps
+        timers_timed = walk.g.timing()                     # mean ms per k_spawn / k_anneal launch over the K timed steps
+        spawn_ms = dict(timers_timed)["spawn"]
         walk.g.set_timing(2)                                # informational stage breakdown from an untimed tail
         walk.run(20, keep_stats=False)
         stage_ms = dict(walk.g.timing())
@@ -175,14 +178,21 @@ def main():
 
     if rank == 0:
         value = nwalk_all / dt
-        # dominant single kernel of the step: k_spawn (one launch per step; the "spawn" timer is the
-        # pair of HIP events hipExtLaunchKernelGGL attaches to that launch on the library's stream:
-        # the kernel's own start/stop timestamps, what rocprofv3 --kernel-trace reports).
-        # Algorithmic bytes per launch = 84 B per child proposal x children.
+        # Dominant kernel = the longest one on the step's critical path: k_anneal (annihilation + rounding + compaction
+        # + estimator sums, one launch per step).  Its timer is the pair of HIP events hipExtLaunchKernelGGL attaches
+        # to that launch on the library's stream: the kernel's own start/stop timestamps, what rocprofv3
+        # --kernel-trace reports.  Algorithmic bytes per launch: 68 B per occupied determinant
+        # (walker read + write) + 58 B per child proposal (26 B read-back + 32 B annihilation slot; the other 26 B
+        # of a spawn's 84 B are its write in k_spawn, reported beside it).
         n_avg, s_avg = nwalk_sum / args.steps, spawn_sum / args.steps
-        dom, dom_ms = "k_spawn", spawn_ms
-        ach = 84.0 * s_avg / (dom_ms * 1e-3) / 1e9
+        timers = dict(timers_timed)
+        if "anneal" in timers:
+            dom, dom_ms, dom_bytes = "k_anneal", timers["anneal"], 68.0 * n_avg + 58.0 * s_avg
+        else:                                  # semistochastic = f keeps the unfused tail: k_spawn is then the longest single kernel
+            dom, dom_ms, dom_bytes = "k_spawn", spawn_ms, 26.0 * s_avg + 34.0 * n_avg
+        ach = dom_bytes / (dom_ms * 1e-3) / 1e9
         step_bytes = 68.0 * n_avg + 84.0 * s_avg
+        default_cfg = (args.system == "c2" and args.target == 1e5 and world == 1)
         line = {
             "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if sharded else "weak",
@@ -194,7 +204,10 @@ def main():
                        "occupied_dets_per_step": n_avg, "spawns_per_step": s_avg, "spawns_per_s": spawn_all / dt,
                        "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": parallelism},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": TRAFFIC_K_SPAWN if (args.system == "c2" and args.target == 1e5 and world == 1) else None, "ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": 84.0 * s_avg,
+                         "traffic": (TRAFFIC_K_ANNEAL if dom == "k_anneal" else TRAFFIC_K_SPAWN) if default_cfg else None, "ms_per_launch": dom_ms,
+                         "algorithmic_bytes_per_launch": dom_bytes,
+                         "other_kernels": {"k_spawn": {"ms_per_launch": spawn_ms, "algorithmic_bytes_per_launch": 26.0 * s_avg + 34.0 * n_avg,
+                                                       "achieved": (26.0 * s_avg + 34.0 * n_avg) / (spawn_ms * 1e-3) / 1e9, "traffic": TRAFFIC_K_SPAWN if default_cfg else None}},
                          "whole_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
                                         "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
                          "stage_ms_per_step": stage_ms},

@@ -1679,18 +1679,22 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long na
   int nb, n_ft = 0;
   if (p.semi) {
     // one kernel from the sorted list to the new walker arrays; the buffers swap roles afterwards
-    TBEG(anneal, st);
+    // timed by the kernel's own start/stop timestamps (hipExtLaunchKernelGGL events) at every timing level: the
+    // per-launch time bench.py reports for the roofline of this, the longest kernel on the critical path
+    int t_anneal = -1;
+    if (c->timing >= 1 && c->nt < NTIMERS) { t_anneal = c->nt++; c->tname[t_anneal] = "anneal"; }
     static const int items_env = getenv("SQMC_ANNEAL_ITEMS") ? atoi(getenv("SQMC_ANNEAL_ITEMS")) : 0;
     const int items = items_env ? items_env : (nall < (1ll << 20) ? 2 : 4);     // small lists want many tiles, large ones short look-back chains
     nb = n_ft = (int)((nall + (long long)TPB * items - 1) / ((long long)TPB * items));
-#define ANNEAL_LAUNCH(I) hipLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, \
-                       c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, n0, nall, p, c->invalid_key, c->pack, mode, seed, step, c->d_sc,          \
-                       c->d_fstate, c->d_fstate + c->cap_ftiles, c->d_fticket)
+#define ANNEAL_ARGS c->w, c->m, skey, perm, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, n0, nall, p,  \
+                    c->invalid_key, c->pack, mode, seed, step, c->d_sc, c->d_fstate, c->d_fstate + c->cap_ftiles, c->d_fticket
+#define ANNEAL_LAUNCH(I) do { if (t_anneal >= 0) hipExtLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, ANNEAL_ARGS); \
+                              else hipLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, ANNEAL_ARGS); } while (0)
     if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 8) ANNEAL_LAUNCH(8); else ANNEAL_LAUNCH(4);
 #undef ANNEAL_LAUNCH
+#undef ANNEAL_ARGS
     std::swap(c->w.up, c->m.up); std::swap(c->w.dn, c->m.dn); std::swap(c->w.wt, c->m.wt); std::swap(c->w.flg, c->m.flg);
     std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed);
-    TEND(anneal, st);
   } else {
     TBEG(merge, st);
     hipLaunchKernelGGL(k_merge, dim3(nbm), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, c->d_wabs_part, n0, nall, p, c->invalid_key, c->pack);
