@@ -280,3 +280,54 @@ static inline void device_radix_sort(u64 *&keys, u32 *&vals, long long n, int nb
   }
   w.k_alt = kb; if (vals) { w.v_alt = vb; vals = va; } keys = ka;
 }
+
+// ------------------------------------------------------------------------ merge of two sorted runs
+// Stable merge on (word >> shift), A before B on equal keys (the walkers of a step are already in
+// order: only the spawns need sorting, then one merge).  Merge path: a 256-thread block per tile
+// of MP_TILE outputs finds the tile's split of A and B by a binary search on its diagonal, stages
+// both segments in LDS, every thread finds its own diagonal there, merges MP_ITEMS outputs
+// sequentially, and the tile leaves through LDS in coalesced rows.
+#define MP_ITEMS 8
+#define MP_TILE (256 * MP_ITEMS)
+// number of A elements among the first d outputs of the merge
+template <typename P>
+__device__ __forceinline__ long long merge_path_split(P A, long long nA, P B, long long nB, long long d, int shift) {
+  long long lo = d > nB ? d - nB : 0, hi = d < nA ? d : nA;
+  while (lo < hi) {
+    const long long i = (lo + hi) >> 1;
+    if ((A[i] >> shift) <= (B[d - i - 1] >> shift)) lo = i + 1; else hi = i;      // A[i] precedes that B element: it is inside
+  }
+  return lo;
+}
+__global__ void __launch_bounds__(256) merge_path_kernel(const u64 *__restrict__ A, long long nA, const u64 *__restrict__ B, long long nB,
+                                                         u64 *__restrict__ out, int shift) {
+  __shared__ u64 sA[MP_TILE], sB[MP_TILE], sO[MP_TILE];
+  __shared__ long long s_split[2];
+  const long long n = nA + nB, d0 = (long long)blockIdx.x * MP_TILE, d1 = (d0 + MP_TILE < n) ? d0 + MP_TILE : n;
+  if (threadIdx.x == 0) s_split[0] = merge_path_split(A, nA, B, nB, d0, shift);
+  if (threadIdx.x == 64) s_split[1] = merge_path_split(A, nA, B, nB, d1, shift);
+  __syncthreads();
+  const long long a0 = s_split[0], a1 = s_split[1], b0 = d0 - a0, b1 = d1 - a1;
+  const int la = (int)(a1 - a0), lb = (int)(b1 - b0), lt = (int)(d1 - d0);
+  for (int k = threadIdx.x; k < la; k += 256) sA[k] = A[a0 + k];
+  for (int k = threadIdx.x; k < lb; k += 256) sB[k] = B[b0 + k];
+  __syncthreads();
+  const int dd = threadIdx.x * MP_ITEMS;
+  if (dd < lt) {
+    int i = (int)merge_path_split((const u64 *)sA, (long long)la, (const u64 *)sB, (long long)lb, (long long)dd, shift), j = dd - i;
+#pragma unroll
+    for (int k = 0; k < MP_ITEMS; k++) {
+      if (dd + k >= lt) break;
+      const bool takeA = (j >= lb) || (i < la && (sA[i] >> shift) <= (sB[j] >> shift));
+      sO[dd + k] = takeA ? sA[i] : sB[j];
+      if (takeA) i++; else j++;
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < lt; k += 256) out[d0 + k] = sO[k];
+}
+static inline void device_merge_sorted(const u64 *A, long long nA, const u64 *B, long long nB, u64 *out, int shift, hipStream_t st) {
+  const long long n = nA + nB;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(merge_path_kernel, dim3((unsigned)((n + MP_TILE - 1) / MP_TILE)), dim3(256), 0, st, A, nA, B, nB, out, shift);
+}

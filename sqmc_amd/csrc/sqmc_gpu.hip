@@ -138,6 +138,7 @@ struct sqmc_gpu_ctx {
   // pipelined head (sqmc_gpu_run, COUNTER discipline, target population reached): gate + scan + spawn of step n+1 are
   // enqueued right behind k_finish of step n, before the host has read step n's sums
   bool pipeline_next, head_ready; StepP head_p; u64 head_cseq; hipEvent_t hev[4];
+  bool residents_sorted;      // the walker arrays are known to be in (up, dn) order: true after every finished step, false after an upload
 };
 
 // ===================================================================== step kernels
@@ -1523,7 +1524,7 @@ int sqmc_gpu_upload_walkers(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, cons
     HIPCHK(hipMemcpy(c->w.flg, f.data(), n * 4, hipMemcpyHostToDevice)); }
   HIPCHK(hipMemcpy(c->w.me, me, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.en, en, n * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->w.ed, ed, n * 8, hipMemcpyHostToDevice));
-  c->nwalk = n;
+  c->nwalk = n; c->residents_sorted = false;      // the host's order is taken as it comes: the next step sorts everything
   if (c->n_imp > 0) {        // my_locations_of_imp_dets, do_walk.f90:2188-2212
     const long long expect = c->d_grow ? c->n_imp_local : c->n_imp;
     std::vector<int> loc; loc.reserve(expect);
@@ -1668,8 +1669,23 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long na
     hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0, c->pack);
   SortWork so; so.k_alt = c->d_keys_alt; so.v_alt = c->d_vals_alt; so.hist = c->d_hist; so.rowtot = c->d_rowtot; so.cap = M;
   u64 *skey = c->d_keys; u32 *perm = c->pack ? (u32 *)nullptr : c->d_vals;
-  device_radix_sort(skey, perm, nall, c->key_bits, so, st, c->pack ? 32 : 0);
-  if (skey != c->d_keys) { c->d_keys_alt = c->d_keys; c->d_keys = skey; if (!c->pack) { c->d_vals_alt = c->d_vals; c->d_vals = perm; } }
+  static const long long merge_min = getenv("SQMC_MERGE_SORT_MIN") ? atoll(getenv("SQMC_MERGE_SORT_MIN")) : (1ll << 20);
+  if (c->pack && p.semi && c->residents_sorted && nall >= merge_min) {
+    // Large lists: the walkers [0, n0) are in order already (every step leaves them so), so only the spawns
+    // [n0, nall) are sorted and one stable merge (walker before spawns on equal keys, spawns in creation order)
+    // gives the order the full sort would.  The merged list lands in the flag array the fused tail does not use.
+    const long long nch = nall - n0;
+    if (nch > 0) {
+      u64 *sk = c->d_keys + n0; u32 *nov = nullptr;
+      so.k_alt = c->d_keys_alt + n0;
+      device_radix_sort(sk, nov, nch, c->key_bits, so, st, 32);
+      device_merge_sorted(c->d_keys, n0, sk, nch, c->d_flags, 32, st);
+      skey = c->d_flags;
+    }
+  } else {
+    device_radix_sort(skey, perm, nall, c->key_bits, so, st, c->pack ? 32 : 0);
+    if (skey != c->d_keys) { c->d_keys_alt = c->d_keys; c->d_keys = skey; if (!c->pack) { c->d_vals_alt = c->d_vals; c->d_vals = perm; } }
+  }
   TEND(sort, st);
   // ---- join: from here on weights are read
   if (join_side_stream) HIPCHK(hipStreamWaitEvent(st, c->e_join, 0));
@@ -1745,7 +1761,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long na
   c->step_no++;
   if (c->h_sc->err) { drop_head(c); return fail(c->h_sc->err, "diagonal_factor<0 after target population has been reached"); }
   const long long nfinal = (long long)(c->h_sc->tot2 & 0xFFFFFFFFull), nimp = (long long)(c->h_sc->tot2 >> 32);
-  c->nwalk = nfinal;
+  c->nwalk = nfinal; c->residents_sorted = true;
   for (int i = 0; i < 16; i++) out[i] = c->h_sc->stats[i];
   if (nfinal == 0) { drop_head(c); return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0"); }
   if (p.semi && nimp != (c->shard_n > 1 || c->d_grow ? c->n_imp_local : c->n_imp)) { drop_head(c); return fail(SQMC_ERR_IMP_BROKEN, "locations of my imp broken"); }

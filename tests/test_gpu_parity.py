@@ -770,6 +770,18 @@ def test_annihilate_door_matches_oracle_merge(oracle, c2_walk, c2_setup, rng_mod
         assert n < n0 + 400
 
 
+def test_spawn_only_sort_and_merge_is_bit_exact():
+    """Large lists sort only the spawns and merge them into the walkers, which are in order already
+    (`SQMC_MERGE_SORT_MIN`, default 2^20 slots).  With the threshold at 0 the trajectory, annihilation
+    and sharded-invariant tests must pass unchanged: same walkers, weights and flags as the oracle."""
+    import subprocess, sys
+    env = dict(os.environ, SQMC_MERGE_SORT_MIN="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "trajectory_bit_exact or annihilate_door or time_sym"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_error_statuses_match_reference_stops(oracle, c2_walk, c2_setup):
     """The reference's own `stop`s come back as status codes with its texts, on
     the same inputs for which the oracle reports them."""
