@@ -3,6 +3,7 @@ inputs.  Integer/bit results must be identical; fp64 results are compared bit fo
 the GPU keeps the reference's operation order (matrix elements, spawn weights, deterministic
 projection) and to 1e-12 relative where it uses tree reductions (estimator sums)."""
 import ctypes as C
+import os
 import numpy as np
 import pytest
 
