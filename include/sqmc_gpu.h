@@ -45,8 +45,10 @@ typedef struct sqmc_gpu_ctx sqmc_gpu_ctx;
 /* RNG discipline.  REPLAY reproduces the reference's single rannyu stream draw for draw
  * (rannyu.f90:54-74 consumed in walker order, do_walk.f90:3577-3583, chemistry.f90:4391-4439,
  * do_walk.f90:7222-7230) and is meant for fixed-seed parity runs; COUNTER keys an
- * independent 48-bit stream on (seed, step, stage, walker/child index) so that every
- * stage is fully parallel.  Both give reals k/2^48 like rannyu. */
+ * independent 48-bit stream on (seed, step, stage, entity) -- the walker index for the spawn
+ * gate, the child index for a proposal, the determinant itself for the rounding draw -- so
+ * that every stage is fully parallel and none needs a rank among the others.  Both give
+ * reals k/2^48 like rannyu. */
 #define SQMC_RNG_REPLAY 0
 #define SQMC_RNG_COUNTER 1
 
