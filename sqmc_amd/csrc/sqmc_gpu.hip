@@ -82,6 +82,7 @@ static void free_walk(WalkArr &a) {
 struct StepP {       // device copy of sqmc_step_params + derived values
   double tau, e_trial, rfi, r_init, min_wt, cutoff;
   int ipow, imind, cti, semi, reached;
+  int nimp_cap;            // entries of the loc_imp array (set by step_tail): spawn records with made-up flags cannot push an index past it
 };
 
 // device-side scalars of a step
@@ -706,7 +707,7 @@ __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64
     }
     w.up[o] = u; w.dn[o] = dd; w.wt[o] = wt; w.flg[o] = fj;
     w.me[o] = m.me[j]; w.en[o] = en; w.ed[o] = ed;
-    if (d == 0 && p.semi) loc_imp[ps >> 32] = (int)o;
+    if (d == 0 && p.semi && (long long)(ps >> 32) < p.nimp_cap) loc_imp[ps >> 32] = (int)o;
     s[0] += wt; s[1] += fabs(wt); s[8] += wt * wt;
     if (ini == 3) s[4] += wt * psg;
     if (d == 0 || (d == -2 && p.cti)) s[6] += fabs(wt);
@@ -851,7 +852,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
     o.up[q0] = r[k].up; o.dn[q0] = r[k].dn; o.wt[q0] = wt; o.flg[q0] = r[k].flg;
     o.me[q0] = r[k].me; o.en[q0] = en; o.ed[q0] = ed;
-    if (d == 0 && p.semi) loc_imp[ex2 >> 32] = (int)q0;
+    if (d == 0 && p.semi && (long long)(ex2 >> 32) < p.nimp_cap) loc_imp[ex2 >> 32] = (int)q0;
     s[0] += wt; s[1] += fabs(wt); s[8] += wt * wt;
     if (ini == 3) s[4] += wt * psg;
     if (d == 0 || (d == -2 && p.cti)) s[6] += fabs(wt);
@@ -1657,7 +1658,9 @@ static void drop_head(sqmc_gpu_ctx *c) {
 }
 // sort -> merge -> round -> compact/estimate -> readback; shared by the single-rank step and
 // the sharded step (where the spawns behind slot n0 arrived from other ranks)
-static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long nall, bool join_side_stream, double out[16]) {
+static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long nall, bool join_side_stream, double out[16]) {
+  StepP p = p_in;
+  p.nimp_cap = c->d_loc_imp ? (int)std::max<long long>(c->n_imp_local, c->n_imp) : 0;     // what set_projector / shard_config allocated
   hipStream_t st = c->st;
   const long long M = c->mwalk;
   const int mode = c->rng_mode; const u64 seed = c->seed64, step = c->step_no;

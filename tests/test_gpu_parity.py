@@ -771,6 +771,85 @@ def test_annihilate_door_matches_oracle_merge(oracle, c2_walk, c2_setup, rng_mod
         assert n < n0 + 400
 
 
+@pytest.mark.parametrize("trial", range(12))
+def test_annihilate_door_random_parameters(oracle, c2_walk, c2_setup, trial):
+    """The merge / initiator / rounding rules under randomly drawn step parameters (r_initiator incl.
+    the -1 switch, initiator_power, initiator_min_distance, c_t_initiator, min_wt) and spawn lists
+    whose runs range from one to several thousand records in mixed signs -- the wavefront-cooperative
+    folds take their general path there.  Walkers, weights and flags equal the oracle's in both RNG disciplines."""
+    rs = np.random.RandomState(900 + trial)
+    rng_mode = trial % 2
+    main = oracle.initial_walkers(c2_setup, 300)
+    n0 = len(main["up"])
+    npool = int(rs.choice([2, 5, 40, 300]))
+    pool = rs.choice(len(c2_setup.ct_up), npool, replace=False)
+    ns = int(rs.choice([3000, 9000]))
+    from_main = rs.rand(ns) < rs.choice([0.02, 0.3])
+    im, ip = rs.randint(0, n0, ns), pool[rs.randint(0, len(pool), ns)]
+    up = np.where(from_main, main["up"][im], c2_setup.ct_up[ip]).astype(np.uint64)
+    dn = np.where(from_main, main["dn"][im], c2_setup.ct_dn[ip]).astype(np.uint64)
+    wt = rs.choice([-1.0, 1.0], ns, p=[0.3, 0.7]) * rs.choice([0.05, 0.2, 0.25, 0.4, 0.5, 0.75, 1.0, 1.5, 2.5], ns)
+    wt[rs.rand(ns) < 0.04] = 0.0
+    impd = rs.choice([-1, 1, 2, 3, 5, 127], ns, p=[0.12, 0.38, 0.25, 0.15, 0.08, 0.02]).astype(np.int8)      # what move_uniform2 can hand out (do_walk.f90:3703-3717)
+    init = np.where(impd == -1, 1, rs.randint(0, 3, ns)).astype(np.int8)
+    prm = dict(tau=c2_setup.tau, e_trial=-75.7, reweight_factor_inv=float(rs.choice([1.0, 0.97, 1.02])), r_initiator=float(rs.choice([0.5, 1.0, 2.0, -1.0])),
+               min_wt=float(rs.choice([0.3, 0.5, 1.0])), always_spawn_cutoff_wt=0.5, initiator_power=int(rs.choice([0, 1, 2])),
+               initiator_min_distance=int(rs.choice([0, 1, 2])), c_t_initiator=int(rs.choice([0, 1])), semistochastic=1, reached_w_abs_gen=2)
+    ow = oracle.OracleWalk(c2_walk, c2_setup, main, 60000, list(SEED), rng_mode=rng_mode)
+    w, nz = ow.w, np.nonzero(wt)[0]
+    for k, j in enumerate(nz):
+        i = n0 + k
+        w.up[i], w.dn[i], w.wt[i], w.imp_distance[i], w.initiator[i] = int(up[j]), int(dn[j]), float(wt[j]), int(impd[j]), int(init[j])
+        w.matrix_elements[i] = w.e_num_walker[i] = w.e_den_walker[i] = 1e51
+    n = n0 + len(nz)
+    p = oracle.StepParams(**prm)
+    L = oracle.lib()
+    L.orc_reduce_my_walker.restype = C.c_int64
+    L.orc_reduce_my_walker.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    L.orc_merge_original_with_spawned2.restype = C.c_int64
+    L.orc_merge_sort_walkers(ow.h, n)
+    n = L.orc_merge_original_with_spawned2(ow.h, n, C.byref(p))
+    n = L.orc_reduce_my_walker(ow.h, n, C.byref(p))
+    ow.w.nwalk = n
+    ref = ow.walkers(); ow.close()
+    ref["wt"] = ref["wt"] * prm["reweight_factor_inv"]
+    g = gpu_ctx_from_oracle(c2_walk, rng_mode=rng_mode, seed=SEED, mwalk=60000)
+    g.set_projector(c2_setup.prj_counts, c2_setup.prj_indices, c2_setup.prj_values)
+    g.set_ct_table(c2_setup.ct_up, c2_setup.ct_dn, c2_setup.ct_num, c2_setup.ct_den)
+    g.upload_walkers(main)
+    try:
+        out = g.annihilate(prm, dict(up=up, dn=dn, wt=wt, imp_distance=impd, initiator=init))
+        got = g.download_walkers()
+    finally:
+        g.close()
+    assert len(got["up"]) == n == int(out[5]), (len(got["up"]), n, prm)
+    for k in ("up", "dn", "wt", "imp_distance", "initiator"):
+        assert np.array_equal(got[k], ref[k]), (k, prm)
+
+
+def test_annihilate_door_refuses_made_up_deterministic_flags(oracle, c2_walk, c2_setup):
+    """Spawn records that claim imp_distance 0 on determinants outside the deterministic space (no move
+    of the reference produces them) must come back as status 5, 'locations of my imp broken'
+    (do_walk.f90:2204), not as an out-of-range write."""
+    from sqmc_amd import SqmcGpuError
+    main = oracle.initial_walkers(c2_setup, 300)
+    rs = np.random.RandomState(5)
+    pool = rs.choice(len(c2_setup.ct_up), 3000, replace=False)
+    up, dn = c2_setup.ct_up[pool].astype(np.uint64), c2_setup.ct_dn[pool].astype(np.uint64)
+    prm = dict(tau=c2_setup.tau, e_trial=-75.7, reweight_factor_inv=1.0, r_initiator=1.0, min_wt=0.5, always_spawn_cutoff_wt=0.5,
+               initiator_power=0, initiator_min_distance=0, c_t_initiator=0, semistochastic=1, reached_w_abs_gen=2)
+    g = gpu_ctx_from_oracle(c2_walk, rng_mode=1, seed=SEED, mwalk=60000)
+    g.set_projector(c2_setup.prj_counts, c2_setup.prj_indices, c2_setup.prj_values)
+    g.set_ct_table(c2_setup.ct_up, c2_setup.ct_dn, c2_setup.ct_num, c2_setup.ct_den)
+    g.upload_walkers(main)
+    try:
+        with pytest.raises(SqmcGpuError) as ei:
+            g.annihilate(prm, dict(up=up, dn=dn, wt=np.full(3000, 1.5), imp_distance=np.zeros(3000, np.int8), initiator=np.ones(3000, np.int8)))
+        assert ei.value.code == 5
+    finally:
+        g.close()
+
+
 def test_spawn_only_sort_and_merge_is_bit_exact():
     """Large lists sort only the spawns and merge them into the walkers, which are in order already
     (`SQMC_MERGE_SORT_MIN`, default 2^20 slots).  With the threshold at 0 the trajectory, annihilation
