@@ -1338,6 +1338,9 @@ int sqmc_gpu_init_chem(const sqmc_chem_cfg *cfg, sqmc_gpu_ctx **out) {
   if (!cfg || !out) return fail(SQMC_ERR_BAD_ARG, "null argument");
   if (cfg->norb < 1 || cfg->norb > SQ_MAXORB) return fail(SQMC_ERR_UNSUPPORTED, "norb must be in 1..64 (one 64-bit word per spin)");
   if (cfg->n_group < 1 || cfg->n_group > SQ_MAXSYM) return fail(SQMC_ERR_UNSUPPORTED, "point group order must be <= 8");
+  if (cfg->nup < 0 || cfg->ndn < 0 || cfg->nup > cfg->norb || cfg->ndn > cfg->norb || cfg->n_core_orb < 0 || cfg->n_core_orb > cfg->ndn || cfg->n_core_orb > cfg->nup ||
+      cfg->nup + cfg->ndn - 2 * cfg->n_core_orb < 2)
+    return fail(SQMC_ERR_BAD_ARG, "nup / ndn / n_core_orb out of range (at least two active electrons: the proposal draws a second one)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SQMC_ERR_HIP, "no HIP device: libsqmc_gpu has no CPU fallback");
   sqmc_gpu_ctx *c = new sqmc_gpu_ctx();
@@ -1370,6 +1373,8 @@ int sqmc_gpu_init_heg(const sqmc_heg_cfg *cfg, sqmc_gpu_ctx **out) {
   if (!cfg || !out || !cfg->k_vectors) return fail(SQMC_ERR_BAD_ARG, "null argument");
   if (cfg->norb < 1 || cfg->norb > SQ_MAXORB) return fail(SQMC_ERR_UNSUPPORTED, "norb must be in 1..64 (one 64-bit word per spin)");
   if (cfg->n_dim != 2 && cfg->n_dim != 3) return fail(SQMC_ERR_BAD_ARG, "n_dim must be 2 or 3");
+  if (cfg->nup < 0 || cfg->ndn < 0 || cfg->nup > cfg->norb || cfg->ndn > cfg->norb || cfg->nup + cfg->ndn < 2)
+    return fail(SQMC_ERR_BAD_ARG, "the electron gas needs at least two electrons (off_diagonal_move_heg draws a pair) and at most norb per spin");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SQMC_ERR_HIP, "no HIP device: libsqmc_gpu has no CPU fallback");
   sqmc_gpu_ctx *c = new sqmc_gpu_ctx();
@@ -1517,6 +1522,8 @@ int sqmc_gpu_upload_walkers(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, cons
   const u64 lim = c->htab.orb_mask;
   for (long long i = 0; i < n; i++) {
     if ((up[i] & ~lim) || (dn[i] & ~lim)) return fail(SQMC_ERR_BAD_ARG, "determinant has bits beyond norb");
+    if (__builtin_popcountll(up[i]) != c->htab.nup || __builtin_popcountll(dn[i]) != c->htab.ndn)
+      return fail(SQMC_ERR_BAD_ARG, "determinant does not hold nup / ndn electrons");
     if (i && !(up[i - 1] < up[i] || (up[i - 1] == up[i] && dn[i - 1] < dn[i]))) return fail(SQMC_ERR_BAD_ARG, "walkers must be sorted by (up,dn) and unique");
   }
   HIPCHK(hipMemcpy(c->w.up, up, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.dn, dn, n * 8, hipMemcpyHostToDevice));
