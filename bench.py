@@ -156,7 +156,7 @@ def main():
         # equilibration + warmup (untimed), then EXACTLY --steps timed steps inside sqmc_gpu_run
         walk.run(args.equil, keep_stats=False)
         walk.run(args.warmup, keep_stats=False)
-        walk.g.set_timing(1)           # HIP events around the k_spawn launch only, accumulated over the timed steps
+        walk.g.set_timing(0 if os.environ.get('SQMC_BENCH_NO_EVENTS') else 1)           # HIP events around the k_spawn / k_anneal launches only, accumulated over the timed steps
         fence()
         t0 = time.perf_counter()
         stats, totals = walk.run(args.steps, keep_stats=True)
@@ -165,7 +165,7 @@ def main():
         nwalk_sum, spawn_sum = float(totals[5]) / (world if sharded else 1), float(totals[15])      # sharded: nwalk is the global count
         e_num, e_den = float((stats[:, 3] * np.sign(stats[:, 2])).sum()), float(np.abs(stats[:, 2]).sum())
         timers_timed = walk.g.timing()                     # mean ms per k_spawn / k_anneal launch over the K timed steps
-        spawn_ms = dict(timers_timed)["spawn"]
+        spawn_ms = dict(timers_timed).get("spawn", float('nan'))
         walk.g.set_timing(2)                                # informational stage breakdown from an untimed tail
         walk.run(20, keep_stats=False)
         stage_ms = dict(walk.g.timing())
@@ -185,7 +185,9 @@ def main():
         # (walker read + write) + 58 B per child proposal (26 B read-back + 32 B annihilation slot; the other 26 B
         # of a spawn's 84 B are its write in k_spawn, reported beside it).
         n_avg, s_avg = nwalk_sum / args.steps, spawn_sum / args.steps
-        timers = dict(timers_timed)
+        timers = {k: v for k, v in dict(timers_timed).items() if v == v}
+        if "anneal" not in timers and "anneal" in stage_ms:      # fewer timed steps than the event stride: take the untimed tail's launches
+            timers["anneal"], spawn_ms = stage_ms["anneal"], stage_ms.get("spawn", spawn_ms)
         if "anneal" in timers:
             dom, dom_ms, dom_bytes = "k_anneal", timers["anneal"], 68.0 * n_avg + 58.0 * s_avg
         else:                                  # semistochastic = f keeps the unfused tail: k_spawn is then the longest single kernel

@@ -1594,8 +1594,12 @@ int sqmc_gpu_get_timing(sqmc_gpu_ctx *c, int32_t *n, const char **names, float *
   return SQMC_OK;
 }
 // stage timers: a pair of HIP events on the stream the stage runs on
-#define TBEG(NAME, STREAM) int t_##NAME = -1; do { if ((c->timing >= 2 || (c->timing == 1 && !strcmp(#NAME, "spawn"))) && c->nt < NTIMERS) { t_##NAME = c->nt++; c->tname[t_##NAME] = #NAME; hipEventRecord(c->ev0[t_##NAME], STREAM); } } while (0)
+#define TBEG(NAME, STREAM) int t_##NAME = -1; do { if ((c->timing >= 2 || (c->timing == 1 && !strcmp(#NAME, "spawn") && c->step_no % 8 == 0)) && c->nt < NTIMERS) { t_##NAME = c->nt++; c->tname[t_##NAME] = #NAME; hipEventRecord(c->ev0[t_##NAME], STREAM); } } while (0)
 #define TEND(NAME, STREAM) do { if (t_##NAME >= 0) hipEventRecord(c->ev1[t_##NAME], STREAM); } while (0)
+// Timing level 1 takes the kernel-exact start/stop events of k_spawn and k_anneal on every SQMC_TIMING_STRIDE-th step only:
+// each timed launch costs about 5 us of the step it sits in, which a throughput measurement should not pay on every step.
+#define SQMC_TIMING_STRIDE 8
+static inline bool kernel_events_on(const sqmc_gpu_ctx *c, u64 step) { return c->timing >= 2 || (c->timing == 1 && step % SQMC_TIMING_STRIDE == 0); }
 
 static int comm_allreduce_stats(sqmc_gpu_ctx *c);
 // Spin on a mailbox word the GPU writes into pinned host memory.  Returns 0 when it arrived, -1
@@ -1708,7 +1712,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
     // timed by the kernel's own start/stop timestamps (hipExtLaunchKernelGGL events) at every timing level: the
     // per-launch time bench.py reports for the roofline of this, the longest kernel on the critical path
     int t_anneal = -1;
-    if (c->timing >= 1 && c->nt < NTIMERS) { t_anneal = c->nt++; c->tname[t_anneal] = "anneal"; }
+    if (kernel_events_on(c, step) && c->nt < NTIMERS) { t_anneal = c->nt++; c->tname[t_anneal] = "anneal"; }
     static const int items_env = getenv("SQMC_ANNEAL_ITEMS") ? atoi(getenv("SQMC_ANNEAL_ITEMS")) : 0;
     const int items = items_env ? items_env : (nall < (1ll << 20) ? 2 : 4);     // small lists want many tiles, large ones short look-back chains
     nb = n_ft = (int)((nall + (long long)TPB * items - 1) / ((long long)TPB * items));
@@ -1752,7 +1756,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
     // reads this step's sums and does its population control.  nall bounds the new walker count.
     c->pipeline_next = false;
     int rh = enqueue_head(c, p, step + 1, nall, true, c->timing >= 2 ? c->hev[0] : nullptr, c->timing >= 2 ? c->hev[1] : nullptr,
-                          c->timing >= 1 ? c->hev[2] : nullptr, c->timing >= 1 ? c->hev[3] : nullptr, &c->head_cseq, fin_in_gate ? &fa : nullptr);
+                          kernel_events_on(c, step + 1) ? c->hev[2] : nullptr, kernel_events_on(c, step + 1) ? c->hev[3] : nullptr, &c->head_cseq, fin_in_gate ? &fa : nullptr);
     if (rh) return rh;
     c->head_ready = true; c->head_p = p;
   }
@@ -1767,7 +1771,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
       HIPCHK(hipMemcpy(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost));
     } else { c->h_sc->tot2 = c->h_mail->tot2; c->h_sc->err = (int)c->h_mail->err; for (int i = 0; i < 16; i++) c->h_sc->stats[i] = c->h_mail->stats[i]; }
   }
-  c->timers_pending = (c->timing != 0);
+  c->timers_pending = kernel_events_on(c, step);
   c->step_no++;
   if (c->h_sc->err) { drop_head(c); return fail(c->h_sc->err, "diagonal_factor<0 after target population has been reached"); }
   const long long nfinal = (long long)(c->h_sc->tot2 & 0xFFFFFFFFull), nimp = (long long)(c->h_sc->tot2 >> 32);
@@ -1795,7 +1799,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   hipStream_t st2 = c->st2;
   int t_gate_scan = -1, t_spawn = -1;
   if (c->timing >= 2 && c->nt < NTIMERS) { t_gate_scan = c->nt++; c->tname[t_gate_scan] = "gate_scan"; }
-  if (c->timing >= 1 && c->nt < NTIMERS) { t_spawn = c->nt++; c->tname[t_spawn] = "spawn"; }
+  if (kernel_events_on(c, step) && c->nt < NTIMERS) { t_spawn = c->nt++; c->tname[t_spawn] = "spawn"; }
   u64 cseq;
   if (c->head_ready) {
     // gate + scan + spawn of this step already run behind k_finish of the last one (pipelined head):
