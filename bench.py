@@ -33,8 +33,8 @@ TRAFFIC_K_SPAWN = 1.97e7      # same file: (2*6500.5 + 6252.1) KiB
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=3000, help="timed steps (0.14 ms each at the default size: a short timed region is at the mercy of one host scheduling hiccup)")
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--target", type=float, default=1e5, help="w_abs_gen_target")
     ap.add_argument("--equil", type=int, default=400, help="untimed equilibration steps before warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -271,11 +271,17 @@ static inline void device_radix_sort(u64 *&keys, u32 *&vals, long long n, int nb
   // and which grows with 2^bits: 8-bit digits there.
   const int maxbits = (n >= RS_LARGE_N) ? 8 : 10;
   const int npass = (nbits + maxbits - 1) / maxbits;
-  int bits = (nbits + npass - 1) / npass; if (bits < 8) bits = 8;
-  for (int pss = 0, shift = shift0; pss < npass; pss++, shift += bits) {
+  // digit widths as even as the templates allow (8, 9 or 10 bits), the wide ones first: 28 bits in three passes
+  // are 10 + 9 + 9, not 10 + 10 + 10 -- every kernel of a pass is a little cheaper with half the bins
+  int left = nbits;
+  for (int pss = 0, shift = shift0; pss < npass; pss++) {
+    int bits = (left + (npass - pss) - 1) / (npass - pss); if (bits < 8) bits = 8;
+    left -= bits; if (left < 0) left = 0;
+    const int used = bits;
     if (bits == 8) radix_pass<8>(ka, va, kb, vb, n, ntiles, shift, w, st);
     else if (bits == 9) radix_pass<9>(ka, va, kb, vb, n, ntiles, shift, w, st);
     else radix_pass<10>(ka, va, kb, vb, n, ntiles, shift, w, st);
+    shift += used;
     u64 *tk = ka; ka = kb; kb = tk; u32 *tv = va; va = vb; vb = tv;
   }
   w.k_alt = kb; if (vals) { w.v_alt = vb; vals = va; } keys = ka;
