@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
@@ -269,7 +270,8 @@ static inline void device_radix_sort(u64 *&keys, u32 *&vals, long long n, int nb
   // Small inputs are launch bound: the fewest passes (10-bit digits).  Large ones are bound by the
   // per-tile histogram matrix, whose column accesses cost a whole memory sector per 4-byte count
   // and which grows with 2^bits: 8-bit digits there.
-  const int maxbits = (n >= RS_LARGE_N) ? 8 : 10;
+  static const int maxbits_env = getenv("SQMC_SORT_MAXBITS") ? atoi(getenv("SQMC_SORT_MAXBITS")) : 0;
+  const int maxbits = (n >= RS_LARGE_N) ? 8 : (maxbits_env ? maxbits_env : 10);
   const int npass = (nbits + maxbits - 1) / maxbits;
   // digit widths as even as the templates allow (8, 9 or 10 bits), the wide ones first: 28 bits in three passes
   // are 10 + 9 + 9, not 10 + 10 + 10 -- every kernel of a pass is a little cheaper with half the bins
