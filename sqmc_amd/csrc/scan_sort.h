@@ -198,6 +198,12 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const u64 *__restrict__
   __shared__ u32 off[RS_RADIX];            // global base of each digit for this tile
   __shared__ u32 wcnt[4][RS_RADIX];        // per-wave digit counts -> per-wave bases
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // the tile's keys are requested first: their latency hides behind the digit-base prologue, which has its own
+  // chain of dependent loads (row totals -> block scan -> this tile's row prefixes)
+  const long long base = (long long)blockIdx.x * RS_TILE + wv * (64 * ROUNDS);
+  u64 kreg[ROUNDS]; u32 vreg[ROUNDS], rnk[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) { long long i = base + r * 64 + lane; kreg[r] = (i < n) ? kin[i] : 0; vreg[r] = (VALS && i < n) ? vin[i] : 0; }
   {   // digit bases = exclusive scan of the row totals (PER per thread + block scan) + this tile's row prefix
     u32 t[PER]; u64 sum = 0;
 #pragma unroll
@@ -208,11 +214,7 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const u64 *__restrict__
   }
   for (int d = tid; d < 4 * RS_RADIX; d += 256) (&wcnt[0][0])[d] = 0;
   __syncthreads();
-  const long long base = (long long)blockIdx.x * RS_TILE + wv * (64 * ROUNDS);
   const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  u64 kreg[ROUNDS]; u32 vreg[ROUNDS], rnk[ROUNDS];
-#pragma unroll
-  for (int r = 0; r < ROUNDS; r++) { long long i = base + r * 64 + lane; kreg[r] = (i < n) ? kin[i] : 0; vreg[r] = (VALS && i < n) ? vin[i] : 0; }
 #pragma unroll
   for (int r = 0; r < ROUNDS; r++) {
     const long long i = base + r * 64 + lane;
