@@ -2233,7 +2233,8 @@ static int rccl_bind() {
   if (g_rccl.lib) return SQMC_OK;
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void *h = nullptr;
-  for (const char *nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+  if (const char *over = getenv("SQMC_RCCL_LIB")) h = dlopen(over, RTLD_NOW | RTLD_LOCAL);       // another library with the same entry points (tests: a transport double)
+  else for (const char *nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
   if (!h) return fail(SQMC_ERR_UNSUPPORTED, std::string("cannot load RCCL: ") + dlerror());
 #define BIND(F) do { *(void **)(&g_rccl.F) = dlsym(h, "nccl" #F); if (!g_rccl.F) return fail(SQMC_ERR_UNSUPPORTED, "RCCL lacks nccl" #F); } while (0)
   BIND(GetUniqueId); BIND(CommInitRank); BIND(CommDestroy); BIND(AllReduce); BIND(AllGather); BIND(Send); BIND(Recv); BIND(GroupStart); BIND(GroupEnd);

@@ -203,3 +203,76 @@ def test_sharded_hubbard_walk_invariants(tmp_path):
     e = res[0]["outs"][10:, 3].sum() / res[0]["outs"][10:, 2].sum()
     assert -14.5 < e < -8.0                 # between the exact ground state (-13.62) and the Neel determinant's neighbourhood
     assert out[1] > 1.5 * W_BEGIN
+
+
+# ---------------------------------------------------------------- in-library exchange with several ranks on one GPU
+FAKE_DIR = os.path.join(ROOT, "tests", "fake_rccl")
+
+
+def _fake_rccl_lib():
+    """tests/fake_rccl: the RCCL entry points the library binds, over POSIX shared memory (test infrastructure)"""
+    import subprocess
+    so, src = os.path.join(FAKE_DIR, "libfake_rccl.so"), os.path.join(FAKE_DIR, "fake_rccl.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-Wno-unused-result", src, "-o", so, "-lrt"])
+    return so
+
+
+def _inlib_multi_worker(rank, world, port, outdir, fake):
+    import torch                                   # noqa: F401
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["SQMC_RCCL_LIB"] = fake             # before the library binds its communication entry points
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # only carries the unique id (MPI_Bcast in the reference's build)
+    import sqmc_amd
+    from sqmc_amd import host as H
+    sqmc_amd.set_device(0)
+    hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+    w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
+    w.attach_rccl()
+    a = np.array([w.step().copy() for _ in range(NSTEPS // 2)])        # sqmc_gpu_shard_step
+    b, _ = w.run(NSTEPS - NSTEPS // 2)                                 # sqmc_gpu_shard_run
+    wk = w.g.download_walkers()
+    owner = w.g.det_owner(wk["up"], wk["dn"], world)
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), outs=np.concatenate([a, b]), owner=owner, n_imp_global=w.n_imp_global, **wk)
+    w.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_in_library_exchange_with_several_ranks(tmp_path, world):
+    """sqmc_gpu_shard_step / sqmc_gpu_shard_run with 2 and 3 ranks: real RCCL refuses several ranks on one
+    GPU, so the library is pointed (SQMC_RCCL_LIB) at a transport double with the same entry points that
+    moves the bytes through shared memory and blocks on every call.  What is under test is the library's
+    side: the count matrix, send/receive offsets and sizes (the double checks that what one rank sends is
+    what the other expects), one group per step on every rank, the all-reduce of the deterministic weights
+    on the second communicator beside the spawn exchange, and the merged result: disjoint ownership, unique
+    determinants, identical sums on every rank, a complete deterministic space."""
+    import torch.multiprocessing as mp
+    fake = _fake_rccl_lib()
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_inlib_multi_worker, args=(r, world, 29600 + world, str(tmp_path), fake)) for r in range(world)]
+    for p in ps: p.start()
+    for p in ps: p.join(300)
+    alive = [p for p in ps if p.is_alive()]
+    for p in alive: p.terminate()
+    assert not alive, "in-library exchange did not finish (deadlock?)"
+    assert all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
+    res = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for r in res[1:]:
+        assert np.array_equal(r["outs"][:, :7], res[0]["outs"][:, :7])
+    keys, n_imp = [], 0
+    for rank, r in enumerate(res):
+        assert np.all(r["owner"] == rank)
+        k = [(int(a), int(b)) for a, b in zip(r["up"], r["dn"])]
+        assert k == sorted(set(k))
+        keys += k
+        n_imp += int((r["imp_distance"] == 0).sum())
+    assert len(keys) == len(set(keys)) and n_imp == int(res[0]["n_imp_global"])
+    out = res[0]["outs"][-1]
+    assert int(out[5]) == len(keys)
+    assert np.isclose(sum(float(np.abs(r["wt"]).sum()) for r in res), out[1], rtol=1e-12)
+    e = res[0]["outs"][10:, 3].sum() / res[0]["outs"][10:, 2].sum()
+    assert -75.80 < e < -75.55 and out[1] > 1.5 * W_BEGIN
