@@ -110,7 +110,7 @@ def main():
             walk = None
         if walk is not None:
             parallelism = "sharded x%d (hash-owned determinants), exchanges driven through torch.distributed" % world
-            if backend == "nccl" and not os.environ.get("SQMC_BENCH_NO_INLIB"):
+            if (backend == "nccl" or os.environ.get("SQMC_RCCL_LIB")) and not os.environ.get("SQMC_BENCH_NO_INLIB"):     # SQMC_RCCL_LIB: rehearsal with the transport double of tests/fake_rccl
                 try:
                     walk.attach_rccl()
                     walk.step()
