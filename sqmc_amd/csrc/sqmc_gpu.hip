@@ -1751,6 +1751,10 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
   if (!fin_in_gate) hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, fa, c->d_sc);
   TEND(estimate, st);
   HIPCHK(hipGetLastError());
+  if (!use_mail) {
+    int rr = comm_allreduce_stats(c); if (rr) return rr;      // do_walk.f90:2778-2790: the sums every rank needs
+    hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(64), 0, st, (const DevScalars *)c->d_sc, c->d_mail, seq);
+  }
   if (c->pipeline_next) {
     // the next step's gate + scan + spawn go out now, behind k_finish: the GPU runs on while the host
     // reads this step's sums and does its population control.  nall bounds the new walker count.
@@ -1759,10 +1763,6 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
                           kernel_events_on(c, step + 1) ? c->hev[2] : nullptr, kernel_events_on(c, step + 1) ? c->hev[3] : nullptr, &c->head_cseq, fin_in_gate ? &fa : nullptr);
     if (rh) return rh;
     c->head_ready = true; c->head_p = p;
-  }
-  if (!use_mail) {
-    int rr = comm_allreduce_stats(c); if (rr) return rr;      // do_walk.f90:2778-2790: the sums every rank needs
-    hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(64), 0, st, (const DevScalars *)c->d_sc, c->d_mail, seq);
   }
   {
     int wr = wait_mail(&c->h_mail->seq, seq, st);
@@ -1866,6 +1866,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   return step_tail(c, p, n0, nall, true, out);
 }
 
+int sqmc_gpu_shard_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]);
 typedef int (*step_fn)(sqmc_gpu_ctx *, const sqmc_step_params *, double *);
 static int run_steps(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats, double totals[16], step_fn one_step) {
   if (!c || !pc || !totals || nsteps < 0) return fail(SQMC_ERR_BAD_ARG, "bad argument");
@@ -1886,8 +1887,8 @@ static int run_steps(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *s
     sp.reached_w_abs_gen = pc->reached_w_abs_gen; sp.reserved = 0;
     // pipelined head: once the target population has been reached tau and r_initiator stay put, and the head of a step
     // (gate, scan, spawn) depends on nothing else that this step's sums could change
-    c->pipeline_next = (one_step == (step_fn)sqmc_gpu_step && it + 1 < nsteps && pc->reached_w_abs_gen == 2 && c->rng_mode != SQMC_RNG_REPLAY &&
-                        !getenv("SQMC_NO_PIPELINE"));
+    c->pipeline_next = ((one_step == (step_fn)sqmc_gpu_step || (one_step == (step_fn)sqmc_gpu_shard_step && c->comm2 != nullptr)) && it + 1 < nsteps &&
+                        pc->reached_w_abs_gen == 2 && c->rng_mode != SQMC_RNG_REPLAY && !getenv("SQMC_NO_PIPELINE"));
     double out[16];
     int r = one_step(c, &sp, out);
     c->pipeline_next = false;
@@ -2078,19 +2079,32 @@ static int shard_begin_impl(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double 
   hipStream_t sx = side ? c->st2 : st;
   if (!side && x_global_dev && c->n_imp > 0) HIPCHK(hipMemsetAsync(x_global_dev, 0, c->n_imp * 8, st));
   const bool mail = (n0 > 0 && M > n0);
-  const u64 cseq = ++c->cnt_seq;
-  if (n0 > 0) {
-    hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
-                       n0, p, c->seed64, c->step_no, c->d_sc, c->pack, 0, FinArgs{});
-    device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st);
-  }
-  if (side) HIPCHK(hipEventRecord(c->e_fork, st));
-  if (n0 > 0) {
-    TBEG(spawn, st);
-    if (M > n0)      // first: it posts the child count to the host mailbox as soon as it starts
-      hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, c->rng_mode, c->seed64, c->step_no, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0);
-    TEND(spawn, st);
+  u64 cseq;
+  if (c->head_ready) {
+    // gate + scan + spawn of this step already run behind the last step's mail (pipelined head of sqmc_gpu_shard_run)
+    c->head_ready = false;
+    const StepP &h = c->head_p;
+    if (!side || n0 <= 0 || M <= n0 || h.tau != p.tau || h.cutoff != p.cutoff || h.semi != p.semi || h.cti != p.cti) {
+      hipStreamSynchronize(st);
+      return fail(SQMC_ERR_BAD_ARG, "internal: the pipelined head of this sharded step does not fit it");
+    }
+    cseq = c->head_cseq;
+    if (kernel_events_on(c, c->step_no) && c->nt < NTIMERS) { const int t = c->nt++; c->tname[t] = "spawn"; std::swap(c->ev0[t], c->hev[2]); std::swap(c->ev1[t], c->hev[3]); }
+  } else {
+    cseq = ++c->cnt_seq;
+    if (n0 > 0) {
+      hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
+                         n0, p, c->seed64, c->step_no, c->d_sc, c->pack, 0, FinArgs{});
+      device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st);
+    }
+    if (side) HIPCHK(hipEventRecord(c->e_fork, st));
+    if (n0 > 0) {
+      TBEG(spawn, st);
+      if (M > n0)      // first: it posts the child count to the host mailbox as soon as it starts
+        hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                           n0, M, p, c->rng_mode, c->seed64, c->step_no, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0);
+      TEND(spawn, st);
+    }
   }
   if (side) {
     HIPCHK(hipStreamWaitEvent(sx, c->e_fork, 0));
