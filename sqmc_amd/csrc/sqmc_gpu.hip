@@ -2021,12 +2021,14 @@ __global__ void __launch_bounds__(TPB) k_pack_send(WalkArr w, const u32 *__restr
   rec[4 * q] = r.up; rec[4 * q + 1] = r.dn; rec[4 * q + 2] = (u64)__double_as_longlong(r.wt); rec[4 * q + 3] = r.flg;
 }
 __global__ void __launch_bounds__(TPB) k_unpack_recv(ChemDev dev, WalkArr w, const u64 *__restrict__ rec, u64 *__restrict__ keys, u32 *__restrict__ vals,
-                                                     long long n0, long long nrecv, int pack) {
+                                                     long long n0, long long nrecv, int pack, const u64 *__restrict__ self_rec, long long self_lo, long long self_hi) {
   long long q = (long long)blockIdx.x * TPB + threadIdx.x;
   if (q >= nrecv) return;
   const long long k = n0 + q;
-  const u64 u = rec[4 * q], d = rec[4 * q + 1];
-  SpawnRec r; r.up = u; r.dn = d; r.wt = __longlong_as_double((long long)rec[4 * q + 2]); r.flg = rec[4 * q + 3] & 0xFFFFFFFFull;
+  // records [self_lo, self_hi) are this rank's own bucket: they are read where k_pack_send left them (no copy into the receive buffer)
+  const u64 *src = (self_rec && q >= self_lo && q < self_hi) ? self_rec + 4 * (q - self_lo) : rec + 4 * q;
+  const u64 u = src[0], d = src[1];
+  SpawnRec r; r.up = u; r.dn = d; r.wt = __longlong_as_double((long long)src[2]); r.flg = src[3] & 0xFFFFFFFFull;
   w.sp[q] = r;
   put_key(keys, vals, k, det_key(dev, u, d), pack);
 }
@@ -2184,7 +2186,8 @@ int sqmc_gpu_shard_pack(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const doubl
 
 // phase 3: the records received from all ranks (rank order, creation order inside a rank) become
 // the spawned walkers behind the occupied slots; then the usual sort / merge / round / estimate.
-static int shard_finish_impl(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const uint64_t *recv_dev, int64_t n_recv, double out[16], bool join) {
+static int shard_finish_impl(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const uint64_t *recv_dev, int64_t n_recv, double out[16], bool join,
+                             const u64 *self_rec = nullptr, long long self_lo = 0, long long self_hi = 0) {
   if (!c || !sp || !out || n_recv < 0) return fail(SQMC_ERR_BAD_ARG, "bad argument");
   hipStream_t st = c->st;
   StepP p; p.tau = sp->tau; p.e_trial = sp->e_trial; p.rfi = sp->reweight_factor_inv; p.r_init = sp->r_initiator; p.min_wt = sp->min_wt;
@@ -2196,7 +2199,7 @@ static int shard_finish_impl(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const 
     return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
   }
   if (n_recv > 0)
-    hipLaunchKernelGGL(k_unpack_recv, dim3(nblk(n_recv)), dim3(TPB), 0, st, c->dev, c->w, (const u64 *)recv_dev, c->d_keys, c->d_vals, n0, (long long)n_recv, c->pack);
+    hipLaunchKernelGGL(k_unpack_recv, dim3(nblk(n_recv)), dim3(TPB), 0, st, c->dev, c->w, (const u64 *)recv_dev, c->d_keys, c->d_vals, n0, (long long)n_recv, c->pack, self_rec, self_lo, self_hi);
   if (n0 + n_recv == 0) {           // an empty shard stays empty this step
     if (join) HIPCHK(hipStreamWaitEvent(st, c->e_join, 0));
     for (int i = 0; i < 16; i++) out[i] = 0.0;
@@ -2347,9 +2350,9 @@ int sqmc_gpu_shard_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[
   if (nch_l > c->xch_cap) return fail(SQMC_ERR_SPAWN_OVERFLOW, "send buffer too small for this step's spawns");
   if (nch_l > 0) {
     hipLaunchKernelGGL(k_pack_send, dim3(nblk(nch_l)), dim3(TPB), 0, st, c->w, order, c->d_send, c->shard_n0, nch_l);
-    HIPCHK(hipMemcpyAsync(c->d_cnt_mine, c->d_rowtot, P * 4, hipMemcpyDeviceToDevice, st));
   } else HIPCHK(hipMemsetAsync(c->d_cnt_mine, 0, P * 4, st));
-  NCCLCHK(g_rccl.AllGather(c->d_cnt_mine, c->d_cnt_all, (size_t)P, ncclUint32, c->comm, st));
+  // the per-destination counts are the digit totals the bucketing pass left in d_rowtot: they go into the all-gather from there
+  NCCLCHK(g_rccl.AllGather(nch_l > 0 ? c->d_rowtot : c->d_cnt_mine, c->d_cnt_all, (size_t)P, ncclUint32, c->comm, st));
   {
     const u64 qs = ++c->cntall_seq;
     hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(256), 0, st, (const u32 *)c->d_cnt_all, P * P, c->d_cnt_mail, qs);
@@ -2375,8 +2378,7 @@ int sqmc_gpu_shard_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[
     if (rc > 0) NCCLCHK(g_rccl.Recv(c->d_recv + 4 * roff[q], (size_t)(4 * rc), ncclUint64, q, c->comm, st));
   }
   NCCLCHK(g_rccl.GroupEnd());
-  if (scnt[me] > 0) HIPCHK(hipMemcpyAsync(c->d_recv + 4 * roff[me], c->d_send + 4 * soff[me], (size_t)scnt[me] * 32, hipMemcpyDeviceToDevice, st));
-  return shard_finish_impl(c, sp, (const uint64_t *)c->d_recv, n_recv, out, side);
+  return shard_finish_impl(c, sp, (const uint64_t *)c->d_recv, n_recv, out, side, c->d_send + 4 * soff[me], roff[me], roff[me] + scnt[me]);
 }
 
 int sqmc_gpu_shard_run(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats, double totals[16]) {
