@@ -139,6 +139,7 @@ struct sqmc_gpu_ctx {
   // pipelined head (sqmc_gpu_run, COUNTER discipline, target population reached): gate + scan + spawn of step n+1 are
   // enqueued right behind k_finish of step n, before the host has read step n's sums
   bool pipeline_next, head_ready; StepP head_p; u64 head_cseq; hipEvent_t hev[4];
+  bool owner_ready;           // this step's k_spawn already wrote the owner key of every child (sharded steps)
   bool residents_sorted;      // the walker arrays are known to be in (up, dn) order: true after every finished step, false after an upload
 };
 
@@ -223,9 +224,13 @@ __global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict
   wt[i] = wt[i] * f;
 }
 
+// rank that owns a determinant (get_det_owner, mpi_routines.f90:419-445: any hash of the determinant mod the number of ranks)
+__host__ __device__ __forceinline__ int det_owner(u64 key, int nranks) { return (int)((sq_mix64(key ^ 0xA5A5A5A5A5A5A5A5ull) >> 17) % (u64)nranks); }
+// sharded steps: k_spawn also notes the destination rank of every child (nranks for a child that made no walker), the key of the bucketing pass
+struct OwnerOut { u64 *okey; u32 *oval; int nranks; };      // okey == nullptr: off
 // a spawned walker (or the "no walker" marker) into slot n0 + c.  do_walk.f90:3700-3731
 __device__ __forceinline__ void spawn_emit(const ChemDev &dev, const WalkArr &w, u64 *__restrict__ keys, u32 *__restrict__ vals, long long n0, long long c,
-                                           u32 pf, u64 ju, u64 jd, double wj, const StepP &p, u64 invalid_key, int pack) {
+                                           u32 pf, u64 ju, u64 jd, double wj, const StepP &p, u64 invalid_key, int pack, const OwnerOut &oo) {
   const long long k = n0 + c;
   if (wj != 0.0) {
     const int pd = flg_impd(pf), pi = flg_init(pf);
@@ -239,9 +244,12 @@ __device__ __forceinline__ void spawn_emit(const ChemDev &dev, const WalkArr &w,
     // not stored, k_merge supplies them for every slot >= n0
     SpawnRec r; r.up = ju; r.dn = jd; r.wt = wj; r.flg = pack_flg(d, ini, 0);
     w.sp[c] = r;
-    put_key(keys, vals, k, det_key(dev, ju, jd), pack);
+    const u64 key = det_key(dev, ju, jd);
+    put_key(keys, vals, k, key, pack);
+    if (oo.okey) { oo.okey[c] = (u64)det_owner(key, oo.nranks); oo.oval[c] = (u32)c; }
   } else {
     w.sp[c].wt = 0.0; put_key(keys, vals, k, invalid_key, pack);     // sorts behind every real determinant
+    if (oo.okey) { oo.okey[c] = (u64)oo.nranks; oo.oval[c] = (u32)c; }
   }
 }
 
@@ -256,7 +264,7 @@ extern "C" int sqmc_gpu_debug_prof(unsigned long long *out) { return (int)hipMem
 __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
                                                const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
                                                long long n0_arg, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc,
-                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device) {
+                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo) {
   const long long n0 = n_on_device ? (long long)sc->nwalk : n0_arg;     // pipelined head: launched before the host learnt the walker count
   // the grid covers the free capacity of the walker arrays; the number of children is read from
   // device memory so that the launch does not wait for the host to learn it
@@ -325,7 +333,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
       wj = proposal_weight(t, dev.integrals, p.tau, iu, id, ju, jd, level, prob);
       wj = wch * wj;
     }
-    spawn_emit(dev, w, keys, vals, n0, c, pflg, ju, jd, wj, p, invalid_key, pack);
+    spawn_emit(dev, w, keys, vals, n0, c, pflg, ju, jd, wj, p, invalid_key, pack, oo);
   }
   PROF(5);
 }
@@ -1625,6 +1633,12 @@ static void collect_timers(sqmc_gpu_ctx *c) {
   }
   c->tsteps++;
 }
+// sharded contexts: k_spawn fills the owner keys of the bucketing pass (arrays that are free until the annihilation)
+static OwnerOut shard_owner_out(sqmc_gpu_ctx *c) {
+  if (!c->d_grow) return OwnerOut{nullptr, nullptr, 0};
+  c->owner_ready = true;
+  return OwnerOut{c->d_flags, (u32 *)c->d_flags2, c->shard_n};
+}
 // The head of a step: spawn gate + child offsets + k_spawn (COUNTER discipline).  With dev_n the
 // walker count is read on the device (sc->nwalk, written by k_finish of the step before) and n0 is
 // only an upper bound that sizes the grids: the pipelined launch behind k_finish of the previous
@@ -1648,14 +1662,15 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   //      host mailbox as soon as it starts.
   HIPCHK(hipEventRecord(c->e_fork, st));
   *cseq = ++c->cnt_seq;
+  const OwnerOut oo = shard_owner_out(c);
   const long long nfree = dev_n ? M : M - n0;          // dev_n: nothing is known about the count but that it is >= 0
   if (nfree > 0) {
     if (s0)
       hipExtLaunchKernelGGL(k_spawn, dim3(nblk(nfree)), dim3(TPB), 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0);
+                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo);
     else
       hipLaunchKernelGGL(k_spawn, dim3(nblk(nfree)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0);
+                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo);
   } else if (s0) { hipEventRecord(s0, st); hipEventRecord(s1, st); }
   HIPCHK(hipGetLastError());
   return SQMC_OK;
@@ -1824,10 +1839,10 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     if (M > n0) {
       if (t_spawn >= 0)
         hipExtLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->ev0[t_spawn], c->ev1[t_spawn], 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0);
+                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0});
       else
         hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0);
+                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0});
     } else if (t_spawn >= 0) { hipEventRecord(c->ev0[t_spawn], st); hipEventRecord(c->ev1[t_spawn], st); }
   } else {
     int r = enqueue_head(c, p, step, n0, false, t_gate_scan >= 0 ? c->ev0[t_gate_scan] : nullptr, t_gate_scan >= 0 ? c->ev1[t_gate_scan] : nullptr,
@@ -1970,7 +1985,6 @@ int sqmc_gpu_annihilate(sqmc_gpu_ctx *c, const sqmc_step_params *sp, int64_t n_s
 // ------------------------------------------------------------------ multi-rank sharding
 // owner of a determinant (the role of get_det_owner, mpi_routines.f90:419-445; any hash will
 // do for ownership)
-__host__ __device__ __forceinline__ int det_owner(u64 key, int nranks) { return (int)((sq_mix64(key ^ 0xA5A5A5A5A5A5A5A5ull) >> 17) % (u64)nranks); }
 __global__ void __launch_bounds__(TPB) k_owner_batch(ChemDev dev, const u64 *up, const u64 *dn, int *owner, long long n, int nranks) {
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i < n) owner[i] = det_owner(det_key(dev, up[i], dn[i]), nranks);
@@ -2104,7 +2118,7 @@ static int shard_begin_impl(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double 
       TBEG(spawn, st);
       if (M > n0)      // first: it posts the child count to the host mailbox as soon as it starts
         hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                           n0, M, p, c->rng_mode, c->seed64, c->step_no, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0);
+                           n0, M, p, c->rng_mode, c->seed64, c->step_no, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, shard_owner_out(c));
       TEND(spawn, st);
     }
   }
@@ -2153,12 +2167,13 @@ static int shard_bucket(sqmc_gpu_ctx *c, const sqmc_step_params *sp, const doubl
   *order = nullptr;
   if (nch > 0) {
     u64 *okey = c->d_flags, *okey_alt = c->d_pos; u32 *oval = (u32 *)c->d_flags2, *oval_alt = (u32 *)c->d_pos2;
-    hipLaunchKernelGGL(k_child_owner, dim3(nblk(nch)), dim3(TPB), 0, st, c->d_keys, okey, oval, n0, nch, c->invalid_key, P, c->pack);
+    if (!c->owner_ready) hipLaunchKernelGGL(k_child_owner, dim3(nblk(nch)), dim3(TPB), 0, st, c->d_keys, okey, oval, n0, nch, c->invalid_key, P, c->pack);
     SortWork so; so.k_alt = okey_alt; so.v_alt = oval_alt; so.hist = c->d_hist; so.rowtot = c->d_rowtot; so.cap = c->mwalk;
     u64 *sk = okey; u32 *sv = oval;
     device_radix_sort(sk, sv, nch, 8, so, st);               // one stable 8-bit pass; rowtot[d] = children per destination
     *order = sv;
   }
+  c->owner_ready = false;
   HIPCHK(hipGetLastError());
   return SQMC_OK;
 }
