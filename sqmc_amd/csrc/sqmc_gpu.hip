@@ -898,6 +898,16 @@ __global__ void k_post_mail(const DevScalars *sc, HostMail *mail, u64 seq) {
 // k_compact needs an agent-scope release in every block and cost more than this launch.
 __global__ void __launch_bounds__(TPB) k_finish(FinArgs f, DevScalars *sc) { finish_all(f, sc); }
 __device__ void finish_all(const FinArgs &f, DevScalars *sc) {
+  if (f.on == 3) {            // sharded step: the sums were finished and all-reduced by kernels before this one; only the mail is left
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < 16; i++) f.mail->stats[i] = sc->stats[i];
+      f.mail->tot2 = sc->tot2; f.mail->err = sc->err;
+      __threadfence_system();
+      f.mail->seq = f.seq;
+    }
+    __syncthreads();
+    return;
+  }
   // the look-back words k_anneal used this step (two arrays, n_ftiles words each) are zero again for the next one
   for (int i = threadIdx.x; i < f.n_ftiles; i += TPB) { f.fstate[i] = 0; f.fstate[f.cap_ftiles + i] = 0; }
   if (threadIdx.x == 0 && f.n_ftiles > 0) *f.fticket = 0;
@@ -1766,16 +1776,19 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
   if (!fin_in_gate) hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, fa, c->d_sc);
   TEND(estimate, st);
   HIPCHK(hipGetLastError());
+  bool mail_in_gate = false;
   if (!use_mail) {
     int rr = comm_allreduce_stats(c); if (rr) return rr;      // do_walk.f90:2778-2790: the sums every rank needs
-    hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(64), 0, st, (const DevScalars *)c->d_sc, c->d_mail, seq);
+    mail_in_gate = c->pipeline_next && p.semi;                 // the next step's gate kernel posts them (one launch less)
+    if (!mail_in_gate) hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(64), 0, st, (const DevScalars *)c->d_sc, c->d_mail, seq);
+    else { memset(&fa, 0, sizeof(fa)); fa.on = 3; fa.mail = c->d_mail; fa.seq = seq; }
   }
   if (c->pipeline_next) {
     // the next step's gate + scan + spawn go out now, behind k_finish: the GPU runs on while the host
     // reads this step's sums and does its population control.  nall bounds the new walker count.
     c->pipeline_next = false;
     int rh = enqueue_head(c, p, step + 1, nall, true, c->timing >= 2 ? c->hev[0] : nullptr, c->timing >= 2 ? c->hev[1] : nullptr,
-                          kernel_events_on(c, step + 1) ? c->hev[2] : nullptr, kernel_events_on(c, step + 1) ? c->hev[3] : nullptr, &c->head_cseq, fin_in_gate ? &fa : nullptr);
+                          kernel_events_on(c, step + 1) ? c->hev[2] : nullptr, kernel_events_on(c, step + 1) ? c->hev[3] : nullptr, &c->head_cseq, (fin_in_gate || mail_in_gate) ? &fa : nullptr);
     if (rh) return rh;
     c->head_ready = true; c->head_p = p;
   }
