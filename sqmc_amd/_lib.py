@@ -30,7 +30,10 @@ class SqmcGpuError(RuntimeError):
 
 def build_library(force=False):
     """hipcc cross-compiles for gfx950 without a GPU present."""
-    src = [os.path.join(_HERE, "csrc", f) for f in ("sqmc_gpu.hip", "chem_device.h", "scan_sort.h")] + [os.path.join(_ROOT, "include", "sqmc_gpu.h")]
+    csrc = os.path.join(_HERE, "csrc")
+    # one translation unit: sqmc_gpu.hip includes every other file of csrc/ textually
+    src = [os.path.join(csrc, "sqmc_gpu.hip")] + sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".inc"))) \
+        + [os.path.join(_ROOT, "include", "sqmc_gpu.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in src):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,0 +1,73 @@
+// door_kernels.h -- batch / test door kernels (matrix elements, proposals, reduce, join)
+// Textually included by sqmc_gpu.hip (one translation unit: the kernels share the ChemTab LDS
+// image, the walker SoA types and the launch helpers defined there); not a standalone header.
+
+// ============================================================ batch / test door kernels
+__global__ void __launch_bounds__(TPB) k_ham_batch(ChemDev dev, const u64 *iu, const u64 *id, const u64 *ju, const u64 *jd, double *h, long long n) {
+  __shared__ ChemTab t;
+  stage_tab(&t, dev.tab, dev.tab_words);
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) h[i] = h_any(t, dev.integrals, iu[i], id[i], ju[i], jd[i]);
+}
+__global__ void __launch_bounds__(TPB) k_ham_chem_batch(ChemDev dev, const u64 *iu, const u64 *id, const u64 *ju, const u64 *jd, double *h, long long n) {
+  __shared__ ChemTab t;
+  stage_tab(&t, dev.tab, dev.tab_words);
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  int lev = excitation_level(iu[i], id[i], ju[i], jd[i]);
+  h[i] = lev < 0 ? 0.0 : h_level(t, dev.integrals, iu[i], id[i], ju[i], jd[i], lev);
+}
+
+// Sparse Hamiltonian among a sorted determinant list by brute force over all pairs: a
+// popcount filter (<= 2 orbital differences, also against the time-reversed partner when
+// time_sym) in front of the Slater-Condon evaluation.  One thread per row, column
+// determinants staged through LDS in tiles.  pass 0 counts, pass 1 fills at the scanned
+// offsets; each row holds its diagonal first, then columns j < i ascending.
+// replaces: generate_sparse_ham_chem_upper_triangular (chemistry.f90:7639-8010)
+__global__ void __launch_bounds__(TPB) k_build_ham(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, long long n, int pass,
+                                                   u64 *__restrict__ counts, const u64 *__restrict__ offs, long long *__restrict__ idx, double *__restrict__ val) {
+  __shared__ ChemTab t;
+  __shared__ u64 su[TPB], sd[TPB];
+  stage_tab(&t, dev.tab, dev.tab_words);
+  const long long r0 = (long long)blockIdx.x * TPB, i = r0 + threadIdx.x;
+  const bool live = i < n;
+  const u64 ui = live ? up[i] : 0, di = live ? dn[i] : 0;
+  u64 cnt = 0; const u64 base = (pass && live) ? offs[i] : 0;
+  if (live) {
+    if (pass) { idx[base] = i + 1; val[base] = h_any(t, dev.integrals, ui, di, ui, di); }
+    cnt = 1;
+  }
+  const long long jend = (r0 + TPB < n) ? r0 + TPB : n;
+  for (long long j0 = 0; j0 < jend; j0 += TPB) {
+    __syncthreads();
+    { long long j = j0 + threadIdx.x; su[threadIdx.x] = (j < n) ? up[j] : 0; sd[threadIdx.x] = (j < n) ? dn[j] : 0; }
+    __syncthreads();
+    if (!live) continue;
+    const int lim = (int)((i - j0 < TPB) ? (i - j0) : TPB);      // only j < i
+    for (int q = 0; q < lim; q++) {
+      const u64 uj = su[q], dj = sd[q];
+      bool cand = (popc64(ui ^ uj) + popc64(di ^ dj)) <= 4;
+      if (!cand && t.time_sym) cand = (popc64(ui ^ dj) + popc64(di ^ uj)) <= 4;
+      if (!cand) continue;
+      const double h = h_any(t, dev.integrals, ui, di, uj, dj);
+      if (h == 0.0) continue;
+      if (pass) { idx[base + cnt] = j0 + q + 1; val[base + cnt] = h; }
+      cnt++;
+    }
+  }
+  if (!pass && live) counts[i] = cnt;
+}
+
+__global__ void __launch_bounds__(TPB) k_propose_batch(ChemDev dev, const u64 *up, const u64 *dn, const u64 *state_in, u64 *ju, u64 *jd,
+                                                       double *wj, u64 *state_out, long long n, double tau) {
+  __shared__ ChemTab t;
+  stage_tab(&t, dev.tab, dev.tab_words);
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  Rng g; g.mode = 0; g.x = state_in[i];
+  u64 a, b; double prob;
+  int level = propose_any(t, g, up[i], dn[i], a, b, prob);
+  double w = 0.0;
+  if (level > 0) w = proposal_weight(t, dev.integrals, tau, up[i], dn[i], a, b, level, prob);
+  ju[i] = a; jd[i] = b; wj[i] = w; state_out[i] = g.x;
+}

@@ -1,0 +1,823 @@
+// walk_kernels.h -- the kernels of one walker step: gate, scan inputs, spawn, annihilation, finish
+// Textually included by sqmc_gpu.hip (one translation unit: the kernels share the ChemTab LDS
+// image, the walker SoA types and the launch helpers defined there); not a standalone header.
+
+// ===================================================================== step kernels
+
+// Everything k_finish does, as arguments: in the pipelined head the first block of the NEXT step's gate
+// kernel does it (one launch less on the critical path).
+struct FinArgs {
+  const double *partials; int nblocks; const double *wabs_part; int nwabs; int mode; u64 *scan_state; u32 *scan_ticket; int n_scan_words;
+  HostMail *mail; u64 seq; u64 *fstate; u32 *fticket; long long cap_ftiles; int n_ftiles; int on;
+};
+__device__ void finish_all(const FinArgs &f, DevScalars *sc);
+// gate + child count (COUNTER discipline).  do_walk.f90:3577-3589
+__global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, const double *__restrict__ wt,
+                                              u64 *__restrict__ nchild, double *__restrict__ wchild, u64 *__restrict__ keys, u32 *__restrict__ vals,
+                                              long long n_arg, StepP p, u64 seed, u64 step, DevScalars *sc, int pack, int n_on_device, FinArgs fin) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  const long long n = n_on_device ? (long long)sc->nwalk : n_arg;      // pipelined head: the grid covers an upper bound
+  if (fin.on && blockIdx.x == 0) finish_all(fin, sc);                  // the last step's final sums and mail, before this step clears the scalars
+  if (i == 0) { sc->n_invalid = 0; sc->tot1 = 0; sc->tot2 = 0; sc->err = 0; }   // every writer of these runs after this kernel
+  if (i >= n) return;
+  put_key(keys, vals, i, det_key(dev, up[i], dn[i]), pack);      // sort key of the walker itself
+  double w = wt[i]; bool spawn, use_wt;
+  if (fabs(w) < p.cutoff) {
+    Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 0, (u64)i);
+    spawn = rng_draw(g) < fabs(w / p.cutoff); use_wt = false;
+  } else { spawn = true; use_wt = true; }
+  long long nc = 0; double wc = 0.0;
+  if (spawn) {
+    if (use_wt) { nc = llround(fabs(w)); if (nc < 1) nc = 1; wc = w / (double)nc; }
+    else { nc = 1; wc = copysign(p.cutoff, w); }
+  }
+  nchild[i] = (u64)nc; wchild[i] = wc;
+}
+
+// REPLAY discipline: one lane walks the walkers in order, consuming the single rannyu
+// stream exactly as the reference does, and records where every child starts in it.
+__global__ void __launch_bounds__(64) k_replay_prepass(const ChemTab *__restrict__ gtab, const u64 *__restrict__ up, const u64 *__restrict__ dn,
+                                                       const double *__restrict__ wt, u64 *__restrict__ nchild, double *__restrict__ wchild,
+                                                       u64 *__restrict__ child_off, u64 *__restrict__ child_state, long long n,
+                                                       long long cap_children, StepP p, DevScalars *sc) {
+  __shared__ ChemTab t;
+  stage_tab(&t, gtab, tab_words_used(gtab->c2_stride));
+  if (threadIdx.x != 0) return;
+  sc->n_invalid = 0; sc->tot1 = 0; sc->tot2 = 0; sc->err = 0;
+  Rng g; g.mode = 0; g.x = sc->lcg;
+  u64 c = 0;
+  for (long long i = 0; i < n; i++) {
+    double w = wt[i]; bool spawn, use_wt;
+    if (fabs(w) < p.cutoff) { spawn = rng_draw(g) < fabs(w / p.cutoff); use_wt = false; }
+    else { spawn = true; use_wt = true; }
+    long long nc = 0; double wc = 0.0;
+    if (spawn) {
+      if (use_wt) { nc = llround(fabs(w)); if (nc < 1) nc = 1; wc = w / (double)nc; }
+      else { nc = 1; wc = copysign(p.cutoff, w); }
+    }
+    nchild[i] = (u64)nc; wchild[i] = wc; child_off[i] = c;
+    u64 iu = up[i], id = dn[i];
+    for (long long k = 0; k < nc; k++) {
+      if ((long long)c < cap_children) child_state[c] = g.x;
+      u64 ju, jd; double pr;
+      propose_any(t, g, iu, id, ju, jd, pr);
+      c++;
+    }
+  }
+  child_off[n] = c;
+  sc->n_children = c; sc->lcg = g.x;
+}
+
+// diagonal death/clone, do_walk.f90:3743-3793
+__global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, double *__restrict__ wt,
+                                              const u32 *__restrict__ flg, double *__restrict__ me, long long n, StepP p, DevScalars *sc) {
+  __shared__ ChemTab t;
+  stage_tab(&t, dev.tab, dev.tab_words);
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  if (p.semi && flg_impd(flg[i]) < 1) return;
+  double hii = me[i];
+  if (hii > 1e50) { hii = h_any(t, dev.integrals, up[i], dn[i], up[i], dn[i]); me[i] = hii; }
+  double f = 1.0 + p.tau * (p.e_trial - hii);
+  if (f < 0) { if (p.reached > 1) sc->err = SQMC_ERR_NEG_DIAG; f = 0; }
+  wt[i] = wt[i] * f;
+}
+
+// rank that owns a determinant (get_det_owner, mpi_routines.f90:419-445: any hash of the determinant mod the number of ranks)
+__host__ __device__ __forceinline__ int det_owner(u64 key, int nranks) { return (int)((sq_mix64(key ^ 0xA5A5A5A5A5A5A5A5ull) >> 17) % (u64)nranks); }
+// sharded steps: k_spawn also notes the destination rank of every child (nranks for a child that made no walker), the key of the bucketing pass
+struct OwnerOut { u64 *okey; u32 *oval; int nranks; };      // okey == nullptr: off
+// a spawned walker (or the "no walker" marker) into slot n0 + c.  do_walk.f90:3700-3731
+__device__ __forceinline__ void spawn_emit(const ChemDev &dev, const WalkArr &w, u64 *__restrict__ keys, u32 *__restrict__ vals, long long n0, long long c,
+                                           u32 pf, u64 ju, u64 jd, double wj, const StepP &p, u64 invalid_key, int pack, const OwnerOut &oo) {
+  const long long k = n0 + c;
+  if (wj != 0.0) {
+    const int pd = flg_impd(pf), pi = flg_init(pf);
+    int d;
+    if (pd == -2) d = p.cti ? 1 : 2; else d = (pd < 126 ? pd : 126) + 1;
+    if (p.semi && pd == 0) d = -1;
+    int ini = (pi >= 2) ? 1 : 0;
+    if (p.cti && pd == -2) ini = 1;
+    if (p.semi && pd == 0) ini = 1;
+    // matrix_elements / e_num / e_den of a spawn are the 1e51 sentinel (do_walk.f90:3728-3730):
+    // not stored, k_merge supplies them for every slot >= n0
+    SpawnRec r; r.up = ju; r.dn = jd; r.wt = wj; r.flg = pack_flg(d, ini, 0);
+    w.sp[c] = r;
+    const u64 key = det_key(dev, ju, jd);
+    put_key(keys, vals, k, key, pack);
+    if (oo.okey) { oo.okey[c] = (u64)det_owner(key, oo.nranks); oo.oval[c] = (u32)c; }
+  } else {
+    w.sp[c].wt = 0.0; put_key(keys, vals, k, invalid_key, pack);     // sorts behind every real determinant
+    if (oo.okey) { oo.okey[c] = (u64)oo.nranks; oo.oval[c] = (u32)c; }
+  }
+}
+
+#ifdef SPAWN_PROF
+__device__ unsigned long long g_prof[8 * 8192];
+#define PROF(K) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_prof[blockIdx.x * 8 + (K)] = wall_clock64(); } while (0)
+extern "C" int sqmc_gpu_debug_prof(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)); }
+#else
+#define PROF(K)
+#endif
+// one thread per child proposal; parent found by binary search in the child offsets
+__global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
+                                               const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
+                                               long long n0_arg, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc,
+                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo) {
+  const long long n0 = n_on_device ? (long long)sc->nwalk : n0_arg;     // pipelined head: launched before the host learnt the walker count
+  // the grid covers the free capacity of the walker arrays; the number of children is read from
+  // device memory so that the launch does not wait for the host to learn it
+  PROF(0);
+  __shared__ ChemTab t;
+  __shared__ u64 s_win[SPAWN_WIN];
+  // Parent of child c = largest i with child_off[i] <= c.  The 256 children of a block have
+  // neighbouring parents, so the block narrows [0,n0) for its first child with 256-way splits
+  // (one round trip per level instead of log2(n0) dependent loads), then every thread finishes
+  // inside a 1024-entry LDS window (global search only if it runs past it).  The first probe, the
+  // table staging and the child count do not depend on each other: they are issued together.
+  const long long c0 = (long long)blockIdx.x * TPB;
+  long long wlo = 0, whi = n0;                       // invariant: child_off[wlo] <= c0, answer for c0 in [wlo, whi)
+  u64 pv = 0;
+  if (whi - wlo > SPAWN_WIN) {
+    const long long stepw = (whi - wlo + TPB - 1) / TPB, probe = wlo + (long long)threadIdx.x * stepw;
+    pv = (probe < whi) ? child_off[probe] : ~0ull;
+  }
+  stage_tab(&t, dev.tab, dev.tab_words);
+  const long long nchildren = (long long)sc->n_children;
+  if (mail && blockIdx.x == 0 && threadIdx.x == 0) {      // the host sizes the sort from this while the kernel runs
+    mail->n_children = (u64)nchildren; __threadfence_system(); mail->cnt_seq = cnt_seq;
+  }
+  if (c0 >= nchildren || n0 + nchildren > cap_all) return;
+  PROF(1);
+  while (whi - wlo > SPAWN_WIN) {
+    const long long stepw = (whi - wlo + TPB - 1) / TPB, probe = wlo + (long long)threadIdx.x * stepw;
+    const int le = (probe < whi && pv <= (u64)c0) ? 1 : 0;
+    const int cnt = __syncthreads_count(le);           // probes are sorted: the first cnt of them are <= c0
+    const long long nlo = wlo + (long long)(cnt - 1) * stepw;
+    whi = (nlo + stepw < whi) ? nlo + stepw : whi; wlo = nlo;
+    if (whi - wlo > SPAWN_WIN) {
+      const long long stepw2 = (whi - wlo + TPB - 1) / TPB, probe2 = wlo + (long long)threadIdx.x * stepw2;
+      pv = (probe2 < whi) ? child_off[probe2] : ~0ull;
+    }
+  }
+  for (int k = threadIdx.x; k < SPAWN_WIN; k += TPB) {  // window keeps going past whi: later children of the block live there
+    const long long i = wlo + k;
+    s_win[k] = (i < n0) ? child_off[i] : ~0ull;
+  }
+  __syncthreads();
+  PROF(2);
+  const long long c = c0 + threadIdx.x;
+  const bool active = c < nchildren;
+  if (active) {
+    long long ip;
+    if (s_win[SPAWN_WIN - 1] <= (u64)c) {                 // beyond the window (many childless parents in between)
+      long long lo = wlo + SPAWN_WIN - 1, hi = n0;
+      while (hi - lo > 1) { long long mid = (lo + hi) >> 1; if (child_off[mid] <= (u64)c) lo = mid; else hi = mid; }
+      ip = lo;
+    } else {
+      int lo = 0, hi = SPAWN_WIN - 1;                     // s_win[lo] <= c < s_win[hi]
+      while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s_win[mid] <= (u64)c) lo = mid; else hi = mid; }
+      ip = wlo + lo;
+    }
+    Rng g; g.mode = mode;
+    g.x = (mode == 0) ? child_state[c] : sq_counter_key(seed, step, 1, (u64)c);
+    const u64 iu = w.up[ip], id = w.dn[ip];
+    const u32 pflg = w.flg[ip]; const double wch = wchild[ip];     // needed at the end: fetched in the same round trip
+    u64 ju, jd; double prob;
+    PROF(3);
+    const int level = propose_any(t, g, iu, id, ju, jd, prob);
+    PROF(4);
+    double wj = 0.0;
+    if (level > 0) {
+      wj = proposal_weight(t, dev.integrals, p.tau, iu, id, ju, jd, level, prob);
+      wj = wch * wj;
+    }
+    spawn_emit(dev, w, keys, vals, n0, c, pflg, ju, jd, wj, p, invalid_key, pack, oo);
+  }
+  PROF(5);
+}
+
+__global__ void __launch_bounds__(TPB) k_main_keys(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, u64 *__restrict__ keys,
+                                                   u32 *__restrict__ vals, long long n, int pack) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) put_key(keys, vals, i, det_key(dev, up[i], dn[i]), pack);
+}
+
+// deterministic projection: x = w(loc); y = A x (rows summed in the reference's order);
+// w(loc) += y + (E_T*tau)*x.   do_walk.f90:2262, 2290, 2321-2323
+__global__ void __launch_bounds__(TPB) k_prj_gather(const double *__restrict__ wt, const int *__restrict__ loc, double *__restrict__ x, long long n) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) x[i] = wt[loc[i]];
+}
+// one wavefront per row: the 64 products of a chunk are formed in parallel (coalesced loads)
+// and parked in LDS, then added in storage order (LDS broadcast reads, only the fp64 adds
+// are on the dependent chain), so y is bit-identical to the reference's sequential
+// accumulation even for the HF row that touches the whole deterministic space.
+__global__ void __launch_bounds__(TPB) k_prj_apply(const int *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val,
+                                                   const double *__restrict__ x, const int *__restrict__ loc, double *__restrict__ wt,
+                                                   long long n, double e_trial, double tau) {
+  __shared__ double sprod[TPB / 64][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * (TPB / 64) + wv;
+  if (i >= n) return;
+  const int b = ptr[i], e = ptr[i + 1];
+  double y = 0.0;
+  for (int base = b; base < e; base += 64) {
+    const int k = base + lane;
+    sprod[wv][lane] = (k < e) ? val[k] * x[col[k]] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    const int cnt = (e - base < 64) ? (e - base) : 64;
+    if (cnt == 64) {
+#pragma unroll
+      for (int l = 0; l < 64; l++) y = y + sprod[wv][l];
+    } else {
+      for (int l = 0; l < cnt; l++) y = y + sprod[wv][l];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) {
+    y = y + e_trial * tau * x[i];
+    wt[loc[i]] = wt[loc[i]] + y;
+  }
+}
+__global__ void __launch_bounds__(TPB) k_scale(double *__restrict__ v, long long n, double r) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) v[i] = v[i] * r;
+}
+
+// integer ** integer of the reference (0**0 = 1)
+__device__ __forceinline__ double ipow_d(int b, int e) { double r = 1.0; for (int i = 0; i < e; i++) r *= (double)b; return r; }
+
+// Annihilation + initiator rules: one thread per run of equal determinants in the sorted
+// order.  Within a run the original walker comes first and spawns keep creation order
+// (stable sort), so the pairwise combination below is the reference's left-to-right scan.
+// do_walk.f90:5866-6083, check_initiator 6838-6872.
+struct MergedRec { u64 up, dn; double wt, me, en, ed; u32 flg; int d; u64 f; };   // f: bit 0 = kept after the merge, bit 32 = small weight, to be rounded
+// block sum of the two pre-merge partials into row `tile` (all 256 threads)
+__device__ __forceinline__ void store_wabs(double *__restrict__ wabs_part, long long tile, double wabs, double cnt) {
+  __shared__ double red[2][TPB / 64];
+  double v = wabs, q = cnt;
+  for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); q += __shfl_down(q, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = v; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) { wabs_part[2 * tile] = red[0][0] + red[0][1] + red[0][2] + red[0][3]; wabs_part[2 * tile + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3]; }
+}
+// The merged walker of sorted slot j (f = 0 for slots that are not the head of a run or are
+// discarded).  The 64 lanes of a wavefront call it together on 64 CONSECUTIVE slots (lane l: slot
+// j0 + l).  Every lane fetches the record of its own slot -- one gather for the whole row, no
+// dependent chain per follower -- and parks weight and flags in LDS; the head of a run then folds
+// its followers in storage order out of LDS (the reference's left-to-right scan).  Only a run
+// that leaves the row needs more loads: the wavefront fetches it 64 records per round trip.
+// load_slot also adds the slot's share of the sums over the pre-merge list
+// (my_w_abs_before_merge_cum, nwalk_before_merge; do_walk.f90:2347-2349) to wabs / cnt.
+struct SlotIn { u64 key; SpawnRec h; double me, en, ed; bool head, real; };
+// all global loads of one slot (independent of every other slot: a thread issues those of its ITEMS slots together)
+__device__ __forceinline__ SlotIn load_slot(const WalkArr &w, const u64 *__restrict__ skey, const u32 *__restrict__ perm,
+                                            long long j, long long n0, long long n_all, u64 invalid_key, int pack, double &wabs, double &cnt) {
+  SlotIn in; in.key = invalid_key; in.h.up = 0; in.h.dn = 0; in.h.wt = 0.0; in.h.flg = 0; in.me = 1e51; in.en = 1e51; in.ed = 1e51;
+  const int lane = threadIdx.x & 63;
+  const bool valid = j < n_all;
+  u32 t = 0;
+  if (valid) { in.key = get_key(skey, j, pack); t = get_perm(skey, perm, j, pack); }
+  u64 kprev = __shfl_up(in.key, 1, 64);                  // key of the slot before: the neighbouring lane has it
+  if (lane == 0) kprev = (valid && j > 0) ? get_key(skey, j - 1, pack) : invalid_key;
+  in.real = valid && in.key != invalid_key;              // children that produced no walker sort last
+  in.head = in.real && !(j > 0 && kprev == in.key);
+  // the head of a run is the resident walker if there is one (stable sort), else the first spawn;
+  // every later walker of a run is a spawn (walkers are unique): its cached values are the 1e51
+  // sentinel, so the reference's min() merges leave me / en / ed unchanged
+  if (in.real) {
+    if ((long long)t >= n0) in.h = w.sp[t - n0];
+    else { in.h.up = w.up[t]; in.h.dn = w.dn[t]; in.h.wt = w.wt[t]; in.h.flg = w.flg[t]; in.me = w.me[t]; in.en = w.en[t]; in.ed = w.ed[t]; }
+    wabs += fabs(in.h.wt); cnt += 1.0;
+  }
+  return in;
+}
+#define MERGE_AHEAD 4
+#define MERGE_SELF 8
+#define SLOT_STOP 0x80000000u     // in the staged flag word: this slot starts a run or holds no walker
+// stage weight and flags of a slot at its place in the tile (LDS); the block synchronises before folding
+__device__ __forceinline__ void stage_slot(const SlotIn &in, double *__restrict__ s_w, u32 *__restrict__ s_f, int idx) {
+  s_w[idx] = in.h.wt; s_f[idx] = (u32)in.h.flg | ((in.head || !in.real) ? SLOT_STOP : 0u);
+}
+// fold the run that starts at in-tile slot idx (if `in` is a head) out of the staged tile; a run that
+// leaves the tile is continued from HBM by the head's wavefront, 64 records per round trip
+__device__ __forceinline__ MergedRec fold_slot(const SlotIn &in, const double *__restrict__ s_w, const u32 *__restrict__ s_f, int idx, int tile_slots,
+                                               const WalkArr &w, const u64 *__restrict__ skey, const u32 *__restrict__ perm,
+                                               long long j, long long n0, long long n_all, const StepP &p, u64 invalid_key, int pack) {
+  const long long n = n_all;
+  MergedRec out; out.up = 0; out.dn = 0; out.wt = 0.0; out.me = 1e51; out.en = 1e51; out.ed = 1e51; out.flg = 0; out.d = 0; out.f = 0;
+  __shared__ double s_w2[TPB / 64][64];
+  __shared__ u32 s_f2[TPB / 64][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const u64 key = in.key; const bool head = in.head;
+  const SpawnRec h = in.h; const double me = in.me, en = in.en, ed = in.ed;
+  double wt = h.wt;
+  int ini = 0, d = 0, ps = 0;
+  long long jj = j + 1;
+#define MERGE_FOLD(W2, FS) do {                                                                     \
+    const double w2_ = (W2); const u32 fs_ = (FS); const int i2 = flg_init(fs_), d2 = flg_impd(fs_); \
+    const bool same_sign = (w2_ * wt > 0);                                                          \
+    if (same_sign) { if (i2 > ini) ini = i2; }                                                      \
+    if (d == -2) { if (d2 == 0) d = 0; }                                                            \
+    else if (d2 == -2) { if (d != 0) d = -2; }                                                      \
+    else if (d != 0 && d != -2) { int a_ = d2 < 0 ? -d2 : d2; if (a_ < d) d = a_; }                 \
+    if (!same_sign) {                                                                               \
+      if (fabs(wt) < fabs(w2_)) { if (ini != 3 || p.r_init == -1.0) ini = i2; }                     \
+      else if (fabs(wt) == fabs(w2_)) { if (ini != 3 || p.r_init == -1.0) ini = 0; }                \
+    }                                                                                               \
+    if (!(d == 0 && d2 == -1)) wt = wt + w2_;                                                       \
+  } while (0)
+  // A head folds the first MERGE_SELF followers of its run itself (most runs end there).  What is
+  // left of a long run (a heavy determinant whose children land on a few neighbours: hundreds of
+  // equal keys) is folded by the whole wavefront, 64 records at a time: out of the staged tile as
+  // far as it reaches, then out of HBM.
+  int lt = idx + 1;                              // next in-tile slot of this lane's run
+  bool pending = false;
+  if (head) {
+    const u32 ft = (u32)h.flg;
+    ini = flg_init(ft); d = flg_impd(ft); ps = flg_psign(ft);
+    if (d == -1 && j > 0) d = 1;                 // 5985-5986 (the very first walker keeps -1 until the end)
+    bool open = true;
+    for (int k = 0; k < MERGE_SELF && lt < tile_slots; k++, lt++) { const u32 fl = s_f[lt]; if (fl & SLOT_STOP) { open = false; break; } MERGE_FOLD(s_w[lt], fl); }
+    jj = j + (lt - idx);
+    pending = open && (lt < tile_slots ? !(s_f[lt] & SLOT_STOP) : (j - idx + tile_slots < n && get_key(skey, j - idx + tile_slots, pack) == key));
+  }
+  // one chunk of up to 64 followers held one per lane (valid lanes form a prefix); returns its length
+  auto fold_chunk = [&](bool valid, double w2, u32 f2, int leader) -> int {
+    const u64 vb = __ballot(valid);
+    const int cnt = (vb == ~0ull) ? 64 : __ffsll((long long)~vb) - 1;
+    // A chunk whose weights all carry the sign of the running sum (the usual case: children of one
+    // parent) needs no sign logic: the initiator flag is a maximum, imp_distance a minimum, and only
+    // the additions stay in order (skipped terms become -0.0, which leaves a non-zero sum unchanged).
+    const double wt_l = __shfl(wt, leader, 64); const int d_l = __shfl(d, leader, 64);
+    const bool use = valid && lane < cnt;
+    const int i2 = flg_init(f2), d2 = flg_impd(f2);
+    const bool plain = !use || (((w2 > 0) == (wt_l > 0)) && fabs(w2) > 1e-150 && d2 != 0 && d2 != -2);
+    if (fabs(wt_l) > 1e-150 && __ballot(plain) == ~0ull) {
+      int im = use ? i2 : 0, dm = use ? (d2 < 0 ? -d2 : d2) : 1 << 20;
+      for (int o = 32; o > 0; o >>= 1) { const int a = __shfl_xor(im, o, 64), b = __shfl_xor(dm, o, 64); im = a > im ? a : im; dm = b < dm ? b : dm; }
+      s_w2[wv][lane] = (use && !(d_l == 0 && d2 == -1)) ? w2 : -0.0;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == leader) {
+        if (im > ini) ini = im;
+        if (d >= 1 && dm < d) d = dm;
+        if (cnt == 64) {
+#pragma unroll
+          for (int l = 0; l < 64; l++) wt = wt + s_w2[wv][l];
+        } else for (int l = 0; l < cnt; l++) wt = wt + s_w2[wv][l];
+        jj += cnt;
+      }
+    } else {
+      s_w2[wv][lane] = w2; s_f2[wv][lane] = f2;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == leader) { for (int l = 0; l < cnt; l++) MERGE_FOLD(s_w2[wv][l], s_f2[wv][l]); jj += cnt; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return cnt;
+  };
+  const long long jn = (j - idx) + tile_slots;   // first slot after the tile
+  for (u64 pend = __ballot(pending); pend; pend &= pend - 1) {
+    const int leader = __ffsll((long long)pend) - 1;
+    int ltl = __shfl(lt, leader, 64);
+    const u64 lkey = __shfl(key, leader, 64);
+    // ---- the part of the run that lies in the staged tile
+    while (ltl < tile_slots) {
+      const int li = ltl + lane;
+      const u32 fl = (li < tile_slots) ? s_f[li] : SLOT_STOP;
+      const bool valid = !(fl & SLOT_STOP);
+      const int cnt = fold_chunk(valid, valid ? s_w[li] : 0.0, fl, leader);
+      ltl += cnt;
+      if (cnt < 64) break;
+    }
+    if (ltl < tile_slots) continue;              // the run ended inside the tile
+    // ---- the run reaches the end of the tile: the rest, if any, comes from HBM
+    long long base = jn;
+    for (bool more = true; more;) {
+      // MERGE_AHEAD rows of 64 records are requested together (one latency for 256 records), then folded row by row
+      double w2q[MERGE_AHEAD]; u32 f2q[MERGE_AHEAD]; bool vq[MERGE_AHEAD];
+#pragma unroll
+      for (int q = 0; q < MERGE_AHEAD; q++) {
+        const long long ix = base + (long long)q * 64 + lane;
+        vq[q] = ix < n && get_key(skey, ix, pack) == lkey;
+        w2q[q] = 0.0; f2q[q] = 0;
+        if (vq[q]) { const u32 sx = get_perm(skey, perm, ix, pack); const SpawnRec r2 = w.sp[sx - n0]; w2q[q] = r2.wt; f2q[q] = (u32)r2.flg; }
+      }
+#pragma unroll
+      for (int q = 0; q < MERGE_AHEAD; q++) {
+        if (!more) break;
+        if (fold_chunk(vq[q], w2q[q], f2q[q], leader) < 64) more = false;
+      }
+      base += 64 * MERGE_AHEAD;
+    }
+  }
+#undef MERGE_FOLD
+  if (!head) return out;
+  // check_initiator
+  {
+    const int dd = d - p.imind > 0 ? d - p.imind : 0;
+    const double thr = p.r_init * ipow_d(dd, p.ipow), aw = fabs(wt);
+    if (ini == 3 && p.r_init >= 0) { if (wt * ps < 1.0) wt = (double)ps; }
+    else if (ini == 2 && ((aw <= thr && d > 0) || ((aw <= p.r_init && !p.cti) && d == -2))) ini = 1;
+    else if (ini < 2 && ((aw > thr && d >= 0) || ((aw > p.r_init || p.cti) && d == -2))) ini = ini + 1;
+  }
+  int dtest = d;
+  if (d == -1) { if (jj >= n || get_key(skey, jj, pack) == invalid_key) dtest = 1; d = 1; }   // 6032-6036 then the last-det test at 6038
+  const bool discard = (((wt == 0.0 && (ini != 3 || p.r_init < 0)) || ini == 0) && dtest >= 1);
+  out.up = h.up; out.dn = h.dn; out.wt = wt; out.flg = pack_flg(d, ini, ps); out.d = d;
+  out.me = me; out.en = en; out.ed = ed;
+  if (!discard) { out.f = 1ull; if (p.semi && d >= 1 && fabs(wt) < p.min_wt) out.f |= (1ull << 32); }
+  return out;
+}
+__global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *__restrict__ skey, const u32 *__restrict__ perm,
+                                               u64 *__restrict__ flags, double *__restrict__ wabs_part, long long n0, long long n_all, StepP p, u64 invalid_key,
+                                               int pack) {
+  const long long j = (long long)blockIdx.x * TPB + threadIdx.x;
+  double wabs = 0.0, cnt = 0.0;
+  __shared__ double s_w[TPB]; __shared__ u32 s_f[TPB];
+  const SlotIn in = load_slot(w, skey, perm, j, n0, n_all, invalid_key, pack, wabs, cnt);
+  stage_slot(in, s_w, s_f, threadIdx.x);
+  __syncthreads();
+  const MergedRec r = fold_slot(in, s_w, s_f, threadIdx.x, TPB, w, skey, perm, j, n0, n_all, p, invalid_key, pack);
+  store_wabs(wabs_part, blockIdx.x, wabs, cnt);
+  if (j >= n_all) return;
+  flags[j] = r.f;
+  if (!(r.f & 1ull)) return;                   // not the head of a run, or discarded: nothing to store
+  m.up[j] = r.up; m.dn[j] = r.dn; m.wt[j] = r.wt; m.flg[j] = r.flg;
+  m.me[j] = r.me; m.en[j] = r.en; m.ed[j] = r.ed;
+}
+
+// stochastic rounding of small weights (reduce_my_walker, do_walk.f90:7196-7254); RNG draws
+// are taken in merged-walker order: REPLAY = skip-ahead of the rannyu LCG by the rank of the
+// draw, COUNTER = stream keyed by the merged index.
+__global__ void __launch_bounds__(TPB) k_round(WalkArr m, const u64 *__restrict__ flags, const u64 *__restrict__ pos, u64 *__restrict__ flags2,
+                                               long long n_all, StepP p, int mode, u64 seed, u64 step, const DevScalars *sc) {
+  long long j = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (j >= n_all) return;
+  const u64 f = flags[j];
+  if (!(f & 1ull)) { flags2[j] = 0; return; }
+  double wt = m.wt[j];
+  if (f >> 32) {
+    const u64 ps = pos[j];
+    double r;
+    if (mode == 0) r = (double)lcg_skip(sc->lcg, (ps >> 32) + 1) * 3.552713678800500929355621337890625e-15;
+    else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, m.up[j] * SQ_GOLDEN + m.dn[j]); r = rng_draw(g); }   // keyed by the determinant
+    if (r < (fabs(wt) / p.min_wt)) wt = copysign(p.min_wt, wt); else wt = 0.0;
+    m.wt[j] = wt;
+  }
+  const int d = flg_impd(m.flg[j]);
+  u64 f2 = 0;
+  // reduce_my_walker drops zero weights outside the deterministic space (7222-7249), join_walker2 every zero weight (7071-7092)
+  const bool drop = p.semi ? (wt == 0.0 && d >= 1) : (wt == 0.0);
+  if (!drop) { f2 = 1ull; if (d == 0) f2 |= (1ull << 32); }
+  flags2[j] = f2;
+}
+
+// join_walker2 (do_walk.f90:6990-7103), the non-semistochastic counterpart of the rounding: the
+// small walkers of one sign are joined along the list -- the pair's weight goes to one of the two
+// with probability proportional to its own weight, one draw per join -- until the running weight
+// exceeds min_wt; positive walkers first, then negative ones.  Which walkers end a chain depends on
+// the running sum, so the chain is followed by ONE lane; the 256 threads of the block only stream
+// the merged list through LDS in 1024-walker tiles (coalesced) ahead of it.  Draws: REPLAY = the
+// rannyu stream in join order, COUNTER = stream keyed by the merged index of the later walker.
+#define JOIN_TILE 1024
+__global__ void __launch_bounds__(TPB) k_join(WalkArr m, const u64 *__restrict__ flags, const u64 *__restrict__ pos, long long n_all, StepP p,
+                                              int mode, u64 seed, u64 step, DevScalars *sc) {
+  __shared__ double s_wt[JOIN_TILE]; __shared__ unsigned int s_rank[JOIN_TILE]; __shared__ unsigned char s_cand[JOIN_TILE];
+  u64 lcg = sc->lcg;
+  for (int pass = 0; pass < 2; pass++) {
+    bool ipair = false; long long j2 = 0; double w2 = 0.0;           // the walker currently carrying the chain and its weight (lane 0)
+    for (long long base = 0; base < n_all; base += JOIN_TILE) {
+      for (int k = threadIdx.x; k < JOIN_TILE; k += TPB) {
+        const long long j = base + k;
+        unsigned char cand = 0; double wt = 0.0; unsigned int rk = 0;
+        if (j < n_all && (flags[j] & 1ull)) {
+          wt = m.wt[j];
+          cand = ((pass == 0 ? wt > 0.0 : wt < 0.0) && fabs(wt) < p.min_wt && flg_init(m.flg[j]) < 3) ? 1 : 0;
+          rk = (unsigned int)(pos[j] & 0xFFFFFFFFull);
+        }
+        s_wt[k] = wt; s_rank[k] = rk; s_cand[k] = cand;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int lim = (n_all - base < JOIN_TILE) ? (int)(n_all - base) : JOIN_TILE;
+        for (int k = 0; k < lim; k++) {
+          if (!s_cand[k]) continue;
+          const long long j = base + k; const double wi = s_wt[k];
+          if (!ipair) { ipair = true; j2 = j; w2 = wi; continue; }
+          const double wttot = fabs(wi) + fabs(w2);
+          double r;
+          if (mode == 0) { lcg = (lcg * SQ_LCG_MULT) & SQ_MASK48; r = (double)lcg * 3.552713678800500929355621337890625e-15; }
+          else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, (u64)s_rank[k]); r = rng_draw(g); }
+          if (r > (fabs(wi) / wttot)) { w2 = copysign(wttot, w2); m.wt[j2] = w2; m.wt[j] = 0.0; }
+          else { m.wt[j2] = 0.0; w2 = copysign(wttot, wi); m.wt[j] = w2; j2 = j; }
+          if (wttot > p.min_wt) ipair = false;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0 && mode == 0) sc->lcg = lcg;
+}
+
+// C(T) lookup: open-addressed hash (linear probing, load <= 1/2) from the determinant's sort
+// key to its row in the C(T) arrays.  Replaces the binary search of
+// binary_search_list_and_update (more_tools.f90:4041-4098): one or two dependent reads
+// instead of log2(n_ct) ~ 17; the 2 MB table is L2-resident.
+#define CT_EMPTY (~0ull)
+__device__ __forceinline__ u64 ct_hash(u64 k) { return sq_mix64(k); }
+__global__ void __launch_bounds__(TPB) k_ct_build(ChemDev dev, const u64 *__restrict__ cu, const u64 *__restrict__ cd, long long n,
+                                                  u64 *__restrict__ hkey, u32 *__restrict__ hidx, u64 mask) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const u64 key = det_key(dev, cu[i], cd[i]);
+  u64 h = ct_hash(key) & mask;
+  while (true) {
+    u64 prev = atomicCAS((unsigned long long *)&hkey[h], CT_EMPTY, key);
+    if (prev == CT_EMPTY) { hidx[h] = (u32)i; return; }
+    h = (h + 1) & mask;
+  }
+}
+__device__ __forceinline__ long long ct_lookup(const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 mask, u64 key) {
+  u64 h = ct_hash(key) & mask;
+  while (true) {
+    const u64 k = hkey[h];
+    if (k == key) return (long long)hidx[h];
+    if (k == CT_EMPTY) return -1;
+    h = (h + 1) & mask;
+  }
+}
+
+#define NSTAT 13
+__device__ void finish_step(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
+                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words);
+// compaction into the walker arrays + reweight (2487) + estimator pieces (2573-2684 and
+// binary_search_list_and_update, more_tools.f90:4041-4098) + per-block partial sums
+__global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64 *__restrict__ flags2, const u64 *__restrict__ pos2,
+                                                 int *__restrict__ loc_imp, const u64 *__restrict__ skey, const u64 *__restrict__ hkey,
+                                                 const u32 *__restrict__ hidx, u64 hmask,
+                                                 const double *__restrict__ cnum, const double *__restrict__ cden,
+                                                 long long n_all, StepP p, double *__restrict__ partials, int pack) {
+  double s[NSTAT];
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
+  for (long long j = (long long)blockIdx.x * TPB + threadIdx.x; j < n_all; j += (long long)gridDim.x * TPB) {
+    if (!(flags2[j] & 1ull)) continue;
+    const u64 ps = pos2[j]; const long long o = (long long)(ps & 0xFFFFFFFFull);
+    const u64 u = m.up[j], dd = m.dn[j];
+    const double wt = m.wt[j] * p.rfi;
+    const u32 fj = m.flg[j]; const int d = flg_impd(fj), ini = flg_init(fj), psg = flg_psign(fj);
+    double en = m.en[j], ed = m.ed[j];
+    if (en > 1e50) {
+      long long q = ct_lookup(hkey, hidx, hmask, get_key(skey, j, pack));
+      if (q < 0) { en = 0.0; ed = 0.0; } else { en = cnum[q]; ed = cden[q]; }
+    }
+    w.up[o] = u; w.dn[o] = dd; w.wt[o] = wt; w.flg[o] = fj;
+    w.me[o] = m.me[j]; w.en[o] = en; w.ed[o] = ed;
+    if (d == 0 && p.semi && (long long)(ps >> 32) < p.nimp_cap) loc_imp[ps >> 32] = (int)o;
+    s[0] += wt; s[1] += fabs(wt); s[8] += wt * wt;
+    if (ini == 3) s[4] += wt * psg;
+    if (d == 0 || (d == -2 && p.cti)) s[6] += fabs(wt);
+    double e_num = en * wt, e_den = ed * wt;
+    if (e_num != 0.0) {
+      if (fabs(e_den) < 1e-22) e_den = fabs(e_den);
+      s[2] += e_den; s[3] += e_num; s[9] += e_num * e_num; s[10] += e_den * e_den;
+      s[11] += e_num * copysign(1.0, e_den); s[12] += fabs(e_den); s[5] += e_num * e_den;
+    }
+  }
+  // deterministic block reduction (wave shuffles, then 4 wave sums in LDS)
+  __shared__ double red[TPB / 64][NSTAT];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) {
+    double v = s[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) red[wv][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NSTAT) {
+    double v = 0.0;
+    for (int q = 0; q < TPB / 64; q++) v += red[q][threadIdx.x];
+    partials[(long long)blockIdx.x * NSTAT + threadIdx.x] = v;
+  }
+}
+// The whole annihilation tail of a semistochastic step in ONE kernel: merge of the sorted list
+// (merge_slot), rank among the kept walkers by a decoupled look-back across tiles, stochastic
+// rounding (reduce_my_walker, do_walk.f90:7196-7254; draws exactly as k_round takes them), rank
+// among the survivors by a second look-back, then compaction into the OTHER walker buffer with the
+// reweighting, the C(T) lookup of first-visit determinants and the per-tile estimator sums
+// (k_compact).  The merged walkers never leave the registers: the intermediate arrays, the two
+// flag/position arrays and four launches of the unfused path (k_merge, scan, k_round, scan,
+// k_compact) are gone.  Tiles are handed out by an atomic ticket (forward progress without
+// co-residency assumptions, as in scan_lookback_kernel); both look-backs use the same tile order.
+#ifdef ANNEAL_PROF
+__device__ unsigned long long g_aprof[8 * 16384];
+#define APROF(K) do { if (threadIdx.x == 0 && tile < 16384) g_aprof[tile * 8 + (K)] = wall_clock64(); } while (0)
+extern "C" int sqmc_gpu_debug_aprof(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_aprof), sizeof(g_aprof)); }
+#else
+#define APROF(K)
+#endif
+template <int ITEMS>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) k_anneal(WalkArr w, WalkArr o, const u64 *__restrict__ skey, const u32 *__restrict__ perm, int *__restrict__ loc_imp,
+                                                const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 hmask,
+                                                const double *__restrict__ cnum, const double *__restrict__ cden,
+                                                double *__restrict__ partials, double *__restrict__ wabs_part, long long n0, long long n_all, StepP p,
+                                                u64 invalid_key, int pack, int mode, u64 seed, u64 step, DevScalars *sc,
+                                                u64 *__restrict__ state1, u64 *__restrict__ state2, u32 *__restrict__ ticket) {
+  constexpr int TILE = TPB * ITEMS;
+  __shared__ u32 s_tile; __shared__ u64 s_ex[2]; __shared__ u64 s_wsum[2][TPB / 64];
+  __shared__ double s_w[TILE]; __shared__ u32 s_f[TILE];          // weight and flags of every slot of the tile
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const u32 tile = s_tile;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // every wavefront owns 64*ITEMS consecutive slots and takes them row by row (lane l: slot r*64 + l)
+  const long long base = (long long)tile * TILE + (long long)wv * (64 * ITEMS) + lane;
+  const bool last_tile = (long long)(tile + 1) * TILE >= n_all;
+  APROF(0);
+  u64 key[ITEMS]; double wabs = 0.0, cnt = 0.0;
+  MergedRec r[ITEMS];
+  {
+    SlotIn in[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) { in[k] = load_slot(w, skey, perm, base + (long long)k * 64, n0, n_all, invalid_key, pack, wabs, cnt); key[k] = in[k].key; }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) stage_slot(in[k], s_w, s_f, wv * (64 * ITEMS) + k * 64 + lane);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) r[k] = fold_slot(in[k], s_w, s_f, wv * (64 * ITEMS) + k * 64 + lane, TILE, w, skey, perm, base + (long long)k * 64, n0, n_all, p, invalid_key, pack);
+  }
+  APROF(1);
+  store_wabs(wabs_part, tile, wabs, cnt);
+  APROF(2);
+  // ---- REPLAY discipline only: rank among the rounding draws of the one rannyu stream (hi word;
+  //      lo = rank among the kept walkers).  The COUNTER discipline keys a draw by its determinant,
+  //      needs no rank, and so spares every tile the wait for the slowest earlier tile.
+  u64 inc[ITEMS], carry = 0, ex = 0, tot = 0;
+  if (mode == 0) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) { const u64 x = wave_incl_scan_u64(r[k].f, lane); inc[k] = x + carry; carry += __shfl(x, 63, 64); }
+    if (lane == 0) s_wsum[0][wv] = carry;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < TPB / 64; q++) { if (q < wv) ex += s_wsum[0][q]; tot += s_wsum[0][q]; }
+    if (threadIdx.x < 64) {
+      const u64 e = lookback_exclusive(state1, tile, tot, threadIdx.x);
+      if (threadIdx.x == 0) { s_ex[0] = e; if (last_tile) sc->tot1 = e + tot; }
+    }
+    __syncthreads();
+    ex += s_ex[0];
+  }
+  APROF(3);
+  u64 f2[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    f2[k] = 0;
+    if (r[k].f & 1ull) {
+      if (r[k].f >> 32) {
+        double rr;
+        if (mode == 0) { const u64 ex1 = ex + inc[k] - r[k].f; rr = (double)lcg_skip(sc->lcg, (ex1 >> 32) + 1) * 3.552713678800500929355621337890625e-15; }
+        else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, r[k].up * SQ_GOLDEN + r[k].dn); rr = rng_draw(g); }
+        if (rr < (fabs(r[k].wt) / p.min_wt)) r[k].wt = copysign(p.min_wt, r[k].wt); else r[k].wt = 0.0;
+      }
+      // reduce_my_walker drops zero weights outside the deterministic space (7222-7249)
+      const bool drop = p.semi ? (r[k].wt == 0.0 && r[k].d >= 1) : (r[k].wt == 0.0);
+      if (!drop) { f2[k] = 1ull; if (r[k].d == 0) f2[k] |= (1ull << 32); }
+    }
+  }
+  // ---- final position (lo) and rank among the deterministic-space walkers (hi)
+  carry = 0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) { const u64 x = wave_incl_scan_u64(f2[k], lane); inc[k] = x + carry; carry += __shfl(x, 63, 64); }
+  if (lane == 0) s_wsum[1][wv] = carry;
+  __syncthreads();
+  ex = 0; tot = 0;
+#pragma unroll
+  for (int q = 0; q < TPB / 64; q++) { if (q < wv) ex += s_wsum[1][q]; tot += s_wsum[1][q]; }
+  if (threadIdx.x < 64) {
+    const u64 e = lookback_exclusive(state2, tile, tot, threadIdx.x);
+    if (threadIdx.x == 0) { s_ex[1] = e; if (last_tile) { sc->tot2 = e + tot; sc->nwalk = (e + tot) & 0xFFFFFFFFull; } }
+  }
+  __syncthreads();
+  ex += s_ex[1];
+  APROF(4);
+  // ---- compaction, reweighting (2487), estimator pieces (2573-2684, more_tools.f90:4041-4098)
+  double s[NSTAT];
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    if (!(f2[k] & 1ull)) continue;
+    const u64 ex2 = ex + inc[k] - f2[k];
+    const long long q0 = (long long)(ex2 & 0xFFFFFFFFull);
+    const double wt = r[k].wt * p.rfi;
+    const int d = r[k].d, ini = flg_init(r[k].flg), psg = flg_psign(r[k].flg);
+    double en = r[k].en, ed = r[k].ed;
+    if (en > 1e50) {
+      const long long q = ct_lookup(hkey, hidx, hmask, key[k]);
+      if (q < 0) { en = 0.0; ed = 0.0; } else { en = cnum[q]; ed = cden[q]; }
+    }
+    o.up[q0] = r[k].up; o.dn[q0] = r[k].dn; o.wt[q0] = wt; o.flg[q0] = r[k].flg;
+    o.me[q0] = r[k].me; o.en[q0] = en; o.ed[q0] = ed;
+    if (d == 0 && p.semi && (long long)(ex2 >> 32) < p.nimp_cap) loc_imp[ex2 >> 32] = (int)q0;
+    s[0] += wt; s[1] += fabs(wt); s[8] += wt * wt;
+    if (ini == 3) s[4] += wt * psg;
+    if (d == 0 || (d == -2 && p.cti)) s[6] += fabs(wt);
+    double e_num = en * wt, e_den = ed * wt;
+    if (e_num != 0.0) {
+      if (fabs(e_den) < 1e-22) e_den = fabs(e_den);
+      s[2] += e_den; s[3] += e_num; s[9] += e_num * e_num; s[10] += e_den * e_den;
+      s[11] += e_num * copysign(1.0, e_den); s[12] += fabs(e_den); s[5] += e_num * e_den;
+    }
+  }
+  __shared__ double red[TPB / 64][NSTAT];
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) {
+    double v = s[k];
+    for (int q = 32; q > 0; q >>= 1) v += __shfl_down(v, q, 64);
+    if (lane == 0) red[wv][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NSTAT) {
+    double v = 0.0;
+    for (int q = 0; q < TPB / 64; q++) v += red[q][threadIdx.x];
+    partials[(long long)tile * NSTAT + threadIdx.x] = v;
+  }
+  APROF(5);
+}
+// posts the (all-reduced) scalars of a sharded step to the host mailbox
+__global__ void k_post_mail(const DevScalars *sc, HostMail *mail, u64 seq) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 16; i++) mail->stats[i] = sc->stats[i];
+  mail->tot2 = sc->tot2; mail->err = sc->err;
+  __threadfence_system();
+  mail->seq = seq;
+}
+// The final reduction stays a kernel of its own: folding it into the last-arriving block of
+// k_compact needs an agent-scope release in every block and cost more than this launch.
+__global__ void __launch_bounds__(TPB) k_finish(FinArgs f, DevScalars *sc) { finish_all(f, sc); }
+__device__ void finish_all(const FinArgs &f, DevScalars *sc) {
+  if (f.on == 3) {            // sharded step: the sums were finished and all-reduced by kernels before this one; only the mail is left
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < 16; i++) f.mail->stats[i] = sc->stats[i];
+      f.mail->tot2 = sc->tot2; f.mail->err = sc->err;
+      __threadfence_system();
+      f.mail->seq = f.seq;
+    }
+    __syncthreads();
+    return;
+  }
+  // the look-back words k_anneal used this step (two arrays, n_ftiles words each) are zero again for the next one
+  for (int i = threadIdx.x; i < f.n_ftiles; i += TPB) { f.fstate[i] = 0; f.fstate[f.cap_ftiles + i] = 0; }
+  if (threadIdx.x == 0 && f.n_ftiles > 0) *f.fticket = 0;
+  finish_step(f.partials, f.nblocks, f.wabs_part, f.nwabs, f.mode, sc, f.scan_state, f.scan_ticket, f.n_scan_words);
+  if (f.mail && threadIdx.x == 0) {
+    for (int i = 0; i < 16; i++) f.mail->stats[i] = sc->stats[i];
+    f.mail->tot2 = sc->tot2; f.mail->err = sc->err;
+    __threadfence_system();
+    f.mail->seq = f.seq;
+  }
+  __syncthreads();
+}
+
+// final reduction: sums block partials
+// (fixed strided order + fixed tree: reproducible run to run), publishes the step's sums,
+// advances the REPLAY stream and re-zeroes the look-back scan states for the next step
+__device__ void finish_step(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
+                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words) {
+  __shared__ double red2[TPB / 64][NSTAT + 2];
+  __shared__ double tot[NSTAT + 2];
+  for (int i = threadIdx.x; i < n_scan_words; i += TPB) scan_state[i] = 0;
+  if (threadIdx.x < 3) scan_ticket[threadIdx.x] = 0;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // every thread first adds up its rows (a row's 13 loads, and several rows, are in flight
+  // together), then one shuffle tree per statistic
+  double acc[NSTAT + 2];
+#pragma unroll
+  for (int k = 0; k < NSTAT + 2; k++) acc[k] = 0.0;
+#pragma unroll 4
+  for (int b = threadIdx.x; b < nblocks; b += TPB) {
+#pragma unroll
+    for (int k = 0; k < NSTAT; k++) acc[k] += partials[(long long)b * NSTAT + k];
+  }
+#pragma unroll 4
+  for (int b = threadIdx.x; b < nwabs; b += TPB) { acc[NSTAT] += wabs_part[2 * b]; acc[NSTAT + 1] += wabs_part[2 * b + 1]; }
+#pragma unroll
+  for (int k = 0; k < NSTAT + 2; k++) {
+    double v = acc[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) red2[wv][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NSTAT + 2) { double v = 0.0; for (int q = 0; q < TPB / 64; q++) v += red2[q][threadIdx.x]; tot[threadIdx.x] = v; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double *o = sc->stats;
+    o[0] = tot[0]; o[1] = tot[1]; o[2] = tot[2]; o[3] = tot[3]; o[4] = tot[4];
+    o[5] = (double)(sc->tot2 & 0xFFFFFFFFull); o[6] = tot[6];
+    sc->nwalk = sc->tot2 & 0xFFFFFFFFull;
+    o[7] = tot[NSTAT + 1]; o[8] = tot[8]; o[9] = tot[9]; o[10] = tot[10];
+    o[11] = tot[11]; o[12] = tot[12]; o[13] = tot[5]; o[14] = tot[NSTAT]; o[15] = (double)sc->n_children;
+    if (mode == 0) sc->lcg = lcg_skip(sc->lcg, sc->tot1 >> 32);
+  }
+}
