@@ -81,11 +81,15 @@ __device__ __forceinline__ u64 lookback_exclusive(u64 *__restrict__ state, u32 t
   if (lane == 0) atomicExch((unsigned long long *)&state[tile], SCAN_ST_INC | (excl + tot));
   return excl;
 }
-template <int SCAN_ITEMS>
+// Extra: work of one additional block (the last of the grid) that has nothing to do with the scan and only wants to
+// run beside it; ScanNoExtra: none.
+struct ScanNoExtra { static constexpr bool on = false; __device__ void operator()() const {} };
+template <int SCAN_ITEMS, class Extra = ScanNoExtra>
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_lookback_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, long long n_arg,
                                                                    u64 *__restrict__ state, u32 *__restrict__ ticket, u64 *__restrict__ total_out,
-                                                                   const u64 *__restrict__ n_dev) {
+                                                                   const u64 *__restrict__ n_dev, Extra extra) {
   constexpr int TILE_ELEMS = SCAN_BLOCK * SCAN_ITEMS;
+  if (Extra::on && blockIdx.x == gridDim.x - 1) { extra(); return; }
   // n_dev: the length lives in device memory (the launch was sized for an upper bound n_arg by a host
   // that does not know it yet); tiles past the end scan zeros and repeat the total
   const long long n = n_dev ? (long long)(*n_dev & 0xFFFFFFFFull) : n_arg;
@@ -134,14 +138,19 @@ __global__ void scan_clear_kernel(u64 *state, u32 *ticket, int ntiles) {
 struct ScanWork { u64 *state; u32 *ticket; long long cap_tiles; bool self_clear; };
 
 // exclusive scan of n u64 values (< 2^62 in total); total (optional) is written on device
-static inline void device_excl_scan_u64(const u64 *in, u64 *out, long long n, u64 *total_out, ScanWork &w, hipStream_t st, const u64 *n_dev = nullptr) {
-  if (n <= 0) { if (total_out) hipMemsetAsync(total_out, 0, sizeof(u64), st); return; }
+// returns the number of look-back words (tiles) the launch may touch
+template <class Extra = ScanNoExtra>
+static inline int device_excl_scan_u64(const u64 *in, u64 *out, long long n, u64 *total_out, ScanWork &w, hipStream_t st, const u64 *n_dev = nullptr, Extra extra = Extra()) {
+  if (n <= 0 && !Extra::on) { if (total_out) hipMemsetAsync(total_out, 0, sizeof(u64), st); return 0; }
+  if (n <= 0) n = 1;
   const bool large = n >= SCAN_LARGE_N;
   const long long tile = (long long)SCAN_BLOCK * (large ? SCAN_ITEMS_LARGE : SCAN_ITEMS_SMALL);
   int ntiles = (int)((n + tile - 1) / tile);
   if (w.self_clear) hipLaunchKernelGGL(scan_clear_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, st, w.state, w.ticket, ntiles);
-  if (large) hipLaunchKernelGGL(scan_lookback_kernel<SCAN_ITEMS_LARGE>, dim3(ntiles), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out, n_dev);
-  else hipLaunchKernelGGL(scan_lookback_kernel<SCAN_ITEMS_SMALL>, dim3(ntiles), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out, n_dev);
+  const int grid = ntiles + (Extra::on ? 1 : 0);
+  if (large) hipLaunchKernelGGL((scan_lookback_kernel<SCAN_ITEMS_LARGE, Extra>), dim3(grid), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out, n_dev, extra);
+  else hipLaunchKernelGGL((scan_lookback_kernel<SCAN_ITEMS_SMALL, Extra>), dim3(grid), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out, n_dev, extra);
+  return ntiles;
 }
 
 // ------------------------------------------------------------------------ radix sort

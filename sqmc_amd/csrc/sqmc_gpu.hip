@@ -140,6 +140,7 @@ struct sqmc_gpu_ctx {
   // enqueued right behind k_finish of step n, before the host has read step n's sums
   bool pipeline_next, head_ready; StepP head_p; u64 head_cseq; hipEvent_t hev[4];
   bool owner_ready;           // this step's k_spawn already wrote the owner key of every child (sharded steps)
+  int scan_flip, scan_used[2];   // gate-fused heads: look-back set of the next head scan, and how many words of each set its last scan may have touched
   bool residents_sorted;      // the walker arrays are known to be in (up, dn) order: true after every finished step, false after an upload
 };
 
@@ -534,15 +535,26 @@ static OwnerOut shard_owner_out(sqmc_gpu_ctx *c) {
 // step, before the host has read that step's sums.  g0/g1 and s0/s1 (may be null) time gate+scan
 // and k_spawn; the child count goes to the host mailbox under sequence number *cseq.
 static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0, bool dev_n, hipEvent_t g0, hipEvent_t g1, hipEvent_t s0, hipEvent_t s1, u64 *cseq,
-                        const FinArgs *fin = nullptr) {
+                        const FinArgs *fin = nullptr, bool gate_done = false) {
   hipStream_t st = c->st;
   const long long M = c->mwalk;
   ScanWork sw0; sw0.state = c->d_scan_state; sw0.ticket = c->d_scan_ticket; sw0.cap_tiles = c->cap_tiles; sw0.self_clear = false;
   FinArgs fa; memset(&fa, 0, sizeof(fa)); if (fin) fa = *fin;
   if (g0) hipEventRecord(g0, st);
-  hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
-                     n0, p, c->seed64, step, c->d_sc, c->pack, dev_n ? 1 : 0, fa);
-  device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st, dev_n ? &c->d_sc->nwalk : nullptr);
+  if (gate_done) {
+    // k_anneal of the step before wrote keys, child counts and child weights; the final sums of that step ride on the
+    // scan as one extra block.  The scan works on look-back set scan_flip while that block re-zeroes the other set
+    // (the one the head scan before this one used).
+    const int f = c->scan_flip;
+    sw0.state = c->d_scan_state + (long long)f * c->cap_tiles; sw0.ticket = c->d_scan_ticket + f;
+    c->scan_used[f] = device_excl_scan_u64<FinExtra>(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st, dev_n ? &c->d_sc->nwalk : nullptr, FinExtra{fa, c->d_sc});
+    c->scan_flip = f ^ 1;
+  } else {
+    hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
+                       n0, p, c->seed64, step, c->d_sc, c->pack, dev_n ? 1 : 0, fa);
+    c->scan_used[0] = device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st, dev_n ? &c->d_sc->nwalk : nullptr);
+    c->scan_flip = 1;          // set 0 stays dirty until a finish re-zeroes it: a gate-fused head that follows works on set 1
+  }
   if (g1) hipEventRecord(g1, st);
   // ---- spawn goes out first: the host is the slower side at the start of a step, and k_spawn
   //      is on the critical path (exactly one k_spawn launch inside this timer: the per-launch time
@@ -570,6 +582,7 @@ static void drop_head(sqmc_gpu_ctx *c) {
   c->head_ready = false;
   hipStreamSynchronize(c->st);
   hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
+  c->scan_used[0] = c->scan_used[1] = 0;
 }
 // sort -> merge -> round -> compact/estimate -> readback; shared by the single-rank step and
 // the sharded step (where the spawns behind slot n0 arrived from other ranks)
@@ -611,6 +624,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
   const bool use_mail = (c->comm == nullptr);          // with a communicator the sums are all-reduced on the device first
   const u64 seq = ++c->mail_seq;
   int nb, n_ft = 0;
+  bool fuse_gate = false;
   if (p.semi) {
     // one kernel from the sorted list to the new walker arrays; the buffers swap roles afterwards
     // timed by the kernel's own start/stop timestamps (hipExtLaunchKernelGGL events) at every timing level: the
@@ -620,13 +634,22 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
     static const int items_env = getenv("SQMC_ANNEAL_ITEMS") ? atoi(getenv("SQMC_ANNEAL_ITEMS")) : 0;
     const int items = items_env ? items_env : (nall < (1ll << 20) ? 2 : 4);     // small lists want many tiles, large ones short look-back chains
     nb = n_ft = (int)((nall + (long long)TPB * items - 1) / ((long long)TPB * items));
+    // pipelined steps: the kernel also does the next step's gate (keys, child counts, child weights) as it places a walker
+    static const bool no_fuse = getenv("SQMC_NO_GATE_FUSION") != nullptr;
+    fuse_gate = c->pipeline_next && use_mail && c->pack && !no_fuse;
+    GateOut go; memset(&go, 0, sizeof(go));
+    if (fuse_gate) {
+      go.on = 1; go.keys = (skey == c->d_keys) ? c->d_keys_alt : c->d_keys;      // never the buffer the kernel reads its sorted words from
+      go.nchild = c->d_nchild; go.wchild = c->d_wchild; go.cutoff = p.cutoff; go.step_next = step + 1;
+    }
 #define ANNEAL_ARGS c->w, c->m, skey, perm, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, n0, nall, p,  \
-                    c->invalid_key, c->pack, mode, seed, step, c->d_sc, c->d_fstate, c->d_fstate + c->cap_ftiles, c->d_fticket
+                    c->invalid_key, c->pack, mode, seed, step, c->d_sc, c->d_fstate, c->d_fstate + c->cap_ftiles, c->d_fticket, go
 #define ANNEAL_LAUNCH(I) do { if (t_anneal >= 0) hipExtLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, ANNEAL_ARGS); \
                               else hipLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, ANNEAL_ARGS); } while (0)
     if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 8) ANNEAL_LAUNCH(8); else ANNEAL_LAUNCH(4);
 #undef ANNEAL_LAUNCH
 #undef ANNEAL_ARGS
+    if (fuse_gate && go.keys == c->d_keys_alt) std::swap(c->d_keys, c->d_keys_alt);      // the next step's spawn kernel appends its keys behind the walkers'
     std::swap(c->w.up, c->m.up); std::swap(c->w.dn, c->m.dn); std::swap(c->w.wt, c->m.wt); std::swap(c->w.flg, c->m.flg);
     std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed);
   } else {
@@ -649,7 +672,13 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
   fa.partials = c->d_partials; fa.nblocks = nb; fa.wabs_part = c->d_wabs_part; fa.nwabs = p.semi ? nb : nbm; fa.mode = mode;
   fa.scan_state = c->d_scan_state; fa.scan_ticket = c->d_scan_ticket; fa.n_scan_words = (int)(3 * c->cap_tiles);
   fa.mail = use_mail ? c->d_mail : (HostMail *)nullptr; fa.seq = seq; fa.fstate = c->d_fstate; fa.fticket = c->d_fticket; fa.cap_ftiles = c->cap_ftiles;
-  fa.n_ftiles = n_ft; fa.on = 1;
+  fa.n_ftiles = n_ft; fa.on = 1; fa.n_tickets = 3; fa.n_children = -1;
+  if (fuse_gate) {       // the finishing block runs beside the next head's scan (look-back set scan_flip): it re-zeroes the other set only
+    const int other = c->scan_flip ^ 1;
+    fa.scan_state = c->d_scan_state + (long long)other * c->cap_tiles; fa.scan_ticket = c->d_scan_ticket + other;
+    fa.n_scan_words = c->scan_used[other]; fa.n_tickets = 1; c->scan_used[other] = 0;
+    fa.n_children = nall - n0;
+  }
   const bool fin_in_gate = c->pipeline_next && p.semi && use_mail;     // the next step's gate kernel does the final sums in its first block
   TBEG(estimate, st);
   if (!fin_in_gate) hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, fa, c->d_sc);
@@ -667,7 +696,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
     // reads this step's sums and does its population control.  nall bounds the new walker count.
     c->pipeline_next = false;
     int rh = enqueue_head(c, p, step + 1, nall, true, c->timing >= 2 ? c->hev[0] : nullptr, c->timing >= 2 ? c->hev[1] : nullptr,
-                          kernel_events_on(c, step + 1) ? c->hev[2] : nullptr, kernel_events_on(c, step + 1) ? c->hev[3] : nullptr, &c->head_cseq, (fin_in_gate || mail_in_gate) ? &fa : nullptr);
+                          kernel_events_on(c, step + 1) ? c->hev[2] : nullptr, kernel_events_on(c, step + 1) ? c->hev[3] : nullptr, &c->head_cseq, (fin_in_gate || mail_in_gate) ? &fa : nullptr, fuse_gate);
     if (rh) return rh;
     c->head_ready = true; c->head_p = p;
   }

@@ -9,9 +9,28 @@
 struct FinArgs {
   const double *partials; int nblocks; const double *wabs_part; int nwabs; int mode; u64 *scan_state; u32 *scan_ticket; int n_scan_words;
   HostMail *mail; u64 seq; u64 *fstate; u32 *fticket; long long cap_ftiles; int n_ftiles; int on;
+  int n_tickets;      // scan tickets behind scan_ticket to reset with the n_scan_words state words (3: all of them)
+  long long n_children;   // >= 0: the step's child count from the host (a finish that rides on the NEXT step's scan must not read the scalar that scan writes)
 };
 __device__ void finish_all(const FinArgs &f, DevScalars *sc);
-// gate + child count (COUNTER discipline).  do_walk.f90:3577-3589
+// spawn gate and child count of one walker (COUNTER discipline: the draw is keyed by step and walker index).  do_walk.f90:3577-3589
+__device__ __forceinline__ void gate_children(double w, double cutoff, u64 seed, u64 step, u64 i, u64 &nchild, double &wchild) {
+  bool spawn, use_wt;
+  if (fabs(w) < cutoff) {
+    Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 0, i);
+    spawn = rng_draw(g) < fabs(w / cutoff); use_wt = false;
+  } else { spawn = true; use_wt = true; }
+  long long nc = 0; double wc = 0.0;
+  if (spawn) {
+    if (use_wt) { nc = llround(fabs(w)); if (nc < 1) nc = 1; wc = w / (double)nc; }
+    else { nc = 1; wc = copysign(cutoff, w); }
+  }
+  nchild = (u64)nc; wchild = wc;
+}
+// What k_gate would compute for the NEXT step, written by k_anneal as it places a walker (pipelined steps: the
+// parameters of the gate do not change any more, and the walker's key is at hand): one kernel less on the critical path.
+struct GateOut { u64 *keys; u64 *nchild; double *wchild; double cutoff; u64 step_next; int on; };
+// gate + child count.
 __global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, const double *__restrict__ wt,
                                               u64 *__restrict__ nchild, double *__restrict__ wchild, u64 *__restrict__ keys, u32 *__restrict__ vals,
                                               long long n_arg, StepP p, u64 seed, u64 step, DevScalars *sc, int pack, int n_on_device, FinArgs fin) {
@@ -21,17 +40,9 @@ __global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict
   if (i == 0) { sc->n_invalid = 0; sc->tot1 = 0; sc->tot2 = 0; sc->err = 0; }   // every writer of these runs after this kernel
   if (i >= n) return;
   put_key(keys, vals, i, det_key(dev, up[i], dn[i]), pack);      // sort key of the walker itself
-  double w = wt[i]; bool spawn, use_wt;
-  if (fabs(w) < p.cutoff) {
-    Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 0, (u64)i);
-    spawn = rng_draw(g) < fabs(w / p.cutoff); use_wt = false;
-  } else { spawn = true; use_wt = true; }
-  long long nc = 0; double wc = 0.0;
-  if (spawn) {
-    if (use_wt) { nc = llround(fabs(w)); if (nc < 1) nc = 1; wc = w / (double)nc; }
-    else { nc = 1; wc = copysign(p.cutoff, w); }
-  }
-  nchild[i] = (u64)nc; wchild[i] = wc;
+  u64 nc; double wc;
+  gate_children(wt[i], p.cutoff, seed, step, (u64)i, nc, wc);
+  nchild[i] = nc; wchild[i] = wc;
 }
 
 // REPLAY discipline: one lane walks the walkers in order, consuming the single rannyu
@@ -73,11 +84,33 @@ __global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict
                                               const u32 *__restrict__ flg, double *__restrict__ me, long long n, StepP p, DevScalars *sc) {
   __shared__ ChemTab t;
   stage_tab(&t, dev.tab, dev.tab_words);
-  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
-  if (i >= n) return;
-  if (p.semi && flg_impd(flg[i]) < 1) return;
-  double hii = me[i];
-  if (hii > 1e50) { hii = h_any(t, dev.integrals, up[i], dn[i], up[i], dn[i]); me[i] = hii; }
+  // Only determinants first occupied in the last step lack H_ii (the 1e51 sentinel), and they sit anywhere in the
+  // sorted list: computed in place every wavefront would pay the whole Slater-Condon sum for a few lanes.  The block
+  // queues them in LDS and its first threads work the queue off densely.
+  __shared__ int q[TPB];
+  __shared__ double hq[TPB];
+  __shared__ int wcnt[TPB / 64];
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  const bool live = i < n && !(p.semi && flg_impd(flg[i]) < 1);
+  double hii = live ? me[i] : 0.0;
+  const bool need = live && hii > 1e50;
+  const u64 bal = __ballot(need);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wcnt[wv] = __popcll(bal);
+  __syncthreads();
+  int base = 0, qn = 0;
+  for (int k = 0; k < TPB / 64; k++) { if (k < wv) base += wcnt[k]; qn += wcnt[k]; }
+  if (need) q[base + __popcll(bal & ((1ull << lane) - 1ull))] = threadIdx.x;
+  __syncthreads();
+  if (qn) {
+    for (int k = threadIdx.x; k < qn; k += TPB) {
+      const long long j = (long long)blockIdx.x * TPB + q[k];
+      me[j] = hq[q[k]] = h_any(t, dev.integrals, up[j], dn[j], up[j], dn[j]);
+    }
+    __syncthreads();
+    if (need) hii = hq[threadIdx.x];
+  }
+  if (!live) return;
   double f = 1.0 + p.tau * (p.e_trial - hii);
   if (f < 0) { if (p.reached > 1) sc->err = SQMC_ERR_NEG_DIAG; f = 0; }
   wt[i] = wt[i] * f;
@@ -550,7 +583,7 @@ __device__ __forceinline__ long long ct_lookup(const u64 *__restrict__ hkey, con
 
 #define NSTAT 13
 __device__ void finish_step(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
-                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words);
+                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words, int n_tickets, long long n_children);
 // compaction into the walker arrays + reweight (2487) + estimator pieces (2573-2684 and
 // binary_search_list_and_update, more_tools.f90:4041-4098) + per-block partial sums
 __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64 *__restrict__ flags2, const u64 *__restrict__ pos2,
@@ -623,7 +656,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                                                 const double *__restrict__ cnum, const double *__restrict__ cden,
                                                 double *__restrict__ partials, double *__restrict__ wabs_part, long long n0, long long n_all, StepP p,
                                                 u64 invalid_key, int pack, int mode, u64 seed, u64 step, DevScalars *sc,
-                                                u64 *__restrict__ state1, u64 *__restrict__ state2, u32 *__restrict__ ticket) {
+                                                u64 *__restrict__ state1, u64 *__restrict__ state2, u32 *__restrict__ ticket, GateOut go) {
   constexpr int TILE = TPB * ITEMS;
   __shared__ u32 s_tile; __shared__ u64 s_ex[2]; __shared__ u64 s_wsum[2][TPB / 64];
   __shared__ double s_w[TILE]; __shared__ u32 s_f[TILE];          // weight and flags of every slot of the tile
@@ -719,6 +752,11 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
     o.up[q0] = r[k].up; o.dn[q0] = r[k].dn; o.wt[q0] = wt; o.flg[q0] = r[k].flg;
     o.me[q0] = r[k].me; o.en[q0] = en; o.ed[q0] = ed;
+    if (go.on) {
+      u64 nc; double wc;
+      gate_children(wt, go.cutoff, seed, go.step_next, (u64)q0, nc, wc);
+      go.keys[q0] = (key[k] << 32) | (u64)q0; go.nchild[q0] = nc; go.wchild[q0] = wc;
+    }
     if (d == 0 && p.semi && (long long)(ex2 >> 32) < p.nimp_cap) loc_imp[ex2 >> 32] = (int)q0;
     s[0] += wt; s[1] += fabs(wt); s[8] += wt * wt;
     if (ini == 3) s[4] += wt * psg;
@@ -756,6 +794,17 @@ __global__ void k_post_mail(const DevScalars *sc, HostMail *mail, u64 seq) {
 // The final reduction stays a kernel of its own: folding it into the last-arriving block of
 // k_compact needs an agent-scope release in every block and cost more than this launch.
 __global__ void __launch_bounds__(TPB) k_finish(FinArgs f, DevScalars *sc) { finish_all(f, sc); }
+// Steps whose gate was computed by k_anneal have no gate kernel to carry the last step's final sums: one extra block of
+// the child-offset scan does them (and clears the step scalars, as the gate kernel would), next to the scan's own tiles.
+// It must not touch the look-back words of the scan it rides on: f.scan_state / f.scan_ticket name the OTHER set.
+struct FinExtra {
+  static constexpr bool on = true;
+  FinArgs f; DevScalars *sc;
+  __device__ void operator()() const {
+    finish_all(f, sc);
+    if (threadIdx.x == 0) { sc->n_invalid = 0; sc->tot1 = 0; sc->tot2 = 0; sc->err = 0; }
+  }
+};
 __device__ void finish_all(const FinArgs &f, DevScalars *sc) {
   if (f.on == 3) {            // sharded step: the sums were finished and all-reduced by kernels before this one; only the mail is left
     if (threadIdx.x == 0) {
@@ -770,7 +819,7 @@ __device__ void finish_all(const FinArgs &f, DevScalars *sc) {
   // the look-back words k_anneal used this step (two arrays, n_ftiles words each) are zero again for the next one
   for (int i = threadIdx.x; i < f.n_ftiles; i += TPB) { f.fstate[i] = 0; f.fstate[f.cap_ftiles + i] = 0; }
   if (threadIdx.x == 0 && f.n_ftiles > 0) *f.fticket = 0;
-  finish_step(f.partials, f.nblocks, f.wabs_part, f.nwabs, f.mode, sc, f.scan_state, f.scan_ticket, f.n_scan_words);
+  finish_step(f.partials, f.nblocks, f.wabs_part, f.nwabs, f.mode, sc, f.scan_state, f.scan_ticket, f.n_scan_words, f.n_tickets, f.n_children);
   if (f.mail && threadIdx.x == 0) {
     for (int i = 0; i < 16; i++) f.mail->stats[i] = sc->stats[i];
     f.mail->tot2 = sc->tot2; f.mail->err = sc->err;
@@ -784,11 +833,11 @@ __device__ void finish_all(const FinArgs &f, DevScalars *sc) {
 // (fixed strided order + fixed tree: reproducible run to run), publishes the step's sums,
 // advances the REPLAY stream and re-zeroes the look-back scan states for the next step
 __device__ void finish_step(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
-                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words) {
+                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words, int n_tickets, long long n_children) {
   __shared__ double red2[TPB / 64][NSTAT + 2];
   __shared__ double tot[NSTAT + 2];
   for (int i = threadIdx.x; i < n_scan_words; i += TPB) scan_state[i] = 0;
-  if (threadIdx.x < 3) scan_ticket[threadIdx.x] = 0;
+  if ((int)threadIdx.x < n_tickets) scan_ticket[threadIdx.x] = 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // every thread first adds up its rows (a row's 13 loads, and several rows, are in flight
   // together), then one shuffle tree per statistic
@@ -817,7 +866,7 @@ __device__ void finish_step(const double *__restrict__ partials, int nblocks, co
     o[5] = (double)(sc->tot2 & 0xFFFFFFFFull); o[6] = tot[6];
     sc->nwalk = sc->tot2 & 0xFFFFFFFFull;
     o[7] = tot[NSTAT + 1]; o[8] = tot[8]; o[9] = tot[9]; o[10] = tot[10];
-    o[11] = tot[11]; o[12] = tot[12]; o[13] = tot[5]; o[14] = tot[NSTAT]; o[15] = (double)sc->n_children;
+    o[11] = tot[11]; o[12] = tot[12]; o[13] = tot[5]; o[14] = tot[NSTAT]; o[15] = (double)(n_children >= 0 ? (u64)n_children : sc->n_children);
     if (mode == 0) sc->lcg = lcg_skip(sc->lcg, sc->tot1 >> 32);
   }
 }

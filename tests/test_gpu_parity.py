@@ -331,9 +331,11 @@ def test_run_loop_equals_stepwise_population_control(oracle, c2_walk, c2_setup):
         res.append((g.download_walkers(), out.copy()))
         g.close()
     (wa, oa), (wb, ob) = res
+    # the run loop pipelines its steps once the target population is reached (the annihilation kernel does the next
+    # step's gate, the scan carries the final sums): same arithmetic, so the same bits as the unpipelined single steps
     assert np.array_equal(wa["up"], wb["up"]) and np.array_equal(wa["dn"], wb["dn"])
-    assert np.allclose(wa["wt"], wb["wt"], rtol=1e-9)
-    assert np.allclose(oa, ob, rtol=1e-9)
+    assert np.array_equal(wa["wt"], wb["wt"])
+    assert np.array_equal(oa, ob)
 
 
 def test_hci_variational_matches_reference_run():
@@ -1205,3 +1207,15 @@ def test_semistochastic_pt_chem_agrees_with_deterministic():
     assert abs(r["pt_big"] - big) < 1e-14
     assert r["pt_diff_std_dev"] <= 1e-4 * 1.0001 and len(r["samples"]) >= 10
     assert abs(r["pt_big"] + r["pt_diff"] - det) < 4 * r["pt_diff_std_dev"]
+
+
+@pytest.mark.gpu
+def test_gate_fused_into_annihilation_is_bit_exact():
+    """Pipelined steps of sqmc_gpu_run: the annihilation kernel computes the next step's gate (keys, child counts, child
+    weights) and the child-offset scan carries the final sums.  600 steps that reach the target population, with the fusion
+    and with SQMC_NO_GATE_FUSION=1 (gate kernel of its own): every per-step sum and the final walkers must be the same bits."""
+    import subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuse_ab.py")], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "first differing step: []" in r.stdout and "walkers equal: True" in r.stdout
