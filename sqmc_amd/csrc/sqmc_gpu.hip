@@ -636,7 +636,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
     nb = n_ft = (int)((nall + (long long)TPB * items - 1) / ((long long)TPB * items));
     // pipelined steps: the kernel also does the next step's gate (keys, child counts, child weights) as it places a walker
     static const bool no_fuse = getenv("SQMC_NO_GATE_FUSION") != nullptr;
-    fuse_gate = c->pipeline_next && use_mail && c->pack && !no_fuse;
+    fuse_gate = c->pipeline_next && c->pack && !no_fuse;
     GateOut go; memset(&go, 0, sizeof(go));
     if (fuse_gate) {
       go.on = 1; go.keys = (skey == c->d_keys) ? c->d_keys_alt : c->d_keys;      // never the buffer the kernel reads its sorted words from
@@ -673,7 +673,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
   fa.scan_state = c->d_scan_state; fa.scan_ticket = c->d_scan_ticket; fa.n_scan_words = (int)(3 * c->cap_tiles);
   fa.mail = use_mail ? c->d_mail : (HostMail *)nullptr; fa.seq = seq; fa.fstate = c->d_fstate; fa.fticket = c->d_fticket; fa.cap_ftiles = c->cap_ftiles;
   fa.n_ftiles = n_ft; fa.on = 1; fa.n_tickets = 3; fa.n_children = -1;
-  if (fuse_gate) {       // the finishing block runs beside the next head's scan (look-back set scan_flip): it re-zeroes the other set only
+  if (fuse_gate && use_mail) {       // the finishing block runs beside the next head's scan (look-back set scan_flip): it re-zeroes the other set only
     const int other = c->scan_flip ^ 1;
     fa.scan_state = c->d_scan_state + (long long)other * c->cap_tiles; fa.scan_ticket = c->d_scan_ticket + other;
     fa.n_scan_words = c->scan_used[other]; fa.n_tickets = 1; c->scan_used[other] = 0;

@@ -801,7 +801,7 @@ struct FinExtra {
   static constexpr bool on = true;
   FinArgs f; DevScalars *sc;
   __device__ void operator()() const {
-    finish_all(f, sc);
+    if (f.on) finish_all(f, sc);
     if (threadIdx.x == 0) { sc->n_invalid = 0; sc->tot1 = 0; sc->tot2 = 0; sc->err = 0; }
   }
 };

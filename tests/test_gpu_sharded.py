@@ -140,6 +140,44 @@ def _inlib_worker(port, outdir):
     w.close()
 
 
+def _inlib_long_worker(port, outdir, w_target, nsteps):
+    import torch                                   # noqa: F401
+    sys.path.insert(0, ROOT)
+    import sqmc_amd
+    from sqmc_amd import host as H
+    sqmc_amd.set_device(0)
+    hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+    w = H.ShardedWalk(hst, w_target, 0, 1, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
+    w.attach_rccl()
+    outs, _ = w.run(nsteps)
+    wk = w.g.download_walkers()
+    np.savez(os.path.join(outdir, "inlib_long.npz"), outs=outs, reached=np.array([w.pc.reached]), **wk)
+    w.close()
+
+
+def test_in_library_pipelined_run_matches_plain_walk(tmp_path):
+    """sqmc_gpu_shard_run past the point where the target population is reached: from there on the steps are
+    pipelined (the annihilation kernel computes the next gate, the next step's scan posts the all-reduced sums).
+    One rank over real RCCL must still walk the plain single-rank trajectory, bit for bit."""
+    import torch.multiprocessing as mp
+    w_target, nsteps = 4000, 300
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_inlib_long_worker, args=(29575, str(tmp_path), w_target, nsteps))
+    p.start(); p.join(600)
+    assert p.exitcode == 0
+    res = np.load(os.path.join(str(tmp_path), "inlib_long.npz"))
+    assert int(res["reached"][0]) == 2
+    from sqmc_amd import host as H
+    hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+    ref = H.GpuWalk(hst, w_target, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
+    outs = np.array([ref.step().copy() for _ in range(nsteps)])
+    wk = ref.g.download_walkers()
+    ref.close()
+    assert np.array_equal(res["up"], wk["up"]) and np.array_equal(res["dn"], wk["dn"])
+    assert np.array_equal(res["wt"], wk["wt"])
+    assert np.allclose(res["outs"], outs, rtol=1e-12, atol=1e-12)
+
+
 def test_in_library_rccl_exchange_single_rank(tmp_path):
     """sqmc_gpu_comm_init / shard_step / shard_run: the exchanges issued by the library itself on
     an RCCL communicator (one rank is what a one-GPU box can host: every RCCL call still runs).
