@@ -256,12 +256,14 @@ def _fake_rccl_lib():
     return so
 
 
-def _inlib_multi_worker(rank, world, port, outdir, fake):
+def _inlib_multi_worker(rank, world, port, outdir, fake, w_target=None, nsteps=None, nofuse=False):
     import torch                                   # noqa: F401
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
+    W_TARGET, NSTEPS = w_target or globals()["W_TARGET"], nsteps or globals()["NSTEPS"]
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["SQMC_RCCL_LIB"] = fake             # before the library binds its communication entry points
+    if nofuse: os.environ["SQMC_NO_GATE_FUSION"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)     # only carries the unique id (MPI_Bcast in the reference's build)
     import sqmc_amd
     from sqmc_amd import host as H
@@ -273,10 +275,46 @@ def _inlib_multi_worker(rank, world, port, outdir, fake):
     b, _ = w.run(NSTEPS - NSTEPS // 2)                                 # sqmc_gpu_shard_run
     wk = w.g.download_walkers()
     owner = w.g.det_owner(wk["up"], wk["dn"], world)
-    np.savez(os.path.join(outdir, "rank%d.npz" % rank), outs=np.concatenate([a, b]), owner=owner, n_imp_global=w.n_imp_global, **wk)
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), outs=np.concatenate([a, b]), owner=owner, n_imp_global=w.n_imp_global,
+             reached=np.array([w.pc.reached]), **wk)
     w.close()
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_in_library_pipelined_exchange_two_ranks(tmp_path):
+    """Two ranks (transport double) run well past the target population, so that sqmc_gpu_shard_run pipelines its steps:
+    the annihilation kernel computes the next gate and the next step's scan posts the all-reduced sums.  The ownership
+    invariants must hold, and the walk must be the same, bit for bit on every rank, as with SQMC_NO_GATE_FUSION=1."""
+    import torch.multiprocessing as mp
+    fake = _fake_rccl_lib()
+    ctx = mp.get_context("spawn")
+    runs = []
+    for k, nofuse in enumerate((False, True)):
+        out = os.path.join(str(tmp_path), "nofuse%d" % k); os.makedirs(out)
+        ps = [ctx.Process(target=_inlib_multi_worker, args=(r, 2, 29620 + k, out, fake, 4000, 300, nofuse)) for r in range(2)]
+        for p in ps: p.start()
+        for p in ps: p.join(300)
+        alive = [p for p in ps if p.is_alive()]
+        for p in alive: p.terminate()
+        assert not alive, "in-library exchange did not finish (deadlock?)"
+        assert all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
+        runs.append([np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)])
+    res = runs[0]
+    assert all(int(r["reached"][0]) == 2 for r in res)
+    assert np.array_equal(res[1]["outs"][:, :7], res[0]["outs"][:, :7])
+    keys = []
+    for rank, r in enumerate(res):
+        assert np.all(r["owner"] == rank)
+        k = [(int(a), int(b)) for a, b in zip(r["up"], r["dn"])]
+        assert k == sorted(set(k))
+        keys += k
+    assert len(keys) == len(set(keys)) and int(res[0]["outs"][-1][5]) == len(keys)
+    e = res[0]["outs"][100:, 3].sum() / res[0]["outs"][100:, 2].sum()
+    assert -75.80 < e < -75.60
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a["outs"], b["outs"])
+        assert np.array_equal(a["up"], b["up"]) and np.array_equal(a["dn"], b["dn"]) and np.array_equal(a["wt"], b["wt"])
 
 
 @pytest.mark.parametrize("world", [2, 3])
