@@ -632,7 +632,9 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
     int t_anneal = -1;
     if (kernel_events_on(c, step) && c->nt < NTIMERS) { t_anneal = c->nt++; c->tname[t_anneal] = "anneal"; }
     static const int items_env = getenv("SQMC_ANNEAL_ITEMS") ? atoi(getenv("SQMC_ANNEAL_ITEMS")) : 0;
-    const int items = items_env ? items_env : (nall < (1ll << 20) ? 2 : 4);     // small lists want many tiles, large ones short look-back chains
+    // small lists want many tiles, large ones short look-back chains; 4 slots per thread spill 31 registers at the 4 waves per SIMD
+    // the kernel wants (3: 8), which only pays from ~10^7 slots on (measured: 0.449 against 0.458 ms/step at 2.5e6 slots, 3.44 against 3.35 at 1.7e7)
+    const int items = items_env ? items_env : (nall < (1ll << 20) ? 2 : (nall < (1ll << 23) ? 3 : 4));
     nb = n_ft = (int)((nall + (long long)TPB * items - 1) / ((long long)TPB * items));
     // pipelined steps: the kernel also does the next step's gate (keys, child counts, child weights) as it places a walker
     static const bool no_fuse = getenv("SQMC_NO_GATE_FUSION") != nullptr;
@@ -646,7 +648,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
                     c->invalid_key, c->pack, mode, seed, step, c->d_sc, c->d_fstate, c->d_fstate + c->cap_ftiles, c->d_fticket, go
 #define ANNEAL_LAUNCH(I) do { if (t_anneal >= 0) hipExtLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, ANNEAL_ARGS); \
                               else hipLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, ANNEAL_ARGS); } while (0)
-    if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 8) ANNEAL_LAUNCH(8); else ANNEAL_LAUNCH(4);
+    if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 3) ANNEAL_LAUNCH(3); else if (items == 8) ANNEAL_LAUNCH(8); else ANNEAL_LAUNCH(4);
 #undef ANNEAL_LAUNCH
 #undef ANNEAL_ARGS
     if (fuse_gate && go.keys == c->d_keys_alt) std::swap(c->d_keys, c->d_keys_alt);      // the next step's spawn kernel appends its keys behind the walkers'

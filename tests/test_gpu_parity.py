@@ -864,6 +864,20 @@ def test_spawn_only_sort_and_merge_is_bit_exact():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("items", [3, 4])
+def test_annihilation_tile_shapes_are_bit_exact(items):
+    """k_anneal handles 2, 3 or 4 sorted slots per thread depending on the length of the list (2 below 2^20 slots, where
+    every other test runs).  SQMC_ANNEAL_ITEMS forces the shapes of the long lists on the short ones: the trajectory,
+    annihilation-door and time-reversal tests must pass unchanged against the oracle."""
+    import subprocess, sys
+    env = dict(os.environ, SQMC_ANNEAL_ITEMS=str(items))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "trajectory_bit_exact or annihilate_door or time_sym"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_error_statuses_match_reference_stops(oracle, c2_walk, c2_setup):
     """The reference's own `stop`s come back as status codes with its texts, on
     the same inputs for which the oracle reports them."""
