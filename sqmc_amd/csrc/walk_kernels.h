@@ -670,12 +670,26 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
   APROF(0);
   u64 key[ITEMS]; double wabs = 0.0, cnt = 0.0;
   MergedRec r[ITEMS];
+  // Three or more slots per thread do not fit the 128 registers of 4 waves per SIMD.  The cached H_ii and the two estimator
+  // pieces of a walker pass through the merge untouched (every later walker of a run is a spawn without them) and are only
+  // needed again at the compaction: they wait in LDS, not in scratch memory (which is HBM traffic: the scratch of all
+  // resident waves is larger than the L2).
+  constexpr bool PARK = ITEMS >= 3;
+  __shared__ double s_park[PARK ? 3 : 1][PARK ? TILE : 1];
   {
     SlotIn in[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) { in[k] = load_slot(w, skey, perm, base + (long long)k * 64, n0, n_all, invalid_key, pack, wabs, cnt); key[k] = in[k].key; }
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) stage_slot(in[k], s_w, s_f, wv * (64 * ITEMS) + k * 64 + lane);
+    if (PARK) {
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) {
+        const int q = wv * (64 * ITEMS) + k * 64 + lane;
+        s_park[0][q] = in[k].me; s_park[PARK ? 1 : 0][q] = in[k].en; s_park[PARK ? 2 : 0][q] = in[k].ed;
+        in[k].me = 1e51; in[k].en = 1e51; in[k].ed = 1e51;
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) r[k] = fold_slot(in[k], s_w, s_f, wv * (64 * ITEMS) + k * 64 + lane, TILE, w, skey, perm, base + (long long)k * 64, n0, n_all, p, invalid_key, pack);
@@ -745,13 +759,14 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     const long long q0 = (long long)(ex2 & 0xFFFFFFFFull);
     const double wt = r[k].wt * p.rfi;
     const int d = r[k].d, ini = flg_init(r[k].flg), psg = flg_psign(r[k].flg);
-    double en = r[k].en, ed = r[k].ed;
+    double me = r[k].me, en = r[k].en, ed = r[k].ed;
+    if (PARK) { const int q = wv * (64 * ITEMS) + k * 64 + lane; me = s_park[0][q]; en = s_park[PARK ? 1 : 0][q]; ed = s_park[PARK ? 2 : 0][q]; }
     if (en > 1e50) {
       const long long q = ct_lookup(hkey, hidx, hmask, key[k]);
       if (q < 0) { en = 0.0; ed = 0.0; } else { en = cnum[q]; ed = cden[q]; }
     }
     o.up[q0] = r[k].up; o.dn[q0] = r[k].dn; o.wt[q0] = wt; o.flg[q0] = r[k].flg;
-    o.me[q0] = r[k].me; o.en[q0] = en; o.ed[q0] = ed;
+    o.me[q0] = me; o.en[q0] = en; o.ed[q0] = ed;
     if (go.on) {
       u64 nc; double wc;
       gate_children(wt, go.cutoff, seed, go.step_next, (u64)q0, nc, wc);
