@@ -583,7 +583,7 @@ __device__ __forceinline__ long long ct_lookup(const u64 *__restrict__ hkey, con
 
 #define NSTAT 13
 __device__ void finish_step(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
-                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words, int n_tickets, long long n_children);
+                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words, int n_tickets, long long n_children, HostMail *mail);
 // compaction into the walker arrays + reweight (2487) + estimator pieces (2573-2684 and
 // binary_search_list_and_update, more_tools.f90:4041-4098) + per-block partial sums
 __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64 *__restrict__ flags2, const u64 *__restrict__ pos2,
@@ -834,10 +834,8 @@ __device__ void finish_all(const FinArgs &f, DevScalars *sc) {
   // the look-back words k_anneal used this step (two arrays, n_ftiles words each) are zero again for the next one
   for (int i = threadIdx.x; i < f.n_ftiles; i += TPB) { f.fstate[i] = 0; f.fstate[f.cap_ftiles + i] = 0; }
   if (threadIdx.x == 0 && f.n_ftiles > 0) *f.fticket = 0;
-  finish_step(f.partials, f.nblocks, f.wabs_part, f.nwabs, f.mode, sc, f.scan_state, f.scan_ticket, f.n_scan_words, f.n_tickets, f.n_children);
+  finish_step(f.partials, f.nblocks, f.wabs_part, f.nwabs, f.mode, sc, f.scan_state, f.scan_ticket, f.n_scan_words, f.n_tickets, f.n_children, f.mail);
   if (f.mail && threadIdx.x == 0) {
-    for (int i = 0; i < 16; i++) f.mail->stats[i] = sc->stats[i];
-    f.mail->tot2 = sc->tot2; f.mail->err = sc->err;
     __threadfence_system();
     f.mail->seq = f.seq;
   }
@@ -848,11 +846,14 @@ __device__ void finish_all(const FinArgs &f, DevScalars *sc) {
 // (fixed strided order + fixed tree: reproducible run to run), publishes the step's sums,
 // advances the REPLAY stream and re-zeroes the look-back scan states for the next step
 __device__ void finish_step(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
-                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words, int n_tickets, long long n_children) {
+                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words, int n_tickets, long long n_children, HostMail *mail) {
   __shared__ double red2[TPB / 64][NSTAT + 2];
   __shared__ double tot[NSTAT + 2];
   for (int i = threadIdx.x; i < n_scan_words; i += TPB) scan_state[i] = 0;
   if ((int)threadIdx.x < n_tickets) scan_ticket[threadIdx.x] = 0;
+  // the scalars the last thread-0 section needs are requested now, with the partials
+  u64 tot2 = 0, nch = 0; int err = 0;
+  if (threadIdx.x == 0) { tot2 = sc->tot2; err = sc->err; nch = n_children >= 0 ? (u64)n_children : sc->n_children; }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // every thread first adds up its rows (a row's 13 loads, and several rows, are in flight
   // together), then one shuffle tree per statistic
@@ -876,12 +877,19 @@ __device__ void finish_step(const double *__restrict__ partials, int nblocks, co
   if (threadIdx.x < NSTAT + 2) { double v = 0.0; for (int q = 0; q < TPB / 64; q++) v += red2[q][threadIdx.x]; tot[threadIdx.x] = v; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double *o = sc->stats;
+    double o[16];
     o[0] = tot[0]; o[1] = tot[1]; o[2] = tot[2]; o[3] = tot[3]; o[4] = tot[4];
-    o[5] = (double)(sc->tot2 & 0xFFFFFFFFull); o[6] = tot[6];
-    sc->nwalk = sc->tot2 & 0xFFFFFFFFull;
+    o[5] = (double)(tot2 & 0xFFFFFFFFull); o[6] = tot[6];
     o[7] = tot[NSTAT + 1]; o[8] = tot[8]; o[9] = tot[9]; o[10] = tot[10];
-    o[11] = tot[11]; o[12] = tot[12]; o[13] = tot[5]; o[14] = tot[NSTAT]; o[15] = (double)(n_children >= 0 ? (u64)n_children : sc->n_children);
+    o[11] = tot[11]; o[12] = tot[12]; o[13] = tot[5]; o[14] = tot[NSTAT]; o[15] = (double)nch;
+#pragma unroll
+    for (int i = 0; i < 16; i++) sc->stats[i] = o[i];
+    sc->nwalk = tot2 & 0xFFFFFFFFull;
+    if (mail) {          // the host's copy goes out from the same registers (finish_all fences and posts the sequence word)
+#pragma unroll
+      for (int i = 0; i < 16; i++) mail->stats[i] = o[i];
+      mail->tot2 = tot2; mail->err = err;
+    }
     if (mode == 0) sc->lcg = lcg_skip(sc->lcg, sc->tot1 >> 32);
   }
 }
