@@ -26,7 +26,7 @@ FCIDUMP = os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # HBM bytes per launch from the PMC passes in profiles/ (FETCH_SIZE doubled as the guide prescribes for
 # gfx950, + WRITE_SIZE, KiB -> bytes), default configuration only
-TRAFFIC_K_ANNEAL = 3.62e7     # profiles/r01_bench_1e5_rocprof_summary.txt: (2*12453.9 + 10401.4) KiB (24 B per surviving walker of it: the next step's gate)
+TRAFFIC_K_ANNEAL = 3.63e7     # profiles/r01_bench_1e5_rocprof_summary.txt: (2*12508.1 + 10399.5) KiB (24 B per surviving walker of it: the next step's gate)
 TRAFFIC_K_SPAWN = 1.97e7      # same file: (2*6500.5 + 6252.1) KiB
 
 
