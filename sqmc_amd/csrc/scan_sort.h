@@ -156,7 +156,9 @@ static inline int device_excl_scan_u64(const u64 *in, u64 *out, long long n, u64
 // ------------------------------------------------------------------------ radix sort
 #define RS_MAX_RADIX 1024                   // 10-bit digits at most
 #define RS_LARGE_N (1ll << 20)
+#ifndef RS_TILE
 #define RS_TILE 1024                        // keys per 256-thread block (4 waves x 4 rounds of 64)
+#endif
 
 // histogram: hist[digit * ntiles + tile]; one 256-thread block (4 waves) per tile of 1024 keys
 template <int BITS>

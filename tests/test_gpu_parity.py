@@ -179,6 +179,19 @@ def test_walk_counter_trajectory_bit_exact(oracle, c2_walk, c2_setup):
     assert len(wg["up"]) > 3000
 
 
+def test_walk_counter_trajectory_bit_exact_at_bench_size(oracle, c2_walk, c2_setup):
+    """BASELINE.json configs[1] at its own size: 10^5 walkers' worth of weight from the first step on, so that within a few
+    steps the lists are those of the bench (> 10^5 occupied determinants, > 2.5 10^5 sorted slots: hundreds of sort, scan and
+    annihilation tiles, long runs of equal determinants on the heavy ones).  Walkers, weights and flags bit for bit
+    against the oracle after 40 steps (integer bookkeeping and sums after every one)."""
+    wg, wc, _, _, og, oc = _run_pair(oracle, c2_walk, c2_setup, 1, 40, 100000, 100000, mwalk=1000000)
+    assert int(og[5]) > 100000 and int(og[7]) > 200000
+    for k in ("up", "dn", "imp_distance", "initiator"):
+        assert np.array_equal(wg[k], wc[k]), k
+    assert np.array_equal(wg["wt"], wc["wt"])
+    assert np.array_equal(wg["matrix_elements"], wc["matrix_elements"])
+
+
 @pytest.mark.parametrize("w_target,nsteps", [(200000, 120), (800000, 140)])
 def test_walk_invariants_large(oracle, c2_walk, c2_setup, w_target, nsteps):
     """Size-independent properties at populations the oracle is not run at (the larger one is past
