@@ -602,25 +602,27 @@ def test_hubbard_matrix_elements_and_proposals_bit_exact(oracle, hub44):
     assert nz > n // 2 and long_draws > n // 10       # the rejection loop of choose_random_electron was exercised
 
 
-@pytest.mark.parametrize("rng_mode,semi,nsteps", [(0, 1, 60), (1, 1, 120), (0, 0, 50)])
-def test_hubbard_walk_trajectory_bit_exact(oracle, hub44, hub_setup, rng_mode, semi, nsteps):
+@pytest.mark.parametrize("rng_mode,semi,nsteps,w_begin,w_target", [(0, 1, 60, 50, 4000), (1, 1, 120, 50, 4000), (0, 0, 50, 50, 4000),
+                                                                  (1, 1, 30, 100000, 100000)])      # the last: ten times configs[0]'s population from step one
+def test_hubbard_walk_trajectory_bit_exact(oracle, hub44, hub_setup, rng_mode, semi, nsteps, w_begin, w_target):
     """BASELINE.json configs[0] (4x4 Hubbard, U/t = 4, half filling): the step pipeline with
     off_diagonal_move_hubbard / hamiltonian_hubbard as the operator pair, semistochastic and plain
     (join_walker2) variants, against the oracle walker for walker."""
     from conftest import gpu_ctx_hub
     s = hub_setup
-    g = gpu_ctx_hub(hub44, rng_mode=rng_mode, seed=SEED, mwalk=400000)
+    mwalk = 400000 if w_target < 50000 else 1500000
+    g = gpu_ctx_hub(hub44, rng_mode=rng_mode, seed=SEED, mwalk=mwalk)
     if semi:
         g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
     g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
-    wk = oracle.initial_walkers(s, 50)
+    wk = oracle.initial_walkers(s, w_begin)
     if not semi:                                   # a purely stochastic population
         wk["imp_distance"] = np.where(wk["imp_distance"] == 0, 1, wk["imp_distance"]).astype(np.int8)
         keep = ~((wk["wt"] == 0) & (wk["initiator"] < 3))
         wk = {k: v[keep] for k, v in wk.items()}
     g.upload_walkers(wk)
-    ow = oracle.OracleWalk(hub44, s, wk, 400000, SEED, rng_mode=rng_mode)
-    pc = oracle.PopControl(s.tau, s.e_trial0, 4000)
+    ow = oracle.OracleWalk(hub44, s, wk, mwalk, SEED, rng_mode=rng_mode)
+    pc = oracle.PopControl(s.tau, s.e_trial0, w_target)
     w_abs = float(np.abs(wk["wt"]).sum())
     for it in range(nsteps):
         r = pc.pre_step(w_abs)
@@ -641,7 +643,7 @@ def test_hubbard_walk_trajectory_bit_exact(oracle, hub44, hub_setup, rng_mode, s
     for k in ("up", "dn", "imp_distance", "initiator"):
         assert np.array_equal(wg[k], wc[k]), k
     assert np.array_equal(wg["wt"], wc["wt"])
-    assert len(wg["up"]) > 300
+    assert len(wg["up"]) > (300 if w_target < 50000 else 50000)
 
 
 def test_hubbard_host_setup_matches_oracle_and_walk_runs(oracle, hub44, hub_setup):
