@@ -192,6 +192,18 @@ def test_walk_counter_trajectory_bit_exact_at_bench_size(oracle, c2_walk, c2_set
     assert np.array_equal(wg["matrix_elements"], wc["matrix_elements"])
 
 
+def test_walk_counter_trajectory_bit_exact_past_2_20_slots(oracle, c2_walk, c2_setup):
+    """The variants long lists switch to -- 8-bit radix passes over the spawns only and a merge with the walkers, which are in
+    order already; 3 slots per thread in the annihilation kernel; the large scan tiles -- start at 2^20 sorted slots.  Twelve
+    steps from 10^6 walkers' worth of weight put every step but the first there: bit for bit against the oracle."""
+    wg, wc, _, _, og, oc = _run_pair(oracle, c2_walk, c2_setup, 1, 12, 1000000, 1000000, mwalk=8000000)
+    assert int(og[7]) > (1 << 20)
+    for k in ("up", "dn", "imp_distance", "initiator"):
+        assert np.array_equal(wg[k], wc[k]), k
+    assert np.array_equal(wg["wt"], wc["wt"])
+    assert np.array_equal(wg["matrix_elements"], wc["matrix_elements"])
+
+
 @pytest.mark.parametrize("w_target,nsteps", [(200000, 120), (800000, 140)])
 def test_walk_invariants_large(oracle, c2_walk, c2_setup, w_target, nsteps):
     """Size-independent properties at populations the oracle is not run at (the larger one is past
