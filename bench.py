@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--target", type=float, default=1e5, help="w_abs_gen_target")
     ap.add_argument("--equil", type=int, default=400, help="untimed equilibration steps before warmup")
+    ap.add_argument("--mwalk", type=int, default=0, help="walker capacity of the single-GPU walk (0: the reference's MWALK = 4 (target/min_wt + n_imp))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--system", default="c2", choices=["c2", "heg", "hubbard"], help="c2 = BASELINE.json configs[1] (the metric's config, default); "
                     "heg = the 14-electron 3D electron gas of configs[3]; hubbard = real-space Hubbard U/t=4 at half filling "
@@ -133,6 +134,7 @@ def main():
         kw = dict(w_begin=min(args.target, 1e4), n_truncate_trial_wf=1, size_deterministic=500) if args.system == "heg" else {}
         if args.system == "hubbard":
             kw = dict(w_begin=min(args.target, 1e4), n_truncate_trial_wf=20, size_deterministic=500, tau_multiplier=0.5)
+        if args.mwalk: kw["mwalk"] = args.mwalk
         walk = H.GpuWalk(hst, args.target, seed=H.rank_seed((1346, 5634, 6635, 4361), rank), **kw)
         if multi:
             parallelism = "replicas x%d (sharded path unavailable)" % world
