@@ -15,7 +15,9 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 #define SCAN_BLOCK 256
+#ifndef SCAN_ITEMS_SMALL
 #define SCAN_ITEMS_SMALL 8                 // elements per thread: small inputs want many tiles (latency) ...
+#endif
 #define SCAN_ITEMS_LARGE 16                // ... large ones few (the look-back chain grows with the number of tiles)
 #define SCAN_LARGE_N (1ll << 19)
 #define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS_SMALL)     // state words are provisioned for the small tile
