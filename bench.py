@@ -49,7 +49,13 @@ def main():
     ap.add_argument("--heg-cutoff", type=float, default=2.3, help="plane-wave cutoff radius (2.3 -> 57 orbitals; the GPU path holds at most 64)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: this process only launches the N ranks (it never touches the GPU, so
+        # nothing that has initialised HIP is ever forked or re-executed) and forwards rank 0's JSON line
+        sys.exit(launch_ranks(args.gpus))
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus != world and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size counts\n" % (args.gpus, world))
     # stdout carries the one JSON line and nothing else: libraries that greet on fd 1 (RCCL prints its version banner there
     # when a communicator is made) are sent to stderr for the length of the run
     sys.stdout.flush()
@@ -59,6 +65,8 @@ def main():
         local = int(os.environ["SQMC_BENCH_DEVICE"])
     import numpy as np
     import torch
+    ndev = max(torch.cuda.device_count(), 1)
+    local = local % ndev                          # more ranks than devices (a rehearsal on a one-GPU box): ranks share cards
     import sqmc_amd
     from sqmc_amd import host as H
     dist = None
@@ -96,7 +104,7 @@ def main():
             torch.cuda.synchronize()
 
     parallelism = "single GPU"
-    walk = None
+    walk, rccl_ranks = None, None
     if multi:
         # weak scaling: the global target grows with the number of GPUs, determinants are sharded by
         # hash ownership and spawns cross ranks through one RCCL all-to-all per step
@@ -126,7 +134,8 @@ def main():
                     ok = torch.zeros(1, device=comm_dev)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if ok.item() >= 1:
-                    parallelism = "sharded x%d (hash-owned determinants), in-library RCCL: all-reduce + all-to-all of spawns + all-reduce per step" % world
+                    rccl_ranks = walk.g.comm_size()
+                    parallelism = "sharded x%d (hash-owned determinants), in-library RCCL (communicator of %d ranks): all-reduce + all-to-all of spawns + all-reduce per step" % (world, rccl_ranks)
                 else:                                     # same walk, exchanges from Python
                     walk.close()
                     walk = H.ShardedWalk(hst, g_target, rank, world, device_index=local, seed=(1346, 5634, 6635, 4361), **skw)
@@ -211,7 +220,8 @@ def main():
                                    {"c2": "size_deterministic=1000, Psi_T 100 dets, tau_multiplier 0.1", "heg": "size_deterministic=500, Psi_T 1 det, tau_multiplier 0.1",
                                     "hubbard": "size_deterministic=500, Psi_T 20 dets, tau_multiplier 0.5"}[args.system]),
                        "occupied_dets_per_step": n_avg, "spawns_per_step": s_avg, "spawns_per_s": spawn_all / dt,
-                       "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": parallelism},
+                       "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": parallelism,
+                       "rccl_ranks": rccl_ranks, "devices": min(world, ndev)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": (TRAFFIC_K_ANNEAL if dom == "k_anneal" else TRAFFIC_K_SPAWN) if default_cfg else None, "ms_per_launch": dom_ms,
                          "algorithmic_bytes_per_launch": dom_bytes,
@@ -229,6 +239,31 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """One child process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torchrun sets them), rendezvous on
+    127.0.0.1.  Rank 0's stdout (the JSON line) is forwarded; the exit code is non-zero if any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %r\n" % bad)
+        return 1
+    return 0
 
 
 def cpu_baseline(walk, hst, n_avg, budget_s=15.0):

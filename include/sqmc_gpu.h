@@ -201,6 +201,10 @@ int sqmc_gpu_annihilate(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, int64_t n_
  * set_projector takes the GLOBAL projector on every rank; shard_config gives, for the k-th
  * deterministic-space walker this rank owns (in its sorted order), its row in that matrix. */
 int sqmc_gpu_det_owner(sqmc_gpu_ctx *ctx, int64_t n, const uint64_t *up, const uint64_t *dn, int32_t nranks, int32_t *owner);
+/* Which hash decides ownership.  0 (default): a mix of the determinant's sort key (cheapest).  1: the reference's own
+ * get_det_owner -> hash -> djb_hash (mpi_routines.f90:419-445, 257-289, 354-379) bit for bit, so that ranks running the
+ * reference and ranks running this library agree on who owns a determinant.  Call before distributing walkers. */
+int sqmc_gpu_set_owner_hash(sqmc_gpu_ctx *ctx, int32_t mode);
 int sqmc_gpu_shard_config(sqmc_gpu_ctx *ctx, int32_t rank, int32_t nranks, int64_t n_imp_local, const int32_t *global_row);
 int sqmc_gpu_shard_begin(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, double *x_global_dev, int64_t *n_children);
 int sqmc_gpu_shard_pack(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, const double *x_global_dev, uint64_t *send_dev,
@@ -221,6 +225,8 @@ int sqmc_gpu_shard_finish(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, const ui
 #define SQMC_COMM_ID_BYTES 128
 int sqmc_gpu_comm_unique_id(uint8_t id[SQMC_COMM_ID_BYTES]);
 int sqmc_gpu_comm_init(sqmc_gpu_ctx *ctx, const uint8_t id[SQMC_COMM_ID_BYTES]);
+/* number of ranks RCCL itself reports for the communicator (ncclCommCount; the reference's ncores, mpi_routines.f90:310) */
+int sqmc_gpu_comm_size(sqmc_gpu_ctx *ctx, int32_t *nranks);
 int sqmc_gpu_shard_step(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, double out_stats[16]);
 int sqmc_gpu_shard_run(sqmc_gpu_ctx *ctx, sqmc_popctl *pc, int64_t nsteps, double *stats /* nsteps*16 or NULL */, double totals[16]);
 

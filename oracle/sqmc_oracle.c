@@ -33,7 +33,10 @@ static uint64_t mix64(uint64_t v) {
 }
 void orc_rng_set_mode(orc_rng *g, int mode) { g->mode = mode; g->step = 0; }
 void orc_rng_seek(orc_rng *g, int stage, uint64_t idx) {
-  if (g->mode == 1) g->ctr = mix64(mix64(g->seed ^ (g->step * 4ull + (uint64_t)stage)) + idx);
+  /* the seed is mixed BEFORE step and stage enter: per-rank seeds differ in their low bits only (do_walk.f90:234 adds the
+   * rank to the last limb), where the step/stage field lives -- unmixed, rank r at step s would reuse rank 0's streams of
+   * another step */
+  if (g->mode == 1) g->ctr = mix64(mix64(mix64(g->seed) ^ (g->step * 4ull + (uint64_t)stage)) + idx);
 }
 /* rannyu.f90:77-87 */
 void orc_savern(const orc_rng *g, int seed[4]) { for (int i = 0; i < 4; i++) seed[i] = g->l[i]; }
@@ -789,6 +792,40 @@ static void msort_idx(const det_t *up, const det_t *dn, int64_t *a, int64_t *tmp
   }
   while (i < na) a[k++] = tmp[i++];
 }
+/* ---- ownership: mpi_routines.f90:354-379 (djb_hash), 257-289 (hash), 419-445 (get_det_owner) ----
+ * hash = PRIME; for word in (det_up, det_dn + OFFSET): test = IEOR(word, X'5555555555555555') * PRIME;
+ * for j = 0, 8, ..., 120: hash = (ishft(hash,5) + hash) + ishft(test, -j).   All INTEGER(16), wrapping; ishft with a
+ * negative count is a LOGICAL right shift; the BOZ constant fills the low 64 bits only. */
+typedef unsigned __int128 u128_t;
+static u128_t orc_u128(uint64_t lo, uint64_t hi) { return ((u128_t)hi << 64) | (u128_t)lo; }
+static u128_t orc_djb_hash_u(u128_t det_up, u128_t det_dn) {
+  const u128_t PRIME = orc_u128(0x000000000000013Bull, 0x0000000001000000ull);            /* 309485009821345068724781371 = 2^88 + 315 (the FNV-128 prime) */
+  const u128_t OFFSET = orc_u128(0x62B821756295C58Dull, 0x6C62272E07BB0142ull);           /* 144066263297769815596495629667062367629 */
+  u128_t hash = PRIME;
+  for (int i = 1; i <= 2; i++) {
+    u128_t tmp = (i == 1) ? det_up : det_dn;
+    if (i == 2) tmp = tmp + OFFSET;
+    for (int j = 0; j < 128; j += 8) {
+      u128_t test_nk = tmp ^ (u128_t)0x5555555555555555ull;
+      test_nk = test_nk * PRIME;
+      hash = ((hash << 5) + hash) + (test_nk >> j);
+    }
+  }
+  return hash;
+}
+void orc_djb_hash(uint64_t up_lo, uint64_t up_hi, uint64_t dn_lo, uint64_t dn_hi, uint64_t hash_out[2]) {
+  const u128_t h = orc_djb_hash_u(orc_u128(up_lo, up_hi), orc_u128(dn_lo, dn_hi));
+  hash_out[0] = (uint64_t)h; hash_out[1] = (uint64_t)(h >> 64);
+}
+/* hashx = int(abs(mod(acc, int(range,ik)))): MOD takes the sign of the dividend */
+int orc_get_det_owner(uint64_t up_lo, uint64_t up_hi, uint64_t dn_lo, uint64_t dn_hi, int ncores) {
+  if (ncores == 1) return 0;
+  const __int128 acc = (__int128)orc_djb_hash_u(orc_u128(up_lo, up_hi), orc_u128(dn_lo, dn_hi));
+  __int128 m = acc % (__int128)ncores;
+  if (m < 0) m = -m;
+  return (int)m;
+}
+
 void orc_merge_sort_walkers(orc_walk *w, int64_t n) {
   int64_t *ord = malloc(n * sizeof(int64_t)), *tmp = malloc(((n + 1) / 2 + 1) * sizeof(int64_t));
   for (int64_t i = 0; i < n; i++) ord[i] = i;

@@ -132,6 +132,12 @@ int  orc_walk_step(const orc_chem *s, orc_walk *w, const orc_step_params *p, dou
 
 /* pieces exposed for component tests */
 void orc_merge_sort_walkers(orc_walk *w, int64_t n);                       /* do_walk.f90:5169-5197 */
+/* get_det_owner (mpi_routines.f90:419-445) -> hash (257-289) -> djb_hash (354-379): the rank that owns a determinant.
+ * Determinants are the reference's 128-bit integers, passed as (low, high) 64-bit halves (conv_128_to_64, 671-680).
+ * PARITY UNPINNED: mpi_routines.f90 does not compile unmodified with this image's flang and the reference holds no
+ * fixture of owners; the restatement follows the source text (wrapping INTEGER(16) arithmetic, logical shifts). */
+void orc_djb_hash(uint64_t up_lo, uint64_t up_hi, uint64_t dn_lo, uint64_t dn_hi, uint64_t hash_out[2]);
+int  orc_get_det_owner(uint64_t up_lo, uint64_t up_hi, uint64_t dn_lo, uint64_t dn_hi, int ncores);
 int64_t orc_merge_original_with_spawned2(orc_walk *w, int64_t n, const orc_step_params *p); /* 5866-6083 */
 int64_t orc_reduce_my_walker(orc_walk *w, int64_t n, const orc_step_params *p);            /* 7196-7254 */
 int64_t orc_join_walker2(orc_walk *w, int64_t n, const orc_step_params *p);                /* 6990-7103 */

@@ -14,8 +14,8 @@ _LIB = None
 EXPORTS = [
     "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_init_heg", "sqmc_gpu_init_hubbard", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_projector",
     "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
-    "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_annihilate", "sqmc_gpu_det_owner", "sqmc_gpu_shard_config",
-    "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init",
+    "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_annihilate", "sqmc_gpu_det_owner", "sqmc_gpu_set_owner_hash", "sqmc_gpu_shard_config",
+    "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init", "sqmc_gpu_comm_size",
     "sqmc_gpu_shard_step", "sqmc_gpu_shard_run", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_spmv_prepare",
     "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_build_spmv_plan", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
     "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_hci_connections_slice", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
@@ -301,6 +301,17 @@ class GpuChem:
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         self.L.sqmc_gpu_comm_init.argtypes = [C.c_void_p, C.c_void_p]
         _chk(self.L.sqmc_gpu_comm_init(self.h, buf))
+
+    def set_owner_hash(self, mode):
+        """0: mix of the sort key (default); 1: the reference's djb_hash (mpi_routines.f90:354-379)"""
+        self.L.sqmc_gpu_set_owner_hash.argtypes = [C.c_void_p, C.c_int32]
+        _chk(self.L.sqmc_gpu_set_owner_hash(self.h, int(mode)))
+
+    def comm_size(self):
+        n = C.c_int32()
+        self.L.sqmc_gpu_comm_size.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(self.L.sqmc_gpu_comm_size(self.h, C.byref(n)))
+        return n.value
 
     def shard_step(self, params):
         p = StepParams(**params); out = np.zeros(16)

@@ -42,10 +42,10 @@ struct ChemTab {
   unsigned short c2[(SQ_MAXORB + 2) * (SQ_MAXORB + 2)];   // only the first c2_stride^2 entries are used/staged
 };
 
-#define SQ_BINOM_STRIDE 33
+#define SQ_BINOM_STRIDE 68              // C(c, i) for every i <= 64, + 3 entries the 4-wide rounds of colex_rank may touch
 struct ChemDev {                        // pointers into HBM, passed by value
   const ChemTab *tab; int tab_words;
-  const u64 *binom;                     // C(c, i) at [c*SQ_BINOM_STRIDE + i], c < 64, i <= 32
+  const u64 *binom;                     // C(c, i) at [c*SQ_BINOM_STRIDE + i], c < 64, i < SQ_BINOM_STRIDE (0 where i > c)
   u64 n_dn_strings;                     // C(norb, ndn)
   const double *integrals;              // 1-based packed
   // HCI heat-bath table (chemistry.f90:900-993)
@@ -126,7 +126,9 @@ __host__ __device__ __forceinline__ u64 sq_mix64(u64 v) {
   v ^= v >> 30; v *= 0xBF58476D1CE4E5B9ull; v ^= v >> 27; v *= 0x94D049BB133111EBull; v ^= v >> 31;
   return v;
 }
-// stream key for the COUNTER discipline: (seed, step, stage, entity index)
+// stream key for the COUNTER discipline: (seed, step, stage, entity index).  `seed` is the MIXED input seed
+// (sqmc_gpu_ctx::seed64 = sq_mix64(48-bit seed)): per-rank seeds differ only in their low bits (do_walk.f90:234),
+// which is where step and stage enter; mixed first, the streams of different ranks never coincide a step apart.
 __host__ __device__ __forceinline__ u64 sq_counter_key(u64 seed, u64 step, int stage, u64 idx) {
   return sq_mix64(sq_mix64(seed ^ (step * 4ull + (u64)stage)) + idx);
 }

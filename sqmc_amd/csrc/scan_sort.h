@@ -278,8 +278,10 @@ static inline void radix_pass(u64 *ka, u32 *va, u64 *kb, u32 *vb, long long n, i
 // (keys only: the caller packed its payload into the bits below shift0, which are not sorted on
 // and ride along -- one scattered 8-byte write per element and pass instead of an 8- and a 4-byte
 // one).
-static inline void device_radix_sort(u64 *&keys, u32 *&vals, long long n, int nbits, SortWork &w, hipStream_t st, int shift0 = 0) {
-  if (n <= 1) return;
+// counts_wanted: the caller reads the digit totals of the (single) pass from w.rowtot afterwards, so a list of one
+// element goes through the pass as well instead of returning untouched with the totals of some earlier sort there.
+static inline void device_radix_sort(u64 *&keys, u32 *&vals, long long n, int nbits, SortWork &w, hipStream_t st, int shift0 = 0, bool counts_wanted = false) {
+  if (n <= 0 || (n == 1 && !counts_wanted)) return;
   int ntiles = (int)((n + RS_TILE - 1) / RS_TILE);
   u64 *ka = keys, *kb = w.k_alt; u32 *va = vals, *vb = vals ? w.v_alt : nullptr;
   // Small inputs are launch bound: the fewest passes (10-bit digits).  Large ones are bound by the
@@ -322,35 +324,43 @@ __device__ __forceinline__ long long merge_path_split(P A, long long nA, P B, lo
   }
   return lo;
 }
-__global__ void __launch_bounds__(256) merge_path_kernel(const u64 *__restrict__ A, long long nA, const u64 *__restrict__ B, long long nB,
-                                                         u64 *__restrict__ out, int shift) {
-  __shared__ u64 sA[MP_TILE], sB[MP_TILE], sO[MP_TILE];
+// VALS: keys and their 32-bit payloads are two arrays (keys wider than 32 bits); the tile is half as long so that the
+// staged payloads fit beside the keys.
+template <bool VALS>
+__global__ void __launch_bounds__(256) merge_path_kernel(const u64 *__restrict__ A, const u32 *__restrict__ Av, long long nA,
+                                                         const u64 *__restrict__ B, const u32 *__restrict__ Bv, long long nB,
+                                                         u64 *__restrict__ out, u32 *__restrict__ outv, int shift) {
+  constexpr int ITEMS = VALS ? MP_ITEMS / 2 : MP_ITEMS, TILE = 256 * ITEMS;
+  __shared__ u64 sA[TILE], sB[TILE], sO[TILE];
+  __shared__ u32 vA[VALS ? TILE : 1], vB[VALS ? TILE : 1], vO[VALS ? TILE : 1];
   __shared__ long long s_split[2];
-  const long long n = nA + nB, d0 = (long long)blockIdx.x * MP_TILE, d1 = (d0 + MP_TILE < n) ? d0 + MP_TILE : n;
+  const long long n = nA + nB, d0 = (long long)blockIdx.x * TILE, d1 = (d0 + TILE < n) ? d0 + TILE : n;
   if (threadIdx.x == 0) s_split[0] = merge_path_split(A, nA, B, nB, d0, shift);
   if (threadIdx.x == 64) s_split[1] = merge_path_split(A, nA, B, nB, d1, shift);
   __syncthreads();
   const long long a0 = s_split[0], a1 = s_split[1], b0 = d0 - a0, b1 = d1 - a1;
   const int la = (int)(a1 - a0), lb = (int)(b1 - b0), lt = (int)(d1 - d0);
-  for (int k = threadIdx.x; k < la; k += 256) sA[k] = A[a0 + k];
-  for (int k = threadIdx.x; k < lb; k += 256) sB[k] = B[b0 + k];
+  for (int k = threadIdx.x; k < la; k += 256) { sA[k] = A[a0 + k]; if (VALS) vA[k] = Av[a0 + k]; }
+  for (int k = threadIdx.x; k < lb; k += 256) { sB[k] = B[b0 + k]; if (VALS) vB[k] = Bv[b0 + k]; }
   __syncthreads();
-  const int dd = threadIdx.x * MP_ITEMS;
+  const int dd = threadIdx.x * ITEMS;
   if (dd < lt) {
     int i = (int)merge_path_split((const u64 *)sA, (long long)la, (const u64 *)sB, (long long)lb, (long long)dd, shift), j = dd - i;
 #pragma unroll
-    for (int k = 0; k < MP_ITEMS; k++) {
+    for (int k = 0; k < ITEMS; k++) {
       if (dd + k >= lt) break;
       const bool takeA = (j >= lb) || (i < la && (sA[i] >> shift) <= (sB[j] >> shift));
       sO[dd + k] = takeA ? sA[i] : sB[j];
+      if (VALS) vO[dd + k] = takeA ? vA[i] : vB[j];
       if (takeA) i++; else j++;
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < lt; k += 256) out[d0 + k] = sO[k];
+  for (int k = threadIdx.x; k < lt; k += 256) { out[d0 + k] = sO[k]; if (VALS) outv[d0 + k] = vO[k]; }
 }
-static inline void device_merge_sorted(const u64 *A, long long nA, const u64 *B, long long nB, u64 *out, int shift, hipStream_t st) {
+static inline void device_merge_sorted(const u64 *A, const u32 *Av, long long nA, const u64 *B, const u32 *Bv, long long nB, u64 *out, u32 *outv, int shift, hipStream_t st) {
   const long long n = nA + nB;
   if (n <= 0) return;
-  hipLaunchKernelGGL(merge_path_kernel, dim3((unsigned)((n + MP_TILE - 1) / MP_TILE)), dim3(256), 0, st, A, nA, B, nB, out, shift);
+  if (outv) hipLaunchKernelGGL(merge_path_kernel<true>, dim3((unsigned)((n + MP_TILE / 2 - 1) / (MP_TILE / 2))), dim3(256), 0, st, A, Av, nA, B, Bv, nB, out, outv, shift);
+  else hipLaunchKernelGGL(merge_path_kernel<false>, dim3((unsigned)((n + MP_TILE - 1) / MP_TILE)), dim3(256), 0, st, A, Av, nA, B, Bv, nB, out, outv, shift);
 }

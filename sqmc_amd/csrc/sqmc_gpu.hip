@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <time.h>
 #include <vector>
 #include <string>
 #include <algorithm>
@@ -96,7 +97,11 @@ struct DevScalars {
   int err;                 // SQMC_ERR_* raised on device
   int pad;
   double stats[16];
+  double red[8];           // sharded steps: what the ranks all-reduce -- the seven global sums and the collective status (256^code summed over ranks)
 };
+// status of a step summed over ranks as 256^code: the highest code any rank raised (codes 1..5, at most 255 ranks: exact in a double)
+__host__ __device__ __forceinline__ double err_encode(int code) { double v = 0.0; if (code > 0) { v = 1.0; for (int k = 0; k < code; k++) v *= 256.0; } return v; }
+__host__ __device__ __forceinline__ int err_decode(double v) { int code = 0; double lim = 256.0; for (int k = 1; k <= 5; k++) { if (v >= lim) code = k; lim *= 256.0; } return code; }
 
 // Mailbox in pinned host memory that the GPU writes directly (no copy kernel, no interrupt): the
 // child count as soon as k_spawn starts, the step's sums at the end of k_finish.  The host spins
@@ -121,13 +126,14 @@ struct sqmc_gpu_ctx {
   long long n_imp, prj_nnz; int *d_prj_ptr, *d_prj_col; double *d_prj_val; int *d_loc_imp, *d_loc_imp_new; double *d_prj_x;
   // C(T)
   long long n_ct; u64 *d_ct_up, *d_ct_dn; double *d_ct_num, *d_ct_den; u64 *d_ct_hkey; u32 *d_ct_hidx; u64 ct_mask;
-  int rng_mode; u64 seed64; u64 step_no;
+  int rng_mode; u64 seed64; u64 step_no;      // seed64: sq_mix64 of the 48-bit input seed, the root of every COUNTER stream key
   DevScalars *d_sc; DevScalars *h_sc;   // h_sc pinned
   HostMail *h_mail, *d_mail; u64 mail_seq, cnt_seq;      // the same pinned words seen from host and device
   bool timers_pending;
   double *d_partials; int n_partial_blocks; double *d_wabs_part; u32 *d_done;
   int key_bits; int pack; u64 invalid_key; u64 *d_binom;
   // multi-rank sharding (owner = hash(det) mod shard_n)
+  int owner_mode;             // SQMC_OWNER_MIX (default) or SQMC_OWNER_DJB (the reference's get_det_owner, bit for bit)
   int shard_rank, shard_n; int *d_grow; long long n_imp_local; long long shard_n0, shard_nch;
   // in-library exchange over RCCL (sqmc_gpu_comm_init): communicator + device staging
   ncclComm_t comm, comm2; double *d_xg; u64 *d_send, *d_recv; long long xch_cap; u32 *d_cnt_mine, *d_cnt_all; u32 *h_cnt_all, *d_cnt_mail;
@@ -174,13 +180,13 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
   c->dev.tab = c->d_tab; c->dev.tab_words = tab_words_used(c->htab.c2_stride); c->dev.integrals = c->d_ints; c->dev.max_double = 0.0;
   {   // binomial table + width of the colex sort key
     std::vector<u64> bn(64 * SQ_BINOM_STRIDE, 0);
-    for (int a = 0; a < 64; a++) { bn[a * SQ_BINOM_STRIDE] = 1; for (int b = 1; b <= 32 && b <= a; b++) bn[a * SQ_BINOM_STRIDE + b] = (b == a) ? 1 : bn[(a - 1) * SQ_BINOM_STRIDE + b - 1] + bn[(a - 1) * SQ_BINOM_STRIDE + b]; }
+    for (int a = 0; a < 64; a++) { bn[a * SQ_BINOM_STRIDE] = 1; for (int b = 1; b <= a; b++) bn[a * SQ_BINOM_STRIDE + b] = (b == a) ? 1 : bn[(a - 1) * SQ_BINOM_STRIDE + b - 1] + bn[(a - 1) * SQ_BINOM_STRIDE + b]; }
     auto choose = [&](int n_, int k_) -> long double { long double r = 1; for (int q = 1; q <= k_; q++) r = r * (n_ - k_ + q) / q; return r; };
     long double tot = choose(cfg->norb, cfg->nup) * choose(cfg->norb, cfg->ndn);
     if (tot >= 9.0e18L) { delete c; return fail(SQMC_ERR_UNSUPPORTED, "determinant space needs more than 63 key bits"); }
     u64 nd = (u64)(choose(cfg->norb, cfg->ndn) + 0.5L), total = (u64)(tot + 0.5L);
     int bits = 1; while (bits < 63 && ((1ull << bits) - 1ull) < total) bits++;
-    c->key_bits = bits; c->invalid_key = (1ull << bits) - 1ull; c->pack = (bits <= 32) ? 1 : 0;
+    c->key_bits = bits; c->invalid_key = (1ull << bits) - 1ull; c->pack = (bits <= 32 && !getenv("SQMC_FORCE_UNPACKED")) ? 1 : 0;      // SQMC_FORCE_UNPACKED: the two-array key layout of wide keys on a system whose keys would pack (tests)
     HIPCHK(hipMalloc(&c->d_binom, bn.size() * 8));
     HIPCHK(hipMemcpy(c->d_binom, bn.data(), bn.size() * 8, hipMemcpyHostToDevice));
     c->dev.binom = c->d_binom; c->dev.n_dn_strings = nd;
@@ -189,7 +195,7 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
   // limbs of the input seed may exceed 12 bits ('(4i4,x,4i4)' reads 4 decimal digits each):
   // rannyu's limb products treat them as coefficients of powers of 2^12, so the state is the SUM
   u64 s48 = (((u64)cfg->irand_seed[0] << 36) + ((u64)cfg->irand_seed[1] << 24) + ((u64)cfg->irand_seed[2] << 12) + (u64)(2 * (cfg->irand_seed[3] / 2) + 1)) & SQ_MASK48;
-  c->seed64 = s48; c->step_no = 0;
+  c->seed64 = sq_mix64(s48); c->step_no = 0;
   c->mwalk = cfg->mwalk > 0 ? cfg->mwalk : 0;
   HIPCHK(hipMalloc(&c->d_sc, sizeof(DevScalars)));
   HIPCHK(hipMemset(c->d_sc, 0, sizeof(DevScalars)));
@@ -472,7 +478,7 @@ int sqmc_gpu_set_rng(sqmc_gpu_ctx *c, const int32_t seed[4]) {
   if (!c) return SQMC_ERR_BAD_ARG;
   u64 x = (((u64)seed[0] << 36) + ((u64)seed[1] << 24) + ((u64)seed[2] << 12) + (u64)(2 * (seed[3] / 2) + 1)) & SQ_MASK48;
   HIPCHK(hipStreamSynchronize(c->st)); HIPCHK(hipMemcpy(&c->d_sc->lcg, &x, 8, hipMemcpyHostToDevice));
-  c->seed64 = x;
+  c->seed64 = sq_mix64(x);
   return SQMC_OK;
 }
 
@@ -502,12 +508,22 @@ static inline bool kernel_events_on(const sqmc_gpu_ctx *c, u64 step) { return c-
 static int comm_allreduce_stats(sqmc_gpu_ctx *c);
 // Spin on a mailbox word the GPU writes into pinned host memory.  Returns 0 when it arrived, -1
 // if the stream drained without it, a hipError_t > 0 if the stream reports an error.
+// A stream that neither drains nor delivers within SQMC_MAIL_TIMEOUT_S seconds (default 300; a step takes milliseconds) is
+// reported as hipErrorLaunchTimeOut instead of spinning for ever: a peer rank that never enters its collective must not
+// turn into a silent hang of the whole job.
 static int wait_mail(volatile u64 *flag, u64 expect, hipStream_t st) {
+  static const double limit_s = getenv("SQMC_MAIL_TIMEOUT_S") ? atof(getenv("SQMC_MAIL_TIMEOUT_S")) : 300.0;
+  struct timespec t0; bool timed = false;
   for (unsigned long it = 1;; it++) {
     if (*flag == expect) return 0;
     if ((it & 0x3FFF) == 0) {
       hipError_t e = hipStreamQuery(st);
       if (e != hipErrorNotReady) { if (*flag == expect) return 0; return e == hipSuccess ? -1 : (int)e; }
+      if ((it & 0xFFFFF) == 0) {
+        struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (!timed) { t0 = t1; timed = true; }
+        else if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > limit_s) return (int)hipErrorLaunchTimeOut;
+      }
     }
     __builtin_ia32_pause();
   }
@@ -525,9 +541,9 @@ static void collect_timers(sqmc_gpu_ctx *c) {
 }
 // sharded contexts: k_spawn fills the owner keys of the bucketing pass (arrays that are free until the annihilation)
 static OwnerOut shard_owner_out(sqmc_gpu_ctx *c) {
-  if (!c->d_grow) return OwnerOut{nullptr, nullptr, 0};
+  if (!c->d_grow) return OwnerOut{nullptr, nullptr, 0, 0};
   c->owner_ready = true;
-  return OwnerOut{c->d_flags, (u32 *)c->d_flags2, c->shard_n};
+  return OwnerOut{c->d_flags, (u32 *)c->d_flags2, c->shard_n, c->owner_mode};
 }
 // The head of a step: spawn gate + child offsets + k_spawn (COUNTER discipline).  With dev_n the
 // walker count is read on the device (sc->nwalk, written by k_finish of the step before) and n0 is
@@ -601,17 +617,18 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
   SortWork so; so.k_alt = c->d_keys_alt; so.v_alt = c->d_vals_alt; so.hist = c->d_hist; so.rowtot = c->d_rowtot; so.cap = M;
   u64 *skey = c->d_keys; u32 *perm = c->pack ? (u32 *)nullptr : c->d_vals;
   static const long long merge_min = getenv("SQMC_MERGE_SORT_MIN") ? atoll(getenv("SQMC_MERGE_SORT_MIN")) : (1ll << 20);
-  if (c->pack && p.semi && c->residents_sorted && nall >= merge_min) {
+  if (p.semi && c->residents_sorted && nall >= merge_min) {
     // Large lists: the walkers [0, n0) are in order already (every step leaves them so), so only the spawns
     // [n0, nall) are sorted and one stable merge (walker before spawns on equal keys, spawns in creation order)
-    // gives the order the full sort would.  The merged list lands in the flag array the fused tail does not use.
+    // gives the order the full sort would.  The merged list lands in the flag arrays the fused tail does not use.
     const long long nch = nall - n0;
     if (nch > 0) {
-      u64 *sk = c->d_keys + n0; u32 *nov = nullptr;
-      so.k_alt = c->d_keys_alt + n0;
-      device_radix_sort(sk, nov, nch, c->key_bits, so, st, 32);
-      device_merge_sorted(c->d_keys, n0, sk, nch, c->d_flags, 32, st);
-      skey = c->d_flags;
+      u64 *sk = c->d_keys + n0; u32 *sv = c->pack ? (u32 *)nullptr : c->d_vals + n0;
+      so.k_alt = c->d_keys_alt + n0; so.v_alt = c->d_vals_alt + n0;
+      device_radix_sort(sk, sv, nch, c->key_bits, so, st, c->pack ? 32 : 0);
+      if (c->pack) device_merge_sorted(c->d_keys, nullptr, n0, sk, nullptr, nch, c->d_flags, nullptr, 32, st);
+      else device_merge_sorted(c->d_keys, c->d_vals, n0, sk, sv, nch, c->d_flags, (u32 *)c->d_flags2, 0, st);
+      skey = c->d_flags; if (!c->pack) perm = (u32 *)c->d_flags2;
     }
   } else {
     device_radix_sort(skey, perm, nall, c->key_bits, so, st, c->pack ? 32 : 0);
@@ -675,6 +692,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
   fa.scan_state = c->d_scan_state; fa.scan_ticket = c->d_scan_ticket; fa.n_scan_words = (int)(3 * c->cap_tiles);
   fa.mail = use_mail ? c->d_mail : (HostMail *)nullptr; fa.seq = seq; fa.fstate = c->d_fstate; fa.fticket = c->d_fticket; fa.cap_ftiles = c->cap_ftiles;
   fa.n_ftiles = n_ft; fa.on = 1; fa.n_tickets = 3; fa.n_children = -1;
+  fa.expect_nimp = (p.semi && !use_mail) ? c->n_imp_local : -1;      // sharded in-library step: 'locations of my imp broken' must reach every rank
   if (fuse_gate && use_mail) {       // the finishing block runs beside the next head's scan (look-back set scan_flip): it re-zeroes the other set only
     const int other = c->scan_flip ^ 1;
     fa.scan_state = c->d_scan_state + (long long)other * c->cap_tiles; fa.scan_ticket = c->d_scan_ticket + other;
@@ -690,8 +708,8 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
   if (!use_mail) {
     int rr = comm_allreduce_stats(c); if (rr) return rr;      // do_walk.f90:2778-2790: the sums every rank needs
     mail_in_gate = c->pipeline_next && p.semi;                 // the next step's gate kernel posts them (one launch less)
-    if (!mail_in_gate) hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(64), 0, st, (const DevScalars *)c->d_sc, c->d_mail, seq);
-    else { memset(&fa, 0, sizeof(fa)); fa.on = 3; fa.mail = c->d_mail; fa.seq = seq; }
+    if (!mail_in_gate) hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(64), 0, st, c->d_sc, c->d_mail, seq);
+    else { memset(&fa, 0, sizeof(fa)); fa.on = 3; fa.mail = c->d_mail; fa.seq = seq; fa.expect_nimp = -1; }
   }
   if (c->pipeline_next) {
     // the next step's gate + scan + spawn go out now, behind k_finish: the GPU runs on while the host
@@ -711,7 +729,12 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
   }
   c->timers_pending = kernel_events_on(c, step);
   c->step_no++;
-  if (c->h_sc->err) { drop_head(c); return fail(c->h_sc->err, "diagonal_factor<0 after target population has been reached"); }
+  if (c->h_sc->err) {          // raised on the device (sharded in-library steps: by any rank, all-reduced)
+    drop_head(c);
+    const int e = c->h_sc->err;
+    return fail(e, e == SQMC_ERR_NEG_DIAG ? "diagonal_factor<0 after target population has been reached" : e == SQMC_ERR_IMP_BROKEN ? "locations of my imp broken" :
+                   e == SQMC_ERR_MWALK ? "nwalk>MWALK" : "step stopped on the device");
+  }
   const long long nfinal = (long long)(c->h_sc->tot2 & 0xFFFFFFFFull), nimp = (long long)(c->h_sc->tot2 >> 32);
   c->nwalk = nfinal; c->residents_sorted = true;
   for (int i = 0; i < 16; i++) out[i] = c->h_sc->stats[i];
@@ -762,10 +785,10 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     if (M > n0) {
       if (t_spawn >= 0)
         hipExtLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->ev0[t_spawn], c->ev1[t_spawn], 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0});
+                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0});
       else
         hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0});
+                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0});
     } else if (t_spawn >= 0) { hipEventRecord(c->ev0[t_spawn], st); hipEventRecord(c->ev1[t_spawn], st); }
   } else {
     int r = enqueue_head(c, p, step, n0, false, t_gate_scan >= 0 ? c->ev0[t_gate_scan] : nullptr, t_gate_scan >= 0 ? c->ev1[t_gate_scan] : nullptr,

@@ -11,6 +11,7 @@ struct FinArgs {
   HostMail *mail; u64 seq; u64 *fstate; u32 *fticket; long long cap_ftiles; int n_ftiles; int on;
   int n_tickets;      // scan tickets behind scan_ticket to reset with the n_scan_words state words (3: all of them)
   long long n_children;   // >= 0: the step's child count from the host (a finish that rides on the NEXT step's scan must not read the scalar that scan writes)
+  long long expect_nimp;  // >= 0: deterministic-space walkers this rank must still hold; anything else raises SQMC_ERR_IMP_BROKEN on the device (sharded steps: the status is all-reduced)
 };
 __device__ void finish_all(const FinArgs &f, DevScalars *sc);
 // spawn gate and child count of one walker (COUNTER discipline: the draw is keyed by step and walker index).  do_walk.f90:3577-3589
@@ -118,8 +119,57 @@ __global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict
 
 // rank that owns a determinant (get_det_owner, mpi_routines.f90:419-445: any hash of the determinant mod the number of ranks)
 __host__ __device__ __forceinline__ int det_owner(u64 key, int nranks) { return (int)((sq_mix64(key ^ 0xA5A5A5A5A5A5A5A5ull) >> 17) % (u64)nranks); }
+// The reference's own ownership function, bit for bit (SQMC_OWNER_DJB): get_det_owner -> hash -> djb_hash,
+// mpi_routines.f90:419-445, 257-289, 354-379, on the reference's 128-bit determinants (here: high halves zero).
+//   hash = PRIME; for word in (det_up, det_dn + OFFSET): test = IEOR(word, X'5555555555555555') * PRIME;
+//                 for j = 0, 8, ..., 120: hash = (ishft(hash,5) + hash) + ishft(test, -j)
+//   owner = abs(mod(hash, ncores))                   wrapping INTEGER(16) arithmetic, logical shifts
+// PRIME = 2^88 + 315 (the FNV-128 prime): x * PRIME = (x << 88) + 315 x.
+struct U128 { u64 lo, hi; };
+__host__ __device__ __forceinline__ U128 add128(U128 a, U128 b) { U128 r; r.lo = a.lo + b.lo; r.hi = a.hi + b.hi + (r.lo < a.lo ? 1ull : 0ull); return r; }
+__host__ __device__ __forceinline__ U128 shr128(U128 a, int j) {
+  U128 r;
+  if (j == 0) return a;
+  if (j < 64) { r.lo = (a.lo >> j) | (a.hi << (64 - j)); r.hi = a.hi >> j; } else { r.lo = a.hi >> (j - 64); r.hi = 0; }
+  return r;
+}
+__host__ __device__ __forceinline__ U128 mul_prime128(U128 x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const u64 carry = __umul64hi(x.lo, 315ull);
+#else
+  const u64 carry = (u64)(((unsigned __int128)x.lo * 315u) >> 64);
+#endif
+  U128 r; r.lo = x.lo * 315ull; r.hi = x.hi * 315ull + carry + (x.lo << 24);
+  return r;
+}
+__host__ __device__ __forceinline__ U128 djb_hash128(u64 up, u64 dn) {
+  U128 hash; hash.lo = 0x13Bull; hash.hi = 0x1000000ull;
+  for (int i = 0; i < 2; i++) {
+    U128 tmp; tmp.lo = i ? dn : up; tmp.hi = 0;
+    if (i) { U128 off; off.lo = 0x62B821756295C58Dull; off.hi = 0x6C62272E07BB0142ull; tmp = add128(tmp, off); }
+    tmp.lo ^= 0x5555555555555555ull;
+    const U128 test = mul_prime128(tmp);
+    for (int j = 0; j < 128; j += 8) {
+      U128 h32; h32.lo = hash.lo << 5; h32.hi = (hash.hi << 5) | (hash.lo >> 59);
+      hash = add128(add128(h32, hash), shr128(test, j));
+    }
+  }
+  return hash;
+}
+__host__ __device__ __forceinline__ int det_owner_djb(u64 up, u64 dn, int nranks) {
+  if (nranks == 1) return 0;
+  U128 h = djb_hash128(up, dn);
+  if (h.hi >> 63) { h.lo = ~h.lo; h.hi = ~h.hi; h.lo += 1; if (h.lo == 0) h.hi += 1; }      // abs(mod(x, n)) = |x| mod n
+  const u64 n = (u64)nranks, two64 = ((~0ull) % n + 1ull) % n;
+  return (int)(((h.hi % n) * two64 + h.lo % n) % n);
+}
+#define SQMC_OWNER_MIX 0
+#define SQMC_OWNER_DJB 1
+__host__ __device__ __forceinline__ int det_owner_any(int mode, u64 key, u64 up, u64 dn, int nranks) {
+  return mode == SQMC_OWNER_DJB ? det_owner_djb(up, dn, nranks) : det_owner(key, nranks);
+}
 // sharded steps: k_spawn also notes the destination rank of every child (nranks for a child that made no walker), the key of the bucketing pass
-struct OwnerOut { u64 *okey; u32 *oval; int nranks; };      // okey == nullptr: off
+struct OwnerOut { u64 *okey; u32 *oval; int nranks; int mode; };      // okey == nullptr: off
 // a spawned walker (or the "no walker" marker) into slot n0 + c.  do_walk.f90:3700-3731
 __device__ __forceinline__ void spawn_emit(const ChemDev &dev, const WalkArr &w, u64 *__restrict__ keys, u32 *__restrict__ vals, long long n0, long long c,
                                            u32 pf, u64 ju, u64 jd, double wj, const StepP &p, u64 invalid_key, int pack, const OwnerOut &oo) {
@@ -138,7 +188,7 @@ __device__ __forceinline__ void spawn_emit(const ChemDev &dev, const WalkArr &w,
     w.sp[c] = r;
     const u64 key = det_key(dev, ju, jd);
     put_key(keys, vals, k, key, pack);
-    if (oo.okey) { oo.okey[c] = (u64)det_owner(key, oo.nranks); oo.oval[c] = (u32)c; }
+    if (oo.okey) { oo.okey[c] = (u64)det_owner_any(oo.mode, key, ju, jd, oo.nranks); oo.oval[c] = (u32)c; }
   } else {
     w.sp[c].wt = 0.0; put_key(keys, vals, k, invalid_key, pack);     // sorts behind every real determinant
     if (oo.okey) { oo.okey[c] = (u64)oo.nranks; oo.oval[c] = (u32)c; }
@@ -583,7 +633,7 @@ __device__ __forceinline__ long long ct_lookup(const u64 *__restrict__ hkey, con
 
 #define NSTAT 13
 __device__ void finish_step(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
-                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words, int n_tickets, long long n_children, HostMail *mail);
+                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words, int n_tickets, long long n_children, HostMail *mail, long long expect_nimp);
 // compaction into the walker arrays + reweight (2487) + estimator pieces (2573-2684 and
 // binary_search_list_and_update, more_tools.f90:4041-4098) + per-block partial sums
 __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64 *__restrict__ flags2, const u64 *__restrict__ pos2,
@@ -799,12 +849,16 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
   APROF(5);
 }
 // posts the (all-reduced) scalars of a sharded step to the host mailbox
-__global__ void k_post_mail(const DevScalars *sc, HostMail *mail, u64 seq) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void post_reduced(DevScalars *sc, HostMail *mail, u64 seq) {
+  for (int i = 0; i < 7; i++) sc->stats[i] = sc->red[i];          // the global sums replace the local ones
   for (int i = 0; i < 16; i++) mail->stats[i] = sc->stats[i];
-  mail->tot2 = sc->tot2; mail->err = sc->err;
+  mail->tot2 = sc->tot2; mail->err = err_decode(sc->red[7]);      // the highest status any rank raised: every rank stops with it
   __threadfence_system();
   mail->seq = seq;
+}
+__global__ void k_post_mail(DevScalars *sc, HostMail *mail, u64 seq) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  post_reduced(sc, mail, seq);
 }
 // The final reduction stays a kernel of its own: folding it into the last-arriving block of
 // k_compact needs an agent-scope release in every block and cost more than this launch.
@@ -822,19 +876,14 @@ struct FinExtra {
 };
 __device__ void finish_all(const FinArgs &f, DevScalars *sc) {
   if (f.on == 3) {            // sharded step: the sums were finished and all-reduced by kernels before this one; only the mail is left
-    if (threadIdx.x == 0) {
-      for (int i = 0; i < 16; i++) f.mail->stats[i] = sc->stats[i];
-      f.mail->tot2 = sc->tot2; f.mail->err = sc->err;
-      __threadfence_system();
-      f.mail->seq = f.seq;
-    }
+    if (threadIdx.x == 0) post_reduced(sc, f.mail, f.seq);
     __syncthreads();
     return;
   }
   // the look-back words k_anneal used this step (two arrays, n_ftiles words each) are zero again for the next one
   for (int i = threadIdx.x; i < f.n_ftiles; i += TPB) { f.fstate[i] = 0; f.fstate[f.cap_ftiles + i] = 0; }
   if (threadIdx.x == 0 && f.n_ftiles > 0) *f.fticket = 0;
-  finish_step(f.partials, f.nblocks, f.wabs_part, f.nwabs, f.mode, sc, f.scan_state, f.scan_ticket, f.n_scan_words, f.n_tickets, f.n_children, f.mail);
+  finish_step(f.partials, f.nblocks, f.wabs_part, f.nwabs, f.mode, sc, f.scan_state, f.scan_ticket, f.n_scan_words, f.n_tickets, f.n_children, f.mail, f.expect_nimp);
   if (f.mail && threadIdx.x == 0) {
     __threadfence_system();
     f.mail->seq = f.seq;
@@ -846,7 +895,7 @@ __device__ void finish_all(const FinArgs &f, DevScalars *sc) {
 // (fixed strided order + fixed tree: reproducible run to run), publishes the step's sums,
 // advances the REPLAY stream and re-zeroes the look-back scan states for the next step
 __device__ void finish_step(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
-                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words, int n_tickets, long long n_children, HostMail *mail) {
+                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words, int n_tickets, long long n_children, HostMail *mail, long long expect_nimp) {
   __shared__ double red2[TPB / 64][NSTAT + 2];
   __shared__ double tot[NSTAT + 2];
   for (int i = threadIdx.x; i < n_scan_words; i += TPB) scan_state[i] = 0;
@@ -885,6 +934,12 @@ __device__ void finish_step(const double *__restrict__ partials, int nblocks, co
 #pragma unroll
     for (int i = 0; i < 16; i++) sc->stats[i] = o[i];
     sc->nwalk = tot2 & 0xFFFFFFFFull;
+    if (expect_nimp >= 0) {      // sharded step: sums and status go through the all-reduce before anything is posted
+      if (!err && (long long)(tot2 >> 32) != expect_nimp) { err = SQMC_ERR_IMP_BROKEN; sc->err = err; }
+#pragma unroll
+      for (int i = 0; i < 7; i++) sc->red[i] = o[i];
+      sc->red[7] = err_encode(err);
+    }
     if (mail) {          // the host's copy goes out from the same registers (finish_all fences and posts the sequence word)
 #pragma unroll
       for (int i = 0; i < 16; i++) mail->stats[i] = o[i];

@@ -695,13 +695,15 @@ class ShardedWalk:
     estimator sums, exactly the three exchanges of the reference's MPI walk."""
 
     def __init__(self, host, w_target, rank, world, w_begin=None, mwalk=None, n_truncate_trial_wf=100, size_deterministic=1000,
-                 tau_multiplier=0.1, e_trial=None, seed=(1346, 5634, 6635, 4361), min_wt=0.5, device_index=0, n_equil_steps=10**9):
+                 tau_multiplier=0.1, e_trial=None, seed=(1346, 5634, 6635, 4361), min_wt=0.5, device_index=0, n_equil_steps=10**9, owner_hash=0):
         import torch
         self.rank, self.world, self.min_wt = rank, world, min_wt
         w_begin = w_begin if w_begin is not None else w_target
         per_rank = w_target / world
         mwalk = mwalk or int(max(6 * (per_rank / min_wt + size_deterministic), 200000))
         self.g = g = host.gpu(rng_mode=RNG_COUNTER, seed=rank_seed(seed, rank), mwalk=mwalk)
+        if owner_hash:
+            g.set_owner_hash(owner_hash)       # 1: the reference's get_det_owner (djb_hash), mpi_routines.f90:354-445
         self.setup = s = host.setup_walk(g, n_truncate_trial_wf, size_deterministic, tau_multiplier)
         g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
         g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)

@@ -62,6 +62,18 @@ def heg_setup(oracle, heg14):
 
 
 @pytest.fixture(scope="session")
+def heg57(oracle):
+    """BASELINE.json configs[3]: 14 electrons (7 up, 7 dn), r_s = 1.0, cutoff 2.3 -> 57 plane waves.  Sort keys need 56
+    bits, so the library keeps keys and walker indices in two arrays (`pack == 0`) -- no other test system does."""
+    return oracle.HegSystem(3, 1.0, 14, 7, 2.3)
+
+
+@pytest.fixture(scope="session")
+def heg57_setup(oracle, heg57):
+    return oracle.setup_walk_heg(heg57, 300, 0.1)
+
+
+@pytest.fixture(scope="session")
 def heg14_hci(oracle, heg14):
     """variational stage of the reference's e2e HEG deck (eps_var 1e-3, one state) in the oracle: ~60 s, shared"""
     return oracle.hci_variational(heg14, 1e-3, n_states=1)

@@ -1,0 +1,22 @@
+"""bench.py --gpus N launches its ranks itself; without a GPU every rank fails and the launcher must say so with a
+non-zero exit code (never a hang, never a made-up line)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_launcher_reports_failed_ranks_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_sharded.py::test_bench_launches_its_own_ranks")
+    env = dict(os.environ, SQMC_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--equil", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "ranks failed" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]

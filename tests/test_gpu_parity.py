@@ -1260,3 +1260,212 @@ def test_gate_fused_into_annihilation_is_bit_exact():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuse_ab.py")], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "first differing step: []" in r.stdout and "walkers equal: True" in r.stdout
+
+
+# ------------------------------------------------------------------ BASELINE.json configs[3]: HEG r_s = 1.0, 57 plane waves (56-bit keys)
+def _heg_pair(oracle, hsys, s, rng_mode, nsteps, w_begin, w_target, mwalk):
+    """oracle and GPU side by side on an electron-gas walk; integer bookkeeping equal after every step"""
+    from conftest import gpu_ctx_heg
+    g = gpu_ctx_heg(hsys, rng_mode=rng_mode, seed=SEED, mwalk=mwalk)
+    g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
+    g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
+    wk = oracle.initial_walkers(s, w_begin)
+    g.upload_walkers(wk)
+    ow = oracle.OracleWalk(hsys, s, wk, mwalk, SEED, rng_mode=rng_mode)
+    pc = oracle.PopControl(s.tau, s.e_trial0, w_target)
+    w_abs = float(np.abs(wk["wt"]).sum())
+    try:
+        for it in range(nsteps):
+            r = pc.pre_step(w_abs)
+            if r != 1.0:
+                ow.scale_projector(r); g.scale_projector(r)
+            st, oc = ow.step(pc.params())
+            og = g.step(pc.params())
+            assert st == 0 and og[5] == oc[5] and og[7] == oc[7] and og[15] == oc[15], (it, og, oc)
+            assert np.allclose(og, oc, rtol=1e-11, atol=1e-11)
+            r = pc.post_step(oc)
+            if r != 1.0:
+                ow.scale_projector(r); g.scale_projector(r)
+            w_abs = oc[1]
+        wg, wc = g.download_walkers(), ow.walkers()
+        rng = (g.rng_state(), ow.rng_state())
+    finally:
+        g.close(); ow.close()
+    return wg, wc, rng, og
+
+
+def test_heg57_keys_are_unpacked(heg57):
+    """the point of this system: C(57,7)^2 needs 56 key bits"""
+    from math import comb
+    assert heg57.norb == 57 and (comb(57, 7) ** 2).bit_length() == 56
+
+
+def test_heg57_matrix_elements_and_proposals_bit_exact(oracle, heg57):
+    """hamiltonian_heg (heg.f90:845-1011) and off_diagonal_move_heg (heg.f90:1344-1598) on the 57-plane-wave basis: every
+    connection of HF, connections of connections, unrelated pairs; 10^4 proposals (det_j, weight, RNG state)."""
+    from conftest import gpu_ctx_heg
+    L = oracle.lib()
+    g = gpu_ctx_heg(heg57)
+    rng = np.random.default_rng(57)
+    cu, cd, _ = heg57.connected(heg57.hf_up, heg57.hf_dn, with_elems=False)
+    nr = 600
+    iu = np.concatenate((np.full(len(cu), heg57.hf_up, np.uint64), cu[1:400], _random_dets(rng, 57, 7, nr)))
+    id_ = np.concatenate((np.full(len(cu), heg57.hf_dn, np.uint64), cd[1:400], _random_dets(rng, 57, 7, nr)))
+    ju = np.concatenate((cu, cu[2:401], _random_dets(rng, 57, 7, nr)))
+    jd = np.concatenate((cd, cd[2:401], _random_dets(rng, 57, 7, nr)))
+    # second-generation pairs: a connection of HF against the connections of another one
+    c2u, c2d, _ = heg57.connected(int(cu[5]), int(cd[5]), with_elems=False)
+    iu = np.concatenate((iu, np.full(len(c2u), cu[5], np.uint64))); id_ = np.concatenate((id_, np.full(len(c2u), cd[5], np.uint64)))
+    ju = np.concatenate((ju, c2u)); jd = np.concatenate((jd, c2d))
+    h_gpu = g.hamiltonian_batch(iu, id_, ju, jd)
+    h_cpu = np.array([heg57.ham(int(a), int(b), int(c), int(d)) for a, b, c, d in zip(iu, id_, ju, jd)])
+    assert np.array_equal(h_gpu, h_cpu) and np.count_nonzero(h_cpu) > len(cu)
+    n = 10000
+    up = np.concatenate((_random_dets(rng, 57, 7, n // 2), np.resize(cu, n - n // 2)))
+    dn = np.concatenate((_random_dets(rng, 57, 7, n // 2), np.resize(cd, n - n // 2)))
+    seeds = rng.integers(0, 4096, size=(n, 4)).astype(np.int32); seeds[:, 3] |= 1
+    tau = 0.0013
+    pju, pjd, wj, sa = g.propose_batch(tau, up, dn, seeds)
+    g.close()
+    r = oracle.Rng(); a, b, w, nd = C.c_uint64(), C.c_uint64(), C.c_double(), C.c_int()
+    nz = 0
+    for i in range(n):
+        L.orc_setrn(C.byref(r), (C.c_int * 4)(*seeds[i]))
+        L.orc_off_diagonal_move_heg(heg57.h, C.byref(r), tau, int(up[i]), int(dn[i]), C.byref(a), C.byref(b), C.byref(w), C.byref(nd))
+        assert w.value == wj[i], (i, w.value, wj[i])
+        assert [r.l[k] for k in range(4)] == list(sa[i])
+        if w.value != 0.0:
+            nz += 1
+            assert (a.value, b.value) == (int(pju[i]), int(pjd[i]))
+    assert nz > n // 20
+
+
+@pytest.mark.parametrize("rng_mode,nsteps", [(0, 110), (1, 160)])
+def test_heg57_walk_trajectory_bit_exact(oracle, heg57, heg57_setup, rng_mode, nsteps):
+    """configs[3]'s system through the whole step with two-array sort records (separate key / index arrays in the
+    radix passes, the unpacked branches of the annihilation kernel, no gate fusion): REPLAY and COUNTER trajectories
+    equal the oracle's walker for walker, bit for bit."""
+    wg, wc, rng, og = _heg_pair(oracle, heg57, heg57_setup, rng_mode, nsteps, 20, 6000, 400000)
+    if rng_mode == 0:
+        assert rng[0] == rng[1]
+    for k in ("up", "dn", "imp_distance", "initiator"):
+        assert np.array_equal(wg[k], wc[k]), k
+    assert np.array_equal(wg["wt"], wc["wt"]) and np.array_equal(wg["matrix_elements"], wc["matrix_elements"])
+    assert len(wg["up"]) > 1500 and int(wg["up"].max()) >= (1 << 32)           # determinants whose up string alone is wider than a packed key
+    assert 13.0 < og[3] / og[2] < 13.7                                          # HF 13.60, correlated ground state below it
+
+
+def test_heg57_walk_past_2_20_slots_bit_exact(oracle, heg57, heg57_setup):
+    """Past 2^20 sorted slots the step sorts the spawns only (7 passes of 8 bits over 56-bit keys, payload array beside
+    them) and merges them into the ordered walkers with the two-array merge-path kernel; 3 slots per thread in the
+    annihilation kernel.  Eight steps from 10^6 walkers' worth of weight (every step but the first proposes more than 2^20
+    children, about half of which find no momentum partner and sort behind the walkers), bit for bit against the oracle."""
+    wg, wc, _, og = _heg_pair(oracle, heg57, heg57_setup, 1, 8, 1000000, 1000000, 8000000)
+    assert int(og[15]) > (1 << 20)
+    for k in ("up", "dn", "imp_distance", "initiator"):
+        assert np.array_equal(wg[k], wc[k]), k
+    assert np.array_equal(wg["wt"], wc["wt"]) and np.array_equal(wg["matrix_elements"], wc["matrix_elements"])
+
+
+@pytest.mark.parametrize("rng_mode,heavy", [(0, False), (1, True)])
+def test_heg57_annihilate_door_matches_oracle_merge(oracle, heg57, heg57_setup, rng_mode, heavy):
+    """sqmc_gpu_annihilate on the 57-plane-wave gas (unpacked sort records): a collision-heavy hand-made spawn list
+    against merge_sort2_up_dn + merge_original_with_spawned2 + reduce_my_walker of the oracle.  `heavy`: a few
+    determinants collect thousands of spawns (runs that span tiles: wavefront-cooperative folds through get_perm)."""
+    s = heg57_setup
+    rs = np.random.RandomState(570 + rng_mode)
+    main = oracle.initial_walkers(s, 300)
+    n0 = len(main["up"])
+    pool = rs.choice(len(s.ct_up), 6 if heavy else 80, replace=False)
+    ns = 14000 if heavy else 4000
+    from_main = rs.rand(ns) < (0.03 if heavy else 0.4)
+    im, ip = rs.randint(0, n0, ns), pool[rs.randint(0, len(pool), ns)]
+    up = np.where(from_main, main["up"][im], s.ct_up[ip]).astype(np.uint64)
+    dn = np.where(from_main, main["dn"][im], s.ct_dn[ip]).astype(np.uint64)
+    wt = rs.choice([-1.0, 1.0], ns) * rs.choice([0.05, 0.2, 0.25, 0.4, 0.5, 0.75, 1.0, 1.5], ns)
+    wt[rs.rand(ns) < 0.05] = 0.0
+    impd = rs.choice([-1, 1, 2, 3, 5], ns).astype(np.int8)
+    init = np.where(impd == -1, 1, rs.randint(0, 2, ns)).astype(np.int8)
+    if heavy:
+        one = (~from_main) & (ip == pool[0])
+        wt[one] = 0.3; impd[one] = 2; init[one] = 0
+        imp_dets = np.nonzero(main["imp_distance"] == 0)[0]
+        sel = rs.rand(ns) < 0.12
+        up[sel], dn[sel] = main["up"][imp_dets[5]], main["dn"][imp_dets[5]]
+        wt[sel] = -0.2; impd[sel] = np.where(rs.rand(int(sel.sum())) < 0.5, -1, 2); init[sel] = 1
+    prm = dict(tau=s.tau, e_trial=s.e_trial0, reweight_factor_inv=0.97, r_initiator=1.0, min_wt=0.5, always_spawn_cutoff_wt=0.5,
+               initiator_power=0, initiator_min_distance=0, c_t_initiator=0, semistochastic=1, reached_w_abs_gen=2)
+    ow = oracle.OracleWalk(heg57, s, main, 50000, list(SEED), rng_mode=rng_mode)
+    w, nz = ow.w, np.nonzero(wt)[0]
+    for k, j in enumerate(nz):
+        i = n0 + k
+        w.up[i], w.dn[i], w.wt[i], w.imp_distance[i], w.initiator[i] = int(up[j]), int(dn[j]), float(wt[j]), int(impd[j]), int(init[j])
+        w.matrix_elements[i] = w.e_num_walker[i] = w.e_den_walker[i] = 1e51
+    n = n0 + len(nz)
+    p = oracle.StepParams(**prm)
+    L = oracle.lib()
+    L.orc_reduce_my_walker.restype = C.c_int64
+    L.orc_reduce_my_walker.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    L.orc_merge_original_with_spawned2.restype = C.c_int64
+    L.orc_merge_sort_walkers(ow.h, n)
+    n = L.orc_merge_original_with_spawned2(ow.h, n, C.byref(p))
+    n = L.orc_reduce_my_walker(ow.h, n, C.byref(p))
+    ow.w.nwalk = n
+    ref = ow.walkers(); ow.close()
+    ref["wt"] = ref["wt"] * prm["reweight_factor_inv"]
+    from conftest import gpu_ctx_heg
+    g = gpu_ctx_heg(heg57, rng_mode=rng_mode, seed=SEED, mwalk=50000)
+    g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
+    g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
+    g.upload_walkers(main)
+    try:
+        out = g.annihilate(prm, dict(up=up, dn=dn, wt=wt, imp_distance=impd, initiator=init))
+        got = g.download_walkers()
+    finally:
+        g.close()
+    assert len(got["up"]) == n == int(out[5])
+    for k in ("up", "dn", "wt", "imp_distance", "initiator"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert int(out[7]) == n0 + len(nz) and n < n0 + len(nz) - 1000
+
+
+def test_forced_unpacked_keys_on_c2_are_bit_exact():
+    """SQMC_FORCE_UNPACKED=1 gives C2 (28-bit keys, normally packed with the walker index into one word) the two-array
+    layout of wide keys.  The trajectory, annihilation-door and time-reversal tests must pass unchanged against the
+    oracle: the two key layouts are compared with each other on the best-pinned system, including the spawn-only sort +
+    two-array merge path (SQMC_MERGE_SORT_MIN=0)."""
+    import subprocess, sys
+    env = dict(os.environ, SQMC_FORCE_UNPACKED="1", SQMC_MERGE_SORT_MIN="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "(trajectory_bit_exact and not heg57 and not past_2_20) or annihilate_door_matches or time_sym_walk"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.parametrize("which", ["c2", "heg57"])
+def test_det_owner_djb_matches_oracle(oracle, c2_walk, heg57, which):
+    """A11: get_det_owner -> hash -> djb_hash (mpi_routines.f90:419-445, 257-289, 354-379) in its 128-bit wrapping
+    arithmetic, GPU (sqmc_gpu_set_owner_hash 1 + sqmc_gpu_det_owner) against the oracle's restatement, for every rank
+    count the sharded step accepts at its ends and in between."""
+    from conftest import gpu_ctx_heg
+    L = oracle.lib()
+    L.orc_get_det_owner.argtypes = [C.c_uint64] * 4 + [C.c_int]
+    rng = np.random.default_rng(11)
+    if which == "c2":
+        g, norb, ne = gpu_ctx_from_oracle(c2_walk), 26, 4
+    else:
+        g, norb, ne = gpu_ctx_heg(heg57), 57, 7
+    n = 4000
+    up, dn = _random_dets(rng, norb, ne, n), _random_dets(rng, norb, ne, n)
+    try:
+        g.set_owner_hash(1)
+        for nranks in (1, 2, 3, 7, 8, 64, 255):
+            got = g.det_owner(up, dn, nranks)
+            ref = np.array([L.orc_get_det_owner(int(a), 0, int(b), 0, nranks) for a, b in zip(up, dn)])
+            assert np.array_equal(got, ref), nranks
+            if nranks == 8:
+                assert np.bincount(got, minlength=8).min() > n // 16      # the reference's hash spreads these determinants
+        g.set_owner_hash(0)
+        assert not np.array_equal(g.det_owner(up, dn, 8), ref8 := np.array([L.orc_get_det_owner(int(a), 0, int(b), 0, 8) for a, b in zip(up, dn)]))
+    finally:
+        g.close()

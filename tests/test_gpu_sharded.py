@@ -13,7 +13,8 @@ SEED = (1346, 5634, 6635, 4361)
 NSTEPS, W_BEGIN, W_TARGET = 40, 2000, 20000
 
 
-def _worker(rank, world, port, outdir, system="c2"):
+def _worker(rank, world, port, outdir, system="c2", w_begin=None, w_target=None, nsteps=None):
+    W_BEGIN, W_TARGET, NSTEPS = w_begin or globals()["W_BEGIN"], w_target or globals()["W_TARGET"], nsteps or globals()["NSTEPS"]
     import torch                                   # before the HIP library (one libamdhip64 per process)
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -25,13 +26,16 @@ def _worker(rank, world, port, outdir, system="c2"):
     if system == "heg":       # 14 electrons, 19 plane waves: the reference's e2e HEG system (BASELINE.json configs[3] is its big brother)
         hst = H.HegHost(3, 0.5, 14, 7, 1.49)
         w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000, n_truncate_trial_wf=1, size_deterministic=250)
+    elif system == "heg57":   # BASELINE.json configs[3] itself: r_s = 1.0, 57 plane waves, 56-bit sort keys (two-array sort records)
+        hst = H.HegHost(3, 1.0, 14, 7, 2.3)
+        w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000, n_truncate_trial_wf=1, size_deterministic=300)
     elif system == "hub":     # BASELINE.json configs[0]: 4x4 Hubbard, U/t = 4, half filling
         hst = H.HubbardHost(4, 4, True, 8, 8, 1.0, 4.0)
         w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000, n_truncate_trial_wf=20, size_deterministic=500,
                           tau_multiplier=0.5)
     else:
         hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
-        w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
+        w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000, owner_hash=1 if system == "c2_djb" else 0)
     outs = []
     for _ in range(NSTEPS):
         outs.append(w.step().copy())
@@ -44,10 +48,10 @@ def _worker(rank, world, port, outdir, system="c2"):
     dist.destroy_process_group()
 
 
-def _run(world, tmp_path, port, system="c2"):
+def _run(world, tmp_path, port, system="c2", **kw):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    ps = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), system)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), system), kwargs=kw) for r in range(world)]
     for p in ps: p.start()
     for p in ps: p.join(600)
     assert all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
@@ -93,6 +97,30 @@ def test_sharded_walk_invariants(tmp_path, world):
     e = res[0]["outs"][10:, 3].sum() / res[0]["outs"][10:, 2].sum()
     assert -75.80 < e < -75.55
     assert out[1] > 1.5 * W_BEGIN                                           # the population grew towards the target
+
+
+def test_sharded_walk_with_the_references_owner_hash(tmp_path):
+    """Ownership by the reference's own get_det_owner / djb_hash (mpi_routines.f90:354-445; sqmc_gpu_set_owner_hash 1): the
+    walk keeps every sharding invariant, and the owner the GPU assigned to every surviving determinant equals the CPU
+    restatement's -- an ownership check against something other than the function that did the sharding."""
+    import ctypes as C
+    from oracle import oracle as O
+    O.build()
+    L = O.lib()
+    L.orc_get_det_owner.argtypes = [C.c_uint64] * 4 + [C.c_int]
+    res = _run(3, tmp_path, 29547, system="c2_djb")
+    keys, n_imp = [], 0
+    for rank, r in enumerate(res):
+        assert np.array_equal(r["outs"][:, :7], res[0]["outs"][:, :7])
+        assert np.all(r["owner"] == rank)
+        assert all(L.orc_get_det_owner(int(a), 0, int(b), 0, 3) == rank for a, b in zip(r["up"], r["dn"]))
+        k = [(int(a), int(b)) for a, b in zip(r["up"], r["dn"])]
+        assert k == sorted(set(k))
+        keys += k
+        n_imp += int((r["imp_distance"] == 0).sum())
+        assert len(k) > 1000                       # the hash balances: no rank is starved
+    assert len(keys) == len(set(keys)) and n_imp == int(res[0]["n_imp_global"])
+    assert int(res[0]["outs"][-1][5]) == len(keys)
 
 
 def _nccl_worker(port, outdir):
@@ -221,6 +249,29 @@ def test_sharded_heg_walk_invariants(tmp_path):
     assert out[1] > 1.5 * W_BEGIN
 
 
+def test_sharded_heg57_walk_invariants(tmp_path):
+    """BASELINE.json configs[3]'s own system (r_s = 1.0, 57 plane waves: 56-bit keys, the two-array sort records) sharded
+    over two ranks: ownership, uniqueness, complete deterministic space, identical all-reduced sums."""
+    res = _run(2, tmp_path, 29585, system="heg57")
+    for r in res[1:]:
+        assert np.array_equal(r["outs"][:, :7], res[0]["outs"][:, :7])
+    keys, n_imp = [], 0
+    for rank, r in enumerate(res):
+        assert np.all(r["owner"] == rank)
+        k = [(int(a), int(b)) for a, b in zip(r["up"], r["dn"])]
+        assert k == sorted(set(k))
+        keys += k
+        n_imp += int((r["imp_distance"] == 0).sum())
+    assert len(keys) == len(set(keys)) and n_imp == int(res[0]["n_imp_global"])
+    assert max(k[0] for k in keys) >= (1 << 32)
+    out = res[0]["outs"][-1]
+    assert int(out[5]) == len(keys)
+    assert np.isclose(sum(float(np.abs(r["wt"]).sum()) for r in res), out[1], rtol=1e-12)
+    e = res[0]["outs"][10:, 3].sum() / res[0]["outs"][10:, 2].sum()
+    assert 13.0 < e < 13.7                  # HF 13.60 at r_s = 1, the correlated state below it
+    assert out[1] > 1.5 * W_BEGIN
+
+
 def test_sharded_hubbard_walk_invariants(tmp_path):
     """BASELINE.json configs[0] lattice (4x4 Hubbard, U/t = 4, half filling) sharded over two ranks:
     off_diagonal_move_hubbard / hamiltonian_hubbard under the same ownership and exchange rules."""
@@ -256,11 +307,12 @@ def _fake_rccl_lib():
     return so
 
 
-def _inlib_multi_worker(rank, world, port, outdir, fake, w_target=None, nsteps=None, nofuse=False):
+def _inlib_multi_worker(rank, world, port, outdir, fake, w_target=None, nsteps=None, nofuse=False, overlap=False, w_begin=None, mwalk_of_rank=None):
     import torch                                   # noqa: F401
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
-    W_TARGET, NSTEPS = w_target or globals()["W_TARGET"], nsteps or globals()["NSTEPS"]
+    W_TARGET, NSTEPS, W_BEGIN = w_target or globals()["W_TARGET"], nsteps or globals()["NSTEPS"], w_begin or globals()["W_BEGIN"]
+    if overlap: os.environ["SQMC_SHARD_OVERLAP"] = "1"     # second communicator + side stream (and with it the pipelined sharded run)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["SQMC_RCCL_LIB"] = fake             # before the library binds its communication entry points
     if nofuse: os.environ["SQMC_NO_GATE_FUSION"] = "1"
@@ -269,14 +321,22 @@ def _inlib_multi_worker(rank, world, port, outdir, fake, w_target=None, nsteps=N
     from sqmc_amd import host as H
     sqmc_amd.set_device(0)
     hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
-    w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
+    w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=(mwalk_of_rank or {}).get(rank, 400000))
     w.attach_rccl()
-    a = np.array([w.step().copy() for _ in range(NSTEPS // 2)])        # sqmc_gpu_shard_step
-    b, _ = w.run(NSTEPS - NSTEPS // 2)                                 # sqmc_gpu_shard_run
-    wk = w.g.download_walkers()
-    owner = w.g.det_owner(wk["up"], wk["dn"], world)
-    np.savez(os.path.join(outdir, "rank%d.npz" % rank), outs=np.concatenate([a, b]), owner=owner, n_imp_global=w.n_imp_global,
-             reached=np.array([w.pc.reached]), **wk)
+    status, outs = 0, []
+    try:
+        for _ in range(NSTEPS // 2):                                   # sqmc_gpu_shard_step
+            outs.append(w.step().copy())
+        b, _ = w.run(NSTEPS - NSTEPS // 2)                             # sqmc_gpu_shard_run
+        outs = np.concatenate([np.array(outs), b])
+    except sqmc_amd.SqmcGpuError as exc:
+        if not mwalk_of_rank:
+            raise
+        status, outs = exc.code, np.array(outs).reshape(-1, 16)        # a walk that is meant to stop: which status, after how many steps
+    wk = w.g.download_walkers() if status == 0 else dict(up=np.zeros(0, np.uint64), dn=np.zeros(0, np.uint64), wt=np.zeros(0), imp_distance=np.zeros(0, np.int8))
+    owner = w.g.det_owner(wk["up"], wk["dn"], world) if status == 0 else np.zeros(0, np.int32)
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), outs=outs, owner=owner, n_imp_global=w.n_imp_global,
+             reached=np.array([w.pc.reached]), status=np.array([status]), **wk)
     w.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -292,7 +352,7 @@ def test_in_library_pipelined_exchange_two_ranks(tmp_path):
     runs = []
     for k, nofuse in enumerate((False, True)):
         out = os.path.join(str(tmp_path), "nofuse%d" % k); os.makedirs(out)
-        ps = [ctx.Process(target=_inlib_multi_worker, args=(r, 2, 29620 + k, out, fake, 4000, 300, nofuse)) for r in range(2)]
+        ps = [ctx.Process(target=_inlib_multi_worker, args=(r, 2, 29620 + k, out, fake, 4000, 300, nofuse, True)) for r in range(2)]
         for p in ps: p.start()
         for p in ps: p.join(300)
         alive = [p for p in ps if p.is_alive()]
@@ -317,8 +377,8 @@ def test_in_library_pipelined_exchange_two_ranks(tmp_path):
         assert np.array_equal(a["up"], b["up"]) and np.array_equal(a["dn"], b["dn"]) and np.array_equal(a["wt"], b["wt"])
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_in_library_exchange_with_several_ranks(tmp_path, world):
+@pytest.mark.parametrize("world,overlap", [(2, False), (3, False), (2, True)])
+def test_in_library_exchange_with_several_ranks(tmp_path, world, overlap):
     """sqmc_gpu_shard_step / sqmc_gpu_shard_run with 2 and 3 ranks: real RCCL refuses several ranks on one
     GPU, so the library is pointed (SQMC_RCCL_LIB) at a transport double with the same entry points that
     moves the bytes through shared memory and blocks on every call.  What is under test is the library's
@@ -329,7 +389,7 @@ def test_in_library_exchange_with_several_ranks(tmp_path, world):
     import torch.multiprocessing as mp
     fake = _fake_rccl_lib()
     ctx = mp.get_context("spawn")
-    ps = [ctx.Process(target=_inlib_multi_worker, args=(r, world, 29600 + world, str(tmp_path), fake)) for r in range(world)]
+    ps = [ctx.Process(target=_inlib_multi_worker, args=(r, world, 29600 + world + 4 * int(overlap), str(tmp_path), fake), kwargs=dict(overlap=overlap)) for r in range(world)]
     for p in ps: p.start()
     for p in ps: p.join(300)
     alive = [p for p in ps if p.is_alive()]
@@ -352,3 +412,68 @@ def test_in_library_exchange_with_several_ranks(tmp_path, world):
     assert np.isclose(sum(float(np.abs(r["wt"]).sum()) for r in res), out[1], rtol=1e-12)
     e = res[0]["outs"][10:, 3].sum() / res[0]["outs"][10:, 2].sum()
     assert -75.80 < e < -75.55 and out[1] > 1.5 * W_BEGIN
+
+
+def test_in_library_exchange_equals_host_driven_at_tiny_population(tmp_path):
+    """The two drivers of the sharded step -- exchanges issued by the library (here over the transport double) and by the
+    host through torch.distributed -- walk the same trajectory bit for bit on three ranks.  The population is a handful
+    of walkers, so that steps in which a rank spawns exactly one child (or none) occur: the per-destination counts of
+    such a step must come from this step's bucketing pass, not from an earlier sort."""
+    import torch.multiprocessing as mp
+    fake = _fake_rccl_lib()
+    ctx = mp.get_context("spawn")
+    world, kw = 3, dict(w_begin=3, w_target=60, nsteps=60)
+    a_dir, b_dir = os.path.join(str(tmp_path), "inlib"), os.path.join(str(tmp_path), "host")
+    os.makedirs(a_dir); os.makedirs(b_dir)
+    ps = [ctx.Process(target=_inlib_multi_worker, args=(r, world, 29640, a_dir, fake), kwargs=dict(w_begin=3, w_target=60, nsteps=60)) for r in range(world)]
+    for p in ps: p.start()
+    for p in ps: p.join(300)
+    alive = [p for p in ps if p.is_alive()]
+    for p in alive: p.terminate()
+    assert not alive and all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
+    a = [np.load(os.path.join(a_dir, "rank%d.npz" % r)) for r in range(world)]
+    b = _run(world, b_dir, 29641, **kw)
+    single = 0
+    for ra, rb in zip(a, b):
+        assert np.array_equal(ra["outs"][:, :7], rb["outs"][:, :7])
+        assert np.array_equal(ra["up"], rb["up"]) and np.array_equal(ra["dn"], rb["dn"]) and np.array_equal(ra["wt"], rb["wt"])
+        single += int((ra["outs"][:, 15] == 1).sum())
+    assert single > 0                        # the case under test really occurred
+
+
+def test_in_library_stop_is_collective(tmp_path):
+    """A rank that runs out of walker slots ('nwalk>MWALK', do_walk.f90:3684-3690) must stop EVERY rank with that status
+    in the same step -- the reference's mpi_stop -- instead of leaving its peers blocked in the next collective: rank 1
+    gets a small MWALK, both ranks must return status 1 after the same number of steps, within the time limit."""
+    import torch.multiprocessing as mp
+    fake = _fake_rccl_lib()
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_inlib_multi_worker, args=(r, 2, 29650, str(tmp_path), fake),
+                      kwargs=dict(w_begin=2000, w_target=40000, nsteps=400, mwalk_of_rank={1: 9000})) for r in range(2)]
+    for p in ps: p.start()
+    for p in ps: p.join(300)
+    alive = [p for p in ps if p.is_alive()]
+    for p in alive: p.terminate()
+    assert not alive, "a rank is still blocked in a collective after its peer stopped"
+    assert all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
+    res = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(2)]
+    assert [int(r["status"][0]) for r in res] == [1, 1]
+    assert len(res[0]["outs"]) == len(res[1]["outs"]) and len(res[0]["outs"]) > 3
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher around it starts two ranks itself (the parent never touches the GPU),
+    forwards rank 0's single JSON line and reports n_gpus = 2; on a one-GPU box the ranks share the card and the
+    exchanges go through gloo (SQMC_BENCH_BACKEND), which is the sharded code path minus the RCCL transport."""
+    import json, subprocess
+    env = dict(os.environ, SQMC_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--equil", "30", "--target", "2e4",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 10 and line["scaling"] == "weak"
+    assert "sharded x2" in line["config"]["parallelism"] and line["config"]["devices"] == 1
+    assert line["value"] > 0 and -75.9 < line["config"]["projected_energy_Ha"] < -75.4
