@@ -24,10 +24,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 FCIDUMP = os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# HBM bytes per launch from the PMC passes in profiles/ (FETCH_SIZE doubled as the guide prescribes for
-# gfx950, + WRITE_SIZE, KiB -> bytes), default configuration only
-TRAFFIC_K_ANNEAL = 3.63e7     # profiles/r01_bench_1e5_rocprof_summary.txt: (2*12508.1 + 10399.5) KiB (24 B per surviving walker of it: the next step's gate)
-TRAFFIC_K_SPAWN = 1.97e7      # same file: (2*6500.5 + 6252.1) KiB
+# HBM bytes per launch of the two kernels: read from the PMC summary the profiling script wrote (tools/profile_bench.sh ->
+# profiles/*_traffic.json, with the commit it was taken at); never typed in here
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_bench_1e5_traffic.json")
+
+
+def load_traffic():
+    try:
+        with open(TRAFFIC_JSON) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -211,6 +218,17 @@ def main():
         ach = dom_bytes / (dom_ms * 1e-3) / 1e9
         step_bytes = 68.0 * n_avg + 84.0 * s_avg
         default_cfg = (args.system == "c2" and args.target == 1e5 and world == 1)
+        tr = load_traffic() if default_cfg else None
+
+        def traffic_of(kern):
+            """PMC traffic per launch: FETCH_SIZE weighted by the calibration of tools/calib_fetch.hip for this kernel's mix of
+            streamed and gathered reads, + WRITE_SIZE; beside it the raw (x1) and guide-default (x2) readings of FETCH_SIZE"""
+            if not tr or kern not in tr.get("kernels", {}):
+                return None, None
+            k = tr["kernels"][kern]
+            return k["hbm_bytes_calibrated"], {"fetch_x1": k["hbm_bytes_x1"], "fetch_x2": k["hbm_bytes_x2"], "calibrated": k["hbm_bytes_calibrated"],
+                                               "source": os.path.relpath(TRAFFIC_JSON, ROOT), "commit": tr.get("commit")}
+
         line = {
             "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if sharded else "weak",
@@ -223,16 +241,21 @@ def main():
                        "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": parallelism,
                        "rccl_ranks": rccl_ranks, "devices": min(world, ndev)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": (TRAFFIC_K_ANNEAL if dom == "k_anneal" else TRAFFIC_K_SPAWN) if default_cfg else None, "ms_per_launch": dom_ms,
+                         "traffic": traffic_of(dom)[0], "traffic_detail": traffic_of(dom)[1], "ms_per_launch": dom_ms,
                          "algorithmic_bytes_per_launch": dom_bytes,
                          "other_kernels": {"k_spawn": {"ms_per_launch": spawn_ms, "algorithmic_bytes_per_launch": 26.0 * s_avg + 34.0 * n_avg,
-                                                       "achieved": (26.0 * s_avg + 34.0 * n_avg) / (spawn_ms * 1e-3) / 1e9, "traffic": TRAFFIC_K_SPAWN if default_cfg else None}},
+                                                       "achieved": (26.0 * s_avg + 34.0 * n_avg) / (spawn_ms * 1e-3) / 1e9, "traffic": traffic_of("k_spawn")[0]}},
                          "whole_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
                                         "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
                          "stage_ms_per_step": stage_ms},
         }
         if not args.no_cpu_baseline and world == 1 and args.system == "c2":
-            line["cpu_baseline"] = cpu_baseline(walk, hst, n_avg)
+            cpu = cpu_leg(walk, hst, n_avg)
+            line["cpu_baseline"] = cpu["one_core"]
+            line["cpu_baseline_all_cores"] = cpu["all_cores"]
+            # the other half of the metric: projected-energy error of the GPU path against the CPU path on identical input
+            line["energy_error_Ha"] = cpu["energy_error_Ha"]
+            line["energy_check"] = cpu["energy_check"]
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     walk.close()
@@ -266,30 +289,106 @@ def launch_ranks(n):
     return 0
 
 
-def cpu_baseline(walk, hst, n_avg, budget_s=15.0):
-    """The oracle (single-thread C restatement of the reference step) on this box's host
-    cores, started from the SAME equilibrated population, for a bounded number of steps."""
+def cpu_leg(walk, hst, n_avg, budget_s=10.0):
+    """The CPU side of the line, on this box's host cores (test infrastructure used as the checker and the baseline, never
+    as the product): the single-thread C restatement of the reference step continues the GPU run's equilibrated
+    population while a SECOND GPU context walks the same population in lock-step (same seed, same step counter, same
+    parameters), so that the projected energies of the two paths over the same steps can be subtracted; then the
+    all-host-cores variant (OpenMP over walkers) from the same population; then a short REPLAY-discipline run (the
+    reference's single rannyu stream) for the per-step deviation at small N."""
     import numpy as np
+    import sqmc_amd
+    from sqmc_amd import host as H
     from oracle import oracle as O
     O.build()
     sysm = O.ChemSystem(FCIDUMP, 8, 4, "d2h", time_sym=False, hf_mode=0)
+    seed = [1346, 5634, 6635, 4361]
     w = walk.g.download_walkers()
     # permanent-initiator signs travel with the walkers on the GPU; the HF det is the only one here
     w["perm_sign"] = np.where(w["initiator"] == 3, 1, 0).astype(np.int8)
     s = walk.setup
-    ow = O.OracleWalk(sysm, s, w, walk.g.mwalk, [1346, 5634, 6635, 4361], rng_mode=1)
-    ow.scale_projector(walk.pc.tau / s.tau)
     prm = walk.pc.params(min_wt=walk.min_wt)
-    t0, n, nw = time.perf_counter(), 0, 0.0
-    while time.perf_counter() - t0 < budget_s and n < 200:
+    ratio = walk.pc.tau / s.tau
+
+    def gpu_replica(rng_mode, walkers, mwalk):
+        g = hst.gpu(rng_mode=rng_mode, seed=tuple(seed), mwalk=mwalk)
+        g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
+        g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
+        g.upload_walkers(walkers)
+        return g
+
+    # ---- one core, in lock-step with a GPU replica
+    O.lib().orc_set_threads(1)
+    ow = O.OracleWalk(sysm, s, w, walk.g.mwalk, seed, rng_mode=1)
+    g2 = gpu_replica(sqmc_amd.RNG_COUNTER, w, walk.g.mwalk)
+    if ratio != 1.0:
+        ow.scale_projector(ratio); g2.scale_projector(ratio)
+    t_cpu, n, nw = 0.0, 0, 0.0
+    num_c = den_c = num_g = den_g = 0.0
+    dev_step, same_count = 0.0, True
+    while t_cpu < budget_s and n < 200:
+        t0 = time.perf_counter()
         st, out = ow.step(prm)
+        t_cpu += time.perf_counter() - t0
         if st != 0:
             break
+        og = g2.step(prm)
         nw += out[5]; n += 1
-    dt = time.perf_counter() - t0
+        num_c += out[3]; den_c += out[2]; num_g += og[3]; den_g += og[2]
+        dev_step = max(dev_step, abs(og[3] / og[2] - out[3] / out[2]))
+        same_count = same_count and og[5] == out[5] and og[15] == out[15]
+    wg, wc = g2.download_walkers(), ow.walkers()
+    identical = bool(same_count and np.array_equal(wg["up"], wc["up"]) and np.array_equal(wg["dn"], wc["dn"]) and np.array_equal(wg["wt"], wc["wt"]))
+    g2.close(); ow.close()
+    one = {"value": nw / t_cpu, "unit": "walker-steps/s", "cores": 1, "kind": "port",
+           "sample": "%d steps of the single-thread C restatement (%.1f s) continuing the GPU run's equilibrated population of %.0f determinants" % (n, t_cpu, n_avg)}
+    e_err = abs(num_g / den_g - num_c / den_c)
+    check = {"steps": n, "e_proj_gpu_Ha": num_g / den_g, "e_proj_cpu_Ha": num_c / den_c, "max_per_step_dev_Ha": dev_step,
+             "walkers_bit_identical_after": identical, "rng": "counter",
+             "what": "|E_proj(GPU) - E_proj(CPU restatement)| over the same %d steps from the same %.0f-determinant population, same seed (target 1e-6 Ha)" % (n, n_avg)}
+    # ---- all host cores
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    O.lib().orc_set_threads(cores)
+    ow = O.OracleWalk(sysm, s, w, walk.g.mwalk, seed, rng_mode=1)
+    if ratio != 1.0:
+        ow.scale_projector(ratio)
+    ow.step(prm)                                             # thread pool start-up is not the measurement
+    t_mt, n_mt, nw_mt = 0.0, 0, 0.0
+    while t_mt < 0.6 * budget_s and n_mt < 400:
+        t0 = time.perf_counter()
+        st, out = ow.step(prm)
+        t_mt += time.perf_counter() - t0
+        if st != 0:
+            break
+        nw_mt += out[5]; n_mt += 1
     ow.close()
-    return {"value": nw / dt, "unit": "walker-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d oracle steps (%.1f s) continuing the GPU run's equilibrated population of %.0f determinants" % (n, dt, n_avg)}
+    O.lib().orc_set_threads(1)
+    allc = {"value": nw_mt / t_mt if t_mt > 0 else None, "unit": "walker-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d steps (%.1f s) of the same restatement with its spawn loop, sort and permutations on %d OpenMP threads (bit-identical results); "
+                      "the linear merge / rounding / estimator scans stay serial" % (n_mt, t_mt, cores)}
+    # ---- REPLAY discipline at small N: the reference's single rannyu stream, draw for draw
+    wk = H.initial_walkers(s, 200)
+    ow = O.OracleWalk(sysm, s, wk, 400000, seed, rng_mode=0)
+    g3 = gpu_replica(sqmc_amd.RNG_REPLAY, wk, 400000)
+    pc = H.PopControl(s.tau, -75.72, 4000)
+    w_abs, dev_r, ident_r = float(np.abs(wk["wt"]).sum()), 0.0, True
+    for _ in range(80):
+        r = pc.pre_step(w_abs)
+        if r != 1.0:
+            ow.scale_projector(r); g3.scale_projector(r)
+        p2 = pc.params()
+        st, oc = ow.step(p2)
+        og = g3.step(p2)
+        dev_r = max(dev_r, abs(og[3] / og[2] - oc[3] / oc[2]))
+        ident_r = ident_r and og[5] == oc[5]
+        r = pc.post_step(oc)
+        if r != 1.0:
+            ow.scale_projector(r); g3.scale_projector(r)
+        w_abs = oc[1]
+    ident_r = bool(ident_r and g3.rng_state() == ow.rng_state() and np.array_equal(g3.download_walkers()["wt"], ow.walkers()["wt"]))
+    g3.close(); ow.close()
+    check["replay_small_n"] = {"steps": 80, "w_abs_gen_target": 4000, "max_per_step_dev_Ha": dev_r, "bit_identical_incl_rng_state": ident_r}
+    return {"one_core": one, "all_cores": allc, "energy_error_Ha": e_err, "energy_check": check}
 
 
 if __name__ == "__main__":

@@ -8,6 +8,7 @@
  */
 #include "sqmc_oracle.h"
 #include <math.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -826,11 +827,43 @@ int orc_get_det_owner(uint64_t up_lo, uint64_t up_hi, uint64_t dn_lo, uint64_t d
   return (int)m;
 }
 
+/* ---- all-host-cores variant of the step (the "OpenMP over walkers" CPU baseline of SURVEY section 8d(ii)) ----
+ * orc_set_threads(n > 1) makes the COUNTER-discipline step run its spawn loop, its sort and its permutations on n
+ * OpenMP threads.  Same algorithms, same operation order per walker, bit-identical results (the COUNTER streams are keyed
+ * by walker / child / determinant, so no draw depends on which thread takes it); the linear scans of
+ * merge_original_with_spawned2, reduce_my_walker and the estimator stay serial. */
+static int g_orc_threads = 1;
+void orc_set_threads(int n) { g_orc_threads = n > 1 ? n : 1; }
+int  orc_get_threads(void) { return g_orc_threads; }
+/* the same recursion with its two halves as OpenMP tasks (each half merges through its own part of tmp[0..n)) */
+static void msort_idx_mt(const det_t *up, const det_t *dn, int64_t *a, int64_t *tmp, int64_t n, int depth) {
+  if (n < 2) return;
+  if (depth <= 0 || n < 8192) { msort_idx(up, dn, a, tmp, n); return; }
+  int64_t na = (n + 1) / 2, nb = n - na;
+#pragma omp task default(shared)
+  msort_idx_mt(up, dn, a, tmp, na, depth - 1);
+#pragma omp task default(shared)
+  msort_idx_mt(up, dn, a + na, tmp + na, nb, depth - 1);
+#pragma omp taskwait
+  memcpy(tmp, a, na * sizeof(int64_t));
+  int64_t i = 0, j = na, k = 0;
+  while (i < na && j < n) {
+    int64_t x = tmp[i], y = a[j];
+    if (up[x] < up[y] || (up[x] == up[y] && dn[x] <= dn[y])) a[k++] = tmp[i++]; else a[k++] = a[j++];
+  }
+  while (i < na) a[k++] = tmp[i++];
+}
 void orc_merge_sort_walkers(orc_walk *w, int64_t n) {
-  int64_t *ord = malloc(n * sizeof(int64_t)), *tmp = malloc(((n + 1) / 2 + 1) * sizeof(int64_t));
+  int64_t *ord = malloc(n * sizeof(int64_t)), *tmp = malloc((n + 2) * sizeof(int64_t));
   for (int64_t i = 0; i < n; i++) ord[i] = i;
-  msort_idx(w->up, w->dn, ord, tmp, n);
-#define PERM(T, A) do { T *b = malloc(n * sizeof(T)); for (int64_t i = 0; i < n; i++) b[i] = (A)[ord[i]]; \
+  if (g_orc_threads > 1) {
+    int depth = 0; while ((1 << depth) < 2 * g_orc_threads) depth++;
+#pragma omp parallel num_threads(g_orc_threads)
+#pragma omp single
+    msort_idx_mt(w->up, w->dn, ord, tmp, n, depth);
+  } else msort_idx(w->up, w->dn, ord, tmp, n);
+#define PERM(T, A) do { T *b = malloc(n * sizeof(T)); _Pragma("omp parallel for num_threads(g_orc_threads) if(g_orc_threads > 1)") \
+                        for (int64_t i = 0; i < n; i++) b[i] = (A)[ord[i]]; \
                         memcpy((A), b, n * sizeof(T)); free(b); } while (0)
   PERM(det_t, w->up); PERM(det_t, w->dn); PERM(double, w->wt); PERM(int8_t, w->imp_distance);
   PERM(int8_t, w->initiator); PERM(double, w->matrix_elements); PERM(double, w->e_num_walker); PERM(double, w->e_den_walker);
@@ -1017,6 +1050,75 @@ static int move_uniform2(const orc_sys *s, orc_walk *w, const orc_step_params *p
   return 0;
 }
 
+/* move_uniform2 for all walkers on g_orc_threads threads (COUNTER discipline only).  Pass 1: gate and child count of every
+ * walker (stream keyed by the walker index); serial prefix sum = the running `attempts` counter of the serial loop; pass 2:
+ * every child from its own stream (keyed by its attempt number) into scratch, death/clone of the parent; pass 3 (serial):
+ * the children that made a walker are appended in attempt order, exactly where the serial loop puts them. */
+static int move_uniform2_mt(const orc_sys *s, orc_walk *w, const orc_step_params *p, int64_t n0, int64_t *attempts) {
+  int64_t *nchild = malloc((n0 + 1) * sizeof(int64_t)), *off = malloc((n0 + 1) * sizeof(int64_t));
+  double *wchild = malloc((n0 + 1) * sizeof(double));
+  int64_t gate_draws = 0;
+#pragma omp parallel for num_threads(g_orc_threads) schedule(static) reduction(+:gate_draws)
+  for (int64_t iw = 0; iw < n0; iw++) {
+    int spawn, use_wt;
+    if (fabs(w->wt[iw]) < p->always_spawn_cutoff_wt) {
+      orc_rng g = w->rng; orc_rng_seek(&g, 0, (uint64_t)iw);
+      spawn = (orc_rannyu(&g) < fabs(w->wt[iw] / p->always_spawn_cutoff_wt)); use_wt = 0; gate_draws++;
+    } else { spawn = 1; use_wt = 1; }
+    long nc = 0; double wc = 0.0;
+    if (spawn) {
+      if (use_wt) { nc = lround(fabs(w->wt[iw])); if (nc < 1) nc = 1; wc = w->wt[iw] / nc; }
+      else { nc = 1; wc = copysign(p->always_spawn_cutoff_wt, w->wt[iw]); }
+    }
+    nchild[iw] = nc; wchild[iw] = wc;
+  }
+  int64_t tot = 0;
+  for (int64_t iw = 0; iw < n0; iw++) { off[iw] = tot; tot += nchild[iw]; }
+  det_t *cu = malloc((tot + 1) * sizeof(det_t)), *cd = malloc((tot + 1) * sizeof(det_t)); double *cw = malloc((tot + 1) * sizeof(double));
+  int64_t draws = 0; int bad = 0;
+#pragma omp parallel for num_threads(g_orc_threads) schedule(dynamic, 256) reduction(+:draws) reduction(|:bad)
+  for (int64_t iw = 0; iw < n0; iw++) {
+    orc_rng g = w->rng;
+    for (int64_t c = 0; c < nchild[iw]; c++) {
+      det_t ju, jd; double wj; int nd;
+      orc_rng_seek(&g, 1, (uint64_t)(off[iw] + c));
+      sys_move(s, &g, p->tau, w->up[iw], w->dn[iw], &ju, &jd, &wj, &nd);
+      draws += nd;
+      cu[off[iw] + c] = ju; cd[off[iw] + c] = jd; cw[off[iw] + c] = wchild[iw] * wj;
+    }
+    if (!p->semistochastic || w->imp_distance[iw] >= 1) {
+      double hii;
+      if (w->matrix_elements[iw] > 1e50) { hii = sys_diag(s, w->up[iw], w->dn[iw]); w->matrix_elements[iw] = hii; }
+      else hii = w->matrix_elements[iw];
+      double f = 1.0 + p->tau * (p->e_trial - hii);
+      if (f < 0) { if (p->reached_w_abs_gen > 1) bad |= 1; f = 0; }
+      w->wt[iw] = w->wt[iw] * f;
+    }
+  }
+  int st = 0;
+  for (int64_t iw = 0; iw < n0 && !st; iw++) {
+    for (int64_t c = 0; c < nchild[iw]; c++) {
+      const double wj = cw[off[iw] + c];
+      if (wj != 0) {
+        int64_t k = w->nwalk++;
+        if (w->nwalk > w->mwalk) { st = 1; break; }
+        w->up[k] = cu[off[iw] + c]; w->dn[k] = cd[off[iw] + c]; w->wt[k] = wj;
+        if (w->imp_distance[iw] == -2) w->imp_distance[k] = p->c_t_initiator ? 1 : 2;
+        else w->imp_distance[k] = (int8_t)((w->imp_distance[iw] < 126 ? w->imp_distance[iw] : 126) + 1);
+        if (p->semistochastic && w->imp_distance[iw] == 0) w->imp_distance[k] = -1;
+        w->initiator[k] = (w->initiator[iw] >= 2) ? 1 : 0;
+        if (p->c_t_initiator && w->imp_distance[iw] == -2) w->initiator[k] = 1;
+        if (p->semistochastic && w->imp_distance[iw] == 0) w->initiator[k] = 1;
+        w->e_num_walker[k] = 1e51; w->e_den_walker[k] = 1e51; w->matrix_elements[k] = 1e51;
+      }
+    }
+  }
+  if (!st && bad) st = 3;
+  w->n_spawn_draws += gate_draws + draws; *attempts = tot;
+  free(nchild); free(off); free(wchild); free(cu); free(cd); free(cw);
+  return st;
+}
+
 /* more_tools.f90:4041-4098 : walkers scanned from the last to the first; lookups only for
  * walkers whose e_num is still the 1e51 sentinel.  The shrinking upper bound of the
  * reference is an optimisation of the same search (both lists sorted). */
@@ -1051,8 +1153,12 @@ int orc_walk_step_heg(const orc_heg *h, orc_walk *w, const orc_step_params *p, d
   orc_sys y = {NULL, h, NULL};
   return walk_step_sys(&y, w, p, out);
 }
+static double orc_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+double orc_prof[8];            /* seconds spent in the stages of the step since the caller last zeroed it: move, project, sort, merge, reduce, estimate */
 static int walk_step_sys(const orc_sys *s, orc_walk *w, const orc_step_params *p, double out[16]) {
   int64_t n0 = w->nwalk, nimp = 0, attempts = 0;
+  double t0 = orc_now(), t1;
+#define LAP(K) do { t1 = orc_now(); orc_prof[K] += t1 - t0; t0 = t1; } while (0)
   int64_t *loc = NULL; double *impw = NULL, *dw = NULL;
   w->n_spawn_draws = 0;
   if (p->semistochastic) {                         /* 2188-2212 */
@@ -1060,10 +1166,15 @@ static int walk_step_sys(const orc_sys *s, orc_walk *w, const orc_step_params *p
     for (int64_t i = 0; i < n0 && nimp < w->n_imp; i++) if (w->imp_distance[i] == 0) { loc[nimp] = i; impw[nimp] = w->wt[i]; nimp++; }
     if (nimp != w->n_imp) { free(loc); free(impw); free(dw); return 5; }
   }
+  if (g_orc_threads > 1 && w->rng.mode == 1) {     /* all-cores variant: same gate, children and death/clone per walker, threads over walkers */
+    int st = move_uniform2_mt(s, w, p, n0, &attempts);
+    if (st) { free(loc); free(impw); free(dw); return st; }
+  } else
   for (int64_t i = 0; i < n0; i++) {               /* 2220-2231 */
     int st = move_uniform2(s, w, p, i, &attempts);
     if (st) { free(loc); free(impw); free(dw); return st; }
   }
+  LAP(0);
   if (p->semistochastic) {                         /* 2255-2325 */
     double *x = malloc((nimp + 1) * sizeof(double));
     for (int64_t i = 0; i < nimp; i++) x[i] = w->wt[loc[i]];
@@ -1074,13 +1185,17 @@ static int walk_step_sys(const orc_sys *s, orc_walk *w, const orc_step_params *p
   }
   free(loc); free(impw); free(dw);
   int64_t n = w->nwalk;
+  LAP(1);
   orc_merge_sort_walkers(w, n);                    /* 2335 */
+  LAP(2);
   double wabs_before = 0; for (int64_t i = 0; i < n; i++) wabs_before += fabs(w->wt[i]);
   int64_t nbefore = n;
   n = orc_merge_original_with_spawned2(w, n, p);   /* 2373 */
+  LAP(3);
   if (p->semistochastic) n = orc_reduce_my_walker(w, n, p);   /* 2473 */
   else n = orc_join_walker2(w, n, p);                          /* 2475 */
   w->nwalk = n;
+  LAP(4);
   for (int64_t i = 0; i < n; i++) w->wt[i] = w->wt[i] * p->reweight_factor_inv;   /* 2487 */
   if (n == 0) return 4;
   double w_gen = 0, w2 = 0, w_abs = 0, w_abs_imp = 0, w_perm = 0; int ip = 0;      /* 2573-2598 */
@@ -1095,6 +1210,8 @@ static int walk_step_sys(const orc_sys *s, orc_walk *w, const orc_step_params *p
   out[6] = w_abs_imp; out[7] = (double)nbefore; out[8] = w2; out[9] = acc[2]; out[10] = acc[3];
   out[11] = acc[4]; out[12] = acc[5]; out[13] = acc[6]; out[14] = wabs_before; out[15] = (double)attempts;
   w->rng.step++;
+  LAP(5);
+#undef LAP
   return 0;
 }
 

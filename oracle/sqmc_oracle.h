@@ -129,6 +129,10 @@ typedef struct {
 orc_walk *orc_walk_new(int64_t mwalk);
 void orc_walk_free(orc_walk *w);
 int  orc_walk_step(const orc_chem *s, orc_walk *w, const orc_step_params *p, double out[16]);
+/* n > 1: the COUNTER-discipline step runs its spawn loop, sort and permutations on n OpenMP threads (bit-identical results):
+ * the all-host-cores CPU baseline of SURVEY section 8d(ii) */
+void orc_set_threads(int n);
+int  orc_get_threads(void);
 
 /* pieces exposed for component tests */
 void orc_merge_sort_walkers(orc_walk *w, int64_t n);                       /* do_walk.f90:5169-5197 */

@@ -435,8 +435,12 @@ def test_in_library_exchange_equals_host_driven_at_tiny_population(tmp_path):
     b = _run(world, b_dir, 29641, **kw)
     single = 0
     for ra, rb in zip(a, b):
-        assert np.array_equal(ra["outs"][:, :7], rb["outs"][:, :7])
-        assert np.array_equal(ra["up"], rb["up"]) and np.array_equal(ra["dn"], rb["dn"]) and np.array_equal(ra["wt"], rb["wt"])
+        # the two all-reduces add the ranks' sums in different orders (rank order here, gloo's ring there): the reduced sums,
+        # and through the population control every weight, agree to round-off; determinants, flags and counts exactly
+        assert np.allclose(ra["outs"][:, :7], rb["outs"][:, :7], rtol=1e-11, atol=1e-13)
+        assert np.array_equal(ra["outs"][:, [5, 7, 15]], rb["outs"][:, [5, 7, 15]])
+        assert np.array_equal(ra["up"], rb["up"]) and np.array_equal(ra["dn"], rb["dn"]) and np.array_equal(ra["imp_distance"], rb["imp_distance"])
+        assert np.allclose(ra["wt"], rb["wt"], rtol=1e-9, atol=0)
         single += int((ra["outs"][:, 15] == 1).sum())
     assert single > 0                        # the case under test really occurred
 

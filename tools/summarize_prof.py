@@ -48,6 +48,61 @@ def main(base, out):
     table('sq', "# separate pass: rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE (per launch)")
     open(out, 'w').write("\n".join(lines) + "\n")
     print("\n".join(lines))
+    traffic_json(base, out, f, w)
+
+
+def traffic_json(base, out, f, w):
+    """profiles/*_traffic.json: what bench.py prints as roofline.traffic.  FETCH_SIZE is calibrated on this box, in this
+    run, with tools/calib_fetch.hip (known byte counts in the step's own access patterns: 8-byte coalesced streams and
+    32-byte gathered records), as MI355X_MICROARCH.md asks for access widths other than 16 B per lane."""
+    import json, os, re
+    cal = {}
+    known = {}
+    log = base + ".calib.log"
+    if os.path.exists(log):
+        for m in re.finditer(r"known_bytes (k_\w+) (\d+)(?: \(\+(\d+) index\))?", open(log).read()):
+            known[m.group(1)] = int(m.group(2)) + int(m.group(3) or 0)
+    cf = collections.defaultdict(list)
+    for fn in glob.glob(base + '/calib/*/*counter_collection.csv'):
+        for r in csv.DictReader(open(fn)):
+            if r['Counter_Name'] == 'FETCH_SIZE':
+                cf[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+    for k, v in cf.items():
+        if k in known and v:
+            fetch = sum(v[1:]) / max(1, len(v[1:])) * 1024.0          # first launch warms the TLBs
+            cal[k] = {"known_bytes": known[k], "fetch_size_bytes": fetch, "bytes_per_fetch_byte": known[k] / fetch if fetch else None}
+    bench = {}
+    for lg in (base + ".fetch.log", base + ".trace.log"):
+        if os.path.exists(lg):
+            for ln in open(lg):
+                if ln.startswith('{"metric"'):
+                    bench = json.loads(ln); break
+        if bench:
+            break
+    n_avg = bench.get("config", {}).get("occupied_dets_per_step"); s_avg = bench.get("config", {}).get("spawns_per_step")
+    f_s = (cal.get("k_stream8") or {}).get("bytes_per_fetch_byte") or 2.0
+    f_g = (cal.get("k_gather32") or {}).get("bytes_per_fetch_byte") or 2.0
+    kernels = {}
+    for name, key in (("k_anneal", "k_anneal"), ("k_spawn", "k_spawn"), ("k_diag", "k_diag")):
+        ks = [k for k in f if key in k]
+        if not ks:
+            continue
+        k = max(ks, key=lambda q: sum(f[q]))
+        fl, wl = f[k][-30:], w.get(k, [0])[-30:]
+        fa, wa = sum(fl) / len(fl) * 1024.0, sum(wl) / len(wl) * 1024.0
+        if name == "k_anneal" and n_avg:
+            a_s, a_g = (8 + 51) * n_avg + 8 * s_avg, 32 * s_avg           # streamed: sorted words + resident walkers; gathered: spawn records
+            f_eff = (a_s + a_g) / (a_s / f_s + a_g / f_g)
+        else:
+            f_eff = f_s
+        kernels[name] = {"kernel": k, "fetch_size_bytes": fa, "write_size_bytes": wa, "hbm_bytes_x1": fa + wa, "hbm_bytes_x2": 2 * fa + wa,
+                         "fetch_factor_used": f_eff, "hbm_bytes_calibrated": f_eff * fa + wa}
+    doc = {"commit": os.environ.get("SQMC_COMMIT", "unknown"), "bench_line": {k: bench.get(k) for k in ("value", "ms_per_step", "steps")},
+           "occupied_dets_per_step": n_avg, "spawns_per_step": s_avg, "calibration": cal, "kernels": kernels,
+           "note": "FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes, averages over the last 30 launches; calibration factors = known bytes / FETCH_SIZE bytes of tools/calib_fetch.hip in the same session"}
+    jp = out.replace("_rocprof_summary.txt", "_traffic.json")
+    json.dump(doc, open(jp, "w"), indent=1)
+    print("wrote", jp)
 
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2])
