@@ -289,6 +289,23 @@ def launch_ranks(n):
     return 0
 
 
+def host_cores():
+    """CPU cores this process may actually use: the cgroup quota where there is one (a GPU box hands a 16-core share of a
+    256-thread host to a one-GPU job), else the affinity mask; never more than the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            tok = open(path).read().split()
+            quota = float(tok[0]) if tok[0] != "max" else -1.0
+            period = float(tok[1]) if len(tok) > 1 else float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return int(os.environ.get("SQMC_BENCH_CORES", min(n, 16)))      # 16: the CPU share of a one-GPU box when no quota is visible
+
+
 def cpu_leg(walk, hst, n_avg, budget_s=10.0):
     """The CPU side of the line, on this box's host cores (test infrastructure used as the checker and the baseline, never
     as the product): the single-thread C restatement of the reference step continues the GPU run's equilibrated
@@ -347,7 +364,7 @@ def cpu_leg(walk, hst, n_avg, budget_s=10.0):
              "walkers_bit_identical_after": identical, "rng": "counter",
              "what": "|E_proj(GPU) - E_proj(CPU restatement)| over the same %d steps from the same %.0f-determinant population, same seed (target 1e-6 Ha)" % (n, n_avg)}
     # ---- all host cores
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     O.lib().orc_set_threads(cores)
     ow = O.OracleWalk(sysm, s, w, walk.g.mwalk, seed, rng_mode=1)
     if ratio != 1.0:

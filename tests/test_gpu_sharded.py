@@ -422,10 +422,10 @@ def test_in_library_exchange_equals_host_driven_at_tiny_population(tmp_path):
     import torch.multiprocessing as mp
     fake = _fake_rccl_lib()
     ctx = mp.get_context("spawn")
-    world, kw = 3, dict(w_begin=3, w_target=60, nsteps=60)
+    world, kw = 3, dict(w_begin=1.5, w_target=3, nsteps=80)
     a_dir, b_dir = os.path.join(str(tmp_path), "inlib"), os.path.join(str(tmp_path), "host")
     os.makedirs(a_dir); os.makedirs(b_dir)
-    ps = [ctx.Process(target=_inlib_multi_worker, args=(r, world, 29640, a_dir, fake), kwargs=dict(w_begin=3, w_target=60, nsteps=60)) for r in range(world)]
+    ps = [ctx.Process(target=_inlib_multi_worker, args=(r, world, 29640, a_dir, fake), kwargs=dict(w_begin=1.5, w_target=3, nsteps=80)) for r in range(world)]
     for p in ps: p.start()
     for p in ps: p.join(300)
     alive = [p for p in ps if p.is_alive()]

@@ -2,7 +2,7 @@
 """The one external walk observable on file -- BASELINE.md section 2's reference run of the walk smoke deck (SURVEY appendix A:
 C2 cc-pVDZ, uniform2, semistochastic, target 1e4, 4 x 100-step blocks after equilibration in sets of 2 blocks) -- against
 the GPU path run with the same deck and schedule under several seeds: block counts, populations, `Energy=`, and the
-singles : doubles mix of the proposals on the equilibrated population.  Writes profiles/r02_survey_walk_pin.json."""
+singles : doubles mix of the proposals on the equilibrated population.  Writes gpurun_out/r02_survey_walk_pin.json (kept as profiles/r02_survey_walk_pin.json)."""
 import io
 import json
 import os
@@ -36,7 +36,8 @@ def main():
     e = np.array([r["energy"] for r in rows])
     out = dict(reference=REF, runs=rows, mean=float(e.mean()), scatter=float(e.std(ddof=1)) if len(e) > 1 else 0.0)
     print("GPU runs: mean %.6f, run-to-run scatter %.6f; reference %.6f(%d)" % (out["mean"], out["scatter"], REF["energy"], round(1e8 * REF["energy_err"])))
-    with open(os.path.join(ROOT, "profiles", "r02_survey_walk_pin.json"), "w") as f:
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)          # copy to profiles/ afterwards: only gpurun_out/ travels back from the GPU box
+    with open(os.path.join(ROOT, "gpurun_out", "r02_survey_walk_pin.json"), "w") as f:
         json.dump(out, f, indent=1)
 
 
