@@ -231,6 +231,9 @@ int sqmc_gpu_shard_step(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, double out
 int sqmc_gpu_shard_run(sqmc_gpu_ctx *ctx, sqmc_popctl *pc, int64_t nsteps, double *stats /* nsteps*16 or NULL */, double totals[16]);
 
 /* RNG state of the REPLAY stream (savern / setrn, rannyu.f90:11-21,77-87) */
+/* How many steps took the short-list tail (block-local partition + one annihilation kernel per key range, no global sort) and
+ * how many of those had to be re-run through the radix tail because a key range outgrew its block (diagnostics, tests). */
+int sqmc_gpu_tail_stats(sqmc_gpu_ctx *ctx, int64_t *bucket_steps, int64_t *bucket_retries);
 int sqmc_gpu_get_rng(sqmc_gpu_ctx *ctx, int32_t seed[4]);
 int sqmc_gpu_set_rng(sqmc_gpu_ctx *ctx, const int32_t seed[4]);
 

@@ -96,7 +96,7 @@ class Walk(C.Structure):
         ("n_ct", C.c_int64), ("ct_up", C.POINTER(C.c_uint64)), ("ct_dn", C.POINTER(C.c_uint64)),
         ("ct_num", C.POINTER(C.c_double)), ("ct_den", C.POINTER(C.c_double)),
         ("n_perm", C.c_int), ("sign_perm", C.POINTER(C.c_int8)),
-        ("rng", Rng), ("n_spawn_draws", C.c_int64),
+        ("rng", Rng), ("n_spawn_draws", C.c_int64), ("key_norb", C.c_int), ("key_ndn", C.c_int),
     ]
 
 
@@ -532,6 +532,7 @@ class OracleWalk:
         self.w.n_ct = len(setup.ct_up)
         self._set_ptr("ct_up", setup.ct_up, C.c_uint64); self._set_ptr("ct_dn", setup.ct_dn, C.c_uint64)
         self._set_ptr("ct_num", setup.ct_num, C.c_double); self._set_ptr("ct_den", setup.ct_den, C.c_double)
+        self.w.key_norb, self.w.key_ndn = int(sysm.norb), int(sysm.ndn)      # COUNTER discipline: rounding draws keyed by the determinant's rank
         sd = (C.c_int * 4)(*seed)
         L.orc_setrn(C.byref(self.w.rng), sd)
         L.orc_rng_set_mode.argtypes = [C.c_void_p, C.c_int]

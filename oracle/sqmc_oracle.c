@@ -933,13 +933,26 @@ int64_t orc_merge_original_with_spawned2(orc_walk *w, int64_t nwalk, const orc_s
   return nn;
 }
 
+/* Rank of a determinant among all determinants with the same electron numbers in (up, then dn) order: the colexicographic
+ * rank of a bit string orders strings of equal popcount like their integer values.  Not in the reference: the key of the
+ * COUNTER discipline's rounding draw (a GPU implementation has this number at hand as its sort key). */
+uint64_t orc_det_rank(int norb, int ndn, det_t up, det_t dn) {
+  static uint64_t bn[65][65]; static int init = 0;
+  if (!init) { for (int a = 0; a < 65; a++) { bn[a][0] = 1; for (int b = 1; b <= a; b++) bn[a][b] = (b == a) ? 1 : bn[a - 1][b - 1] + bn[a - 1][b]; } init = 1; }
+  uint64_t ru = 0, rd = 0; int i = 1;
+  for (det_t x = up; x; x &= x - 1, i++) ru += bn[trailz(x)][i];
+  i = 1;
+  for (det_t x = dn; x; x &= x - 1, i++) rd += bn[trailz(x)][i];
+  return ru * bn[norb][ndn] + rd;
+}
 /* do_walk.f90:7196-7254 (hf_to_psit = false) */
 int64_t orc_reduce_my_walker(orc_walk *w, int64_t n, const orc_step_params *p) {
   for (int64_t i = 0; i < n; i++)
     if (w->imp_distance[i] >= 1 && fabs(w->wt[i]) < p->min_wt) {
       /* COUNTER discipline: the draw is keyed by the determinant itself, so that no rank among the
        * merged walkers is needed to find it (REPLAY takes the next number of the one stream) */
-      orc_rng_seek(&w->rng, 2, (uint64_t)w->up[i] * 0x9E3779B97F4A7C15ull + (uint64_t)w->dn[i]);
+      orc_rng_seek(&w->rng, 2, w->key_norb ? orc_det_rank(w->key_norb, w->key_ndn, w->up[i], w->dn[i])
+                                           : (uint64_t)w->up[i] * 0x9E3779B97F4A7C15ull + (uint64_t)w->dn[i]);
       if (orc_rannyu(&w->rng) < (fabs(w->wt[i]) / p->min_wt)) w->wt[i] = copysign(p->min_wt, w->wt[i]);
       else w->wt[i] = 0.0;
     }

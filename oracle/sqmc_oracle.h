@@ -116,7 +116,11 @@ typedef struct {
   int n_perm; int8_t *sign_perm;
   orc_rng rng;
   int64_t n_spawn_draws;            /* RNG draws consumed in the last step      */
+  /* COUNTER discipline only: norb and the number of dn electrons, from which the rounding draw's key -- the determinant's
+   * rank in (up, dn) order, colex_rank(up) C(norb, ndn) + colex_rank(dn) -- is computed (0: not set, keyed by up*phi + dn) */
+  int key_norb, key_ndn;
 } orc_walk;
+uint64_t orc_det_rank(int norb, int ndn, det_t up, det_t dn);
 
 typedef struct {
   double tau, e_trial, reweight_factor_inv, r_initiator, min_wt, always_spawn_cutoff_wt;

@@ -1,0 +1,350 @@
+// bucket_kernels.h -- the annihilation tail of a semistochastic step for SHORT lists, in two launches instead of ten.
+// Textually included by sqmc_gpu.hip behind walk_kernels.h (same translation unit, same types).
+//
+// At 10^5 walkers a step is a chain of dependent launches, not bandwidth: the stable radix sort of the (walkers + spawns)
+// list alone was nine kernels (54 us of a 122 us step) in front of the one-kernel annihilation.  Here the sort never
+// leaves the chip:
+//
+//   k_bucket_partition   one block per 256 children: every child finds its bucket among B key ranges -- the splitters are
+//                        the keys of the resident walkers at positions b n0 / B, which every step leaves sorted, so buckets
+//                        hold equal shares of the residents and (the population moves slowly) nearly equal shares of the
+//                        spawns -- and the block writes its children grouped by bucket (stable counting sort in LDS) with
+//                        the B+1 group offsets.  No counts cross blocks, no atomics, no scan kernel.
+//   k_anneal_bucket      one block per bucket: gathers its children from every partition block (two dependent loads),
+//                        sorts them by key in LDS (stable radix on the bits that vary inside the bucket's key range),
+//                        ranks them against its residents by binary search (residents first on equal keys, spawns in
+//                        creation order: the order of merge_sort2_up_dn, do_walk.f90:5411-5614), folds every run of equal
+//                        determinants with the rules of merge_original_with_spawned2 (5866-6083), rounds small weights
+//                        (reduce_my_walker, 7196-7254), and compacts into the other walker buffer through one decoupled
+//                        look-back over the buckets -- reweighting, C(T) lookup, estimator sums and the next step's gate as
+//                        in k_anneal.
+//
+// A bucket that does not fit the LDS of its block (a population that moved more than the head-room in one step) raises
+// DevScalars::retry and nothing else: the kernel only ever writes the OTHER walker buffer and scratch, so the host re-runs
+// the tail of that step through the radix path and keeps the bucket path off for a while.  COUNTER discipline, packed keys.
+#pragma once
+
+#define BK_T 256
+#define BK_CAP_S 2560                 // spawns of one bucket
+#define BK_CAP_R 1536                 // residents of one bucket
+#define BK_CAP_T 3584                 // both
+#define BK_CAP_ROWS 2560              // partition blocks (256 children each)
+#define BK_MAXB 1024
+#define BK_TARGET 1150                // slots per bucket the host aims at (B = nall / BK_TARGET, at most one block per CU while that holds)
+#define BK_STOP 0x80000000u           // in the merged-order array (source index: residents [0, R), sorted spawns [R, R + S)): this slot starts a run
+
+struct BucketArgs {
+  int B, nsb;                          // buckets, partition blocks
+  u64 *words;                          // nsb x 256 sort words of the children, grouped by bucket inside each block
+  unsigned short *segoff;              // nsb rows of B+1 group offsets
+  u64 *state; u32 *ticket;             // look-back over the buckets
+  int force_retry;                     // tests: behave as if a bucket did not fit
+};
+
+// ------------------------------------------------------------------------------------------------ partition
+__global__ void __launch_bounds__(BK_T) k_bucket_partition(const u64 *__restrict__ keys, long long n0, long long nch, u64 invalid_key, BucketArgs ba) {
+  __shared__ u32 spl[BK_MAXB];
+  __shared__ u32 wcnt[BK_T / 64][BK_MAXB];
+  const int B = ba.B, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long c = (long long)blockIdx.x * BK_T + tid;
+  u64 word = 0; u32 key = 0; bool valid = false;
+  if (c < nch) word = keys[n0 + c];
+  for (int b = tid; b < B; b += BK_T) spl[b] = b ? (u32)(keys[((long long)b * n0) / B] >> 32) : 0u;      // first key of bucket b
+  for (int d = tid; d < (BK_T / 64) * BK_MAXB; d += BK_T) (&wcnt[0][0])[d] = 0;
+  if (c < nch) { key = (u32)(word >> 32); valid = (u64)key != invalid_key; }
+  __syncthreads();
+  int bkt = 0;
+  if (valid) {                         // the last bucket whose first key is <= key (bucket 0 starts at -infinity)
+    int lo = 0, hi = B;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (spl[mid] <= key) lo = mid; else hi = mid; }
+    bkt = lo;
+  }
+  // stable rank among the children of the block that go to the same bucket: ballots inside the wave, counters across waves
+  u64 same = __ballot(valid);
+  int nbit = 1; while ((1 << nbit) < B) nbit++;
+  for (int q = 0; q < nbit; q++) { const u64 m = __ballot((bkt >> q) & 1); same &= ((bkt >> q) & 1) ? m : ~m; }
+  const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const u32 rank = (u32)__popcll(same & lt);
+  if (valid && rank == 0) wcnt[wv][bkt] = (u32)__popcll(same);
+  __syncthreads();
+  // group offsets: exclusive scan over the buckets of the four waves' counts; wcnt becomes the base of each wave's share
+  constexpr int PER = BK_MAXB / BK_T;
+  u32 t4[PER]; u64 sum = 0;
+#pragma unroll
+  for (int q = 0; q < PER; q++) { const int b = tid * PER + q; u32 s = 0; if (b < B) for (int v = 0; v < BK_T / 64; v++) s += wcnt[v][b]; t4[q] = s; sum += s; }
+  u64 tot; u32 ex = (u32)block_excl_scan_u64(sum, &tot);
+  unsigned short *row = ba.segoff + (long long)blockIdx.x * (B + 1);
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const int b = tid * PER + q;
+    if (b < B) { row[b] = (unsigned short)ex; u32 a = ex; for (int v = 0; v < BK_T / 64; v++) { const u32 cn = wcnt[v][b]; wcnt[v][b] = a; a += cn; } }
+    ex += t4[q];
+  }
+  if (tid == 0) row[B] = (unsigned short)tot;
+  __syncthreads();
+  if (valid) ba.words[(long long)blockIdx.x * BK_T + wcnt[wv][bkt] + rank] = word;
+}
+
+// ------------------------------------------------------------------------------------------------ annihilation per bucket
+// merge_original_with_spawned2's pairwise combination (do_walk.f90:5897-5950) of a follower (w2, flags fs) into the
+// running walker of its determinant: the same statement as MERGE_FOLD of fold_slot
+__device__ __forceinline__ void bk_fold(double &wt, int &ini, int &d, double w2, u32 fs, const StepP &p) {
+  const int i2 = flg_init(fs), d2 = flg_impd(fs);
+  const bool same_sign = (w2 * wt > 0);
+  if (same_sign) { if (i2 > ini) ini = i2; }
+  if (d == -2) { if (d2 == 0) d = 0; }
+  else if (d2 == -2) { if (d != 0) d = -2; }
+  else if (d != 0 && d != -2) { const int a_ = d2 < 0 ? -d2 : d2; if (a_ < d) d = a_; }
+  if (!same_sign) {
+    if (fabs(wt) < fabs(w2)) { if (ini != 3 || p.r_init == -1.0) ini = i2; }
+    else if (fabs(wt) == fabs(w2)) { if (ini != 3 || p.r_init == -1.0) ini = 0; }
+  }
+  if (!(d == 0 && d2 == -1)) wt = wt + w2;
+}
+
+__global__ void __launch_bounds__(BK_T) k_anneal_bucket(WalkArr w, WalkArr o, const u64 *__restrict__ rkeys, int *__restrict__ loc_imp,
+                                                        const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 hmask,
+                                                        const double *__restrict__ cnum, const double *__restrict__ cden,
+                                                        double *__restrict__ partials, double *__restrict__ wabs_part, long long n0, long long nch, StepP p,
+                                                        u64 invalid_key, u64 seed, u64 step, DevScalars *sc, BucketArgs ba, GateOut go) {
+  // ---- LDS: the whole bucket lives here
+  __shared__ u64 sw[BK_CAP_S], sw2[BK_CAP_S];            // sort words of the spawns (double buffer)
+  __shared__ u32 rk[BK_CAP_R];                            // keys of the residents
+  __shared__ double s_w[BK_CAP_T]; __shared__ u32 s_f[BK_CAP_T];   // weight / flags by SOURCE: residents [0, R), sorted spawns [R, R + S); later the merged walker of a run, at its head
+  __shared__ u32 m2s[BK_CAP_T];                           // merged order -> source (| BK_STOP at the first slot of a run)
+  __shared__ unsigned short rnk[BK_CAP_T];               // sort: rank inside its digit; later: rank of a kept walker inside the bucket
+  __shared__ u32 scratch[(BK_T / 64) * 1024];             // rows of the gather (offset u16 + base u32), then the digit counters of the sort
+  __shared__ u32 s_tile; __shared__ u64 s_ex; __shared__ int s_over; __shared__ u32 s_kmin, s_kmax;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) { s_tile = atomicAdd(ba.ticket, 1u); s_over = 0; }
+  __syncthreads();
+  const int b = (int)s_tile, B = ba.B, nsb = ba.nsb;
+  const long long r_lo = ((long long)b * n0) / B, r_hi = ((long long)(b + 1) * n0) / B;
+  const int R = (int)(r_hi - r_lo);
+  // key range of the bucket (the sort only looks at the bits that vary inside it)
+  if (tid == 0) s_kmin = b ? (u32)(rkeys[r_lo] >> 32) : 0u;
+  if (tid == 64) s_kmax = (b + 1 < B) ? (u32)(rkeys[r_hi] >> 32) - 1u : (u32)invalid_key;
+  unsigned short *seg_lo = (unsigned short *)scratch; u32 *seg_base = scratch + (BK_CAP_ROWS / 2 + 4);     // u16 x ROWS, then u32 x (ROWS + 1)
+  bool fits = nsb <= BK_CAP_ROWS && R <= BK_CAP_R;
+  // ---- rows: where the bucket's children lie in every partition block.  Thread t owns rows [t C, (t+1) C): all loads first.
+  int S = 0;
+  if (fits) {
+    const int C = (nsb + BK_T - 1) / BK_T;       // <= 10
+    unsigned short lo_[BK_CAP_ROWS / BK_T], hi_[BK_CAP_ROWS / BK_T];
+#pragma unroll
+    for (int q = 0; q < BK_CAP_ROWS / BK_T; q++) {
+      const int t = tid * C + q;
+      lo_[q] = 0; hi_[q] = 0;
+      if (q < C && t < nsb) { const unsigned short *rp = ba.segoff + (long long)t * (B + 1) + b; lo_[q] = rp[0]; hi_[q] = rp[1]; }
+    }
+    u64 mine = 0;
+#pragma unroll
+    for (int q = 0; q < BK_CAP_ROWS / BK_T; q++) mine += (u64)(hi_[q] - lo_[q]);
+    u64 tot; u32 ex = (u32)block_excl_scan_u64(mine, &tot);
+#pragma unroll
+    for (int q = 0; q < BK_CAP_ROWS / BK_T; q++) {
+      const int t = tid * C + q;
+      if (q < C && t < nsb) { seg_lo[t] = lo_[q]; seg_base[t] = ex; ex += (u32)(hi_[q] - lo_[q]); }
+    }
+    if (tid == 0) seg_base[nsb] = (u32)tot;
+    S = (int)tot;
+    fits = S <= BK_CAP_S && R + S <= BK_CAP_T && !ba.force_retry;
+  }
+  const int T = R + S;
+  if (!fits) {
+    // nothing was written that the radix path would miss; the look-back must still see this bucket
+    if (tid == 0) { atomicExch((int *)&sc->retry, 1); }
+    if (tid < 64) lookback_exclusive(ba.state, (u32)b, 0ull, tid);
+    return;
+  }
+  __syncthreads();
+  // ---- gather: residents' keys (coalesced) and the children's sort words, partition block by partition block (= creation order)
+  for (int i = tid; i < R; i += BK_T) rk[i] = (u32)(rkeys[r_lo + i] >> 32);
+  for (int t = tid; t < nsb; t += BK_T) {
+    const u32 base = seg_base[t], cnt = seg_base[t + 1] - base;
+    const u64 *src = ba.words + (long long)t * BK_T + seg_lo[t];
+    for (u32 k = 0; k < cnt; k++) sw[base + k] = src[k];
+  }
+  __syncthreads();
+  // ---- stable LDS radix sort of the spawn words on key - kmin
+  u64 *sa = sw, *sb = sw2;
+  {
+    const u32 kmin = s_kmin, span = s_kmax - kmin;
+    int nbits = 0; while (nbits < 32 && (span >> nbits)) nbits++;
+    const int npass = (nbits + 9) / 10, dbits = npass ? (nbits + npass - 1) / npass : 0;
+    const int chunk = ((S + BK_T - 1) / BK_T) * 64;             // consecutive elements one wave ranks, in rounds of 64
+    u32(*wcnt)[1024] = (u32(*)[1024])scratch;
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int ps = 0, shift = 0; ps < npass && S > 1; ps++, shift += dbits) {
+      const u32 mask = (1u << dbits) - 1u;
+      for (int d = tid; d < (BK_T / 64) * 1024; d += BK_T) scratch[d] = 0;
+      __syncthreads();
+      const int beg = wv * chunk, end = (beg + chunk < S) ? beg + chunk : S;
+      for (int base = beg; base < end; base += 64) {
+        const int idx = base + lane; const bool valid = idx < end;
+        const u32 dig = valid ? ((((u32)(sa[idx] >> 32) - kmin) >> shift) & mask) : 0u;
+        u64 same = __ballot(valid);
+        for (int q = 0; q < dbits; q++) { const u64 m = __ballot((dig >> q) & 1); same &= ((dig >> q) & 1) ? m : ~m; }
+        const u32 rank = (u32)__popcll(same & lt), cnt = (u32)__popcll(same);
+        u32 prev = 0;
+        if (valid) prev = wcnt[wv][dig];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) wcnt[wv][dig] = prev + cnt;
+        __builtin_amdgcn_wave_barrier();
+        if (valid) rnk[idx] = (unsigned short)(prev + rank);
+      }
+      __syncthreads();
+      {   // digit bases: exclusive scan over the digits of the waves' counts
+        u32 t4[4]; u64 sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int d = tid * 4 + q; u32 s = 0; for (int v = 0; v < BK_T / 64; v++) s += wcnt[v][d]; t4[q] = s; sum += s; }
+        u64 tt; u32 ex = (u32)block_excl_scan_u64(sum, &tt);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int d = tid * 4 + q; u32 a = ex; for (int v = 0; v < BK_T / 64; v++) { const u32 cn = wcnt[v][d]; wcnt[v][d] = a; a += cn; } ex += t4[q]; }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < S; idx += BK_T) {
+        const u64 x = sa[idx];
+        const u32 dig = ((((u32)(x >> 32)) - kmin) >> shift) & mask;
+        sb[wcnt[idx / chunk][dig] + rnk[idx]] = x;
+      }
+      __syncthreads();
+      u64 *tp = sa; sa = sb; sb = tp;
+    }
+  }
+  // ---- records by source (all loads independent of the searches below); sums over the pre-merge list (do_walk.f90:2347-2349)
+  double wabs = 0.0, cnt = 0.0;
+  for (int i = tid; i < R; i += BK_T) { const double x = w.wt[r_lo + i]; s_w[i] = x; s_f[i] = w.flg[r_lo + i]; wabs += fabs(x); cnt += 1.0; }
+  for (int j = tid; j < S; j += BK_T) {
+    const long long cidx = (long long)(u32)sa[j] - n0;                    // the word's low half is the walker slot n0 + child
+    const SpawnRec *rp = w.sp + cidx;
+    const double x = rp->wt; const u32 f = (u32)rp->flg;
+    s_w[R + j] = x; s_f[R + j] = f; wabs += fabs(x); cnt += 1.0;
+  }
+  // ---- merged order: a resident goes behind the spawns with smaller keys, a spawn behind the residents with keys <= its own
+  for (int i = tid; i < R; i += BK_T) {
+    const u32 k = rk[i];
+    int lo = 0, hi = S;                                                    // spawns with key < k
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((u32)(sa[mid] >> 32) < k) lo = mid + 1; else hi = mid; }
+    m2s[i + lo] = BK_STOP | (u32)i;
+  }
+  for (int j = tid; j < S; j += BK_T) {
+    const u32 k = (u32)(sa[j] >> 32);
+    int lo = 0, hi = R;                                                    // residents with key <= k
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (rk[mid] <= k) lo = mid + 1; else hi = mid; }
+    const bool on_resident = lo > 0 && rk[lo - 1] == k;
+    const bool head = !on_resident && (j == 0 || (u32)(sa[j - 1] >> 32) != k);
+    m2s[j + lo] = (head ? BK_STOP : 0u) | (u32)(R + j);
+  }
+  __syncthreads();
+  store_wabs(wabs_part, b, wabs, cnt);
+  // ---- runs: the head folds its followers in merged order, then check_initiator, the discard rule and the rounding;
+  //      the merged walker stays at the head's source slot (weight, packed flags); rnk[q] = 1 kept, 0x101 kept in the deterministic space
+  for (int q = tid; q < T; q += BK_T) {
+    const u32 e = m2s[q];
+    unsigned short keep = 0;
+    if (e & BK_STOP) {
+      const int si = (int)(e & ~BK_STOP);
+      double wt = s_w[si]; const u32 f0 = s_f[si];
+      int ini = flg_init(f0), d = flg_impd(f0); const int psg = flg_psign(f0);
+      if (d == -1 && !(b == 0 && q == 0)) d = 1;                          // 5985-5986 (the very first walker keeps -1 until the end)
+      int qq = q + 1;
+      for (; qq < T; qq++) { const u32 e2 = m2s[qq]; if (e2 & BK_STOP) break; bk_fold(wt, ini, d, s_w[e2], s_f[e2], p); }
+      {   // check_initiator, do_walk.f90:6838-6872
+        const int dd = d - p.imind > 0 ? d - p.imind : 0;
+        const double thr = p.r_init * ipow_d(dd, p.ipow), aw = fabs(wt);
+        if (ini == 3 && p.r_init >= 0) { if (wt * psg < 1.0) wt = (double)psg; }
+        else if (ini == 2 && ((aw <= thr && d > 0) || ((aw <= p.r_init && !p.cti) && d == -2))) ini = 1;
+        else if (ini < 2 && ((aw > thr && d >= 0) || ((aw > p.r_init || p.cti) && d == -2))) ini = ini + 1;
+      }
+      int dtest = d;
+      if (d == -1) { if (b == B - 1 && qq >= T) dtest = 1; d = 1; }          // 6032-6036 then the last-det test at 6038
+      const bool discard = (((wt == 0.0 && (ini != 3 || p.r_init < 0)) || ini == 0) && dtest >= 1);
+      if (!discard) {
+        if (d >= 1 && fabs(wt) < p.min_wt) {                                // reduce_my_walker, 7196-7254: the draw is keyed by the determinant's rank (its sort key)
+          const u32 kk = (si < R) ? rk[si] : (u32)(sa[si - R] >> 32);
+          Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, (u64)kk);
+          if (rng_draw(g) < (fabs(wt) / p.min_wt)) wt = copysign(p.min_wt, wt); else wt = 0.0;
+        }
+        if (!(wt == 0.0 && d >= 1)) keep = (d == 0) ? 0x101 : 0x1;        // zero weights outside the deterministic space are dropped (7222-7249)
+      }
+      s_w[si] = wt; s_f[si] = pack_flg(d, ini, psg);
+    }
+    rnk[q] = keep;
+  }
+  __syncthreads();
+  // ---- rank of every kept walker inside the bucket (lo 16 bits: position, hi: index among the deterministic-space walkers):
+  //      each thread scans a contiguous share of the merged order; then one look-back over the buckets
+  u32 *s_rank = (u32 *)sb;                              // the idle sort buffer
+  u64 ex_glob;
+  {
+    const int C = (T + BK_T - 1) / BK_T, beg = tid * C, end = (beg + C < T) ? beg + C : T;
+    u64 mine = 0;
+    for (int q = beg; q < end; q++) { const unsigned short k = rnk[q]; mine += (u64)(k & 1) | ((u64)(k >> 8) << 32); }
+    u64 tot; u64 ex = block_excl_scan_u64(mine, &tot);
+    for (int q = beg; q < end; q++) {
+      const unsigned short k = rnk[q];
+      if (k & 1) { s_rank[q] = (u32)(ex & 0xFFFFull) | ((u32)(ex >> 32) << 16); ex += (u64)1 | ((u64)(k >> 8) << 32); }
+      else s_rank[q] = 0xFFFFFFFFu;
+    }
+    if (tid < 64) {
+      const u64 e = lookback_exclusive(ba.state, (u32)b, tot, tid);
+      if (tid == 0) { s_ex = e; if (b == B - 1) { sc->tot2 = e + tot; sc->nwalk = (e + tot) & 0xFFFFFFFFull; } }
+    }
+    __syncthreads();
+    ex_glob = s_ex;
+  }
+  // ---- compaction into the other buffer, reweighting (2487), estimator pieces (2573-2684, more_tools.f90:4041-4098), next gate
+  double st[NSTAT];
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) st[k] = 0.0;
+  for (int q = tid; q < T; q += BK_T) {
+    const u32 r = s_rank[q];
+    if (r == 0xFFFFFFFFu) continue;
+    const int si = (int)(m2s[q] & ~BK_STOP);
+    const long long q0 = (long long)(ex_glob & 0xFFFFFFFFull) + (long long)(r & 0xFFFFu);
+    const long long qd = (long long)(ex_glob >> 32) + (long long)(r >> 16);
+    u64 up, dn, key; double me = 1e51, en = 1e51, ed = 1e51;
+    if (si < R) { const long long ix = r_lo + si; up = w.up[ix]; dn = w.dn[ix]; me = w.me[ix]; en = w.en[ix]; ed = w.ed[ix]; key = rk[si]; }
+    else { const u64 x = sa[si - R]; const SpawnRec *rp = w.sp + ((long long)(u32)x - n0); up = rp->up; dn = rp->dn; key = x >> 32; }
+    const double wt = s_w[si] * p.rfi;
+    const u32 fl = s_f[si];
+    const int d = flg_impd(fl), ini = flg_init(fl), psg = flg_psign(fl);
+    if (en > 1e50) {
+      const long long h = ct_lookup(hkey, hidx, hmask, key);
+      if (h < 0) { en = 0.0; ed = 0.0; } else { en = cnum[h]; ed = cden[h]; }
+    }
+    o.up[q0] = up; o.dn[q0] = dn; o.wt[q0] = wt; o.flg[q0] = fl;
+    o.me[q0] = me; o.en[q0] = en; o.ed[q0] = ed;
+    if (go.on) {
+      u64 nc; double wc;
+      gate_children(wt, go.cutoff, seed, go.step_next, (u64)q0, nc, wc);
+      go.keys[q0] = (key << 32) | (u64)q0; go.nchild[q0] = nc; go.wchild[q0] = wc;
+    }
+    if (d == 0 && p.semi && qd < p.nimp_cap) loc_imp[qd] = (int)q0;
+    st[0] += wt; st[1] += fabs(wt); st[8] += wt * wt;
+    if (ini == 3) st[4] += wt * psg;
+    if (d == 0 || (d == -2 && p.cti)) st[6] += fabs(wt);
+    double e_num = en * wt, e_den = ed * wt;
+    if (e_num != 0.0) {
+      if (fabs(e_den) < 1e-22) e_den = fabs(e_den);
+      st[2] += e_den; st[3] += e_num; st[9] += e_num * e_num; st[10] += e_den * e_den;
+      st[11] += e_num * copysign(1.0, e_den); st[12] += fabs(e_den); st[5] += e_num * e_den;
+    }
+  }
+  __shared__ double red[BK_T / 64][NSTAT];
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) {
+    double v = st[k];
+    for (int q = 32; q > 0; q >>= 1) v += __shfl_down(v, q, 64);
+    if (lane == 0) red[wv][k] = v;
+  }
+  __syncthreads();
+  if (tid < NSTAT) {
+    double v = 0.0;
+    for (int q = 0; q < BK_T / 64; q++) v += red[q][tid];
+    partials[(long long)b * NSTAT + tid] = v;
+  }
+  // how full the fullest bucket was (per mille of the caps): the host keeps the bucket path off while the head-room is thin
+  if (tid == 0) { const int fs = (1000 * S) / BK_CAP_S, ft = (1000 * T) / BK_CAP_T; atomicMax((unsigned int *)&sc->bk_fill, (unsigned int)(fs > ft ? fs : ft)); }
+}

@@ -89,9 +89,10 @@ struct ScanNoExtra { static constexpr bool on = false; __device__ void operator(
 template <int SCAN_ITEMS, class Extra = ScanNoExtra>
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_lookback_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, long long n_arg,
                                                                    u64 *__restrict__ state, u32 *__restrict__ ticket, u64 *__restrict__ total_out,
-                                                                   const u64 *__restrict__ n_dev, Extra extra) {
+                                                                   const u64 *__restrict__ n_dev, Extra extra, const int *__restrict__ skip) {
   constexpr int TILE_ELEMS = SCAN_BLOCK * SCAN_ITEMS;
   if (Extra::on && blockIdx.x == gridDim.x - 1) { extra(); return; }
+  if (skip && *skip) return;                    // the caller's "do nothing" switch (set before this kernel was enqueued behind its producer)
   // n_dev: the length lives in device memory (the launch was sized for an upper bound n_arg by a host
   // that does not know it yet); tiles past the end scan zeros and repeat the total
   const long long n = n_dev ? (long long)(*n_dev & 0xFFFFFFFFull) : n_arg;
@@ -142,7 +143,8 @@ struct ScanWork { u64 *state; u32 *ticket; long long cap_tiles; bool self_clear;
 // exclusive scan of n u64 values (< 2^62 in total); total (optional) is written on device
 // returns the number of look-back words (tiles) the launch may touch
 template <class Extra = ScanNoExtra>
-static inline int device_excl_scan_u64(const u64 *in, u64 *out, long long n, u64 *total_out, ScanWork &w, hipStream_t st, const u64 *n_dev = nullptr, Extra extra = Extra()) {
+static inline int device_excl_scan_u64(const u64 *in, u64 *out, long long n, u64 *total_out, ScanWork &w, hipStream_t st, const u64 *n_dev = nullptr, Extra extra = Extra(),
+                                       const int *skip = nullptr) {
   if (n <= 0 && !Extra::on) { if (total_out) hipMemsetAsync(total_out, 0, sizeof(u64), st); return 0; }
   if (n <= 0) n = 1;
   const bool large = n >= SCAN_LARGE_N;
@@ -150,8 +152,8 @@ static inline int device_excl_scan_u64(const u64 *in, u64 *out, long long n, u64
   int ntiles = (int)((n + tile - 1) / tile);
   if (w.self_clear) hipLaunchKernelGGL(scan_clear_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, st, w.state, w.ticket, ntiles);
   const int grid = ntiles + (Extra::on ? 1 : 0);
-  if (large) hipLaunchKernelGGL((scan_lookback_kernel<SCAN_ITEMS_LARGE, Extra>), dim3(grid), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out, n_dev, extra);
-  else hipLaunchKernelGGL((scan_lookback_kernel<SCAN_ITEMS_SMALL, Extra>), dim3(grid), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out, n_dev, extra);
+  if (large) hipLaunchKernelGGL((scan_lookback_kernel<SCAN_ITEMS_LARGE, Extra>), dim3(grid), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out, n_dev, extra, skip);
+  else hipLaunchKernelGGL((scan_lookback_kernel<SCAN_ITEMS_SMALL, Extra>), dim3(grid), dim3(SCAN_BLOCK), 0, st, in, out, n, w.state, w.ticket, total_out, n_dev, extra, skip);
   return ntiles;
 }
 

@@ -95,9 +95,10 @@ struct DevScalars {
   u64 tot2;                // packed scan total 2: lo = final walkers, hi = det-space walkers
   u64 nwalk;               // walkers after the last finished step (k_finish); the next step's head kernels read it when the host does not know it yet
   int err;                 // SQMC_ERR_* raised on device
-  int pad;
+  int retry;               // the bucket tail met a bucket that does not fit its block: nothing of this step's tail counts, the host re-runs it (sticky: only the host clears it)
   double stats[16];
   double red[8];           // sharded steps: what the ranks all-reduce -- the seven global sums and the collective status (256^code summed over ranks)
+  unsigned int bk_fill, pad2;   // bucket tail: fill of the fullest bucket this step, per mille of the LDS caps
 };
 // status of a step summed over ranks as 256^code: the highest code any rank raised (codes 1..5, at most 255 ranks: exact in a double)
 __host__ __device__ __forceinline__ double err_encode(int code) { double v = 0.0; if (code > 0) { v = 1.0; for (int k = 0; k < code; k++) v *= 256.0; } return v; }
@@ -109,6 +110,7 @@ __host__ __device__ __forceinline__ int err_decode(double v) { int code = 0; dou
 struct HostMail {
   volatile u64 seq; u64 tot2; long long err; double stats[16];
   volatile u64 cnt_seq; u64 n_children;
+  u64 retry, bk_fill;      // bucket tail: see DevScalars
 };
 
 #define NTIMERS 32
@@ -147,10 +149,14 @@ struct sqmc_gpu_ctx {
   bool pipeline_next, head_ready; StepP head_p; u64 head_cseq; hipEvent_t hev[4];
   bool owner_ready;           // this step's k_spawn already wrote the owner key of every child (sharded steps)
   int scan_flip, scan_used[2];   // gate-fused heads: look-back set of the next head scan, and how many words of each set its last scan may have touched
-  bool residents_sorted;      // the walker arrays are known to be in (up, dn) order: true after every finished step, false after an upload
+  bool residents_sorted;      // the walker arrays are known to be in (up, dn) order: true after every finished step and after an upload (which refuses unsorted lists)
+  unsigned short *d_segoff; long long segoff_cap;      // bucket tail: group offsets of the partition blocks
+  int bk_holdoff;             // steps for which the bucket tail stays off (after a bucket overflowed or came close)
+  long long bk_steps, bk_retries;
 };
 
 #include "walk_kernels.h"
+#include "bucket_kernels.h"
 #include "door_kernels.h"
 #include "hci_kernels.h"
 #include "spmv_kernels.h"
@@ -221,10 +227,12 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
     c->cap_tiles = (M + SCAN_TILE - 1) / SCAN_TILE + 1;
     HIPCHK(hipMalloc(&c->d_scan_state, 3 * c->cap_tiles * 8)); HIPCHK(hipMalloc(&c->d_scan_ticket, 3 * 4));
     HIPCHK(hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8)); HIPCHK(hipMemset(c->d_scan_ticket, 0, 3 * 4));
-    c->cap_ftiles = nblk(M) + 1;
+    c->cap_ftiles = std::max<long long>(nblk(M) + 1, BK_MAXB + 1);
+    c->segoff_cap = ((std::min<long long>(M, 1ll << 20) + BK_T - 1) / BK_T + 1) * (BK_MAXB + 1);
+    HIPCHK(hipMalloc(&c->d_segoff, c->segoff_cap * sizeof(unsigned short)));
     HIPCHK(hipMalloc(&c->d_fstate, 2 * c->cap_ftiles * 8)); HIPCHK(hipMalloc(&c->d_fticket, 4));
     HIPCHK(hipMemset(c->d_fstate, 0, 2 * c->cap_ftiles * 8)); HIPCHK(hipMemset(c->d_fticket, 0, 4));
-    c->n_partial_blocks = nblk(M);
+    c->n_partial_blocks = std::max(nblk(M), BK_MAXB);
     HIPCHK(hipMalloc(&c->d_partials, ((long long)c->n_partial_blocks * NSTAT + 128) * 8));
     HIPCHK(hipMalloc(&c->d_wabs_part, ((long long)c->n_partial_blocks * 2 + 2) * 8));
     HIPCHK(hipMalloc(&c->d_done, 4)); HIPCHK(hipMemset(c->d_done, 0, 4));
@@ -341,7 +349,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
     free_walk(c->w); free_walk(c->m);
     hipFree(c->d_nchild); hipFree(c->d_child_off); hipFree(c->d_wchild); hipFree(c->d_child_state);
     hipFree(c->d_keys); hipFree(c->d_keys_alt); hipFree(c->d_vals); hipFree(c->d_vals_alt); hipFree(c->d_hist); hipFree(c->d_rowtot);
-    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done);
+    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done); hipFree(c->d_segoff);
   }
   hipFree(c->d_binom); hipFree(c->d_grow);
   comm_release(c);
@@ -436,7 +444,7 @@ int sqmc_gpu_upload_walkers(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, cons
     HIPCHK(hipMemcpy(c->w.flg, f.data(), n * 4, hipMemcpyHostToDevice)); }
   HIPCHK(hipMemcpy(c->w.me, me, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.en, en, n * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->w.ed, ed, n * 8, hipMemcpyHostToDevice));
-  c->nwalk = n; c->residents_sorted = false;      // the host's order is taken as it comes: the next step sorts everything
+  c->nwalk = n; c->residents_sorted = true;       // checked above: sorted and unique
   if (c->n_imp > 0) {        // my_locations_of_imp_dets, do_walk.f90:2188-2212
     const long long expect = c->d_grow ? c->n_imp_local : c->n_imp;
     std::vector<int> loc; loc.reserve(expect);
@@ -468,6 +476,11 @@ int sqmc_gpu_download_walkers(sqmc_gpu_ctx *c, int64_t cap, int64_t *n, uint64_t
   return SQMC_OK;
 }
 
+int sqmc_gpu_tail_stats(sqmc_gpu_ctx *c, int64_t *bucket_steps, int64_t *bucket_retries) {
+  if (!c || !bucket_steps || !bucket_retries) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  *bucket_steps = c->bk_steps; *bucket_retries = c->bk_retries;
+  return SQMC_OK;
+}
 int sqmc_gpu_get_rng(sqmc_gpu_ctx *c, int32_t seed[4]) {
   if (!c) return SQMC_ERR_BAD_ARG;
   u64 x; HIPCHK(hipStreamSynchronize(c->st)); HIPCHK(hipMemcpy(&x, &c->d_sc->lcg, 8, hipMemcpyDeviceToHost));
@@ -563,12 +576,13 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
     // (the one the head scan before this one used).
     const int f = c->scan_flip;
     sw0.state = c->d_scan_state + (long long)f * c->cap_tiles; sw0.ticket = c->d_scan_ticket + f;
-    c->scan_used[f] = device_excl_scan_u64<FinExtra>(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st, dev_n ? &c->d_sc->nwalk : nullptr, FinExtra{fa, c->d_sc});
+    c->scan_used[f] = device_excl_scan_u64<FinExtra>(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st, dev_n ? &c->d_sc->nwalk : nullptr, FinExtra{fa, c->d_sc},
+                                                             dev_n ? &c->d_sc->retry : nullptr);
     c->scan_flip = f ^ 1;
   } else {
     hipLaunchKernelGGL(k_gate, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_keys, c->d_vals,
                        n0, p, c->seed64, step, c->d_sc, c->pack, dev_n ? 1 : 0, fa);
-    c->scan_used[0] = device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st, dev_n ? &c->d_sc->nwalk : nullptr);
+    c->scan_used[0] = device_excl_scan_u64(c->d_nchild, c->d_child_off, n0, &c->d_sc->n_children, sw0, st, dev_n ? &c->d_sc->nwalk : nullptr, ScanNoExtra(), dev_n ? &c->d_sc->retry : nullptr);
     c->scan_flip = 1;          // set 0 stays dirty until a finish re-zeroes it: a gate-fused head that follows works on set 1
   }
   if (g1) hipEventRecord(g1, st);
@@ -602,7 +616,8 @@ static void drop_head(sqmc_gpu_ctx *c) {
 }
 // sort -> merge -> round -> compact/estimate -> readback; shared by the single-rank step and
 // the sharded step (where the spawns behind slot n0 arrived from other ranks)
-static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long nall, bool join_side_stream, double out[16]) {
+#define SQMC_INTERNAL_RETRY 1000      // step_tail_impl: the bucket tail gave up, nothing of it counts; run the radix tail
+static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long nall, bool join_side_stream, double out[16], bool allow_bucket) {
   StepP p = p_in;
   p.nimp_cap = c->d_loc_imp ? (int)std::max<long long>(c->n_imp_local, c->n_imp) : 0;     // what set_projector / shard_config allocated
   hipStream_t st = c->st;
@@ -617,7 +632,32 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
   SortWork so; so.k_alt = c->d_keys_alt; so.v_alt = c->d_vals_alt; so.hist = c->d_hist; so.rowtot = c->d_rowtot; so.cap = M;
   u64 *skey = c->d_keys; u32 *perm = c->pack ? (u32 *)nullptr : c->d_vals;
   static const long long merge_min = getenv("SQMC_MERGE_SORT_MIN") ? atoll(getenv("SQMC_MERGE_SORT_MIN")) : (1ll << 20);
-  if (p.semi && c->residents_sorted && nall >= merge_min) {
+  // Short lists (the launch-bound regime): no global sort at all.  The spawns are partitioned block-locally into B key
+  // ranges whose splitters are resident walkers (sorted since the last step), and one block per range sorts, merges and
+  // annihilates its share in LDS (bucket_kernels.h).  Needs packed keys, the COUNTER discipline, ordered residents.
+  static const int bucket_env = getenv("SQMC_BUCKET") ? atoi(getenv("SQMC_BUCKET")) : 1;
+  static const long long bucket_max = getenv("SQMC_BUCKET_MAX") ? atoll(getenv("SQMC_BUCKET_MAX")) : (1ll << 20);
+  BucketArgs ba; memset(&ba, 0, sizeof(ba));
+  bool bucket = false;
+  if (allow_bucket && bucket_env && c->pack && p.semi && mode == SQMC_RNG_COUNTER && c->residents_sorted && !c->d_grow && c->comm == nullptr &&
+      nall > n0 && nall < bucket_max && nall < merge_min && n0 >= 64) {
+    if (c->bk_holdoff > 0) c->bk_holdoff--;
+    else {
+      const long long nch = nall - n0;
+      static const long long bk_target = getenv("SQMC_BUCKET_TARGET") ? atoll(getenv("SQMC_BUCKET_TARGET")) : BK_TARGET;     // tests: huge targets make buckets overflow
+      long long B = (nall + bk_target - 1) / bk_target; if (B > BK_MAXB) B = BK_MAXB; if (B > n0) B = n0; if (B < 1) B = 1;
+      const long long nsb = (nch + BK_T - 1) / BK_T;
+      if (nsb <= BK_CAP_ROWS && (n0 + B - 1) / B <= BK_CAP_R && nsb * (B + 1) <= c->segoff_cap) {
+        bucket = true;
+        static const int force_every = getenv("SQMC_BUCKET_FORCE_RETRY") ? atoi(getenv("SQMC_BUCKET_FORCE_RETRY")) : 0;      // tests: every n-th bucket step gives up
+        ba.force_retry = (force_every > 0 && (c->bk_steps % force_every) == force_every - 1) ? 1 : 0;
+        ba.B = (int)B; ba.nsb = (int)nsb; ba.words = c->d_flags; ba.segoff = c->d_segoff; ba.state = c->d_fstate; ba.ticket = c->d_fticket;
+        hipLaunchKernelGGL(k_bucket_partition, dim3((unsigned)nsb), dim3(BK_T), 0, st, (const u64 *)c->d_keys, n0, nch, c->invalid_key, ba);
+      }
+    }
+  }
+  if (bucket) {
+  } else if (p.semi && c->residents_sorted && nall >= merge_min) {
     // Large lists: the walkers [0, n0) are in order already (every step leaves them so), so only the spawns
     // [n0, nall) are sorted and one stable merge (walker before spawns on equal keys, spawns in creation order)
     // gives the order the full sort would.  The merged list lands in the flag arrays the fused tail does not use.
@@ -652,7 +692,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
     // small lists want many tiles, large ones short look-back chains; 4 slots per thread spill 31 registers at the 4 waves per SIMD
     // the kernel wants (3: 8), which only pays from ~10^7 slots on (measured: 0.449 against 0.458 ms/step at 2.5e6 slots, 3.44 against 3.35 at 1.7e7)
     const int items = items_env ? items_env : (nall < (1ll << 20) ? 2 : (nall < (1ll << 23) ? 3 : 4));
-    nb = n_ft = (int)((nall + (long long)TPB * items - 1) / ((long long)TPB * items));
+    nb = n_ft = bucket ? ba.B : (int)((nall + (long long)TPB * items - 1) / ((long long)TPB * items));
     // pipelined steps: the kernel also does the next step's gate (keys, child counts, child weights) as it places a walker
     static const bool no_fuse = getenv("SQMC_NO_GATE_FUSION") != nullptr;
     fuse_gate = c->pipeline_next && c->pack && !no_fuse;
@@ -665,7 +705,14 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
                     c->invalid_key, c->pack, mode, seed, step, c->d_sc, c->d_fstate, c->d_fstate + c->cap_ftiles, c->d_fticket, go
 #define ANNEAL_LAUNCH(I) do { if (t_anneal >= 0) hipExtLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, ANNEAL_ARGS); \
                               else hipLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, ANNEAL_ARGS); } while (0)
-    if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 3) ANNEAL_LAUNCH(3); else ANNEAL_LAUNCH(4);
+    if (bucket) {
+#define BUCKET_ARGS c->w, c->m, (const u64 *)c->d_keys, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, \
+                    n0, nall - n0, p, c->invalid_key, seed, step, c->d_sc, ba, go
+      if (t_anneal >= 0) hipExtLaunchKernelGGL(k_anneal_bucket, dim3(nb), dim3(BK_T), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, BUCKET_ARGS);
+      else hipLaunchKernelGGL(k_anneal_bucket, dim3(nb), dim3(BK_T), 0, st, BUCKET_ARGS);
+#undef BUCKET_ARGS
+      c->bk_steps++;
+    } else if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 3) ANNEAL_LAUNCH(3); else ANNEAL_LAUNCH(4);
 #undef ANNEAL_LAUNCH
 #undef ANNEAL_ARGS
     if (fuse_gate && go.keys == c->d_keys_alt) std::swap(c->d_keys, c->d_keys_alt);      // the next step's spawn kernel appends its keys behind the walkers'
@@ -678,7 +725,7 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
     TEND(merge, st);
     TBEG(round, st);
     hipLaunchKernelGGL(k_join, dim3(1), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, nall, p, mode, seed, step, c->d_sc);
-    hipLaunchKernelGGL(k_round, dim3(nblk(nall)), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, c->d_flags2, nall, p, mode, seed, step, c->d_sc);
+    hipLaunchKernelGGL(k_round, dim3(nblk(nall)), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, c->d_flags2, nall, p, mode, seed, step, c->d_sc, skey, c->pack);
     device_excl_scan_u64(c->d_flags2, c->d_pos2, nall, &c->d_sc->tot2, sw[2], st);
     TEND(round, st);
     nb = std::min(nblk(nall), 2048);
@@ -725,7 +772,26 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
     if (wr > 0) return fail(SQMC_ERR_HIP, std::string("step failed on the device: ") + hipGetErrorString((hipError_t)wr));
     if (wr < 0) {            // stream drained without the mail: read the scalars the slow way
       HIPCHK(hipMemcpy(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost));
-    } else { c->h_sc->tot2 = c->h_mail->tot2; c->h_sc->err = (int)c->h_mail->err; for (int i = 0; i < 16; i++) c->h_sc->stats[i] = c->h_mail->stats[i]; }
+    } else { c->h_sc->tot2 = c->h_mail->tot2; c->h_sc->err = (int)c->h_mail->err; for (int i = 0; i < 16; i++) c->h_sc->stats[i] = c->h_mail->stats[i];
+             c->h_sc->retry = (int)c->h_mail->retry; c->h_sc->bk_fill = (unsigned int)c->h_mail->bk_fill; }
+  }
+  if (bucket) {
+    if (c->h_sc->retry) {
+      // A bucket outgrew its block.  The kernel wrote only the other walker buffer and scratch; the head of the next step,
+      // if it was enqueued, saw the flag and did nothing.  Undo the host's bookkeeping and let the caller run the radix tail.
+      drop_head(c);
+      hipStreamSynchronize(st);
+      hipMemset(c->d_fstate, 0, 2 * c->cap_ftiles * 8); hipMemset(c->d_fticket, 0, 4);
+      hipMemset(&c->d_sc->retry, 0, sizeof(int)); hipMemset(&c->d_sc->bk_fill, 0, sizeof(unsigned int));
+      c->h_sc->retry = 0;
+      std::swap(c->w.up, c->m.up); std::swap(c->w.dn, c->m.dn); std::swap(c->w.wt, c->m.wt); std::swap(c->w.flg, c->m.flg);
+      std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed);
+      if (fuse_gate) std::swap(c->d_keys, c->d_keys_alt);
+      c->pipeline_next = false; c->bk_retries++;
+      { static const int hold = getenv("SQMC_BUCKET_HOLDOFF") ? atoi(getenv("SQMC_BUCKET_HOLDOFF")) : 64; c->bk_holdoff = hold; }
+      return SQMC_INTERNAL_RETRY;
+    }
+    if (c->h_sc->bk_fill > 800) c->bk_holdoff = 16;        // thin head-room: radix tail for a while
   }
   c->timers_pending = kernel_events_on(c, step);
   c->step_no++;
@@ -741,6 +807,12 @@ static int step_tail(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long
   if (nfinal == 0) { drop_head(c); return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0"); }
   if (p.semi && nimp != (c->shard_n > 1 || c->d_grow ? c->n_imp_local : c->n_imp)) { drop_head(c); return fail(SQMC_ERR_IMP_BROKEN, "locations of my imp broken"); }
   return SQMC_OK;
+}
+
+static int step_tail(sqmc_gpu_ctx *c, const StepP &p, long long n0, long long nall, bool join_side_stream, double out[16]) {
+  int r = step_tail_impl(c, p, n0, nall, join_side_stream, out, true);
+  if (r == SQMC_INTERNAL_RETRY) r = step_tail_impl(c, p, n0, nall, false, out, false);
+  return r;
 }
 
 int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {

@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   const long long n = n_on_device ? (long long)sc->nwalk : n_arg;      // pipelined head: the grid covers an upper bound
   if (fin.on && blockIdx.x == 0) finish_all(fin, sc);                  // the last step's final sums and mail, before this step clears the scalars
+  if (n_on_device && sc->retry) return;                                // pipelined head of a step whose predecessor's bucket tail gave up: the host re-runs that tail first
   if (i == 0) { sc->n_invalid = 0; sc->tot1 = 0; sc->tot2 = 0; sc->err = 0; }   // every writer of these runs after this kernel
   if (i >= n) return;
   put_key(keys, vals, i, det_key(dev, up[i], dn[i]), pack);      // sort key of the walker itself
@@ -207,6 +208,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
                                                const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
                                                long long n0_arg, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc,
                                                HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo) {
+  if (n_on_device && sc->retry) return;                                 // see k_gate
   const long long n0 = n_on_device ? (long long)sc->nwalk : n0_arg;     // pipelined head: launched before the host learnt the walker count
   // the grid covers the free capacity of the walker arrays; the number of children is read from
   // device memory so that the launch does not wait for the host to learn it
@@ -532,9 +534,9 @@ __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *
 
 // stochastic rounding of small weights (reduce_my_walker, do_walk.f90:7196-7254); RNG draws
 // are taken in merged-walker order: REPLAY = skip-ahead of the rannyu LCG by the rank of the
-// draw, COUNTER = stream keyed by the merged index.
+// draw, COUNTER = stream keyed by the determinant's rank in (up, dn) order (its sort key).
 __global__ void __launch_bounds__(TPB) k_round(WalkArr m, const u64 *__restrict__ flags, const u64 *__restrict__ pos, u64 *__restrict__ flags2,
-                                               long long n_all, StepP p, int mode, u64 seed, u64 step, const DevScalars *sc) {
+                                               long long n_all, StepP p, int mode, u64 seed, u64 step, const DevScalars *sc, const u64 *__restrict__ skey, int pack) {
   long long j = (long long)blockIdx.x * TPB + threadIdx.x;
   if (j >= n_all) return;
   const u64 f = flags[j];
@@ -544,7 +546,7 @@ __global__ void __launch_bounds__(TPB) k_round(WalkArr m, const u64 *__restrict_
     const u64 ps = pos[j];
     double r;
     if (mode == 0) r = (double)lcg_skip(sc->lcg, (ps >> 32) + 1) * 3.552713678800500929355621337890625e-15;
-    else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, m.up[j] * SQ_GOLDEN + m.dn[j]); r = rng_draw(g); }   // keyed by the determinant
+    else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, get_key(skey, j, pack)); r = rng_draw(g); }   // keyed by the determinant's rank = its sort key
     if (r < (fabs(wt) / p.min_wt)) wt = copysign(p.min_wt, wt); else wt = 0.0;
     m.wt[j] = wt;
   }
@@ -774,7 +776,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
       if (r[k].f >> 32) {
         double rr;
         if (mode == 0) { const u64 ex1 = ex + inc[k] - r[k].f; rr = (double)lcg_skip(sc->lcg, (ex1 >> 32) + 1) * 3.552713678800500929355621337890625e-15; }
-        else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, r[k].up * SQ_GOLDEN + r[k].dn); rr = rng_draw(g); }
+        else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, key[k]); rr = rng_draw(g); }      // keyed by the determinant's rank = its sort key
         if (rr < (fabs(r[k].wt) / p.min_wt)) r[k].wt = copysign(p.min_wt, r[k].wt); else r[k].wt = 0.0;
       }
       // reduce_my_walker drops zero weights outside the deterministic space (7222-7249)
@@ -944,7 +946,9 @@ __device__ void finish_step(const double *__restrict__ partials, int nblocks, co
 #pragma unroll
       for (int i = 0; i < 16; i++) mail->stats[i] = o[i];
       mail->tot2 = tot2; mail->err = err;
+      mail->retry = (u64)sc->retry; mail->bk_fill = (u64)sc->bk_fill;
     }
+    sc->bk_fill = 0;
     if (mode == 0) sc->lcg = lcg_skip(sc->lcg, sc->tot1 >> 32);
   }
 }

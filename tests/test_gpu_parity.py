@@ -166,6 +166,7 @@ def _run_pair(oracle, sysm, setup, rng_mode, nsteps, w_begin, w_target, mwalk=40
         w_abs = out_c[1]
     wg, wc = g.download_walkers(), ow.walkers()
     rng_g, rng_c = g.rng_state(), ow.rng_state()
+    _run_pair.tail_stats = g.tail_stats()
     g.close(); ow.close()
     return wg, wc, rng_g, rng_c, out_g, out_c
 
@@ -199,6 +200,10 @@ def test_walk_counter_trajectory_bit_exact_at_bench_size(oracle, c2_walk, c2_set
     against the oracle after 40 steps (integer bookkeeping and sums after every one)."""
     wg, wc, _, _, og, oc = _run_pair(oracle, c2_walk, c2_setup, 1, 40, 100000, 100000, mwalk=1000000)
     assert int(og[5]) > 100000 and int(og[7]) > 200000
+    if os.environ.get("SQMC_BUCKET_FORCE_RETRY"):
+        assert _run_pair.tail_stats[1] >= 10                                         # the rollback really ran
+    elif not os.environ.get("SQMC_BUCKET") == "0" and not os.environ.get("SQMC_FORCE_UNPACKED") and not os.environ.get("SQMC_MERGE_SORT_MIN"):
+        assert _run_pair.tail_stats[0] >= 39 and _run_pair.tail_stats[1] == 0      # this size is what the short-list tail is for
     for k in ("up", "dn", "imp_distance", "initiator"):
         assert np.array_equal(wg[k], wc[k]), k
     assert np.array_equal(wg["wt"], wc["wt"])
@@ -1482,3 +1487,18 @@ def test_det_owner_djb_matches_oracle(oracle, c2_walk, heg57, which):
         assert not np.array_equal(g.det_owner(up, dn, 8), ref8 := np.array([L.orc_get_det_owner(int(a), 0, int(b), 0, 8) for a, b in zip(up, dn)]))
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("env,expect", [(dict(SQMC_BUCKET="0"), "off"), (dict(SQMC_BUCKET_FORCE_RETRY="3", SQMC_BUCKET_HOLDOFF="0"), "retry")])
+def test_bucket_tail_variants_are_bit_exact(env, expect):
+    """Short lists (< 2^20 sorted slots, packed keys, COUNTER discipline) take the bucket tail: block-local partition of the
+    spawns into key ranges + one annihilation kernel per range, no global sort.  SQMC_BUCKET=0 sends the same tests through
+    the radix tail; SQMC_BUCKET_FORCE_RETRY=3 makes every third bucket step behave as if a range did not fit its block's LDS:
+    it raises the retry flag and is re-run through the radix tail (the rollback of the host's bookkeeping, and the
+    pipelined head that must do nothing).  Trajectories, the annihilation door and the pipelined run must equal the oracle."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "(trajectory_bit_exact and not heg57 and not past_2_20) or annihilate_door_matches or run_loop_equals or gate_fused"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
