@@ -1023,7 +1023,8 @@ static void sys_move(const orc_sys *y, orc_rng *g, double tau, det_t u, det_t d,
 static int move_uniform2(const orc_sys *s, orc_walk *w, const orc_step_params *p, int64_t iw, int64_t *attempts) {
   int spawn, use_wt;
   if (fabs(w->wt[iw]) < p->always_spawn_cutoff_wt) {
-    orc_rng_seek(&w->rng, 0, (uint64_t)iw);
+    /* COUNTER discipline: the gate's draw is keyed by the determinant's rank in (up, dn) order, like the rounding draw */
+    orc_rng_seek(&w->rng, 0, w->key_norb ? orc_det_rank(w->key_norb, w->key_ndn, w->up[iw], w->dn[iw]) : (uint64_t)iw);
     spawn = (orc_rannyu(&w->rng) < fabs(w->wt[iw] / p->always_spawn_cutoff_wt)); use_wt = 0; w->n_spawn_draws++;
   } else { spawn = 1; use_wt = 1; }
   if (spawn) {
@@ -1075,7 +1076,7 @@ static int move_uniform2_mt(const orc_sys *s, orc_walk *w, const orc_step_params
   for (int64_t iw = 0; iw < n0; iw++) {
     int spawn, use_wt;
     if (fabs(w->wt[iw]) < p->always_spawn_cutoff_wt) {
-      orc_rng g = w->rng; orc_rng_seek(&g, 0, (uint64_t)iw);
+      orc_rng g = w->rng; orc_rng_seek(&g, 0, w->key_norb ? orc_det_rank(w->key_norb, w->key_ndn, w->up[iw], w->dn[iw]) : (uint64_t)iw);
       spawn = (orc_rannyu(&g) < fabs(w->wt[iw] / p->always_spawn_cutoff_wt)); use_wt = 0; gate_draws++;
     } else { spawn = 1; use_wt = 1; }
     long nc = 0; double wc = 0.0;

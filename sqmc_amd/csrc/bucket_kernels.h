@@ -24,65 +24,17 @@
 // the tail of that step through the radix path and keeps the bucket path off for a while.  COUNTER discipline, packed keys.
 #pragma once
 
-#define BK_T 256
-#define BK_CAP_S 2560                 // spawns of one bucket
-#define BK_CAP_R 1536                 // residents of one bucket
-#define BK_CAP_T 3584                 // both
-#define BK_CAP_ROWS 2560              // partition blocks (256 children each)
-#define BK_MAXB 1024
-#define BK_TARGET 1150                // slots per bucket the host aims at (B = nall / BK_TARGET, at most one block per CU while that holds)
-#define BK_STOP 0x80000000u           // in the merged-order array (source index: residents [0, R), sorted spawns [R, R + S)): this slot starts a run
-
-struct BucketArgs {
-  int B, nsb;                          // buckets, partition blocks
-  u64 *words;                          // nsb x 256 sort words of the children, grouped by bucket inside each block
-  unsigned short *segoff;              // nsb rows of B+1 group offsets
-  u64 *state; u32 *ticket;             // look-back over the buckets
-  int force_retry;                     // tests: behave as if a bucket did not fit
-};
-
-// ------------------------------------------------------------------------------------------------ partition
+// stand-alone: for spawn lists that did not come out of k_spawn (the annihilation door) or heads launched without it
 __global__ void __launch_bounds__(BK_T) k_bucket_partition(const u64 *__restrict__ keys, long long n0, long long nch, u64 invalid_key, BucketArgs ba) {
   __shared__ u32 spl[BK_MAXB];
   __shared__ u32 wcnt[BK_T / 64][BK_MAXB];
-  const int B = ba.B, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long long c = (long long)blockIdx.x * BK_T + tid;
+  const long long c = (long long)blockIdx.x * BK_T + threadIdx.x;
   u64 word = 0; u32 key = 0; bool valid = false;
   if (c < nch) word = keys[n0 + c];
-  for (int b = tid; b < B; b += BK_T) spl[b] = b ? (u32)(keys[((long long)b * n0) / B] >> 32) : 0u;      // first key of bucket b
-  for (int d = tid; d < (BK_T / 64) * BK_MAXB; d += BK_T) (&wcnt[0][0])[d] = 0;
+  bucket_partition_stage(spl, wcnt, keys, n0, ba.B);
   if (c < nch) { key = (u32)(word >> 32); valid = (u64)key != invalid_key; }
   __syncthreads();
-  int bkt = 0;
-  if (valid) {                         // the last bucket whose first key is <= key (bucket 0 starts at -infinity)
-    int lo = 0, hi = B;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (spl[mid] <= key) lo = mid; else hi = mid; }
-    bkt = lo;
-  }
-  // stable rank among the children of the block that go to the same bucket: ballots inside the wave, counters across waves
-  u64 same = __ballot(valid);
-  int nbit = 1; while ((1 << nbit) < B) nbit++;
-  for (int q = 0; q < nbit; q++) { const u64 m = __ballot((bkt >> q) & 1); same &= ((bkt >> q) & 1) ? m : ~m; }
-  const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const u32 rank = (u32)__popcll(same & lt);
-  if (valid && rank == 0) wcnt[wv][bkt] = (u32)__popcll(same);
-  __syncthreads();
-  // group offsets: exclusive scan over the buckets of the four waves' counts; wcnt becomes the base of each wave's share
-  constexpr int PER = BK_MAXB / BK_T;
-  u32 t4[PER]; u64 sum = 0;
-#pragma unroll
-  for (int q = 0; q < PER; q++) { const int b = tid * PER + q; u32 s = 0; if (b < B) for (int v = 0; v < BK_T / 64; v++) s += wcnt[v][b]; t4[q] = s; sum += s; }
-  u64 tot; u32 ex = (u32)block_excl_scan_u64(sum, &tot);
-  unsigned short *row = ba.segoff + (long long)blockIdx.x * (B + 1);
-#pragma unroll
-  for (int q = 0; q < PER; q++) {
-    const int b = tid * PER + q;
-    if (b < B) { row[b] = (unsigned short)ex; u32 a = ex; for (int v = 0; v < BK_T / 64; v++) { const u32 cn = wcnt[v][b]; wcnt[v][b] = a; a += cn; } }
-    ex += t4[q];
-  }
-  if (tid == 0) row[B] = (unsigned short)tot;
-  __syncthreads();
-  if (valid) ba.words[(long long)blockIdx.x * BK_T + wcnt[wv][bkt] + rank] = word;
+  bucket_partition_block(spl, wcnt, valid, key, word, (long long)blockIdx.x, ba);
 }
 
 // ------------------------------------------------------------------------------------------------ annihilation per bucket
@@ -102,21 +54,43 @@ __device__ __forceinline__ void bk_fold(double &wt, int &ini, int &d, double w2,
   if (!(d == 0 && d2 == -1)) wt = wt + w2;
 }
 
-__global__ void __launch_bounds__(BK_T) k_anneal_bucket(WalkArr w, WalkArr o, const u64 *__restrict__ rkeys, int *__restrict__ loc_imp,
-                                                        const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 hmask,
-                                                        const double *__restrict__ cnum, const double *__restrict__ cden,
-                                                        double *__restrict__ partials, double *__restrict__ wabs_part, long long n0, long long nch, StepP p,
-                                                        u64 invalid_key, u64 seed, u64 step, DevScalars *sc, BucketArgs ba, GateOut go) {
+// block-wide exclusive scan for the BK_AT threads of the annihilation kernel (total in every thread)
+#define BK_AT 512                      // threads of k_anneal_bucket: one block per CU, so the block itself has to keep the memory pipes busy
+__device__ __forceinline__ u64 bk_block_excl_scan(u64 v, u64 *total) {
+  __shared__ u64 wsum[BK_AT / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const u64 inc = wave_incl_scan_u64(v, lane);
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  u64 off = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < BK_AT / 64; i++) { if (i < wv) off += wsum[i]; tot += wsum[i]; }
+  __syncthreads();
+  *total = tot;
+  return off + inc - v;
+}
+// elements one thread handles per phase at the caps (loops are unrolled to these so that all loads of a phase are in flight)
+#define BK_PER_ROWS ((BK_CAP_ROWS + BK_AT - 1) / BK_AT)
+#define BK_PER_S ((BK_CAP_S + BK_AT - 1) / BK_AT)
+#define BK_PER_R ((BK_CAP_R + BK_AT - 1) / BK_AT)
+#define BK_PER_T ((BK_CAP_T + BK_AT - 1) / BK_AT)
+
+__global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, const u64 *__restrict__ rkeys, int *__restrict__ loc_imp,
+                                                         const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 hmask,
+                                                         const double *__restrict__ cnum, const double *__restrict__ cden,
+                                                         double *__restrict__ partials, double *__restrict__ wabs_part, long long n0, long long nch, StepP p,
+                                                         u64 invalid_key, u64 seed, u64 step, DevScalars *sc, BucketArgs ba, GateOut go) {
   // ---- LDS: the whole bucket lives here
   __shared__ u64 sw[BK_CAP_S], sw2[BK_CAP_S];            // sort words of the spawns (double buffer)
   __shared__ u32 rk[BK_CAP_R];                            // keys of the residents
   __shared__ double s_w[BK_CAP_T]; __shared__ u32 s_f[BK_CAP_T];   // weight / flags by SOURCE: residents [0, R), sorted spawns [R, R + S); later the merged walker of a run, at its head
   __shared__ u32 m2s[BK_CAP_T];                           // merged order -> source (| BK_STOP at the first slot of a run)
-  __shared__ unsigned short rnk[BK_CAP_T];               // sort: rank inside its digit; later: rank of a kept walker inside the bucket
-  __shared__ u32 scratch[(BK_T / 64) * 1024];             // rows of the gather (offset u16 + base u32), then the digit counters of the sort
-  __shared__ u32 s_tile; __shared__ u64 s_ex; __shared__ int s_over; __shared__ u32 s_kmin, s_kmax;
+  __shared__ unsigned short rnk[BK_CAP_T];               // sort: rank inside its digit; later: keep code of a merged slot
+  __shared__ u32 scratch[(BK_AT / 64) * 1024];            // rows of the gather (offset u16 + base u32), then the digit counters of the sort
+  __shared__ u32 s_tile; __shared__ u64 s_ex; __shared__ u32 s_kmin, s_kmax;
+  __shared__ double s_red[BK_AT / 64][NSTAT + 2];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) { s_tile = atomicAdd(ba.ticket, 1u); s_over = 0; }
+  if (tid == 0) s_tile = atomicAdd(ba.ticket, 1u);
   __syncthreads();
   const int b = (int)s_tile, B = ba.B, nsb = ba.nsb;
   const long long r_lo = ((long long)b * n0) / B, r_hi = ((long long)(b + 1) * n0) / B;
@@ -127,22 +101,26 @@ __global__ void __launch_bounds__(BK_T) k_anneal_bucket(WalkArr w, WalkArr o, co
   unsigned short *seg_lo = (unsigned short *)scratch; u32 *seg_base = scratch + (BK_CAP_ROWS / 2 + 4);     // u16 x ROWS, then u32 x (ROWS + 1)
   bool fits = nsb <= BK_CAP_ROWS && R <= BK_CAP_R;
   // ---- rows: where the bucket's children lie in every partition block.  Thread t owns rows [t C, (t+1) C): all loads first.
+  //      The residents' keys are requested in the same round trip.
+  u32 rk_reg[BK_PER_R];
+#pragma unroll
+  for (int q = 0; q < BK_PER_R; q++) { const int i = tid + q * BK_AT; rk_reg[q] = (fits && i < R) ? (u32)(rkeys[r_lo + i] >> 32) : 0u; }
   int S = 0;
   if (fits) {
-    const int C = (nsb + BK_T - 1) / BK_T;       // <= 10
-    unsigned short lo_[BK_CAP_ROWS / BK_T], hi_[BK_CAP_ROWS / BK_T];
+    const int C = (nsb + BK_AT - 1) / BK_AT;
+    unsigned short lo_[BK_PER_ROWS], hi_[BK_PER_ROWS];
 #pragma unroll
-    for (int q = 0; q < BK_CAP_ROWS / BK_T; q++) {
+    for (int q = 0; q < BK_PER_ROWS; q++) {
       const int t = tid * C + q;
       lo_[q] = 0; hi_[q] = 0;
       if (q < C && t < nsb) { const unsigned short *rp = ba.segoff + (long long)t * (B + 1) + b; lo_[q] = rp[0]; hi_[q] = rp[1]; }
     }
     u64 mine = 0;
 #pragma unroll
-    for (int q = 0; q < BK_CAP_ROWS / BK_T; q++) mine += (u64)(hi_[q] - lo_[q]);
-    u64 tot; u32 ex = (u32)block_excl_scan_u64(mine, &tot);
+    for (int q = 0; q < BK_PER_ROWS; q++) mine += (u64)(hi_[q] - lo_[q]);
+    u64 tot; u32 ex = (u32)bk_block_excl_scan(mine, &tot);
 #pragma unroll
-    for (int q = 0; q < BK_CAP_ROWS / BK_T; q++) {
+    for (int q = 0; q < BK_PER_ROWS; q++) {
       const int t = tid * C + q;
       if (q < C && t < nsb) { seg_lo[t] = lo_[q]; seg_base[t] = ex; ex += (u32)(hi_[q] - lo_[q]); }
     }
@@ -153,17 +131,29 @@ __global__ void __launch_bounds__(BK_T) k_anneal_bucket(WalkArr w, WalkArr o, co
   const int T = R + S;
   if (!fits) {
     // nothing was written that the radix path would miss; the look-back must still see this bucket
-    if (tid == 0) { atomicExch((int *)&sc->retry, 1); }
+    if (tid == 0) atomicExch((int *)&sc->retry, 1);
     if (tid < 64) lookback_exclusive(ba.state, (u32)b, 0ull, tid);
     return;
   }
+#pragma unroll
+  for (int q = 0; q < BK_PER_R; q++) { const int i = tid + q * BK_AT; if (i < R) rk[i] = rk_reg[q]; }
   __syncthreads();
-  // ---- gather: residents' keys (coalesced) and the children's sort words, partition block by partition block (= creation order)
-  for (int i = tid; i < R; i += BK_T) rk[i] = (u32)(rkeys[r_lo + i] >> 32);
-  for (int t = tid; t < nsb; t += BK_T) {
-    const u32 base = seg_base[t], cnt = seg_base[t + 1] - base;
-    const u64 *src = ba.words + (long long)t * BK_T + seg_lo[t];
-    for (u32 k = 0; k < cnt; k++) sw[base + k] = src[k];
+  // ---- gather the children's sort words, partition block by partition block (= creation order): word j of the bucket lies in
+  //      the row whose base is the last one <= j
+  {
+    u64 wv_[BK_PER_S];
+#pragma unroll
+    for (int q = 0; q < BK_PER_S; q++) {
+      const int j = tid + q * BK_AT;
+      wv_[q] = 0;
+      if (j < S) {
+        int lo = 0, hi = nsb;                        // seg_base[lo] <= j < seg_base[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg_base[mid] <= (u32)j) lo = mid; else hi = mid; }
+        wv_[q] = ba.words[(long long)lo * BK_T + seg_lo[lo] + ((u32)j - seg_base[lo])];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < BK_PER_S; q++) { const int j = tid + q * BK_AT; if (j < S) sw[j] = wv_[q]; }
   }
   __syncthreads();
   // ---- stable LDS radix sort of the spawn words on key - kmin
@@ -172,12 +162,12 @@ __global__ void __launch_bounds__(BK_T) k_anneal_bucket(WalkArr w, WalkArr o, co
     const u32 kmin = s_kmin, span = s_kmax - kmin;
     int nbits = 0; while (nbits < 32 && (span >> nbits)) nbits++;
     const int npass = (nbits + 9) / 10, dbits = npass ? (nbits + npass - 1) / npass : 0;
-    const int chunk = ((S + BK_T - 1) / BK_T) * 64;             // consecutive elements one wave ranks, in rounds of 64
+    const int chunk = ((S + BK_AT - 1) / BK_AT) * 64;             // consecutive elements one wave ranks, in rounds of 64
     u32(*wcnt)[1024] = (u32(*)[1024])scratch;
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int ps = 0, shift = 0; ps < npass && S > 1; ps++, shift += dbits) {
       const u32 mask = (1u << dbits) - 1u;
-      for (int d = tid; d < (BK_T / 64) * 1024; d += BK_T) scratch[d] = 0;
+      for (int d = tid; d < (BK_AT / 64) * 1024; d += BK_AT) scratch[d] = 0;
       __syncthreads();
       const int beg = wv * chunk, end = (beg + chunk < S) ? beg + chunk : S;
       for (int base = beg; base < end; base += 64) {
@@ -194,16 +184,16 @@ __global__ void __launch_bounds__(BK_T) k_anneal_bucket(WalkArr w, WalkArr o, co
         if (valid) rnk[idx] = (unsigned short)(prev + rank);
       }
       __syncthreads();
-      {   // digit bases: exclusive scan over the digits of the waves' counts
-        u32 t4[4]; u64 sum = 0;
+      {   // digit bases: exclusive scan over the digits of the waves' counts (two digits per thread)
+        u32 t2[2]; u64 sum = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int d = tid * 4 + q; u32 s = 0; for (int v = 0; v < BK_T / 64; v++) s += wcnt[v][d]; t4[q] = s; sum += s; }
-        u64 tt; u32 ex = (u32)block_excl_scan_u64(sum, &tt);
+        for (int q = 0; q < 2; q++) { const int d = tid * 2 + q; u32 s2 = 0; for (int v = 0; v < BK_AT / 64; v++) s2 += wcnt[v][d]; t2[q] = s2; sum += s2; }
+        u64 tt; u32 ex = (u32)bk_block_excl_scan(sum, &tt);
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int d = tid * 4 + q; u32 a = ex; for (int v = 0; v < BK_T / 64; v++) { const u32 cn = wcnt[v][d]; wcnt[v][d] = a; a += cn; } ex += t4[q]; }
+        for (int q = 0; q < 2; q++) { const int d = tid * 2 + q; u32 a = ex; for (int v = 0; v < BK_AT / 64; v++) { const u32 cn = wcnt[v][d]; wcnt[v][d] = a; a += cn; } ex += t2[q]; }
       }
       __syncthreads();
-      for (int idx = tid; idx < S; idx += BK_T) {
+      for (int idx = tid; idx < S; idx += BK_AT) {
         const u64 x = sa[idx];
         const u32 dig = ((((u32)(x >> 32)) - kmin) >> shift) & mask;
         sb[wcnt[idx / chunk][dig] + rnk[idx]] = x;
@@ -212,23 +202,30 @@ __global__ void __launch_bounds__(BK_T) k_anneal_bucket(WalkArr w, WalkArr o, co
       u64 *tp = sa; sa = sb; sb = tp;
     }
   }
-  // ---- records by source (all loads independent of the searches below); sums over the pre-merge list (do_walk.f90:2347-2349)
+  // ---- records by source, all requested before any is used; sums over the pre-merge list (do_walk.f90:2347-2349)
   double wabs = 0.0, cnt = 0.0;
-  for (int i = tid; i < R; i += BK_T) { const double x = w.wt[r_lo + i]; s_w[i] = x; s_f[i] = w.flg[r_lo + i]; wabs += fabs(x); cnt += 1.0; }
-  for (int j = tid; j < S; j += BK_T) {
-    const long long cidx = (long long)(u32)sa[j] - n0;                    // the word's low half is the walker slot n0 + child
-    const SpawnRec *rp = w.sp + cidx;
-    const double x = rp->wt; const u32 f = (u32)rp->flg;
-    s_w[R + j] = x; s_f[R + j] = f; wabs += fabs(x); cnt += 1.0;
+  {
+    double rw[BK_PER_R]; u32 rf[BK_PER_R]; double sw_[BK_PER_S]; u64 sf_[BK_PER_S];
+#pragma unroll
+    for (int q = 0; q < BK_PER_R; q++) { const int i = tid + q * BK_AT; rw[q] = 0.0; rf[q] = 0; if (i < R) { rw[q] = w.wt[r_lo + i]; rf[q] = w.flg[r_lo + i]; } }
+#pragma unroll
+    for (int q = 0; q < BK_PER_S; q++) {
+      const int j = tid + q * BK_AT; sw_[q] = 0.0; sf_[q] = 0;
+      if (j < S) { const SpawnRec *rp = w.sp + ((long long)(u32)sa[j] - n0); sw_[q] = rp->wt; sf_[q] = rp->flg; }     // the word's low half is the walker slot n0 + child
+    }
+#pragma unroll
+    for (int q = 0; q < BK_PER_R; q++) { const int i = tid + q * BK_AT; if (i < R) { s_w[i] = rw[q]; s_f[i] = rf[q]; wabs += fabs(rw[q]); cnt += 1.0; } }
+#pragma unroll
+    for (int q = 0; q < BK_PER_S; q++) { const int j = tid + q * BK_AT; if (j < S) { s_w[R + j] = sw_[q]; s_f[R + j] = (u32)sf_[q]; wabs += fabs(sw_[q]); cnt += 1.0; } }
   }
   // ---- merged order: a resident goes behind the spawns with smaller keys, a spawn behind the residents with keys <= its own
-  for (int i = tid; i < R; i += BK_T) {
+  for (int i = tid; i < R; i += BK_AT) {
     const u32 k = rk[i];
     int lo = 0, hi = S;                                                    // spawns with key < k
     while (lo < hi) { const int mid = (lo + hi) >> 1; if ((u32)(sa[mid] >> 32) < k) lo = mid + 1; else hi = mid; }
     m2s[i + lo] = BK_STOP | (u32)i;
   }
-  for (int j = tid; j < S; j += BK_T) {
+  for (int j = tid; j < S; j += BK_AT) {
     const u32 k = (u32)(sa[j] >> 32);
     int lo = 0, hi = R;                                                    // residents with key <= k
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (rk[mid] <= k) lo = mid + 1; else hi = mid; }
@@ -237,10 +234,9 @@ __global__ void __launch_bounds__(BK_T) k_anneal_bucket(WalkArr w, WalkArr o, co
     m2s[j + lo] = (head ? BK_STOP : 0u) | (u32)(R + j);
   }
   __syncthreads();
-  store_wabs(wabs_part, b, wabs, cnt);
   // ---- runs: the head folds its followers in merged order, then check_initiator, the discard rule and the rounding;
   //      the merged walker stays at the head's source slot (weight, packed flags); rnk[q] = 1 kept, 0x101 kept in the deterministic space
-  for (int q = tid; q < T; q += BK_T) {
+  for (int q = tid; q < T; q += BK_AT) {
     const u32 e = m2s[q];
     unsigned short keep = 0;
     if (e & BK_STOP) {
@@ -278,10 +274,10 @@ __global__ void __launch_bounds__(BK_T) k_anneal_bucket(WalkArr w, WalkArr o, co
   u32 *s_rank = (u32 *)sb;                              // the idle sort buffer
   u64 ex_glob;
   {
-    const int C = (T + BK_T - 1) / BK_T, beg = tid * C, end = (beg + C < T) ? beg + C : T;
+    const int C = (T + BK_AT - 1) / BK_AT, beg = tid * C, end = (beg + C < T) ? beg + C : T;
     u64 mine = 0;
     for (int q = beg; q < end; q++) { const unsigned short k = rnk[q]; mine += (u64)(k & 1) | ((u64)(k >> 8) << 32); }
-    u64 tot; u64 ex = block_excl_scan_u64(mine, &tot);
+    u64 tot; u64 ex = bk_block_excl_scan(mine, &tot);
     for (int q = beg; q < end; q++) {
       const unsigned short k = rnk[q];
       if (k & 1) { s_rank[q] = (u32)(ex & 0xFFFFull) | ((u32)(ex >> 32) << 16); ex += (u64)1 | ((u64)(k >> 8) << 32); }
@@ -294,56 +290,71 @@ __global__ void __launch_bounds__(BK_T) k_anneal_bucket(WalkArr w, WalkArr o, co
     __syncthreads();
     ex_glob = s_ex;
   }
-  // ---- compaction into the other buffer, reweighting (2487), estimator pieces (2573-2684, more_tools.f90:4041-4098), next gate
+  // ---- compaction into the other buffer, reweighting (2487), estimator pieces (2573-2684, more_tools.f90:4041-4098), next gate.
+  //      Two slots per thread and round: their loads (record, then C(T) probe) are in flight together.
   double st[NSTAT];
 #pragma unroll
   for (int k = 0; k < NSTAT; k++) st[k] = 0.0;
-  for (int q = tid; q < T; q += BK_T) {
-    const u32 r = s_rank[q];
-    if (r == 0xFFFFFFFFu) continue;
-    const int si = (int)(m2s[q] & ~BK_STOP);
-    const long long q0 = (long long)(ex_glob & 0xFFFFFFFFull) + (long long)(r & 0xFFFFu);
-    const long long qd = (long long)(ex_glob >> 32) + (long long)(r >> 16);
-    u64 up, dn, key; double me = 1e51, en = 1e51, ed = 1e51;
-    if (si < R) { const long long ix = r_lo + si; up = w.up[ix]; dn = w.dn[ix]; me = w.me[ix]; en = w.en[ix]; ed = w.ed[ix]; key = rk[si]; }
-    else { const u64 x = sa[si - R]; const SpawnRec *rp = w.sp + ((long long)(u32)x - n0); up = rp->up; dn = rp->dn; key = x >> 32; }
-    const double wt = s_w[si] * p.rfi;
-    const u32 fl = s_f[si];
-    const int d = flg_impd(fl), ini = flg_init(fl), psg = flg_psign(fl);
-    if (en > 1e50) {
-      const long long h = ct_lookup(hkey, hidx, hmask, key);
-      if (h < 0) { en = 0.0; ed = 0.0; } else { en = cnum[h]; ed = cden[h]; }
+  constexpr int CB = 2;
+  for (int q0b = tid; q0b < T; q0b += CB * BK_AT) {
+    int si_[CB]; u32 r_[CB]; u64 up_[CB], dn_[CB], key_[CB]; double me_[CB], en_[CB], ed_[CB]; long long hh_[CB];
+#pragma unroll
+    for (int z = 0; z < CB; z++) {
+      const int q = q0b + z * BK_AT;
+      r_[z] = (q < T) ? s_rank[q] : 0xFFFFFFFFu;
+      si_[z] = 0; up_[z] = 0; dn_[z] = 0; key_[z] = 0; me_[z] = 1e51; en_[z] = 1e51; ed_[z] = 1e51; hh_[z] = -2;
+      if (r_[z] != 0xFFFFFFFFu) {
+        const int si = (int)(m2s[q] & ~BK_STOP); si_[z] = si;
+        if (si < R) { const long long ix = r_lo + si; up_[z] = w.up[ix]; dn_[z] = w.dn[ix]; me_[z] = w.me[ix]; en_[z] = w.en[ix]; ed_[z] = w.ed[ix]; key_[z] = rk[si]; }
+        else { const u64 x = sa[si - R]; const SpawnRec *rp = w.sp + ((long long)(u32)x - n0); up_[z] = rp->up; dn_[z] = rp->dn; key_[z] = x >> 32; }
+      }
     }
-    o.up[q0] = up; o.dn[q0] = dn; o.wt[q0] = wt; o.flg[q0] = fl;
-    o.me[q0] = me; o.en[q0] = en; o.ed[q0] = ed;
-    if (go.on) {
-      u64 nc; double wc;
-      gate_children(wt, go.cutoff, seed, go.step_next, (u64)q0, nc, wc);
-      go.keys[q0] = (key << 32) | (u64)q0; go.nchild[q0] = nc; go.wchild[q0] = wc;
-    }
-    if (d == 0 && p.semi && qd < p.nimp_cap) loc_imp[qd] = (int)q0;
-    st[0] += wt; st[1] += fabs(wt); st[8] += wt * wt;
-    if (ini == 3) st[4] += wt * psg;
-    if (d == 0 || (d == -2 && p.cti)) st[6] += fabs(wt);
-    double e_num = en * wt, e_den = ed * wt;
-    if (e_num != 0.0) {
-      if (fabs(e_den) < 1e-22) e_den = fabs(e_den);
-      st[2] += e_den; st[3] += e_num; st[9] += e_num * e_num; st[10] += e_den * e_den;
-      st[11] += e_num * copysign(1.0, e_den); st[12] += fabs(e_den); st[5] += e_num * e_den;
+#pragma unroll
+    for (int z = 0; z < CB; z++) if (r_[z] != 0xFFFFFFFFu && en_[z] > 1e50) hh_[z] = ct_lookup(hkey, hidx, hmask, key_[z]);
+#pragma unroll
+    for (int z = 0; z < CB; z++) if (hh_[z] != -2) { if (hh_[z] < 0) { en_[z] = 0.0; ed_[z] = 0.0; } else { en_[z] = cnum[hh_[z]]; ed_[z] = cden[hh_[z]]; } }
+#pragma unroll
+    for (int z = 0; z < CB; z++) {
+      if (r_[z] == 0xFFFFFFFFu) continue;
+      const int si = si_[z];
+      const long long q0 = (long long)(ex_glob & 0xFFFFFFFFull) + (long long)(r_[z] & 0xFFFFu);
+      const long long qd = (long long)(ex_glob >> 32) + (long long)(r_[z] >> 16);
+      const double wt = s_w[si] * p.rfi;
+      const u32 fl = s_f[si];
+      const int d = flg_impd(fl), ini = flg_init(fl), psg = flg_psign(fl);
+      const double en = en_[z], ed = ed_[z];
+      o.up[q0] = up_[z]; o.dn[q0] = dn_[z]; o.wt[q0] = wt; o.flg[q0] = fl;
+      o.me[q0] = me_[z]; o.en[q0] = en; o.ed[q0] = ed;
+      if (go.on) {
+        u64 nc; double wc;
+        gate_children(wt, go.cutoff, seed, go.step_next, key_[z], nc, wc);
+        go.keys[q0] = (key_[z] << 32) | (u64)q0; go.nchild[q0] = nc; go.wchild[q0] = wc;
+      }
+      if (d == 0 && p.semi && qd < p.nimp_cap) loc_imp[qd] = (int)q0;
+      st[0] += wt; st[1] += fabs(wt); st[8] += wt * wt;
+      if (ini == 3) st[4] += wt * psg;
+      if (d == 0 || (d == -2 && p.cti)) st[6] += fabs(wt);
+      double e_num = en * wt, e_den = ed * wt;
+      if (e_num != 0.0) {
+        if (fabs(e_den) < 1e-22) e_den = fabs(e_den);
+        st[2] += e_den; st[3] += e_num; st[9] += e_num * e_num; st[10] += e_den * e_den;
+        st[11] += e_num * copysign(1.0, e_den); st[12] += fabs(e_den); st[5] += e_num * e_den;
+      }
     }
   }
-  __shared__ double red[BK_T / 64][NSTAT];
+  // block sums: the 13 estimator pieces and the two pre-merge sums
 #pragma unroll
-  for (int k = 0; k < NSTAT; k++) {
-    double v = st[k];
+  for (int k = 0; k < NSTAT + 2; k++) {
+    double v = (k < NSTAT) ? st[k] : (k == NSTAT ? wabs : cnt);
     for (int q = 32; q > 0; q >>= 1) v += __shfl_down(v, q, 64);
-    if (lane == 0) red[wv][k] = v;
+    if (lane == 0) s_red[wv][k] = v;
   }
   __syncthreads();
-  if (tid < NSTAT) {
+  if (tid < NSTAT + 2) {
     double v = 0.0;
-    for (int q = 0; q < BK_T / 64; q++) v += red[q][tid];
-    partials[(long long)b * NSTAT + tid] = v;
+    for (int q = 0; q < BK_AT / 64; q++) v += s_red[q][tid];
+    if (tid < NSTAT) partials[(long long)b * NSTAT + tid] = v;
+    else wabs_part[2 * b + (tid - NSTAT)] = v;
   }
   // how full the fullest bucket was (per mille of the caps): the host keeps the bucket path off while the head-room is thin
   if (tid == 0) { const int fs = (1000 * S) / BK_CAP_S, ft = (1000 * T) / BK_CAP_T; atomicMax((unsigned int *)&sc->bk_fill, (unsigned int)(fs > ft ? fs : ft)); }

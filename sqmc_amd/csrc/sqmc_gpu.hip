@@ -31,6 +31,7 @@
 #include "../../include/sqmc_gpu.h"
 #include "chem_device.h"
 #include "scan_sort.h"
+#include "bucket_partition.h"
 
 #define TPB 256
 #define SPAWN_WIN 1024
@@ -151,6 +152,7 @@ struct sqmc_gpu_ctx {
   int scan_flip, scan_used[2];   // gate-fused heads: look-back set of the next head scan, and how many words of each set its last scan may have touched
   bool residents_sorted;      // the walker arrays are known to be in (up, dn) order: true after every finished step and after an upload (which refuses unsorted lists)
   unsigned short *d_segoff; long long segoff_cap;      // bucket tail: group offsets of the partition blocks
+  BucketArgs head_ba; long long last_nall;      // partition already done by the head's k_spawn (B > 0), and the length of the last sorted list (sizes the next one)
   int bk_holdoff;             // steps for which the bucket tail stays off (after a bucket overflowed or came close)
   long long bk_steps, bk_retries;
 };
@@ -563,6 +565,18 @@ static OwnerOut shard_owner_out(sqmc_gpu_ctx *c) {
 // only an upper bound that sizes the grids: the pipelined launch behind k_finish of the previous
 // step, before the host has read that step's sums.  g0/g1 and s0/s1 (may be null) time gate+scan
 // and k_spawn; the child count goes to the host mailbox under sequence number *cseq.
+// what does not change from step to step about the short-list (bucket) tail
+static inline bool bucket_static_ok(const sqmc_gpu_ctx *c, const StepP &p) {
+  static const int bucket_env = getenv("SQMC_ANNEAL_ITEMS") ? 0 : (getenv("SQMC_BUCKET") ? atoi(getenv("SQMC_BUCKET")) : 1);      // a forced tile shape asks for the radix tail's kernel
+  return bucket_env && c->pack && p.semi && c->rng_mode == SQMC_RNG_COUNTER && !c->d_grow && c->comm == nullptr;
+}
+static inline long long bucket_count(long long nall) {
+  static const long long bk_target = getenv("SQMC_BUCKET_TARGET") ? atoll(getenv("SQMC_BUCKET_TARGET")) : BK_TARGET;
+  long long B = (nall + bk_target - 1) / bk_target;
+  // one block per CU (its LDS is the bucket): up to 256 blocks run at once; a few blocks more would wait for a whole second round
+  if (B > 256 && nall <= 256 * (long long)(bk_target + bk_target / 4)) B = 256;
+  return B < 1 ? 1 : (B > BK_MAXB ? BK_MAXB : B);
+}
 static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0, bool dev_n, hipEvent_t g0, hipEvent_t g1, hipEvent_t s0, hipEvent_t s1, u64 *cseq,
                         const FinArgs *fin = nullptr, bool gate_done = false) {
   hipStream_t st = c->st;
@@ -594,14 +608,31 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   HIPCHK(hipEventRecord(c->e_fork, st));
   *cseq = ++c->cnt_seq;
   const OwnerOut oo = shard_owner_out(c);
+  // short lists: k_spawn groups its children by key range as it emits them (the bucket tail then needs no partition kernel).
+  // The list's length is not known yet: the last step's sizes it; the tail checks that everything fitted before it relies on it.
+  BucketArgs hb; memset(&hb, 0, sizeof(hb));
+  {
+    static const long long merge_min = getenv("SQMC_MERGE_SORT_MIN") ? atoll(getenv("SQMC_MERGE_SORT_MIN")) : (1ll << 20);
+    static const bool no_fuse = getenv("SQMC_BUCKET_NO_SPAWN_FUSION") != nullptr;
+    const long long n_known = dev_n ? c->nwalk : n0;                   // dev_n: the walkers of the step that is finishing, not of this one -- close
+    const long long est = c->last_nall > 0 ? c->last_nall : 0;
+    if (!no_fuse && bucket_static_ok(c, p) && c->residents_sorted && c->bk_holdoff == 0 && est > 0 && est < merge_min && est < (1ll << 20) && n_known >= 256) {
+      long long B = bucket_count(est); if (B > n_known / 2) B = n_known / 2;
+      if (B >= 1) {
+        hb.B = (int)B; hb.words = c->d_flags; hb.segoff = c->d_segoff; hb.state = c->d_fstate; hb.ticket = c->d_fticket;
+        hb.nsb = (int)std::min<long long>(std::min<long long>(c->segoff_cap / (B + 1), M / BK_T), BK_CAP_ROWS);      // rows there is room for
+      }
+    }
+    c->head_ba = hb;
+  }
   const long long nfree = dev_n ? M : M - n0;          // dev_n: nothing is known about the count but that it is >= 0
   if (nfree > 0) {
     if (s0)
-      hipExtLaunchKernelGGL(k_spawn, dim3(nblk(nfree)), dim3(TPB), 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo);
+      hipExtLaunchKernelGGL(k_spawn, dim3(nblk(nfree)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
+                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb);
     else
-      hipLaunchKernelGGL(k_spawn, dim3(nblk(nfree)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo);
+      hipLaunchKernelGGL(k_spawn, dim3(nblk(nfree)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb);
   } else if (s0) { hipEventRecord(s0, st); hipEventRecord(s1, st); }
   HIPCHK(hipGetLastError());
   return SQMC_OK;
@@ -635,25 +666,27 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
   // Short lists (the launch-bound regime): no global sort at all.  The spawns are partitioned block-locally into B key
   // ranges whose splitters are resident walkers (sorted since the last step), and one block per range sorts, merges and
   // annihilates its share in LDS (bucket_kernels.h).  Needs packed keys, the COUNTER discipline, ordered residents.
-  static const int bucket_env = getenv("SQMC_BUCKET") ? atoi(getenv("SQMC_BUCKET")) : 1;
   static const long long bucket_max = getenv("SQMC_BUCKET_MAX") ? atoll(getenv("SQMC_BUCKET_MAX")) : (1ll << 20);
   BucketArgs ba; memset(&ba, 0, sizeof(ba));
   bool bucket = false;
-  if (allow_bucket && bucket_env && c->pack && p.semi && mode == SQMC_RNG_COUNTER && c->residents_sorted && !c->d_grow && c->comm == nullptr &&
-      nall > n0 && nall < bucket_max && nall < merge_min && n0 >= 64) {
+  const BucketArgs head_ba = c->head_ba; c->head_ba.B = 0;             // consumed (or ignored) by this tail
+  c->last_nall = nall;
+  if (allow_bucket && bucket_static_ok(c, p) && c->residents_sorted && nall > n0 && nall < bucket_max && nall < merge_min && n0 >= 64) {
     if (c->bk_holdoff > 0) c->bk_holdoff--;
     else {
-      const long long nch = nall - n0;
-      static const long long bk_target = getenv("SQMC_BUCKET_TARGET") ? atoll(getenv("SQMC_BUCKET_TARGET")) : BK_TARGET;     // tests: huge targets make buckets overflow
-      long long B = (nall + bk_target - 1) / bk_target; if (B > BK_MAXB) B = BK_MAXB; if (B > n0) B = n0; if (B < 1) B = 1;
-      const long long nsb = (nch + BK_T - 1) / BK_T;
-      if (nsb <= BK_CAP_ROWS && (n0 + B - 1) / B <= BK_CAP_R && nsb * (B + 1) <= c->segoff_cap) {
-        bucket = true;
-        static const int force_every = getenv("SQMC_BUCKET_FORCE_RETRY") ? atoi(getenv("SQMC_BUCKET_FORCE_RETRY")) : 0;      // tests: every n-th bucket step gives up
-        ba.force_retry = (force_every > 0 && (c->bk_steps % force_every) == force_every - 1) ? 1 : 0;
-        ba.B = (int)B; ba.nsb = (int)nsb; ba.words = c->d_flags; ba.segoff = c->d_segoff; ba.state = c->d_fstate; ba.ticket = c->d_fticket;
-        hipLaunchKernelGGL(k_bucket_partition, dim3((unsigned)nsb), dim3(BK_T), 0, st, (const u64 *)c->d_keys, n0, nch, c->invalid_key, ba);
+      const long long nch = nall - n0, nsb = (nch + BK_T - 1) / BK_T;
+      static const int force_every = getenv("SQMC_BUCKET_FORCE_RETRY") ? atoi(getenv("SQMC_BUCKET_FORCE_RETRY")) : 0;      // tests: every n-th bucket step gives up
+      if (head_ba.B > 0 && head_ba.B <= n0 && nsb <= head_ba.nsb && (n0 + head_ba.B - 1) / head_ba.B <= BK_CAP_R) {
+        bucket = true; ba = head_ba; ba.nsb = (int)nsb;                  // k_spawn partitioned its children already
+      } else {
+        long long B = bucket_count(nall); if (B > n0) B = n0;
+        if (nsb <= BK_CAP_ROWS && (n0 + B - 1) / B <= BK_CAP_R && nsb * (B + 1) <= c->segoff_cap && nsb * BK_T <= M) {
+          bucket = true;
+          ba.B = (int)B; ba.nsb = (int)nsb; ba.words = c->d_flags; ba.segoff = c->d_segoff; ba.state = c->d_fstate; ba.ticket = c->d_fticket;
+          hipLaunchKernelGGL(k_bucket_partition, dim3((unsigned)nsb), dim3(BK_T), 0, st, (const u64 *)c->d_keys, n0, nch, c->invalid_key, ba);
+        }
       }
+      if (bucket) ba.force_retry = (force_every > 0 && (c->bk_steps % force_every) == force_every - 1) ? 1 : 0;
     }
   }
   if (bucket) {
@@ -708,8 +741,8 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     if (bucket) {
 #define BUCKET_ARGS c->w, c->m, (const u64 *)c->d_keys, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, \
                     n0, nall - n0, p, c->invalid_key, seed, step, c->d_sc, ba, go
-      if (t_anneal >= 0) hipExtLaunchKernelGGL(k_anneal_bucket, dim3(nb), dim3(BK_T), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, BUCKET_ARGS);
-      else hipLaunchKernelGGL(k_anneal_bucket, dim3(nb), dim3(BK_T), 0, st, BUCKET_ARGS);
+      if (t_anneal >= 0) hipExtLaunchKernelGGL(k_anneal_bucket, dim3(nb), dim3(BK_AT), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, BUCKET_ARGS);
+      else hipLaunchKernelGGL(k_anneal_bucket, dim3(nb), dim3(BK_AT), 0, st, BUCKET_ARGS);
 #undef BUCKET_ARGS
       c->bk_steps++;
     } else if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 3) ANNEAL_LAUNCH(3); else ANNEAL_LAUNCH(4);
@@ -788,10 +821,10 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed);
       if (fuse_gate) std::swap(c->d_keys, c->d_keys_alt);
       c->pipeline_next = false; c->bk_retries++;
-      { static const int hold = getenv("SQMC_BUCKET_HOLDOFF") ? atoi(getenv("SQMC_BUCKET_HOLDOFF")) : 64; c->bk_holdoff = hold; }
+      { static const int hold = getenv("SQMC_BUCKET_HOLDOFF") ? atoi(getenv("SQMC_BUCKET_HOLDOFF")) : 8; c->bk_holdoff = hold; }
       return SQMC_INTERNAL_RETRY;
     }
-    if (c->h_sc->bk_fill > 800) c->bk_holdoff = 16;        // thin head-room: radix tail for a while
+    if (c->h_sc->bk_fill > 850) c->bk_holdoff = 4;         // thin head-room: radix tail for a few steps
   }
   c->timers_pending = kernel_events_on(c, step);
   c->step_no++;
@@ -857,10 +890,10 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     if (M > n0) {
       if (t_spawn >= 0)
         hipExtLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->ev0[t_spawn], c->ev1[t_spawn], 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0});
+                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{});
       else
         hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0});
+                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{});
     } else if (t_spawn >= 0) { hipEventRecord(c->ev0[t_spawn], st); hipEventRecord(c->ev1[t_spawn], st); }
   } else {
     int r = enqueue_head(c, p, step, n0, false, t_gate_scan >= 0 ? c->ev0[t_gate_scan] : nullptr, t_gate_scan >= 0 ? c->ev1[t_gate_scan] : nullptr,

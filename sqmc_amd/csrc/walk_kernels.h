@@ -14,7 +14,8 @@ struct FinArgs {
   long long expect_nimp;  // >= 0: deterministic-space walkers this rank must still hold; anything else raises SQMC_ERR_IMP_BROKEN on the device (sharded steps: the status is all-reduced)
 };
 __device__ void finish_all(const FinArgs &f, DevScalars *sc);
-// spawn gate and child count of one walker (COUNTER discipline: the draw is keyed by step and walker index).  do_walk.f90:3577-3589
+// spawn gate and child count of one walker (COUNTER discipline: the draw is keyed by step and the determinant's rank in
+// (up, dn) order = its sort key `i`, so that it can be taken before the walker's position in the new list is known).  do_walk.f90:3577-3589
 __device__ __forceinline__ void gate_children(double w, double cutoff, u64 seed, u64 step, u64 i, u64 &nchild, double &wchild) {
   bool spawn, use_wt;
   if (fabs(w) < cutoff) {
@@ -41,9 +42,10 @@ __global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict
   if (n_on_device && sc->retry) return;                                // pipelined head of a step whose predecessor's bucket tail gave up: the host re-runs that tail first
   if (i == 0) { sc->n_invalid = 0; sc->tot1 = 0; sc->tot2 = 0; sc->err = 0; }   // every writer of these runs after this kernel
   if (i >= n) return;
-  put_key(keys, vals, i, det_key(dev, up[i], dn[i]), pack);      // sort key of the walker itself
+  const u64 kk = det_key(dev, up[i], dn[i]);
+  put_key(keys, vals, i, kk, pack);      // sort key of the walker itself
   u64 nc; double wc;
-  gate_children(wt[i], p.cutoff, seed, step, (u64)i, nc, wc);
+  gate_children(wt[i], p.cutoff, seed, step, kk, nc, wc);
   nchild[i] = nc; wchild[i] = wc;
 }
 
@@ -172,8 +174,8 @@ __host__ __device__ __forceinline__ int det_owner_any(int mode, u64 key, u64 up,
 // sharded steps: k_spawn also notes the destination rank of every child (nranks for a child that made no walker), the key of the bucketing pass
 struct OwnerOut { u64 *okey; u32 *oval; int nranks; int mode; };      // okey == nullptr: off
 // a spawned walker (or the "no walker" marker) into slot n0 + c.  do_walk.f90:3700-3731
-__device__ __forceinline__ void spawn_emit(const ChemDev &dev, const WalkArr &w, u64 *__restrict__ keys, u32 *__restrict__ vals, long long n0, long long c,
-                                           u32 pf, u64 ju, u64 jd, double wj, const StepP &p, u64 invalid_key, int pack, const OwnerOut &oo) {
+__device__ __forceinline__ u64 spawn_emit(const ChemDev &dev, const WalkArr &w, u64 *__restrict__ keys, u32 *__restrict__ vals, long long n0, long long c,
+                                          u32 pf, u64 ju, u64 jd, double wj, const StepP &p, u64 invalid_key, int pack, const OwnerOut &oo) {
   const long long k = n0 + c;
   if (wj != 0.0) {
     const int pd = flg_impd(pf), pi = flg_init(pf);
@@ -190,9 +192,11 @@ __device__ __forceinline__ void spawn_emit(const ChemDev &dev, const WalkArr &w,
     const u64 key = det_key(dev, ju, jd);
     put_key(keys, vals, k, key, pack);
     if (oo.okey) { oo.okey[c] = (u64)det_owner_any(oo.mode, key, ju, jd, oo.nranks); oo.oval[c] = (u32)c; }
+    return key;
   } else {
     w.sp[c].wt = 0.0; put_key(keys, vals, k, invalid_key, pack);     // sorts behind every real determinant
     if (oo.okey) { oo.okey[c] = (u64)oo.nranks; oo.oval[c] = (u32)c; }
+    return invalid_key;
   }
 }
 
@@ -207,7 +211,7 @@ extern "C" int sqmc_gpu_debug_prof(unsigned long long *out) { return (int)hipMem
 __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
                                                const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
                                                long long n0_arg, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc,
-                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo) {
+                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo, BucketArgs ba) {
   if (n_on_device && sc->retry) return;                                 // see k_gate
   const long long n0 = n_on_device ? (long long)sc->nwalk : n0_arg;     // pipelined head: launched before the host learnt the walker count
   // the grid covers the free capacity of the walker arrays; the number of children is read from
@@ -215,6 +219,9 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   PROF(0);
   __shared__ ChemTab t;
   __shared__ u64 s_win[SPAWN_WIN];
+  // short lists (ba.B > 0): the block also groups its children by key range for the bucket tail (bucket_kernels.h)
+  extern __shared__ u32 s_part[];      // BK_PART_LDS bytes when the launch partitions, none otherwise (large populations keep their occupancy)
+  u32 *s_spl = s_part; u32 (*s_wcnt)[BK_MAXB] = (u32 (*)[BK_MAXB])(s_part + BK_MAXB);
   // Parent of child c = largest i with child_off[i] <= c.  The 256 children of a block have
   // neighbouring parents, so the block narrows [0,n0) for its first child with 256-way splits
   // (one round trip per level instead of log2(n0) dependent loads), then every thread finishes
@@ -233,6 +240,8 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
     mail->n_children = (u64)nchildren; __threadfence_system(); mail->cnt_seq = cnt_seq;
   }
   if (c0 >= nchildren || n0 + nchildren > cap_all) return;
+  const bool part = ba.B > 0 && (int)blockIdx.x < ba.nsb;                  // rows beyond the room the host provided: the tail will see that and use its own partition
+  if (part) bucket_partition_stage(s_spl, s_wcnt, keys, n0, ba.B);     // resident keys [0, n0) of the same array the children's keys go to; a barrier follows below
   PROF(1);
   while (whi - wlo > SPAWN_WIN) {
     const long long stepw = (whi - wlo + TPB - 1) / TPB, probe = wlo + (long long)threadIdx.x * stepw;
@@ -253,6 +262,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   PROF(2);
   const long long c = c0 + threadIdx.x;
   const bool active = c < nchildren;
+  u64 ckey = invalid_key;
   if (active) {
     long long ip;
     if (s_win[SPAWN_WIN - 1] <= (u64)c) {                 // beyond the window (many childless parents in between)
@@ -277,8 +287,9 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
       wj = proposal_weight(t, dev.integrals, p.tau, iu, id, ju, jd, level, prob);
       wj = wch * wj;
     }
-    spawn_emit(dev, w, keys, vals, n0, c, pflg, ju, jd, wj, p, invalid_key, pack, oo);
+    ckey = spawn_emit(dev, w, keys, vals, n0, c, pflg, ju, jd, wj, p, invalid_key, pack, oo);
   }
+  if (part) bucket_partition_block(s_spl, s_wcnt, active && ckey != invalid_key, (u32)ckey, (ckey << 32) | (u64)(n0 + c), (long long)blockIdx.x, ba);
   PROF(5);
 }
 
@@ -821,7 +832,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     o.me[q0] = me; o.en[q0] = en; o.ed[q0] = ed;
     if (go.on) {
       u64 nc; double wc;
-      gate_children(wt, go.cutoff, seed, go.step_next, (u64)q0, nc, wc);
+      gate_children(wt, go.cutoff, seed, go.step_next, key[k], nc, wc);
       go.keys[q0] = (key[k] << 32) | (u64)q0; go.nchild[q0] = nc; go.wchild[q0] = wc;
     }
     if (d == 0 && p.semi && (long long)(ex2 >> 32) < p.nimp_cap) loc_imp[ex2 >> 32] = (int)q0;
