@@ -54,6 +54,14 @@ __device__ __forceinline__ void bk_fold(double &wt, int &ini, int &d, double w2,
   if (!(d == 0 && d2 == -1)) wt = wt + w2;
 }
 
+#ifdef BUCKET_PROF
+// build with -DBUCKET_PROF (tools/bucket_prof.py): wall-clock stamps (100 MHz) of every bucket at the phase boundaries
+__device__ unsigned long long g_bprof[16 * 1024];
+#define BPROF(K) do { if (threadIdx.x == 0 && b < 1024) g_bprof[b * 16 + (K)] = wall_clock64(); } while (0)
+extern "C" int sqmc_gpu_debug_bprof(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bprof), sizeof(g_bprof)); }
+#else
+#define BPROF(K)
+#endif
 // block-wide exclusive scan for the BK_AT threads of the annihilation kernel (total in every thread)
 #define BK_AT 512                      // threads of k_anneal_bucket: one block per CU, so the block itself has to keep the memory pipes busy
 __device__ __forceinline__ u64 bk_block_excl_scan(u64 v, u64 *total) {
@@ -95,6 +103,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
   const int b = (int)s_tile, B = ba.B, nsb = ba.nsb;
   const long long r_lo = ((long long)b * n0) / B, r_hi = ((long long)(b + 1) * n0) / B;
   const int R = (int)(r_hi - r_lo);
+  BPROF(0);
   // key range of the bucket (the sort only looks at the bits that vary inside it)
   if (tid == 0) s_kmin = b ? (u32)(rkeys[r_lo] >> 32) : 0u;
   if (tid == 64) s_kmax = (b + 1 < B) ? (u32)(rkeys[r_hi] >> 32) - 1u : (u32)invalid_key;
@@ -138,6 +147,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
 #pragma unroll
   for (int q = 0; q < BK_PER_R; q++) { const int i = tid + q * BK_AT; if (i < R) rk[i] = rk_reg[q]; }
   __syncthreads();
+  BPROF(1);
   // ---- gather the children's sort words, partition block by partition block (= creation order): word j of the bucket lies in
   //      the row whose base is the last one <= j
   {
@@ -156,6 +166,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     for (int q = 0; q < BK_PER_S; q++) { const int j = tid + q * BK_AT; if (j < S) sw[j] = wv_[q]; }
   }
   __syncthreads();
+  BPROF(2);
   // ---- stable LDS radix sort of the spawn words on key - kmin
   u64 *sa = sw, *sb = sw2;
   {
@@ -202,6 +213,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
       u64 *tp = sa; sa = sb; sb = tp;
     }
   }
+  BPROF(3);
   // ---- records by source, all requested before any is used; sums over the pre-merge list (do_walk.f90:2347-2349)
   double wabs = 0.0, cnt = 0.0;
   {
@@ -218,6 +230,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
 #pragma unroll
     for (int q = 0; q < BK_PER_S; q++) { const int j = tid + q * BK_AT; if (j < S) { s_w[R + j] = sw_[q]; s_f[R + j] = (u32)sf_[q]; wabs += fabs(sw_[q]); cnt += 1.0; } }
   }
+  BPROF(4);
   // ---- merged order: a resident goes behind the spawns with smaller keys, a spawn behind the residents with keys <= its own
   for (int i = tid; i < R; i += BK_AT) {
     const u32 k = rk[i];
@@ -234,6 +247,8 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     m2s[j + lo] = (head ? BK_STOP : 0u) | (u32)(R + j);
   }
   __syncthreads();
+  BPROF(5);
+  u32 *s_nc = scratch;                                  // the sort's counters are idle from here on: child count of every kept walker, then its prefix
   // ---- runs: the head folds its followers in merged order, then check_initiator, the discard rule and the rounding;
   //      the merged walker stays at the head's source slot (weight, packed flags); rnk[q] = 1 kept, 0x101 kept in the deterministic space
   for (int q = tid; q < T; q += BK_AT) {
@@ -265,31 +280,53 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
         if (!(wt == 0.0 && d >= 1)) keep = (d == 0) ? 0x101 : 0x1;        // zero weights outside the deterministic space are dropped (7222-7249)
       }
       s_w[si] = wt; s_f[si] = pack_flg(d, ini, psg);
+      if (go.child_off && keep) {                                           // the next step's spawn gate: only the child count is needed before the positions are
+        const u32 kk = (si < R) ? rk[si] : (u32)(sa[si - R] >> 32);
+        u64 nc; double wc;
+        gate_children(wt * p.rfi, go.cutoff, seed, go.step_next, (u64)kk, nc, wc);
+        s_nc[q] = (u32)nc;
+      }
     }
     rnk[q] = keep;
   }
   __syncthreads();
   // ---- rank of every kept walker inside the bucket (lo 16 bits: position, hi: index among the deterministic-space walkers):
   //      each thread scans a contiguous share of the merged order; then one look-back over the buckets
+  BPROF(6);
   u32 *s_rank = (u32 *)sb;                              // the idle sort buffer
+  // packed running value of the look-back: position (20 bits), index among the deterministic-space walkers (18), children (24)
   u64 ex_glob;
   {
     const int C = (T + BK_AT - 1) / BK_AT, beg = tid * C, end = (beg + C < T) ? beg + C : T;
+    const bool ch = go.child_off != nullptr;
     u64 mine = 0;
-    for (int q = beg; q < end; q++) { const unsigned short k = rnk[q]; mine += (u64)(k & 1) | ((u64)(k >> 8) << 32); }
+    for (int q = beg; q < end; q++) { const unsigned short k = rnk[q]; if (k & 1) mine += 1ull | ((u64)(k >> 8) << 20) | (ch ? ((u64)s_nc[q] << 38) : 0ull); }
     u64 tot; u64 ex = bk_block_excl_scan(mine, &tot);
     for (int q = beg; q < end; q++) {
       const unsigned short k = rnk[q];
-      if (k & 1) { s_rank[q] = (u32)(ex & 0xFFFFull) | ((u32)(ex >> 32) << 16); ex += (u64)1 | ((u64)(k >> 8) << 32); }
-      else s_rank[q] = 0xFFFFFFFFu;
+      if (k & 1) {
+        s_rank[q] = (u32)(ex & 0xFFFull) | ((u32)((ex >> 20) & 0x3FFFFull) << 12);       // inside the bucket: position < 4096, deterministic index < 2^18
+        const u64 add = 1ull | ((u64)(k >> 8) << 20) | (ch ? ((u64)s_nc[q] << 38) : 0ull);
+        if (ch) s_nc[q] = (u32)(ex >> 38);
+        ex += add;
+      } else s_rank[q] = 0xFFFFFFFFu;
     }
     if (tid < 64) {
       const u64 e = lookback_exclusive(ba.state, (u32)b, tot, tid);
-      if (tid == 0) { s_ex = e; if (b == B - 1) { sc->tot2 = e + tot; sc->nwalk = (e + tot) & 0xFFFFFFFFull; } }
+      if (tid == 0) {
+        s_ex = e;
+        if (b == B - 1) {
+          const u64 all = e + tot, npos = all & 0xFFFFFull, ndet = (all >> 20) & 0x3FFFFull;
+          sc->tot2 = npos | (ndet << 32); sc->nwalk = npos;
+          if (ch) sc->n_children = all >> 38;
+        }
+      }
     }
     __syncthreads();
     ex_glob = s_ex;
+    BPROF(9);
   }
+  BPROF(7);
   // ---- compaction into the other buffer, reweighting (2487), estimator pieces (2573-2684, more_tools.f90:4041-4098), next gate.
   //      Two slots per thread and round: their loads (record, then C(T) probe) are in flight together.
   double st[NSTAT];
@@ -317,8 +354,8 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     for (int z = 0; z < CB; z++) {
       if (r_[z] == 0xFFFFFFFFu) continue;
       const int si = si_[z];
-      const long long q0 = (long long)(ex_glob & 0xFFFFFFFFull) + (long long)(r_[z] & 0xFFFFu);
-      const long long qd = (long long)(ex_glob >> 32) + (long long)(r_[z] >> 16);
+      const long long q0 = (long long)(ex_glob & 0xFFFFFull) + (long long)(r_[z] & 0xFFFu);
+      const long long qd = (long long)((ex_glob >> 20) & 0x3FFFFull) + (long long)(r_[z] >> 12);
       const double wt = s_w[si] * p.rfi;
       const u32 fl = s_f[si];
       const int d = flg_impd(fl), ini = flg_init(fl), psg = flg_psign(fl);
@@ -328,7 +365,8 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
       if (go.on) {
         u64 nc; double wc;
         gate_children(wt, go.cutoff, seed, go.step_next, key_[z], nc, wc);
-        go.keys[q0] = (key_[z] << 32) | (u64)q0; go.nchild[q0] = nc; go.wchild[q0] = wc;
+        go.keys[q0] = (key_[z] << 32) | (u64)q0; go.wchild[q0] = wc;
+        if (go.child_off) go.child_off[q0] = (ex_glob >> 38) + (u64)s_nc[q0b + z * BK_AT]; else go.nchild[q0] = nc;
       }
       if (d == 0 && p.semi && qd < p.nimp_cap) loc_imp[qd] = (int)q0;
       st[0] += wt; st[1] += fabs(wt); st[8] += wt * wt;
@@ -342,6 +380,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
       }
     }
   }
+  BPROF(8);
   // block sums: the 13 estimator pieces and the two pre-merge sums
 #pragma unroll
   for (int k = 0; k < NSTAT + 2; k++) {
@@ -357,5 +396,6 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     else wabs_part[2 * b + (tid - NSTAT)] = v;
   }
   // how full the fullest bucket was (per mille of the caps): the host keeps the bucket path off while the head-room is thin
+  BPROF(10);
   if (tid == 0) { const int fs = (1000 * S) / BK_CAP_S, ft = (1000 * T) / BK_CAP_T; atomicMax((unsigned int *)&sc->bk_fill, (unsigned int)(fs > ft ? fs : ft)); }
 }

@@ -152,6 +152,8 @@ struct sqmc_gpu_ctx {
   int scan_flip, scan_used[2];   // gate-fused heads: look-back set of the next head scan, and how many words of each set its last scan may have touched
   bool residents_sorted;      // the walker arrays are known to be in (up, dn) order: true after every finished step and after an upload (which refuses unsorted lists)
   unsigned short *d_segoff; long long segoff_cap;      // bucket tail: group offsets of the partition blocks
+  bool head_offsets_done;     // the bucket tail of the step before wrote this step's child offsets and total (no scan launch in the head)
+  double last_wabs;           // sum |w| after the last step (bounds the next step's child count)
   BucketArgs head_ba; long long last_nall;      // partition already done by the head's k_spawn (B > 0), and the length of the last sorted list (sizes the next one)
   int bk_holdoff;             // steps for which the bucket tail stays off (after a bucket overflowed or came close)
   long long bk_steps, bk_retries;
@@ -584,7 +586,13 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   ScanWork sw0; sw0.state = c->d_scan_state; sw0.ticket = c->d_scan_ticket; sw0.cap_tiles = c->cap_tiles; sw0.self_clear = false;
   FinArgs fa; memset(&fa, 0, sizeof(fa)); if (fin) fa = *fin;
   if (g0) hipEventRecord(g0, st);
-  if (gate_done) {
+  FinArgs spawn_fin; memset(&spawn_fin, 0, sizeof(spawn_fin));
+  if (gate_done && c->head_offsets_done) {
+    // the bucket tail of the step before wrote keys, child weights, child OFFSETS and their total: nothing to scan.  That
+    // step's final sums ride on k_spawn as one extra block.
+    c->head_offsets_done = false;
+    spawn_fin = fa;
+  } else if (gate_done) {
     // k_anneal of the step before wrote keys, child counts and child weights; the final sums of that step ride on the
     // scan as one extra block.  The scan works on look-back set scan_flip while that block re-zeroes the other set
     // (the one the head scan before this one used).
@@ -628,11 +636,11 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   const long long nfree = dev_n ? M : M - n0;          // dev_n: nothing is known about the count but that it is >= 0
   if (nfree > 0) {
     if (s0)
-      hipExtLaunchKernelGGL(k_spawn, dim3(nblk(nfree)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb);
+      hipExtLaunchKernelGGL(k_spawn, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
+                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin);
     else
-      hipLaunchKernelGGL(k_spawn, dim3(nblk(nfree)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb);
+      hipLaunchKernelGGL(k_spawn, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin);
   } else if (s0) { hipEventRecord(s0, st); hipEventRecord(s1, st); }
   HIPCHK(hipGetLastError());
   return SQMC_OK;
@@ -733,6 +741,8 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     if (fuse_gate) {
       go.on = 1; go.keys = (skey == c->d_keys) ? c->d_keys_alt : c->d_keys;      // never the buffer the kernel reads its sorted words from
       go.nchild = c->d_nchild; go.wchild = c->d_wchild; go.cutoff = p.cutoff; go.step_next = step + 1;
+      static const bool no_off = getenv("SQMC_BUCKET_NO_OFFSETS") != nullptr;
+      if (bucket && use_mail && !no_off && c->n_imp < (1ll << 18) && c->last_wabs > 0 && c->last_wabs < 4.0e6) go.child_off = c->d_child_off;     // 24 bits of the look-back word hold the children
     }
 #define ANNEAL_ARGS c->w, c->m, skey, perm, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, n0, nall, p,  \
                     c->invalid_key, c->pack, mode, seed, step, c->d_sc, c->d_fstate, c->d_fstate + c->cap_ftiles, c->d_fticket, go
@@ -745,6 +755,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       else hipLaunchKernelGGL(k_anneal_bucket, dim3(nb), dim3(BK_AT), 0, st, BUCKET_ARGS);
 #undef BUCKET_ARGS
       c->bk_steps++;
+      c->head_offsets_done = (go.child_off != nullptr);
     } else if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 3) ANNEAL_LAUNCH(3); else ANNEAL_LAUNCH(4);
 #undef ANNEAL_LAUNCH
 #undef ANNEAL_ARGS
@@ -820,7 +831,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       std::swap(c->w.up, c->m.up); std::swap(c->w.dn, c->m.dn); std::swap(c->w.wt, c->m.wt); std::swap(c->w.flg, c->m.flg);
       std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed);
       if (fuse_gate) std::swap(c->d_keys, c->d_keys_alt);
-      c->pipeline_next = false; c->bk_retries++;
+      c->pipeline_next = false; c->bk_retries++; c->head_offsets_done = false;
       { static const int hold = getenv("SQMC_BUCKET_HOLDOFF") ? atoi(getenv("SQMC_BUCKET_HOLDOFF")) : 8; c->bk_holdoff = hold; }
       return SQMC_INTERNAL_RETRY;
     }
@@ -837,6 +848,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
   const long long nfinal = (long long)(c->h_sc->tot2 & 0xFFFFFFFFull), nimp = (long long)(c->h_sc->tot2 >> 32);
   c->nwalk = nfinal; c->residents_sorted = true;
   for (int i = 0; i < 16; i++) out[i] = c->h_sc->stats[i];
+  c->last_wabs = out[1];
   if (nfinal == 0) { drop_head(c); return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0"); }
   if (p.semi && nimp != (c->shard_n > 1 || c->d_grow ? c->n_imp_local : c->n_imp)) { drop_head(c); return fail(SQMC_ERR_IMP_BROKEN, "locations of my imp broken"); }
   return SQMC_OK;
@@ -890,10 +902,10 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     if (M > n0) {
       if (t_spawn >= 0)
         hipExtLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->ev0[t_spawn], c->ev1[t_spawn], 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{});
+                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{});
       else
         hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{});
+                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{});
     } else if (t_spawn >= 0) { hipEventRecord(c->ev0[t_spawn], st); hipEventRecord(c->ev1[t_spawn], st); }
   } else {
     int r = enqueue_head(c, p, step, n0, false, t_gate_scan >= 0 ? c->ev0[t_gate_scan] : nullptr, t_gate_scan >= 0 ? c->ev1[t_gate_scan] : nullptr,

@@ -31,7 +31,8 @@ __device__ __forceinline__ void gate_children(double w, double cutoff, u64 seed,
 }
 // What k_gate would compute for the NEXT step, written by k_anneal as it places a walker (pipelined steps: the
 // parameters of the gate do not change any more, and the walker's key is at hand): one kernel less on the critical path.
-struct GateOut { u64 *keys; u64 *nchild; double *wchild; double cutoff; u64 step_next; int on; };
+struct GateOut { u64 *keys; u64 *nchild; double *wchild; double cutoff; u64 step_next; int on;
+                 u64 *child_off; };      // child_off != null (bucket tail only): the kernel also writes the next step's child offsets and total -- no scan launch
 // gate + child count.
 __global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, const double *__restrict__ wt,
                                               u64 *__restrict__ nchild, double *__restrict__ wchild, u64 *__restrict__ keys, u32 *__restrict__ vals,
@@ -211,7 +212,10 @@ extern "C" int sqmc_gpu_debug_prof(unsigned long long *out) { return (int)hipMem
 __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
                                                const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
                                                long long n0_arg, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc,
-                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo, BucketArgs ba) {
+                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo, BucketArgs ba, FinArgs fin) {
+  // steps whose child offsets came out of the bucket tail have no scan launch to carry the last step's final sums: one extra
+  // block of this kernel does them (it runs beside the spawning blocks; nothing it touches is read by them)
+  if (fin.on && blockIdx.x == gridDim.x - 1) { finish_all(fin, const_cast<DevScalars *>(sc)); return; }
   if (n_on_device && sc->retry) return;                                 // see k_gate
   const long long n0 = n_on_device ? (long long)sc->nwalk : n0_arg;     // pipelined head: launched before the host learnt the walker count
   // the grid covers the free capacity of the walker arrays; the number of children is read from
@@ -915,7 +919,7 @@ __device__ void finish_step(const double *__restrict__ partials, int nblocks, co
   if ((int)threadIdx.x < n_tickets) scan_ticket[threadIdx.x] = 0;
   // the scalars the last thread-0 section needs are requested now, with the partials
   u64 tot2 = 0, nch = 0; int err = 0;
-  if (threadIdx.x == 0) { tot2 = sc->tot2; err = sc->err; nch = n_children >= 0 ? (u64)n_children : sc->n_children; }
+  if (threadIdx.x == 0) { tot2 = sc->tot2; err = atomicExch(&sc->err, 0); nch = n_children >= 0 ? (u64)n_children : sc->n_children; }      // read and clear: the next step's death/clone kernel may already be running
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // every thread first adds up its rows (a row's 13 loads, and several rows, are in flight
   // together), then one shuffle tree per statistic

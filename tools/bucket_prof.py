@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Where the time of k_anneal_bucket goes: rebuilds the library with -DBUCKET_PROF on the GPU box, runs the bench
+configuration for a few hundred steps and prints, per phase, the mean / max over the buckets of the last step (wall clock,
+100 MHz ticks -> us).  Restores the normal build afterwards."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["SQMC_EXTRA_CFLAGS"] = "-DBUCKET_PROF"
+import torch  # noqa: F401
+import sqmc_amd
+sqmc_amd.build_library(force=True)
+from sqmc_amd import host as H
+
+target = float(sys.argv[1]) if len(sys.argv) > 1 else 1e5
+hst = H.ChemHost(os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP"), 8, 4, "d2h")
+w = H.GpuWalk(hst, target, seed=(1346, 5634, 6635, 4361))
+w.run(500, keep_stats=False)
+L = sqmc_amd.load_library()
+buf = (C.c_uint64 * (16 * 1024))()
+assert L.sqmc_gpu_debug_bprof(buf) == 0
+a = np.array(buf, dtype=np.int64).reshape(1024, 16)
+print("tail stats", w.g.tail_stats())
+nb = int((a[:, 0] > 0).sum())
+a = a[:nb]
+t0 = a[:, 0].min()
+names = ["ticket+rows issue", "rows scan", "gather words", "sort", "records", "merge order", "fold+round", "chunk scan", "lookback", "compaction", "sums"]
+print("buckets", nb, "kernel span %.1f us" % ((a[:, 10].max() - t0) / 100.0))
+print("start skew: mean %.1f max %.1f us" % ((a[:, 0] - t0).mean() / 100.0, (a[:, 0] - t0).max() / 100.0))
+seq = [0, 1, 2, 3, 4, 5, 6, 9, 8, 10]            # stamp 7 sits right behind 9
+names = ["rows (loads + scan)", "gather words", "LDS sort", "records", "merge order", "fold + round + gate count", "chunk scan + look-back", "compaction", "block sums"]
+for k in range(1, len(seq)):
+    d = (a[:, seq[k]] - a[:, seq[k - 1]]) / 100.0
+    print("%-28s mean %6.2f  max %6.2f us" % (names[k - 1], d.mean(), d.max()))
+w.close()
+os.environ.pop("SQMC_EXTRA_CFLAGS")
+sqmc_amd.build_library(force=True)
