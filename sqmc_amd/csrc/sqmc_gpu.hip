@@ -144,7 +144,8 @@ struct sqmc_gpu_ctx {
   // timing
   int timing; hipEvent_t ev0[NTIMERS], ev1[NTIMERS]; const char *tname[NTIMERS]; int nt; float tms[NTIMERS];
   double tsum[NTIMERS]; long long tsteps;         // accumulated over the steps since sqmc_gpu_set_timing
-  hipStream_t st2; hipEvent_t e_fork, e_join, e_cnt;    // second stream: death + deterministic projection beside spawn + sort
+  hipStream_t st2; hipEvent_t e_fork, e_join, e_cnt;    // second stream: death/clone beside spawn + sort
+  hipStream_t st3; hipEvent_t e_join3;                   // third stream: the deterministic projection (it touches the deterministic-space walkers only, death/clone all the others)
   // pipelined head (sqmc_gpu_run, COUNTER discipline, target population reached): gate + scan + spawn of step n+1 are
   // enqueued right behind k_finish of step n, before the host has read step n's sums
   bool pipeline_next, head_ready; StepP head_p; u64 head_cseq; hipEvent_t hev[4];
@@ -242,7 +243,8 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
     HIPCHK(hipMalloc(&c->d_done, 4)); HIPCHK(hipMemset(c->d_done, 0, 4));
   }
   for (int i = 0; i < NTIMERS; i++) { HIPCHK(hipEventCreate(&c->ev0[i])); HIPCHK(hipEventCreate(&c->ev1[i])); }
-  HIPCHK(hipStreamCreate(&c->st2));
+  HIPCHK(hipStreamCreate(&c->st2)); HIPCHK(hipStreamCreate(&c->st3));
+  HIPCHK(hipEventCreateWithFlags(&c->e_join3, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->e_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->e_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->e_cnt, hipEventDisableTiming));
   for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->hev[i]));
@@ -364,6 +366,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   for (int i = 0; i < NTIMERS; i++) { hipEventDestroy(c->ev0[i]); hipEventDestroy(c->ev1[i]); }
   hipEventDestroy(c->e_fork); hipEventDestroy(c->e_join); hipEventDestroy(c->e_cnt);
   for (int i = 0; i < 4; i++) hipEventDestroy(c->hev[i]);
+  hipEventDestroy(c->e_join3); hipStreamDestroy(c->st3);
   hipStreamDestroy(c->st2); hipStreamDestroy(c->st);
   delete c;
   return SQMC_OK;
@@ -502,7 +505,7 @@ int sqmc_gpu_set_rng(sqmc_gpu_ctx *c, const int32_t seed[4]) {
 static void collect_timers(sqmc_gpu_ctx *c);
 int sqmc_gpu_set_timing(sqmc_gpu_ctx *c, int on) {
   if (!c) return SQMC_ERR_BAD_ARG;
-  hipStreamSynchronize(c->st); hipStreamSynchronize(c->st2); c->timers_pending = false;
+  hipStreamSynchronize(c->st); hipStreamSynchronize(c->st2); hipStreamSynchronize(c->st3); c->timers_pending = false;
   c->timing = on; c->tsteps = 0; c->nt = 0;
   for (int i = 0; i < NTIMERS; i++) c->tsum[i] = 0.0;
   return SQMC_OK;
@@ -614,6 +617,12 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   //      over the whole free capacity with a device-side child count and posts that count to the
   //      host mailbox as soon as it starts.
   HIPCHK(hipEventRecord(c->e_fork, st));
+  if (dev_n && !c->d_grow) {
+    // pipelined head: the diagonal elements of the determinants the last step created depend on nothing the host still has to
+    // decide -- they are computed now, on the side stream, beside the scan and k_spawn; death/clone later finds them cached
+    HIPCHK(hipStreamWaitEvent(c->st2, c->e_fork, 0));
+    hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, c->st2, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc, 1);
+  }
   *cseq = ++c->cnt_seq;
   const OwnerOut oo = shard_owner_out(c);
   // short lists: k_spawn groups its children by key range as it emits them (the bucket tail then needs no partition kernel).
@@ -717,7 +726,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
   }
   TEND(sort, st);
   // ---- join: from here on weights are read
-  if (join_side_stream) HIPCHK(hipStreamWaitEvent(st, c->e_join, 0));
+  if (join_side_stream) { HIPCHK(hipStreamWaitEvent(st, c->e_join, 0)); if (p.semi && !c->d_grow) HIPCHK(hipStreamWaitEvent(st, c->e_join3, 0)); }
   const int nbm = nblk(nall);
   const bool use_mail = (c->comm == nullptr);          // with a communicator the sums are all-reduced on the device first
   const u64 seq = ++c->mail_seq;
@@ -916,15 +925,20 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   //      the spawn kernel (it uses the child weights of the gate) nor the sort reads
   HIPCHK(hipStreamWaitEvent(st2, c->e_fork, 0));
   TBEG(diag, st2);
-  hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, st2, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc);
+  hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, st2, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc, 0);
   TEND(diag, st2);
-  TBEG(project, st2);
+  // the projection reads and writes the weights of the deterministic-space walkers only (imp_distance 0), death/clone skips
+  // exactly those: the two run side by side
+  hipStream_t st3 = p.semi ? c->st3 : st2;
+  if (p.semi) HIPCHK(hipStreamWaitEvent(st3, c->e_fork, 0));
+  TBEG(project, st3);
   if (p.semi) {
-    hipLaunchKernelGGL(k_prj_gather, dim3(nblk(c->n_imp)), dim3(TPB), 0, st2, c->w.wt, c->d_loc_imp, c->d_prj_x, c->n_imp);
-    hipLaunchKernelGGL(k_prj_apply, dim3(nblk(c->n_imp, TPB / 64)), dim3(TPB), 0, st2, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, c->d_prj_x, c->d_loc_imp, c->w.wt,
+    hipLaunchKernelGGL(k_prj_gather, dim3(nblk(c->n_imp)), dim3(TPB), 0, st3, c->w.wt, c->d_loc_imp, c->d_prj_x, c->n_imp);
+    hipLaunchKernelGGL(k_prj_apply, dim3(nblk(c->n_imp, TPB / 64)), dim3(TPB), 0, st3, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, c->d_prj_x, c->d_loc_imp, c->w.wt,
                        c->n_imp, p.e_trial, p.tau);
+    HIPCHK(hipEventRecord(c->e_join3, st3));
   }
-  TEND(project, st2);
+  TEND(project, st3);
   HIPCHK(hipEventRecord(c->e_join, st2));
   HIPCHK(hipGetLastError());
   // ---- the child count, from the mailbox (or the slow way when there was no k_spawn launch)
@@ -936,7 +950,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     else nch = (long long)c->h_mail->n_children;
   } else { u64 v; HIPCHK(hipMemcpyAsync(&v, &c->d_sc->n_children, 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); nch = (long long)v; }
   if (n0 + nch > M) {
-    hipStreamSynchronize(st); hipStreamSynchronize(st2);
+    hipStreamSynchronize(st); hipStreamSynchronize(st2); hipStreamSynchronize(c->st3);
     hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
     return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
   }

@@ -85,8 +85,11 @@ __global__ void __launch_bounds__(64) k_replay_prepass(const ChemTab *__restrict
 }
 
 // diagonal death/clone, do_walk.f90:3743-3793
+// fill_only: only the missing H_ii are computed (pipelined head: the walker count is read on the device, weights are not touched)
 __global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, double *__restrict__ wt,
-                                              const u32 *__restrict__ flg, double *__restrict__ me, long long n, StepP p, DevScalars *sc) {
+                                              const u32 *__restrict__ flg, double *__restrict__ me, long long n_arg, StepP p, DevScalars *sc, int fill_only) {
+  if (fill_only && sc->retry) return;
+  const long long n = fill_only ? (long long)sc->nwalk : n_arg;
   __shared__ ChemTab t;
   stage_tab(&t, dev.tab, dev.tab_words);
   // Only determinants first occupied in the last step lack H_ii (the 1e51 sentinel), and they sit anywhere in the
@@ -115,7 +118,7 @@ __global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict
     __syncthreads();
     if (need) hii = hq[threadIdx.x];
   }
-  if (!live) return;
+  if (!live || fill_only) return;
   double f = 1.0 + p.tau * (p.e_trial - hii);
   if (f < 0) { if (p.reached > 1) sc->err = SQMC_ERR_NEG_DIAG; f = 0; }
   wt[i] = wt[i] * f;
