@@ -77,6 +77,45 @@ __device__ __forceinline__ u64 bk_block_excl_scan(u64 v, u64 *total) {
   *total = tot;
   return off + inc - v;
 }
+// Look-back over the buckets with the whole block: every thread polls its own predecessors (two at most: B <= BK_MAXB), so the
+// running value of all earlier buckets arrives in ONE round trip once they have published, instead of 64 predecessors per
+// poll.  Same words and protocol as lookback_exclusive (status in the top two bits: 1 = this bucket's own total, 2 = running total
+// up to and including it).  All BK_AT threads call it; returns the exclusive running value in every thread.
+__device__ __forceinline__ u64 bk_lookback_wide(u64 *__restrict__ state, int b, u64 tot) {
+  __shared__ int s_pstar[BK_AT / 64]; __shared__ u64 s_part[BK_AT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (b == 0) { if (tid == 0) atomicExch((unsigned long long *)&state[0], SCAN_ST_INC | tot); return 0; }
+  if (tid == 0) atomicExch((unsigned long long *)&state[b], SCAN_ST_AGG | tot);
+  u64 w_[BK_MAXB / BK_AT]; int ix_[BK_MAXB / BK_AT];
+  int pstar = -1;
+#pragma unroll
+  for (int q = 0; q < BK_MAXB / BK_AT; q++) {
+    const int idx = b - 1 - tid - q * BK_AT; ix_[q] = idx; w_[q] = 0;
+    if (idx >= 0) {
+      u64 w;
+      do { w = atomicAdd((unsigned long long *)&state[idx], 0ull); } while ((w >> 62) == 0);
+      w_[q] = w;
+      if ((w >> 62) == 2 && idx > pstar) pstar = idx;
+    }
+  }
+  // the nearest predecessor that already carries a running total
+  for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(pstar, o, 64); pstar = x > pstar ? x : pstar; }
+  if (lane == 0) s_pstar[wv] = pstar;
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < BK_AT / 64; v++) pstar = s_pstar[v] > pstar ? s_pstar[v] : pstar;
+  u64 sum = 0;
+#pragma unroll
+  for (int q = 0; q < BK_MAXB / BK_AT; q++) if (ix_[q] >= 0 && ix_[q] >= pstar) sum += w_[q] & SCAN_VAL_MASK;
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  if (lane == 0) s_part[wv] = sum;
+  __syncthreads();
+  u64 excl = 0;
+#pragma unroll
+  for (int v = 0; v < BK_AT / 64; v++) excl += s_part[v];
+  if (tid == 0) atomicExch((unsigned long long *)&state[b], SCAN_ST_INC | (excl + tot));
+  return excl;
+}
 // elements one thread handles per phase at the caps (loops are unrolled to these so that all loads of a phase are in flight)
 #define BK_PER_ROWS ((BK_CAP_ROWS + BK_AT - 1) / BK_AT)
 #define BK_PER_S ((BK_CAP_S + BK_AT - 1) / BK_AT)
@@ -95,7 +134,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
   __shared__ u32 m2s[BK_CAP_T];                           // merged order -> source (| BK_STOP at the first slot of a run)
   __shared__ unsigned short rnk[BK_CAP_T];               // sort: rank inside its digit; later: keep code of a merged slot
   __shared__ u32 scratch[(BK_AT / 64) * 1024];            // rows of the gather (offset u16 + base u32), then the digit counters of the sort
-  __shared__ u32 s_tile; __shared__ u64 s_ex; __shared__ u32 s_kmin, s_kmax;
+  __shared__ u32 s_tile; __shared__ u32 s_kmin, s_kmax;
   __shared__ double s_red[BK_AT / 64][NSTAT + 2];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) s_tile = atomicAdd(ba.ticket, 1u);
@@ -311,19 +350,13 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
         ex += add;
       } else s_rank[q] = 0xFFFFFFFFu;
     }
-    if (tid < 64) {
-      const u64 e = lookback_exclusive(ba.state, (u32)b, tot, tid);
-      if (tid == 0) {
-        s_ex = e;
-        if (b == B - 1) {
-          const u64 all = e + tot, npos = all & 0xFFFFFull, ndet = (all >> 20) & 0x3FFFFull;
-          sc->tot2 = npos | (ndet << 32); sc->nwalk = npos;
-          if (ch) sc->n_children = all >> 38;
-        }
-      }
+    __syncthreads();                                 // ranks and child prefixes are read row-wise below
+    ex_glob = bk_lookback_wide(ba.state, b, tot);
+    if (tid == 0 && b == B - 1) {
+      const u64 all = ex_glob + tot, npos = all & 0xFFFFFull, ndet = (all >> 20) & 0x3FFFFull;
+      sc->tot2 = npos | (ndet << 32); sc->nwalk = npos;
+      if (ch) sc->n_children = all >> 38;
     }
-    __syncthreads();
-    ex_glob = s_ex;
     BPROF(9);
   }
   BPROF(7);

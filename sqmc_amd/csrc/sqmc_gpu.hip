@@ -617,7 +617,8 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   //      over the whole free capacity with a device-side child count and posts that count to the
   //      host mailbox as soon as it starts.
   HIPCHK(hipEventRecord(c->e_fork, st));
-  if (dev_n && !c->d_grow) {
+  static const bool no_early = getenv("SQMC_NO_EARLY_HII") != nullptr;
+  if (dev_n && !c->d_grow && !no_early) {
     // pipelined head: the diagonal elements of the determinants the last step created depend on nothing the host still has to
     // decide -- they are computed now, on the side stream, beside the scan and k_spawn; death/clone later finds them cached
     HIPCHK(hipStreamWaitEvent(c->st2, c->e_fork, 0));
@@ -726,7 +727,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
   }
   TEND(sort, st);
   // ---- join: from here on weights are read
-  if (join_side_stream) { HIPCHK(hipStreamWaitEvent(st, c->e_join, 0)); if (p.semi && !c->d_grow) HIPCHK(hipStreamWaitEvent(st, c->e_join3, 0)); }
+  if (join_side_stream) { HIPCHK(hipStreamWaitEvent(st, c->e_join, 0)); if (p.semi && !c->d_grow && !getenv("SQMC_NO_ST3")) HIPCHK(hipStreamWaitEvent(st, c->e_join3, 0)); }
   const int nbm = nblk(nall);
   const bool use_mail = (c->comm == nullptr);          // with a communicator the sums are all-reduced on the device first
   const u64 seq = ++c->mail_seq;
@@ -929,14 +930,15 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   TEND(diag, st2);
   // the projection reads and writes the weights of the deterministic-space walkers only (imp_distance 0), death/clone skips
   // exactly those: the two run side by side
-  hipStream_t st3 = p.semi ? c->st3 : st2;
-  if (p.semi) HIPCHK(hipStreamWaitEvent(st3, c->e_fork, 0));
+  static const bool no_st3 = getenv("SQMC_NO_ST3") != nullptr;
+  hipStream_t st3 = (p.semi && !no_st3) ? c->st3 : st2;
+  if (st3 != st2) HIPCHK(hipStreamWaitEvent(st3, c->e_fork, 0));
   TBEG(project, st3);
   if (p.semi) {
     hipLaunchKernelGGL(k_prj_gather, dim3(nblk(c->n_imp)), dim3(TPB), 0, st3, c->w.wt, c->d_loc_imp, c->d_prj_x, c->n_imp);
     hipLaunchKernelGGL(k_prj_apply, dim3(nblk(c->n_imp, TPB / 64)), dim3(TPB), 0, st3, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, c->d_prj_x, c->d_loc_imp, c->w.wt,
                        c->n_imp, p.e_trial, p.tau);
-    HIPCHK(hipEventRecord(c->e_join3, st3));
+    if (st3 != st2) HIPCHK(hipEventRecord(c->e_join3, st3));
   }
   TEND(project, st3);
   HIPCHK(hipEventRecord(c->e_join, st2));
