@@ -203,6 +203,51 @@ class ChemSystem:
         return counts, idx, val
 
 
+class HeatBath:
+    """orc_hb handle: tables of setup_efficient_heatbath (chemistry.f90:872-1230) for a ChemSystem, and the move
+    off_diagonal_move_chem_efficient_heatbath (5086-5347) with its proposal-probability function (5431-5549)."""
+
+    def __init__(self, sysm):
+        L = lib()
+        L.orc_hb_setup.restype = C.c_void_p
+        L.orc_hb_setup.argtypes = [C.c_void_p]
+        L.orc_off_diagonal_move_chem_heatbath.restype = C.c_int
+        L.orc_off_diagonal_move_chem_heatbath.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint64, C.c_uint64] + [C.c_void_p] * 5
+        L.orc_hb_proposal_prob.restype = C.c_double
+        L.orc_hb_proposal_prob.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint64] * 4 + [C.c_int, C.c_double]
+        self.sysm, self.L = sysm, L
+        self.h = L.orc_hb_setup(sysm.h)
+        if not self.h:
+            raise RuntimeError("orc_hb_setup failed")
+        self.s = HbTables.from_address(self.h)
+        self.unbiased = bool(self.s.unbiased)
+
+    def move(self, rng, tau, up, dn):
+        """one proposal; returns [(det_j_up, det_j_dn, weight_j, excite_level), ...] for the 0, 1 or 2 new determinants, and the draws used"""
+        ju, jd, w, lev, nd = (C.c_uint64 * 2)(), (C.c_uint64 * 2)(), (C.c_double * 2)(), (C.c_int * 2)(), C.c_int()
+        n = self.L.orc_off_diagonal_move_chem_heatbath(self.sysm.h, self.h, C.byref(rng), tau, int(up), int(dn), ju, jd, w, lev, C.byref(nd))
+        return [(ju[k], jd[k], w[k], lev[k]) for k in range(2) if lev[k] >= 0 and (k < n or w[k] != 0.0)], n, nd.value
+
+    def proposal_prob(self, iu, id_, ju, jd, level, elem):
+        return self.L.orc_hb_proposal_prob(self.sysm.h, self.h, int(iu), int(id_), int(ju), int(jd), int(level), float(elem))
+
+    def close(self):
+        if self.h:
+            self.L.orc_hb_free.argtypes = [C.c_void_p]
+            self.L.orc_hb_free(self.h); self.h = None
+
+
+class HbTables(C.Structure):
+    _fields_ = [("norb", C.c_int), ("nup", C.c_int), ("ndn", C.c_int), ("n_core", C.c_int), ("n_orb_uniq_sym", C.c_int), ("unbiased", C.c_int),
+                ("size_same", C.c_int64), ("size_opp", C.c_int64), ("n_pairs", C.c_int64),
+                ("one", C.POINTER(C.c_double)), ("two", C.POINTER(C.c_double)),
+                ("three_same", C.POINTER(C.c_double)), ("three_opp", C.POINTER(C.c_double)), ("j3_same", C.POINTER(C.c_int)), ("j3_opp", C.POINTER(C.c_int)),
+                ("q3_same", C.POINTER(C.c_double)), ("q3_opp", C.POINTER(C.c_double)),
+                ("four_same", C.POINTER(C.c_float)), ("four_opp", C.POINTER(C.c_float)), ("j4_same", C.POINTER(C.c_int)), ("j4_opp", C.POINTER(C.c_int)),
+                ("q4_same", C.POINTER(C.c_float)), ("q4_opp", C.POINTER(C.c_float)),
+                ("htot_same", C.POINTER(C.c_double)), ("htot_opp", C.POINTER(C.c_double))]
+
+
 def spmv_sym_upper(counts, idx, val, x):
     y = np.zeros_like(x)
     lib().orc_spmv_sym_upper(len(counts), _p(counts), _p(idx), _p(val), _p(np.ascontiguousarray(x)), _p(y))

@@ -83,6 +83,25 @@ double orc_hamiltonian(const orc_chem *s, det_t iu, det_t id, det_t ju, det_t jd
 void orc_off_diagonal_move_chem(const orc_chem *s, orc_rng *g, double tau, det_t iu, det_t id,
                                 det_t *ju, det_t *jd, double *weight_j, int *n_draws);
 
+/* ---- efficient heat-bath proposal (oracle/sqmc_oracle_hb.c): chemistry.f90:872-1230, 5086-5816, 9154-9375 ---- */
+typedef struct {
+  int norb, nup, ndn, n_core, n_orb_uniq_sym, unbiased;
+  int64_t size_same, size_opp, n_pairs;
+  double *one, *two;                                  /* one_orbital_probabilities(norb), two_orbital_probabilities(2norb,2norb); 1-based with an unused 0 row */
+  double *three_same, *three_opp; int *j3_same, *j3_opp; double *q3_same, *q3_opp;      /* (norb+1)^3, [i][j][k] */
+  float *four_same, *four_opp; int *j4_same, *j4_opp; float *q4_same, *q4_opp;          /* single precision, as the reference stores them; [same_index] / [opposite_index] */
+  double *htot_same, *htot_opp;                       /* Htot_same(combine_2(i,j), k), Htot_opposite(i,j,k) */
+} orc_hb;
+orc_hb *orc_hb_setup(const orc_chem *c);
+void    orc_hb_free(orc_hb *h);
+int64_t orc_hb_same_index(const orc_hb *h, int f1, int f2, int t1, int t2);
+int64_t orc_hb_opposite_index(const orc_hb *h, int f1, int f2, int t1, int t2);
+/* returns n_new_dets (0, 1 or 2: a single larger than all its doubles together comes back WITH a double, do_walk.f90:3604-3611) */
+int orc_off_diagonal_move_chem_heatbath(const orc_chem *c, const orc_hb *h, orc_rng *g, double tau, det_t iu, det_t id,
+                                        det_t ju[2], det_t jd[2], double weight_j[2], int excite_level[2], int *n_draws);
+/* probability with which det_i -> det_j would be proposed (proposal_prob_efficient_heatbath, 5431-5549) */
+double orc_hb_proposal_prob(const orc_chem *c, const orc_hb *h, det_t iu, det_t id, det_t ju, det_t jd, int excite_level, double off_diag_elem);
+
 /* connections */
 int orc_find_connected_dets_chem(const orc_chem *s, det_t up, det_t dn, det_t *cu, det_t *cd,
                                  double *elems, int cap);
