@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
                                                          const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 hmask,
                                                          const double *__restrict__ cnum, const double *__restrict__ cden,
                                                          double *__restrict__ partials, double *__restrict__ wabs_part, long long n0, long long nch, StepP p,
-                                                         u64 invalid_key, u64 seed, u64 step, DevScalars *sc, BucketArgs ba, GateOut go) {
+                                                         u64 invalid_key, u64 seed, u64 step, DevScalars *sc, BucketArgs ba, GateOut go, FusedSide fs) {
   // ---- LDS: the whole bucket lives here
   __shared__ u64 sw[BK_CAP_S], sw2[BK_CAP_S];            // sort words of the spawns (double buffer)
   __shared__ u32 rk[BK_CAP_R];                            // keys of the residents
@@ -253,23 +253,72 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     }
   }
   BPROF(3);
-  // ---- records by source, all requested before any is used; sums over the pre-merge list (do_walk.f90:2347-2349)
-  double wabs = 0.0, cnt = 0.0;
+  // ---- records by source, all requested before any is used.  With fs.on the block also does what the side-stream kernels
+  //      did: death/clone (do_walk.f90:3743-3793) of the residents outside the deterministic space as their weights arrive ...
+  __shared__ int s_nq;
+  if (tid == 0) s_nq = 0;
+  __syncthreads();
   {
-    double rw[BK_PER_R]; u32 rf[BK_PER_R]; double sw_[BK_PER_S]; u64 sf_[BK_PER_S];
+    double rw[BK_PER_R]; u32 rf[BK_PER_R]; double rm[BK_PER_R]; double sw_[BK_PER_S]; u64 sf_[BK_PER_S];
 #pragma unroll
-    for (int q = 0; q < BK_PER_R; q++) { const int i = tid + q * BK_AT; rw[q] = 0.0; rf[q] = 0; if (i < R) { rw[q] = w.wt[r_lo + i]; rf[q] = w.flg[r_lo + i]; } }
+    for (int q = 0; q < BK_PER_R; q++) {
+      const int i = tid + q * BK_AT; rw[q] = 0.0; rf[q] = 0; rm[q] = 0.0;
+      if (i < R) { rw[q] = w.wt[r_lo + i]; rf[q] = w.flg[r_lo + i]; if (fs.on) rm[q] = w.me[r_lo + i]; }
+    }
 #pragma unroll
     for (int q = 0; q < BK_PER_S; q++) {
       const int j = tid + q * BK_AT; sw_[q] = 0.0; sf_[q] = 0;
       if (j < S) { const SpawnRec *rp = w.sp + ((long long)(u32)sa[j] - n0); sw_[q] = rp->wt; sf_[q] = rp->flg; }     // the word's low half is the walker slot n0 + child
     }
 #pragma unroll
-    for (int q = 0; q < BK_PER_R; q++) { const int i = tid + q * BK_AT; if (i < R) { s_w[i] = rw[q]; s_f[i] = rf[q]; wabs += fabs(rw[q]); cnt += 1.0; } }
+    for (int q = 0; q < BK_PER_R; q++) {
+      const int i = tid + q * BK_AT;
+      if (i < R) {
+        double x = rw[q];
+        if (fs.on) {
+          const int impd = flg_impd(rf[q]);
+          if (!(p.semi && impd < 1)) {
+            double f = 1.0 + p.tau * (p.e_trial - rm[q]);
+            if (f < 0) { if (p.reached > 1) sc->err = SQMC_ERR_NEG_DIAG; f = 0; }
+            x = x * f;
+          } else if (impd == 0) rnk[atomicAdd(&s_nq, 1)] = (unsigned short)i;        // a deterministic-space walker: queued for the projection
+        }
+        s_w[i] = x; s_f[i] = rf[q];
+      }
+    }
 #pragma unroll
-    for (int q = 0; q < BK_PER_S; q++) { const int j = tid + q * BK_AT; if (j < S) { s_w[R + j] = sw_[q]; s_f[R + j] = (u32)sf_[q]; wabs += fabs(sw_[q]); cnt += 1.0; } }
+    for (int q = 0; q < BK_PER_S; q++) { const int j = tid + q * BK_AT; if (j < S) { s_w[R + j] = sw_[q]; s_f[R + j] = (u32)sf_[q]; } }
   }
-  BPROF(4);
+  __syncthreads();
+  // ---- ... and the deterministic projection w(loc) += (-tau H + tau E_T) w(loc) (do_walk.f90:2255-2325,
+  //      fast_sparse_matrix_multiply_upper_triangular): one wavefront per queued walker, its row's products formed 256 at a time
+  //      (all loads of a round in flight) and added in storage order, exactly as k_prj_apply adds them
+  if (fs.on && s_nq > 0) {
+    double *sprod = (double *)scratch + wv * 256;         // 8 waves x 256 products = 16 KB of the idle counter space
+    const int nq = s_nq;
+    for (int qi = wv; qi < nq; qi += BK_AT / 64) {
+      const int i = (int)rnk[qi];
+      const int row = (int)w.irk[r_lo + i];
+      const int b0 = fs.ptr[row], e0 = fs.ptr[row + 1];
+      double y = 0.0;
+      for (int base = b0; base < e0; base += 256) {
+        double pr[4];
+#pragma unroll
+        for (int z = 0; z < 4; z++) { const int k = base + z * 64 + lane; pr[z] = (k < e0) ? fs.val[k] * fs.x_in[fs.col[k]] : 0.0; }
+#pragma unroll
+        for (int z = 0; z < 4; z++) sprod[z * 64 + lane] = pr[z];
+        __builtin_amdgcn_wave_barrier();
+        const int cntk = (e0 - base < 256) ? (e0 - base) : 256;
+        for (int l = 0; l < cntk; l++) y = y + sprod[l];
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (lane == 0) { y = y + p.e_trial * p.tau * fs.x_in[row]; s_w[i] = s_w[i] + y; }
+    }
+  }
+  __syncthreads();
+  // ---- sums over the pre-merge list (do_walk.f90:2347-2349), after death/clone and projection as the reference takes them
+  double wabs = 0.0, cnt = 0.0;
+  for (int x = tid; x < T; x += BK_AT) { wabs += fabs(s_w[x]); cnt += 1.0; }
   // ---- merged order: a resident goes behind the spawns with smaller keys, a spawn behind the residents with keys <= its own
   for (int i = tid; i < R; i += BK_AT) {
     const u32 k = rk[i];
@@ -401,7 +450,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
         go.keys[q0] = (key_[z] << 32) | (u64)q0; go.wchild[q0] = wc;
         if (go.child_off) go.child_off[q0] = (ex_glob >> 38) + (u64)s_nc[q0b + z * BK_AT]; else go.nchild[q0] = nc;
       }
-      if (d == 0 && p.semi && qd < p.nimp_cap) loc_imp[qd] = (int)q0;
+      if (d == 0 && p.semi && qd < p.nimp_cap) { loc_imp[qd] = (int)q0; o.irk[q0] = (u32)qd; if (fs.x_out) fs.x_out[qd] = wt; }
       st[0] += wt; st[1] += fabs(wt); st[8] += wt * wt;
       if (ini == 3) st[4] += wt * psg;
       if (d == 0 || (d == -2 && p.cti)) st[6] += fabs(wt);

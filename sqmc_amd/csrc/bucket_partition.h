@@ -13,6 +13,12 @@
 #define BK_TARGET 1150                // slots per bucket the host aims at (B = nall / BK_TARGET, at most one block per CU while that holds)
 #define BK_STOP 0x80000000u           // in the merged-order array (source index: residents [0, R), sorted spawns [R, R + S)): this slot starts a run
 
+// What the bucket tail does itself instead of the side-stream kernels when `on`: death/clone of every resident outside the
+// deterministic space (k_diag's multiplication; the H_ii are all cached by then) and the deterministic projection of the residents
+// inside it (k_prj_gather + k_prj_apply), row by row in storage order.  x_in = the deterministic-space weights by row as the
+// LAST step left them (written by that step's bucket tail into x_out, with every such walker's row in WalkArr::irk).
+struct FusedSide { int on; const int *ptr, *col; const double *val; const double *x_in; double *x_out; };
+
 struct BucketArgs {
   int B, nsb;                          // buckets, partition blocks
   u64 *words;                          // nsb x 256 sort words of the children, grouped by bucket inside each block

@@ -48,6 +48,7 @@ struct __attribute__((aligned(32))) SpawnRec { u64 up, dn; double wt; u64 flg; }
 struct WalkArr {
   SpawnRec *sp;            // spawn c of the step lives in sp[c]; walker slots >= nwalk of the SoA arrays are unused during a step
   u64 *up, *dn; double *wt; u32 *flg; double *me, *en, *ed;
+  u32 *irk;                // for a deterministic-space walker (imp_distance 0): its row in the projector = its rank among them (written by the bucket tail)
 };
 // imp_distance / initiator / perm_sign packed in one word: a gather through the sort
 // permutation costs one access instead of three
@@ -74,11 +75,12 @@ static int alloc_walk(WalkArr &a, long long n, bool with_spawn_records) {
   HIPCHK(hipMalloc(&a.up, n * 8)); HIPCHK(hipMalloc(&a.dn, n * 8)); HIPCHK(hipMalloc(&a.wt, n * 8));
   HIPCHK(hipMalloc(&a.flg, n * 4));
   HIPCHK(hipMalloc(&a.me, n * 8)); HIPCHK(hipMalloc(&a.en, n * 8)); HIPCHK(hipMalloc(&a.ed, n * 8));
+  HIPCHK(hipMalloc(&a.irk, n * 4));
   return 0;
 }
 static void free_walk(WalkArr &a) {
   hipFree(a.sp); hipFree(a.up); hipFree(a.dn); hipFree(a.wt); hipFree(a.flg);
-  hipFree(a.me); hipFree(a.en); hipFree(a.ed);
+  hipFree(a.me); hipFree(a.en); hipFree(a.ed); hipFree(a.irk);
 }
 
 struct StepP {       // device copy of sqmc_step_params + derived values
@@ -153,6 +155,9 @@ struct sqmc_gpu_ctx {
   int scan_flip, scan_used[2];   // gate-fused heads: look-back set of the next head scan, and how many words of each set its last scan may have touched
   bool residents_sorted;      // the walker arrays are known to be in (up, dn) order: true after every finished step and after an upload (which refuses unsorted lists)
   unsigned short *d_segoff; long long segoff_cap;      // bucket tail: group offsets of the partition blocks
+  double *d_prj_xs[2]; int xs_cur; bool xs_valid;      // snapshots of the deterministic-space weights by row, written by the bucket tail for the NEXT step's projection (two: one is read while the other is written)
+  bool side_pending;          // death/clone and the projection of this step have not been launched as kernels: the bucket tail does them itself, any other tail must launch them first
+  bool head_hii;              // the pipelined head filled the missing H_ii of this step's walkers
   bool head_offsets_done;     // the bucket tail of the step before wrote this step's child offsets and total (no scan launch in the head)
   double last_wabs;           // sum |w| after the last step (bounds the next step's child count)
   BucketArgs head_ba; long long last_nall;      // partition already done by the head's k_spawn (B > 0), and the length of the last sorted list (sizes the next one)
@@ -243,7 +248,8 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
     HIPCHK(hipMalloc(&c->d_done, 4)); HIPCHK(hipMemset(c->d_done, 0, 4));
   }
   for (int i = 0; i < NTIMERS; i++) { HIPCHK(hipEventCreate(&c->ev0[i])); HIPCHK(hipEventCreate(&c->ev1[i])); }
-  HIPCHK(hipStreamCreate(&c->st2)); HIPCHK(hipStreamCreate(&c->st3));
+  if (getenv("SQMC_ONE_STREAM")) { c->st2 = c->st; c->st3 = c->st; }      // experiment: no side streams (their fork/join costs event latencies)
+  else { HIPCHK(hipStreamCreate(&c->st2)); HIPCHK(hipStreamCreate(&c->st3)); }
   HIPCHK(hipEventCreateWithFlags(&c->e_join3, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->e_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->e_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->e_cnt, hipEventDisableTiming));
@@ -360,14 +366,15 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   hipFree(c->d_binom); hipFree(c->d_grow);
   comm_release(c);
   hipFree(c->d_tab); hipFree(c->d_ints); hipFree(c->d_hb_r); hipFree(c->d_hb_s); hipFree(c->d_hb_absH); hipFree(c->d_pq_ind); hipFree(c->d_pq_count);
-  hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x);
+  hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x); hipFree(c->d_prj_xs[0]); hipFree(c->d_prj_xs[1]);
   hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den); hipFree(c->d_ct_hkey); hipFree(c->d_ct_hidx);
   hipFree(c->d_sc); hipHostFree(c->h_sc); if (c->h_mail) hipHostFree((void *)c->h_mail);
   for (int i = 0; i < NTIMERS; i++) { hipEventDestroy(c->ev0[i]); hipEventDestroy(c->ev1[i]); }
   hipEventDestroy(c->e_fork); hipEventDestroy(c->e_join); hipEventDestroy(c->e_cnt);
   for (int i = 0; i < 4; i++) hipEventDestroy(c->hev[i]);
-  hipEventDestroy(c->e_join3); hipStreamDestroy(c->st3);
-  hipStreamDestroy(c->st2); hipStreamDestroy(c->st);
+  hipEventDestroy(c->e_join3); if (c->st3 != c->st) hipStreamDestroy(c->st3);
+  if (c->st2 != c->st) hipStreamDestroy(c->st2);
+  hipStreamDestroy(c->st);
   delete c;
   return SQMC_OK;
 }
@@ -396,6 +403,9 @@ int sqmc_gpu_set_projector(sqmc_gpu_ctx *c, int64_t n_imp, int64_t nnz, const in
   c->n_imp = n_imp; c->prj_nnz = (long long)col.size();
   HIPCHK(hipMalloc(&c->d_prj_ptr, (n_imp + 1) * 4)); HIPCHK(hipMalloc(&c->d_prj_col, (col.size() + 1) * 4)); HIPCHK(hipMalloc(&c->d_prj_val, (v.size() + 1) * 8));
   HIPCHK(hipMalloc(&c->d_loc_imp, (n_imp + 1) * 4)); HIPCHK(hipMalloc(&c->d_prj_x, (n_imp + 1) * 8));
+  hipFree(c->d_prj_xs[0]); hipFree(c->d_prj_xs[1]);
+  HIPCHK(hipMalloc(&c->d_prj_xs[0], (n_imp + 1) * 8)); HIPCHK(hipMalloc(&c->d_prj_xs[1], (n_imp + 1) * 8));
+  c->xs_valid = false; c->xs_cur = 0;
   HIPCHK(hipMemcpy(c->d_prj_ptr, ptr.data(), (n_imp + 1) * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->d_prj_col, col.data(), col.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->d_prj_val, v.data(), v.size() * 8, hipMemcpyHostToDevice));
@@ -452,6 +462,7 @@ int sqmc_gpu_upload_walkers(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, cons
   HIPCHK(hipMemcpy(c->w.me, me, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.en, en, n * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->w.ed, ed, n * 8, hipMemcpyHostToDevice));
   c->nwalk = n; c->residents_sorted = true;       // checked above: sorted and unique
+  c->xs_valid = false;
   if (c->n_imp > 0) {        // my_locations_of_imp_dets, do_walk.f90:2188-2212
     const long long expect = c->d_grow ? c->n_imp_local : c->n_imp;
     std::vector<int> loc; loc.reserve(expect);
@@ -623,7 +634,9 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
     // decide -- they are computed now, on the side stream, beside the scan and k_spawn; death/clone later finds them cached
     HIPCHK(hipStreamWaitEvent(c->st2, c->e_fork, 0));
     hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, c->st2, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc, 1);
-  }
+    HIPCHK(hipEventRecord(c->e_join, c->st2));          // a tail that does death/clone itself still has to wait for these
+    c->head_hii = true;
+  } else c->head_hii = false;
   *cseq = ++c->cnt_seq;
   const OwnerOut oo = shard_owner_out(c);
   // short lists: k_spawn groups its children by key range as it emits them (the bucket tail then needs no partition kernel).
@@ -665,6 +678,31 @@ static void drop_head(sqmc_gpu_ctx *c) {
 }
 // sort -> merge -> round -> compact/estimate -> readback; shared by the single-rank step and
 // the sharded step (where the spawns behind slot n0 arrived from other ranks)
+// death/clone (k_diag) and the deterministic projection as kernels of their own: on the two side streams, forked at e_fork and
+// joined by e_join / e_join3 -- or, `serial`, on the main stream (a tail that found them still pending)
+static int launch_side_kernels(sqmc_gpu_ctx *c, const StepP &p, long long n0, bool serial) {
+  hipStream_t st2 = serial ? c->st : c->st2;
+  if (!serial) HIPCHK(hipStreamWaitEvent(st2, c->e_fork, 0));
+  TBEG(diag, st2);
+  hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, st2, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc, 0);
+  TEND(diag, st2);
+  // the projection reads and writes the weights of the deterministic-space walkers only (imp_distance 0), death/clone skips
+  // exactly those: the two run side by side
+  static const bool no_st3 = getenv("SQMC_NO_ST3") != nullptr;
+  hipStream_t st3 = (p.semi && !no_st3 && !serial) ? c->st3 : st2;
+  if (st3 != st2) HIPCHK(hipStreamWaitEvent(st3, c->e_fork, 0));
+  TBEG(project, st3);
+  if (p.semi) {
+    hipLaunchKernelGGL(k_prj_gather, dim3(nblk(c->n_imp)), dim3(TPB), 0, st3, c->w.wt, c->d_loc_imp, c->d_prj_x, c->n_imp);
+    hipLaunchKernelGGL(k_prj_apply, dim3(nblk(c->n_imp, TPB / 64)), dim3(TPB), 0, st3, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, c->d_prj_x, c->d_loc_imp, c->w.wt,
+                       c->n_imp, p.e_trial, p.tau);
+    if (st3 != st2) HIPCHK(hipEventRecord(c->e_join3, st3));
+  }
+  TEND(project, st3);
+  if (!serial) HIPCHK(hipEventRecord(c->e_join, st2));
+  HIPCHK(hipGetLastError());
+  return SQMC_OK;
+}
 #define SQMC_INTERNAL_RETRY 1000      // step_tail_impl: the bucket tail gave up, nothing of it counts; run the radix tail
 static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long nall, bool join_side_stream, double out[16], bool allow_bucket) {
   StepP p = p_in;
@@ -706,6 +744,10 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       }
       if (bucket) ba.force_retry = (force_every > 0 && (c->bk_steps % force_every) == force_every - 1) ? 1 : 0;
     }
+  }
+  if (!bucket && c->side_pending) {          // the head counted on the bucket tail for death/clone and the projection: do them now, in line
+    c->side_pending = false;
+    int rs = launch_side_kernels(c, p, n0, true); if (rs) return rs;
   }
   if (bucket) {
   } else if (p.semi && c->residents_sorted && nall >= merge_min) {
@@ -759,8 +801,11 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
 #define ANNEAL_LAUNCH(I) do { if (t_anneal >= 0) hipExtLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, ANNEAL_ARGS); \
                               else hipLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, ANNEAL_ARGS); } while (0)
     if (bucket) {
+      FusedSide fs; memset(&fs, 0, sizeof(fs));
+      fs.on = c->side_pending ? 1 : 0; fs.ptr = c->d_prj_ptr; fs.col = c->d_prj_col; fs.val = c->d_prj_val;
+      fs.x_in = c->d_prj_xs[c->xs_cur]; fs.x_out = c->d_prj_xs[c->xs_cur ^ 1];
 #define BUCKET_ARGS c->w, c->m, (const u64 *)c->d_keys, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, \
-                    n0, nall - n0, p, c->invalid_key, seed, step, c->d_sc, ba, go
+                    n0, nall - n0, p, c->invalid_key, seed, step, c->d_sc, ba, go, fs
       if (t_anneal >= 0) hipExtLaunchKernelGGL(k_anneal_bucket, dim3(nb), dim3(BK_AT), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, BUCKET_ARGS);
       else hipLaunchKernelGGL(k_anneal_bucket, dim3(nb), dim3(BK_AT), 0, st, BUCKET_ARGS);
 #undef BUCKET_ARGS
@@ -771,7 +816,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
 #undef ANNEAL_ARGS
     if (fuse_gate && go.keys == c->d_keys_alt) std::swap(c->d_keys, c->d_keys_alt);      // the next step's spawn kernel appends its keys behind the walkers'
     std::swap(c->w.up, c->m.up); std::swap(c->w.dn, c->m.dn); std::swap(c->w.wt, c->m.wt); std::swap(c->w.flg, c->m.flg);
-    std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed);
+    std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed); std::swap(c->w.irk, c->m.irk);
   } else {
     TBEG(merge, st);
     hipLaunchKernelGGL(k_merge, dim3(nbm), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, c->d_wabs_part, n0, nall, p, c->invalid_key, c->pack);
@@ -839,7 +884,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       hipMemset(&c->d_sc->retry, 0, sizeof(int)); hipMemset(&c->d_sc->bk_fill, 0, sizeof(unsigned int));
       c->h_sc->retry = 0;
       std::swap(c->w.up, c->m.up); std::swap(c->w.dn, c->m.dn); std::swap(c->w.wt, c->m.wt); std::swap(c->w.flg, c->m.flg);
-      std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed);
+      std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed); std::swap(c->w.irk, c->m.irk);
       if (fuse_gate) std::swap(c->d_keys, c->d_keys_alt);
       c->pipeline_next = false; c->bk_retries++; c->head_offsets_done = false;
       { static const int hold = getenv("SQMC_BUCKET_HOLDOFF") ? atoi(getenv("SQMC_BUCKET_HOLDOFF")) : 8; c->bk_holdoff = hold; }
@@ -857,6 +902,8 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
   }
   const long long nfinal = (long long)(c->h_sc->tot2 & 0xFFFFFFFFull), nimp = (long long)(c->h_sc->tot2 >> 32);
   c->nwalk = nfinal; c->residents_sorted = true;
+  if (bucket && p.semi) { c->xs_cur ^= 1; c->xs_valid = true; } else c->xs_valid = false;
+  c->side_pending = false;
   for (int i = 0; i < 16; i++) out[i] = c->h_sc->stats[i];
   c->last_wabs = out[1];
   if (nfinal == 0) { drop_head(c); return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0"); }
@@ -889,6 +936,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   if (c->timing >= 2 && c->nt < NTIMERS) { t_gate_scan = c->nt++; c->tname[t_gate_scan] = "gate_scan"; }
   if (kernel_events_on(c, step) && c->nt < NTIMERS) { t_spawn = c->nt++; c->tname[t_spawn] = "spawn"; }
   u64 cseq;
+  const bool from_head = c->head_ready;
   if (c->head_ready) {
     // gate + scan + spawn of this step already run behind k_finish of the last one (pipelined head):
     // they only depend on parameters that are constant once the target population has been reached
@@ -922,27 +970,15 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
                          t_spawn >= 0 ? c->ev0[t_spawn] : nullptr, t_spawn >= 0 ? c->ev1[t_spawn] : nullptr, &cseq);
     if (r) return r;
   }
-  // ---- fork: death/clone and the deterministic projection only touch weights, which neither
-  //      the spawn kernel (it uses the child weights of the gate) nor the sort reads
-  HIPCHK(hipStreamWaitEvent(st2, c->e_fork, 0));
-  TBEG(diag, st2);
-  hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, st2, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc, 0);
-  TEND(diag, st2);
-  // the projection reads and writes the weights of the deterministic-space walkers only (imp_distance 0), death/clone skips
-  // exactly those: the two run side by side
-  static const bool no_st3 = getenv("SQMC_NO_ST3") != nullptr;
-  hipStream_t st3 = (p.semi && !no_st3) ? c->st3 : st2;
-  if (st3 != st2) HIPCHK(hipStreamWaitEvent(st3, c->e_fork, 0));
-  TBEG(project, st3);
-  if (p.semi) {
-    hipLaunchKernelGGL(k_prj_gather, dim3(nblk(c->n_imp)), dim3(TPB), 0, st3, c->w.wt, c->d_loc_imp, c->d_prj_x, c->n_imp);
-    hipLaunchKernelGGL(k_prj_apply, dim3(nblk(c->n_imp, TPB / 64)), dim3(TPB), 0, st3, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, c->d_prj_x, c->d_loc_imp, c->w.wt,
-                       c->n_imp, p.e_trial, p.tau);
-    if (st3 != st2) HIPCHK(hipEventRecord(c->e_join3, st3));
+  // ---- death/clone and the deterministic projection: side streams beside spawn + sort -- or nothing at all here when the
+  //      bucket tail is going to do them itself (pipelined steps whose missing H_ii the head already filled and whose
+  //      deterministic weights the last bucket tail left row by row)
+  {
+    static const bool no_fused_side = getenv("SQMC_NO_FUSED_SIDE") != nullptr;
+    c->side_pending = !no_fused_side && from_head && c->head_hii && c->xs_valid && p.semi && bucket_static_ok(c, p) && c->bk_holdoff == 0 && c->head_ba.B > 0;
+    c->head_hii = false;
+    if (!c->side_pending) { int r = launch_side_kernels(c, p, n0, false); if (r) return r; }
   }
-  TEND(project, st3);
-  HIPCHK(hipEventRecord(c->e_join, st2));
-  HIPCHK(hipGetLastError());
   // ---- the child count, from the mailbox (or the slow way when there was no k_spawn launch)
   long long nch;
   if (M > n0) {

@@ -10,7 +10,8 @@ def main(base, which=-30):
     kd = [t for t in tabs if 'kernel_dispatch' in t][0]
     ks = [t for t in tabs if 'info_kernel_symbol' in t][0]
     rows = list(c.execute("select s.kernel_name, d.start, d.end, d.queue_id from %s d join %s s on d.kernel_id = s.id order by d.start" % (kd, ks)))
-    idx = [i for i, r in enumerate(rows) if 'k_gate' in r[0]]
+    anchor = sys.argv[3] if len(sys.argv) > 3 else 'k_gate'        # a kernel that runs once per step
+    idx = [i for i, r in enumerate(rows) if anchor in r[0]]
     i0, i1 = idx[which], idx[which + 1]
     t0, prev_end = rows[i0][1], None
     for r in rows[i0:i1 + 1]:
