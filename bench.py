@@ -239,7 +239,8 @@ def main():
                                     "hubbard": "size_deterministic=500, Psi_T 20 dets, tau_multiplier 0.5"}[args.system]),
                        "occupied_dets_per_step": n_avg, "spawns_per_step": s_avg, "spawns_per_s": spawn_all / dt,
                        "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": parallelism,
-                       "rccl_ranks": rccl_ranks, "devices": min(world, ndev)},
+                       "rccl_ranks": rccl_ranks, "devices": min(world, ndev),
+                       "short_list_tail": dict(zip(("bucket_steps", "rerun_through_radix_tail"), walk.g.tail_stats()))},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic_of(dom)[0], "traffic_detail": traffic_of(dom)[1], "ms_per_launch": dom_ms,
                          "algorithmic_bytes_per_launch": dom_bytes,

@@ -255,15 +255,12 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
   BPROF(3);
   // ---- records by source, all requested before any is used.  With fs.on the block also does what the side-stream kernels
   //      did: death/clone (do_walk.f90:3743-3793) of the residents outside the deterministic space as their weights arrive ...
-  __shared__ int s_nq;
-  if (tid == 0) s_nq = 0;
-  __syncthreads();
   {
-    double rw[BK_PER_R]; u32 rf[BK_PER_R]; double rm[BK_PER_R]; double sw_[BK_PER_S]; u64 sf_[BK_PER_S];
+    double rw[BK_PER_R]; u32 rf[BK_PER_R]; double rm[BK_PER_R]; u32 rr[BK_PER_R]; double sw_[BK_PER_S]; u64 sf_[BK_PER_S];
 #pragma unroll
     for (int q = 0; q < BK_PER_R; q++) {
-      const int i = tid + q * BK_AT; rw[q] = 0.0; rf[q] = 0; rm[q] = 0.0;
-      if (i < R) { rw[q] = w.wt[r_lo + i]; rf[q] = w.flg[r_lo + i]; if (fs.on) rm[q] = w.me[r_lo + i]; }
+      const int i = tid + q * BK_AT; rw[q] = 0.0; rf[q] = 0; rm[q] = 0.0; rr[q] = 0;
+      if (i < R) { rw[q] = w.wt[r_lo + i]; rf[q] = w.flg[r_lo + i]; if (fs.on) { rm[q] = w.me[r_lo + i]; rr[q] = w.irk[r_lo + i]; } }
     }
 #pragma unroll
     for (int q = 0; q < BK_PER_S; q++) {
@@ -281,39 +278,17 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
             double f = 1.0 + p.tau * (p.e_trial - rm[q]);
             if (f < 0) { if (p.reached > 1) sc->err = SQMC_ERR_NEG_DIAG; f = 0; }
             x = x * f;
-          } else if (impd == 0) rnk[atomicAdd(&s_nq, 1)] = (unsigned short)i;        // a deterministic-space walker: queued for the projection
+          } else if (impd == 0) {                       // ... and the projection's last line for those inside it: w(loc) += (A x)(row) + E_T tau x(row), k_prj_apply's statements
+            double y = fs.y[rr[q]];
+            y = y + p.e_trial * p.tau * fs.x_in[rr[q]];
+            x = x + y;
+          }
         }
         s_w[i] = x; s_f[i] = rf[q];
       }
     }
 #pragma unroll
     for (int q = 0; q < BK_PER_S; q++) { const int j = tid + q * BK_AT; if (j < S) { s_w[R + j] = sw_[q]; s_f[R + j] = (u32)sf_[q]; } }
-  }
-  __syncthreads();
-  // ---- ... and the deterministic projection w(loc) += (-tau H + tau E_T) w(loc) (do_walk.f90:2255-2325,
-  //      fast_sparse_matrix_multiply_upper_triangular): one wavefront per queued walker, its row's products formed 256 at a time
-  //      (all loads of a round in flight) and added in storage order, exactly as k_prj_apply adds them
-  if (fs.on && s_nq > 0) {
-    double *sprod = (double *)scratch + wv * 256;         // 8 waves x 256 products = 16 KB of the idle counter space
-    const int nq = s_nq;
-    for (int qi = wv; qi < nq; qi += BK_AT / 64) {
-      const int i = (int)rnk[qi];
-      const int row = (int)w.irk[r_lo + i];
-      const int b0 = fs.ptr[row], e0 = fs.ptr[row + 1];
-      double y = 0.0;
-      for (int base = b0; base < e0; base += 256) {
-        double pr[4];
-#pragma unroll
-        for (int z = 0; z < 4; z++) { const int k = base + z * 64 + lane; pr[z] = (k < e0) ? fs.val[k] * fs.x_in[fs.col[k]] : 0.0; }
-#pragma unroll
-        for (int z = 0; z < 4; z++) sprod[z * 64 + lane] = pr[z];
-        __builtin_amdgcn_wave_barrier();
-        const int cntk = (e0 - base < 256) ? (e0 - base) : 256;
-        for (int l = 0; l < cntk; l++) y = y + sprod[l];
-        __builtin_amdgcn_wave_barrier();
-      }
-      if (lane == 0) { y = y + p.e_trial * p.tau * fs.x_in[row]; s_w[i] = s_w[i] + y; }
-    }
   }
   __syncthreads();
   // ---- sums over the pre-merge list (do_walk.f90:2347-2349), after death/clone and projection as the reference takes them

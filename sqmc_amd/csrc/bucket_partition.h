@@ -14,10 +14,12 @@
 #define BK_STOP 0x80000000u           // in the merged-order array (source index: residents [0, R), sorted spawns [R, R + S)): this slot starts a run
 
 // What the bucket tail does itself instead of the side-stream kernels when `on`: death/clone of every resident outside the
-// deterministic space (k_diag's multiplication; the H_ii are all cached by then) and the deterministic projection of the residents
-// inside it (k_prj_gather + k_prj_apply), row by row in storage order.  x_in = the deterministic-space weights by row as the
+// deterministic space (k_diag's multiplication; the H_ii are all cached by then) and the last line of the deterministic projection
+// of the residents inside it, w += (A x)(row) + E_T tau x(row) (k_prj_apply's), with A x already there.  x_in = the deterministic-space weights by row as the
 // LAST step left them (written by that step's bucket tail into x_out, with every such walker's row in WalkArr::irk).
-struct FusedSide { int on; const int *ptr, *col; const double *val; const double *x_in; double *x_out; };
+struct FusedSide { int on; const double *y; const double *x_in; double *x_out; };      // y = A x_in, row by row, from the spare blocks of k_spawn (PrjPre)
+// the matrix-vector part of the projection, which needs nothing the host still has to decide: computed by spare blocks of k_spawn
+struct PrjPre { int n_imp; const int *ptr, *col; const double *val; const double *x; double *y; };
 
 struct BucketArgs {
   int B, nsb;                          // buckets, partition blocks

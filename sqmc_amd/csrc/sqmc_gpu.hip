@@ -155,6 +155,7 @@ struct sqmc_gpu_ctx {
   int scan_flip, scan_used[2];   // gate-fused heads: look-back set of the next head scan, and how many words of each set its last scan may have touched
   bool residents_sorted;      // the walker arrays are known to be in (up, dn) order: true after every finished step and after an upload (which refuses unsorted lists)
   unsigned short *d_segoff; long long segoff_cap;      // bucket tail: group offsets of the partition blocks
+  double *d_prj_y; const double *head_prj_x; bool head_y_done;      // A x of the pipelined head's spare k_spawn blocks, the x it used
   double *d_prj_xs[2]; int xs_cur; bool xs_valid;      // snapshots of the deterministic-space weights by row, written by the bucket tail for the NEXT step's projection (two: one is read while the other is written)
   bool side_pending;          // death/clone and the projection of this step have not been launched as kernels: the bucket tail does them itself, any other tail must launch them first
   bool head_hii;              // the pipelined head filled the missing H_ii of this step's walkers
@@ -366,7 +367,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   hipFree(c->d_binom); hipFree(c->d_grow);
   comm_release(c);
   hipFree(c->d_tab); hipFree(c->d_ints); hipFree(c->d_hb_r); hipFree(c->d_hb_s); hipFree(c->d_hb_absH); hipFree(c->d_pq_ind); hipFree(c->d_pq_count);
-  hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x); hipFree(c->d_prj_xs[0]); hipFree(c->d_prj_xs[1]);
+  hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x); hipFree(c->d_prj_xs[0]); hipFree(c->d_prj_xs[1]); hipFree(c->d_prj_y);
   hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den); hipFree(c->d_ct_hkey); hipFree(c->d_ct_hidx);
   hipFree(c->d_sc); hipHostFree(c->h_sc); if (c->h_mail) hipHostFree((void *)c->h_mail);
   for (int i = 0; i < NTIMERS; i++) { hipEventDestroy(c->ev0[i]); hipEventDestroy(c->ev1[i]); }
@@ -403,8 +404,8 @@ int sqmc_gpu_set_projector(sqmc_gpu_ctx *c, int64_t n_imp, int64_t nnz, const in
   c->n_imp = n_imp; c->prj_nnz = (long long)col.size();
   HIPCHK(hipMalloc(&c->d_prj_ptr, (n_imp + 1) * 4)); HIPCHK(hipMalloc(&c->d_prj_col, (col.size() + 1) * 4)); HIPCHK(hipMalloc(&c->d_prj_val, (v.size() + 1) * 8));
   HIPCHK(hipMalloc(&c->d_loc_imp, (n_imp + 1) * 4)); HIPCHK(hipMalloc(&c->d_prj_x, (n_imp + 1) * 8));
-  hipFree(c->d_prj_xs[0]); hipFree(c->d_prj_xs[1]);
-  HIPCHK(hipMalloc(&c->d_prj_xs[0], (n_imp + 1) * 8)); HIPCHK(hipMalloc(&c->d_prj_xs[1], (n_imp + 1) * 8));
+  hipFree(c->d_prj_xs[0]); hipFree(c->d_prj_xs[1]); hipFree(c->d_prj_y);
+  HIPCHK(hipMalloc(&c->d_prj_xs[0], (n_imp + 1) * 8)); HIPCHK(hipMalloc(&c->d_prj_xs[1], (n_imp + 1) * 8)); HIPCHK(hipMalloc(&c->d_prj_y, (n_imp + 1) * 8));
   c->xs_valid = false; c->xs_cur = 0;
   HIPCHK(hipMemcpy(c->d_prj_ptr, ptr.data(), (n_imp + 1) * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->d_prj_col, col.data(), col.size() * 4, hipMemcpyHostToDevice));
@@ -601,6 +602,13 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   FinArgs fa; memset(&fa, 0, sizeof(fa)); if (fin) fa = *fin;
   if (g0) hipEventRecord(g0, st);
   FinArgs spawn_fin; memset(&spawn_fin, 0, sizeof(spawn_fin));
+  PrjPre pp; memset(&pp, 0, sizeof(pp));
+  c->head_y_done = false;
+  if (dev_n && c->head_prj_x && c->n_imp > 0 && !c->d_grow) {       // the tail that enqueues this head is a bucket tail: its deterministic weights, row by row, are this step's x
+    pp.n_imp = (int)c->n_imp; pp.ptr = c->d_prj_ptr; pp.col = c->d_prj_col; pp.val = c->d_prj_val; pp.x = c->head_prj_x; pp.y = c->d_prj_y;
+    c->head_y_done = true;
+  }
+  c->head_prj_x = nullptr;
   if (gate_done && c->head_offsets_done) {
     // the bucket tail of the step before wrote keys, child weights, child OFFSETS and their total: nothing to scan.  That
     // step's final sums ride on k_spawn as one extra block.
@@ -659,11 +667,11 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   const long long nfree = dev_n ? M : M - n0;          // dev_n: nothing is known about the count but that it is >= 0
   if (nfree > 0) {
     if (s0)
-      hipExtLaunchKernelGGL(k_spawn, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin);
+      hipExtLaunchKernelGGL(k_spawn, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
+                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, nblk(nfree));
     else
-      hipLaunchKernelGGL(k_spawn, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin);
+      hipLaunchKernelGGL(k_spawn, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, nblk(nfree));
   } else if (s0) { hipEventRecord(s0, st); hipEventRecord(s1, st); }
   HIPCHK(hipGetLastError());
   return SQMC_OK;
@@ -802,8 +810,10 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
                               else hipLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, ANNEAL_ARGS); } while (0)
     if (bucket) {
       FusedSide fs; memset(&fs, 0, sizeof(fs));
-      fs.on = c->side_pending ? 1 : 0; fs.ptr = c->d_prj_ptr; fs.col = c->d_prj_col; fs.val = c->d_prj_val;
+      fs.on = c->side_pending ? 1 : 0; fs.y = c->d_prj_y;
       fs.x_in = c->d_prj_xs[c->xs_cur]; fs.x_out = c->d_prj_xs[c->xs_cur ^ 1];
+      static const bool no_fs = getenv("SQMC_NO_FUSED_SIDE") != nullptr;
+      if (c->pipeline_next && p.semi && !no_fs) c->head_prj_x = fs.x_out;      // the head enqueued below may multiply the projector into it
 #define BUCKET_ARGS c->w, c->m, (const u64 *)c->d_keys, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, \
                     n0, nall - n0, p, c->invalid_key, seed, step, c->d_sc, ba, go, fs
       if (t_anneal >= 0) hipExtLaunchKernelGGL(k_anneal_bucket, dim3(nb), dim3(BK_AT), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, BUCKET_ARGS);
@@ -960,10 +970,10 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     if (M > n0) {
       if (t_spawn >= 0)
         hipExtLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->ev0[t_spawn], c->ev1[t_spawn], 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{});
+                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{}, PrjPre{}, nblk(M - n0));
       else
         hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{});
+                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{}, PrjPre{}, nblk(M - n0));
     } else if (t_spawn >= 0) { hipEventRecord(c->ev0[t_spawn], st); hipEventRecord(c->ev1[t_spawn], st); }
   } else {
     int r = enqueue_head(c, p, step, n0, false, t_gate_scan >= 0 ? c->ev0[t_gate_scan] : nullptr, t_gate_scan >= 0 ? c->ev1[t_gate_scan] : nullptr,
@@ -975,7 +985,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   //      deterministic weights the last bucket tail left row by row)
   {
     static const bool no_fused_side = getenv("SQMC_NO_FUSED_SIDE") != nullptr;
-    c->side_pending = !no_fused_side && from_head && c->head_hii && c->xs_valid && p.semi && bucket_static_ok(c, p) && c->bk_holdoff == 0 && c->head_ba.B > 0;
+    c->side_pending = !no_fused_side && from_head && c->head_hii && c->head_y_done && c->xs_valid && p.semi && bucket_static_ok(c, p) && c->bk_holdoff == 0 && c->head_ba.B > 0;
     c->head_hii = false;
     if (!c->side_pending) { int r = launch_side_kernels(c, p, n0, false); if (r) return r; }
   }

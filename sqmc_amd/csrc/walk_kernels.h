@@ -204,6 +204,28 @@ __device__ __forceinline__ u64 spawn_emit(const ChemDev &dev, const WalkArr &w, 
   }
 }
 
+// (A x)(row) with the row's products added in storage order (fast_sparse_matrix_multiply_upper_triangular, more_tools.f90:3622-3670,
+// as k_prj_apply adds them): one wavefront, 64 products per round trip
+__device__ __forceinline__ void prj_row_product(const PrjPre &pp, int row) {
+  __shared__ double s_prod[TPB / 64][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = pp.ptr[row], e = pp.ptr[row + 1];
+  double y = 0.0;
+  for (int base = b; base < e; base += 64) {
+    const int k = base + lane;
+    s_prod[wv][lane] = (k < e) ? pp.val[k] * pp.x[pp.col[k]] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    const int cnt = (e - base < 64) ? (e - base) : 64;
+    if (cnt == 64) {
+#pragma unroll
+      for (int l = 0; l < 64; l++) y = y + s_prod[wv][l];
+    } else {
+      for (int l = 0; l < cnt; l++) y = y + s_prod[wv][l];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) pp.y[row] = y;
+}
 #ifdef SPAWN_PROF
 __device__ unsigned long long g_prof[8 * 8192];
 #define PROF(K) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_prof[blockIdx.x * 8 + (K)] = wall_clock64(); } while (0)
@@ -215,10 +237,19 @@ extern "C" int sqmc_gpu_debug_prof(unsigned long long *out) { return (int)hipMem
 __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
                                                const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
                                                long long n0_arg, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc,
-                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo, BucketArgs ba, FinArgs fin) {
-  // steps whose child offsets came out of the bucket tail have no scan launch to carry the last step's final sums: one extra
-  // block of this kernel does them (it runs beside the spawning blocks; nothing it touches is read by them)
-  if (fin.on && blockIdx.x == gridDim.x - 1) { finish_all(fin, const_cast<DevScalars *>(sc)); return; }
+                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo, BucketArgs ba, FinArgs fin, PrjPre pp, int extra0) {
+  // Blocks from extra0 on do not spawn.  Steps whose child offsets came out of the bucket tail have no scan launch to carry the
+  // last step's final sums: block extra0 does them (it runs beside the spawning blocks; nothing it touches is read by them).
+  // The blocks behind it multiply the deterministic projector into last step's deterministic weights, one wavefront per row:
+  // the part of the projection that needs nothing the host still has to decide (E_T enters in the tail, bucket_kernels.h).
+  if ((int)blockIdx.x >= extra0) {
+    const int xb = (int)blockIdx.x - extra0;
+    if (fin.on && xb == 0) { finish_all(fin, const_cast<DevScalars *>(sc)); return; }
+    if (n_on_device && sc->retry) return;
+    const int row = (xb - (fin.on ? 1 : 0)) * (TPB / 64) + (int)(threadIdx.x >> 6);
+    if (pp.n_imp > 0 && row < pp.n_imp) prj_row_product(pp, row);
+    return;
+  }
   if (n_on_device && sc->retry) return;                                 // see k_gate
   const long long n0 = n_on_device ? (long long)sc->nwalk : n0_arg;     // pipelined head: launched before the host learnt the walker count
   // the grid covers the free capacity of the walker arrays; the number of children is read from
