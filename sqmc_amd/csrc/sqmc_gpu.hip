@@ -636,15 +636,11 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   //      over the whole free capacity with a device-side child count and posts that count to the
   //      host mailbox as soon as it starts.
   HIPCHK(hipEventRecord(c->e_fork, st));
+  // pipelined head: the diagonal elements of the determinants the last step created depend on nothing the host still has to
+  // decide -- spare blocks of k_spawn compute them; death/clone later finds them cached
   static const bool no_early = getenv("SQMC_NO_EARLY_HII") != nullptr;
-  if (dev_n && !c->d_grow && !no_early) {
-    // pipelined head: the diagonal elements of the determinants the last step created depend on nothing the host still has to
-    // decide -- they are computed now, on the side stream, beside the scan and k_spawn; death/clone later finds them cached
-    HIPCHK(hipStreamWaitEvent(c->st2, c->e_fork, 0));
-    hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, c->st2, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc, 1);
-    HIPCHK(hipEventRecord(c->e_join, c->st2));          // a tail that does death/clone itself still has to wait for these
-    c->head_hii = true;
-  } else c->head_hii = false;
+  const int hii_blocks = (dev_n && !c->d_grow && !no_early) ? nblk(n0) : 0;
+  c->head_hii = hii_blocks > 0;
   *cseq = ++c->cnt_seq;
   const OwnerOut oo = shard_owner_out(c);
   // short lists: k_spawn groups its children by key range as it emits them (the bucket tail then needs no partition kernel).
@@ -667,11 +663,11 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   const long long nfree = dev_n ? M : M - n0;          // dev_n: nothing is known about the count but that it is >= 0
   if (nfree > 0) {
     if (s0)
-      hipExtLaunchKernelGGL(k_spawn, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, nblk(nfree));
+      hipExtLaunchKernelGGL(k_spawn, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + hii_blocks + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
+                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, nblk(nfree), hii_blocks);
     else
-      hipLaunchKernelGGL(k_spawn, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, nblk(nfree));
+      hipLaunchKernelGGL(k_spawn, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + hii_blocks + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, nblk(nfree), hii_blocks);
   } else if (s0) { hipEventRecord(s0, st); hipEventRecord(s1, st); }
   HIPCHK(hipGetLastError());
   return SQMC_OK;
@@ -970,10 +966,10 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     if (M > n0) {
       if (t_spawn >= 0)
         hipExtLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->ev0[t_spawn], c->ev1[t_spawn], 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{}, PrjPre{}, nblk(M - n0));
+                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{}, PrjPre{}, nblk(M - n0), 0);
       else
         hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{}, PrjPre{}, nblk(M - n0));
+                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{}, PrjPre{}, nblk(M - n0), 0);
     } else if (t_spawn >= 0) { hipEventRecord(c->ev0[t_spawn], st); hipEventRecord(c->ev1[t_spawn], st); }
   } else {
     int r = enqueue_head(c, p, step, n0, false, t_gate_scan >= 0 ? c->ev0[t_gate_scan] : nullptr, t_gate_scan >= 0 ? c->ev1[t_gate_scan] : nullptr,
@@ -1003,7 +999,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
   }
   const long long nall = n0 + nch;
-  return step_tail(c, p, n0, nall, true, out);
+  return step_tail(c, p, n0, nall, !c->side_pending, out);       // nothing ran on the side streams when the tail does that work itself
 }
 
 int sqmc_gpu_shard_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]);

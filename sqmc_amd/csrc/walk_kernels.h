@@ -84,21 +84,17 @@ __global__ void __launch_bounds__(64) k_replay_prepass(const ChemTab *__restrict
   sc->n_children = c; sc->lcg = g.x;
 }
 
-// diagonal death/clone, do_walk.f90:3743-3793
-// fill_only: only the missing H_ii are computed (pipelined head: the walker count is read on the device, weights are not touched)
-__global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, double *__restrict__ wt,
-                                              const u32 *__restrict__ flg, double *__restrict__ me, long long n_arg, StepP p, DevScalars *sc, int fill_only) {
-  if (fill_only && sc->retry) return;
-  const long long n = fill_only ? (long long)sc->nwalk : n_arg;
-  __shared__ ChemTab t;
-  stage_tab(&t, dev.tab, dev.tab_words);
+// diagonal death/clone, do_walk.f90:3743-3793, of the 256 walkers of block `blk` (t: the ChemTab image in LDS, staged by the caller)
+// fill_only: only the missing H_ii are computed (pipelined head: weights are not touched)
+__device__ __forceinline__ void diag_block(const ChemTab &t, const ChemDev &dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, double *__restrict__ wt,
+                                           const u32 *__restrict__ flg, double *__restrict__ me, long long n, const StepP &p, DevScalars *sc, int fill_only, long long blk) {
   // Only determinants first occupied in the last step lack H_ii (the 1e51 sentinel), and they sit anywhere in the
   // sorted list: computed in place every wavefront would pay the whole Slater-Condon sum for a few lanes.  The block
   // queues them in LDS and its first threads work the queue off densely.
   __shared__ int q[TPB];
   __shared__ double hq[TPB];
   __shared__ int wcnt[TPB / 64];
-  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  const long long i = blk * TPB + threadIdx.x;
   const bool live = i < n && !(p.semi && flg_impd(flg[i]) < 1);
   double hii = live ? me[i] : 0.0;
   const bool need = live && hii > 1e50;
@@ -112,7 +108,7 @@ __global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict
   __syncthreads();
   if (qn) {
     for (int k = threadIdx.x; k < qn; k += TPB) {
-      const long long j = (long long)blockIdx.x * TPB + q[k];
+      const long long j = blk * TPB + q[k];
       me[j] = hq[q[k]] = h_any(t, dev.integrals, up[j], dn[j], up[j], dn[j]);
     }
     __syncthreads();
@@ -122,6 +118,14 @@ __global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict
   double f = 1.0 + p.tau * (p.e_trial - hii);
   if (f < 0) { if (p.reached > 1) sc->err = SQMC_ERR_NEG_DIAG; f = 0; }
   wt[i] = wt[i] * f;
+}
+__global__ void __launch_bounds__(TPB) k_diag(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, double *__restrict__ wt,
+                                              const u32 *__restrict__ flg, double *__restrict__ me, long long n_arg, StepP p, DevScalars *sc, int fill_only) {
+  if (fill_only && sc->retry) return;
+  const long long n = fill_only ? (long long)sc->nwalk : n_arg;
+  __shared__ ChemTab t;
+  stage_tab(&t, dev.tab, dev.tab_words);
+  diag_block(t, dev, up, dn, wt, flg, me, n, p, sc, fill_only, (long long)blockIdx.x);
 }
 
 // rank that owns a determinant (get_det_owner, mpi_routines.f90:419-445: any hash of the determinant mod the number of ranks)
@@ -237,7 +241,8 @@ extern "C" int sqmc_gpu_debug_prof(unsigned long long *out) { return (int)hipMem
 __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
                                                const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
                                                long long n0_arg, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc,
-                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo, BucketArgs ba, FinArgs fin, PrjPre pp, int extra0) {
+                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo, BucketArgs ba, FinArgs fin, PrjPre pp, int extra0,
+                                               int hii_blocks) {
   // Blocks from extra0 on do not spawn.  Steps whose child offsets came out of the bucket tail have no scan launch to carry the
   // last step's final sums: block extra0 does them (it runs beside the spawning blocks; nothing it touches is read by them).
   // The blocks behind it multiply the deterministic projector into last step's deterministic weights, one wavefront per row:
@@ -246,7 +251,16 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
     const int xb = (int)blockIdx.x - extra0;
     if (fin.on && xb == 0) { finish_all(fin, const_cast<DevScalars *>(sc)); return; }
     if (n_on_device && sc->retry) return;
-    const int row = (xb - (fin.on ? 1 : 0)) * (TPB / 64) + (int)(threadIdx.x >> 6);
+    // behind the finishing block: hii_blocks blocks that fill in the H_ii of the determinants the last step created (what the
+    // death/clone of this step's tail needs; nothing the spawning blocks read), then the rows of the projector
+    const int hb0 = xb - (fin.on ? 1 : 0);
+    if (hb0 < hii_blocks) {
+      __shared__ ChemTab th;
+      stage_tab(&th, dev.tab, dev.tab_words);
+      diag_block(th, dev, w.up, w.dn, w.wt, w.flg, w.me, (long long)sc->nwalk, p, const_cast<DevScalars *>(sc), 1, (long long)hb0);
+      return;
+    }
+    const int row = (hb0 - hii_blocks) * (TPB / 64) + (int)(threadIdx.x >> 6);
     if (pp.n_imp > 0 && row < pp.n_imp) prj_row_product(pp, row);
     return;
   }
