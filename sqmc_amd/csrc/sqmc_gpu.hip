@@ -158,7 +158,7 @@ struct sqmc_gpu_ctx {
   double *d_prj_y; const double *head_prj_x; bool head_y_done;      // A x of the pipelined head's spare k_spawn blocks, the x it used
   double *d_prj_xs[2]; int xs_cur; bool xs_valid;      // snapshots of the deterministic-space weights by row, written by the bucket tail for the NEXT step's projection (two: one is read while the other is written)
   bool side_pending;          // death/clone and the projection of this step have not been launched as kernels: the bucket tail does them itself, any other tail must launch them first
-  bool head_hii;              // the pipelined head filled the missing H_ii of this step's walkers
+  bool head_hii, head_hii_joined;     // the pipelined head fills the missing H_ii of this step's walkers (joined: inside k_spawn itself, nothing to wait for)
   bool head_offsets_done;     // the bucket tail of the step before wrote this step's child offsets and total (no scan launch in the head)
   double last_wabs;           // sum |w| after the last step (bounds the next step's child count)
   BucketArgs head_ba; long long last_nall;      // partition already done by the head's k_spawn (B > 0), and the length of the last sorted list (sizes the next one)
@@ -637,10 +637,19 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   //      host mailbox as soon as it starts.
   HIPCHK(hipEventRecord(c->e_fork, st));
   // pipelined head: the diagonal elements of the determinants the last step created depend on nothing the host still has to
-  // decide -- spare blocks of k_spawn compute them; death/clone later finds them cached
+  // decide: they are computed now, beside the scan and k_spawn -- by a kernel on the side stream (default), or by spare blocks of
+  // k_spawn itself (SQMC_HII_IN_SPAWN=1: no cross-stream join, but the extra LDS costs k_spawn its occupancy: 122 against 110 us
+  // per step at 10^5 walkers).  Death/clone later finds them cached.
   static const bool no_early = getenv("SQMC_NO_EARLY_HII") != nullptr;
-  const int hii_blocks = (dev_n && !c->d_grow && !no_early) ? nblk(n0) : 0;
-  c->head_hii = hii_blocks > 0;
+  static const bool hii_in_spawn = getenv("SQMC_HII_IN_SPAWN") != nullptr;
+  const bool early = dev_n && !c->d_grow && !no_early;
+  const int hii_blocks = (early && hii_in_spawn) ? nblk(n0) : 0;
+  if (early && !hii_in_spawn) {
+    HIPCHK(hipStreamWaitEvent(c->st2, c->e_fork, 0));
+    hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, c->st2, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc, 1);
+    HIPCHK(hipEventRecord(c->e_join, c->st2));          // a tail that does death/clone itself still has to wait for these
+  }
+  c->head_hii = early; c->head_hii_joined = early && hii_in_spawn;
   *cseq = ++c->cnt_seq;
   const OwnerOut oo = shard_owner_out(c);
   // short lists: k_spawn groups its children by key range as it emits them (the bucket tail then needs no partition kernel).
@@ -983,6 +992,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     static const bool no_fused_side = getenv("SQMC_NO_FUSED_SIDE") != nullptr;
     c->side_pending = !no_fused_side && from_head && c->head_hii && c->head_y_done && c->xs_valid && p.semi && bucket_static_ok(c, p) && c->bk_holdoff == 0 && c->head_ba.B > 0;
     c->head_hii = false;
+    if (!c->side_pending) c->head_hii_joined = false;
     if (!c->side_pending) { int r = launch_side_kernels(c, p, n0, false); if (r) return r; }
   }
   // ---- the child count, from the mailbox (or the slow way when there was no k_spawn launch)
@@ -999,7 +1009,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
   }
   const long long nall = n0 + nch;
-  return step_tail(c, p, n0, nall, !c->side_pending, out);       // nothing ran on the side streams when the tail does that work itself
+  return step_tail(c, p, n0, nall, !(c->side_pending && c->head_hii_joined), out);       // nothing ran on the side streams when the tail does that work itself and the H_ii came out of k_spawn
 }
 
 int sqmc_gpu_shard_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]);
