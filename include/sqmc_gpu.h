@@ -109,6 +109,35 @@ int sqmc_gpu_init_hubbard(const sqmc_hubbard_cfg *cfg, sqmc_gpu_ctx **out);
 int sqmc_gpu_finalize(sqmc_gpu_ctx *ctx);
 const char *sqmc_gpu_last_error(void);
 
+/* proposal_method 'fast_heatbath': the tables setup_efficient_heatbath builds when run_type /= hci (chemistry.f90:1002-1225),
+ * handed over exactly as the reference holds them (module variables of chemistry.f90:52-75; Fortran column-major order, the
+ * four-index arrays and their alias tables 1-D and single precision, indexed by same_index / opposite_index, 9154-9193).
+ * After this call sqmc_gpu_step spawns with off_diagonal_move_chem_efficient_heatbath (5086-5347) instead of
+ * off_diagonal_move_chem: every child may add TWO walkers (a single excitation larger than all its doubles together comes
+ * back with a double, do_walk.f90:3604-3611 -> add_walker 7584-7697), so a step needs room for 2 x children spawned walkers.
+ * COUNTER discipline only.  Systems for which check_heatbath_unbiased (9330-9375) fails are the caller's to refuse, as the
+ * reference does (1215-1223).  tests/golden/README_heatbath.md records what parity is defined against. */
+typedef struct {
+  int32_t norb, reserved;
+  const double *one_orbital_probabilities;                 /* (norb) */
+  const double *two_orbital_probabilities;                 /* (2 norb, 2 norb) */
+  const double *three_orbital_probabilities_same_spin;     /* (norb, norb, norb), normalised over the last index */
+  const double *three_orbital_probabilities_opposite_spin;
+  const int32_t *J_three_orbital_probabilities_same_spin, *J_three_orbital_probabilities_opposite_spin;   /* alias tables, (norb, norb, norb) */
+  const double *q_three_orbital_probabilities_same_spin, *q_three_orbital_probabilities_opposite_spin;
+  int64_t size_same, size_opposite;                        /* same_index(norb,norb,norb,norb), opposite_index(norb,norb,norb,norb) */
+  const float *four_orbital_probabilities_same_spin, *four_orbital_probabilities_opposite_spin;
+  const int32_t *J_four_orbital_probabilities_same_spin, *J_four_orbital_probabilities_opposite_spin;
+  const float *q_four_orbital_probabilities_same_spin, *q_four_orbital_probabilities_opposite_spin;
+  const double *Htot_same;                                 /* (combine_2_indices(norb, norb), norb) */
+  const double *Htot_opposite;                             /* (norb, norb, norb) */
+} sqmc_heatbath_tables;
+int sqmc_gpu_set_heatbath_tables(sqmc_gpu_ctx *ctx, const sqmc_heatbath_tables *t);
+/* n proposals of off_diagonal_move_chem_efficient_heatbath, each from its own rannyu state seeds[4 i .. 4 i + 3] (test door, like
+ * sqmc_gpu_propose_batch): det_j and weight_j = -tau H_ij / p of the two slots of proposal i at [2 i] and [2 i + 1] (weight 0: no move). */
+int sqmc_gpu_propose_heatbath_batch(sqmc_gpu_ctx *ctx, int64_t n, double tau, const uint64_t *up, const uint64_t *dn, const int32_t *seeds,
+                                    uint64_t *det_j_up, uint64_t *det_j_dn, double *weight_j, int32_t *seeds_after);
+
 /* replaces: dtm_hb / pq_ind / pq_count built by setup_efficient_heatbath (chemistry.f90:900-993).
  * hb_r/hb_s/hb_absH: n_hb records sorted by descending absH inside each (p,q) class;
  * pq_ind (1-based start) / pq_count indexed by combine_2_indices(p,q) in [1, n_pq]. */

@@ -231,6 +231,28 @@ class HeatBath:
     def proposal_prob(self, iu, id_, ju, jd, level, elem):
         return self.L.orc_hb_proposal_prob(self.sysm.h, self.h, int(iu), int(id_), int(ju), int(jd), int(level), float(elem))
 
+    def fortran_arrays(self):
+        """the tables in the reference's own (Fortran, column-major, 1-based -> flat) layout: what a Fortran host would pass through
+        sqmc_gpu_set_heatbath_tables with c_loc of the module arrays of chemistry.f90:52-75"""
+        s, n = self.s, self.s.norb
+        n1 = n + 1
+        g = lambda ptr, count, dt: np.ctypeslib.as_array(ptr, shape=(count,)).astype(dt, copy=True)
+        one = g(s.one, n1, np.float64)[1:]
+        two = g(s.two, (2 * n + 1) ** 2, np.float64).reshape(2 * n + 1, 2 * n + 1)[1:, 1:]
+        def t3(ptr, dt):
+            a = g(ptr, n1 ** 3, dt).reshape(n1, n1, n1)[1:, 1:, 1:]
+            return np.asfortranarray(a).reshape(-1, order="F")            # (i,j,k) column-major
+        npairs = s.n_pairs
+        hs = g(s.htot_same, (npairs + 1) * n1, np.float64).reshape(npairs + 1, n1)[1:, 1:]
+        return dict(norb=n, one=one, two=np.asfortranarray(two).reshape(-1, order="F"),
+                    three_same=t3(s.three_same, np.float64), three_opp=t3(s.three_opp, np.float64),
+                    j3_same=t3(s.j3_same, np.int32), j3_opp=t3(s.j3_opp, np.int32), q3_same=t3(s.q3_same, np.float64), q3_opp=t3(s.q3_opp, np.float64),
+                    size_same=s.size_same, size_opp=s.size_opp,
+                    four_same=g(s.four_same, s.size_same + 1, np.float32)[1:], four_opp=g(s.four_opp, s.size_opp + 1, np.float32)[1:],
+                    j4_same=g(s.j4_same, s.size_same + 1, np.int32)[1:], j4_opp=g(s.j4_opp, s.size_opp + 1, np.int32)[1:],
+                    q4_same=g(s.q4_same, s.size_same + 1, np.float32)[1:], q4_opp=g(s.q4_opp, s.size_opp + 1, np.float32)[1:],
+                    htot_same=np.asfortranarray(hs).reshape(-1, order="F"), htot_opp=t3(s.htot_opp, np.float64))
+
     def close(self):
         if self.h:
             self.L.orc_hb_free.argtypes = [C.c_void_p]
@@ -553,9 +575,9 @@ def initial_walkers(s, w_abs_gen_begin, r_initiator=1.0, initiator_power=0):
 class OracleWalk:
     """orc_walk handle fed from numpy arrays."""
 
-    def __init__(self, sysm, setup, walkers, mwalk, seed, rng_mode=0):
+    def __init__(self, sysm, setup, walkers, mwalk, seed, rng_mode=0, heatbath=None):
         L = lib()
-        self.sysm, self.L = sysm, L
+        self.sysm, self.L, self.hb = sysm, L, heatbath          # heatbath: a HeatBath of sysm -> proposal_method fast_heatbath
         self.h = L.orc_walk_new(mwalk)
         self.w = Walk.from_address(self.h)
         self._keep = []
@@ -599,6 +621,9 @@ class OracleWalk:
     def step(self, params):
         out = np.zeros(16)
         p = StepParams(**params)
+        if self.hb is not None:
+            self.L.orc_walk_step_heatbath.argtypes = [C.c_void_p] * 5
+            return self.L.orc_walk_step_heatbath(self.sysm.h, self.hb.h, self.h, C.byref(p), _p(out)), out
         fn = (self.L.orc_walk_step_heg if isinstance(self.sysm, HegSystem) else
               self.L.orc_walk_step_hubbard if isinstance(self.sysm, HubbardSystem) else self.L.orc_walk_step)
         st = fn(self.sysm.h, self.h, C.byref(p), _p(out))

@@ -1007,7 +1007,7 @@ int64_t orc_join_walker2(orc_walk *w, int64_t n, const orc_step_params *p) {
 }
 
 /* system dispatch of the walk: 'chem' or 'heg' (do_walk.f90:3599-3633, 3745-3769) */
-typedef struct { const orc_chem *chem; const orc_heg *heg; const orc_hub *hub; } orc_sys;
+typedef struct { const orc_chem *chem; const orc_heg *heg; const orc_hub *hub; const orc_hb *hb; } orc_sys;      /* hb: chem with proposal_method fast_heatbath */
 static double sys_diag(const orc_sys *y, det_t u, det_t d) {
   if (y->hub) return orc_hamiltonian_hubbard(y->hub, u, d, u, d);
   return y->chem ? orc_hamiltonian(y->chem, u, d, u, d) : orc_hamiltonian_heg(y->heg, u, d, u, d);
@@ -1034,9 +1034,15 @@ static int move_uniform2(const orc_sys *s, orc_walk *w, const orc_step_params *p
     for (long c = 1; c <= nchild; c++) {
       det_t ju, jd; double wj; int nd;
       orc_rng_seek(&w->rng, 1, (uint64_t)(*attempts));
-      sys_move(s, &w->rng, p->tau, w->up[iw], w->dn[iw], &ju, &jd, &wj, &nd);
+      det_t ju2[2], jd2[2]; double wj2[2] = {0.0, 0.0}; int lev2[2], nnew = 1;
+      if (s->hb) {          /* fast_heatbath: up to two determinants per child, each through add_walker (do_walk.f90:3604-3611, 7584-7697) */
+        orc_off_diagonal_move_chem_heatbath(s->chem, s->hb, &w->rng, p->tau, w->up[iw], w->dn[iw], ju2, jd2, wj2, lev2, &nd);
+        nnew = 2;
+      } else { sys_move(s, &w->rng, p->tau, w->up[iw], w->dn[iw], &ju2[0], &jd2[0], &wj2[0], &nd); }
       w->n_spawn_draws += nd; (*attempts)++;
-      wj = wchild * wj;
+      for (int kk = 0; kk < nnew; kk++) {
+      ju = ju2[kk]; jd = jd2[kk];
+      wj = wchild * wj2[kk];
       if (wj != 0) {
         int64_t k = w->nwalk++;
         if (w->nwalk > w->mwalk) return 1;
@@ -1048,6 +1054,7 @@ static int move_uniform2(const orc_sys *s, orc_walk *w, const orc_step_params *p
         if (p->c_t_initiator && w->imp_distance[iw] == -2) w->initiator[k] = 1;
         if (p->semistochastic && w->imp_distance[iw] == 0) w->initiator[k] = 1;
         w->e_num_walker[k] = 1e51; w->e_den_walker[k] = 1e51; w->matrix_elements[k] = 1e51;
+      }
       }
     }
   }
@@ -1088,7 +1095,8 @@ static int move_uniform2_mt(const orc_sys *s, orc_walk *w, const orc_step_params
   }
   int64_t tot = 0;
   for (int64_t iw = 0; iw < n0; iw++) { off[iw] = tot; tot += nchild[iw]; }
-  det_t *cu = malloc((tot + 1) * sizeof(det_t)), *cd = malloc((tot + 1) * sizeof(det_t)); double *cw = malloc((tot + 1) * sizeof(double));
+  const int spc = s->hb ? 2 : 1;                    /* slots per child */
+  det_t *cu = malloc((spc * tot + 2) * sizeof(det_t)), *cd = malloc((spc * tot + 2) * sizeof(det_t)); double *cw = malloc((spc * tot + 2) * sizeof(double));
   int64_t draws = 0; int bad = 0;
 #pragma omp parallel for num_threads(g_orc_threads) schedule(dynamic, 256) reduction(+:draws) reduction(|:bad)
   for (int64_t iw = 0; iw < n0; iw++) {
@@ -1096,9 +1104,16 @@ static int move_uniform2_mt(const orc_sys *s, orc_walk *w, const orc_step_params
     for (int64_t c = 0; c < nchild[iw]; c++) {
       det_t ju, jd; double wj; int nd;
       orc_rng_seek(&g, 1, (uint64_t)(off[iw] + c));
-      sys_move(s, &g, p->tau, w->up[iw], w->dn[iw], &ju, &jd, &wj, &nd);
+      const int64_t slot = spc * (off[iw] + c);
+      if (s->hb) {
+        det_t ju2[2], jd2[2]; double wj2[2]; int lev2[2];
+        orc_off_diagonal_move_chem_heatbath(s->chem, s->hb, &g, p->tau, w->up[iw], w->dn[iw], ju2, jd2, wj2, lev2, &nd);
+        for (int kk = 0; kk < 2; kk++) { cu[slot + kk] = ju2[kk]; cd[slot + kk] = jd2[kk]; cw[slot + kk] = wchild[iw] * wj2[kk]; }
+      } else {
+        sys_move(s, &g, p->tau, w->up[iw], w->dn[iw], &ju, &jd, &wj, &nd);
+        cu[slot] = ju; cd[slot] = jd; cw[slot] = wchild[iw] * wj;
+      }
       draws += nd;
-      cu[off[iw] + c] = ju; cd[off[iw] + c] = jd; cw[off[iw] + c] = wchild[iw] * wj;
     }
     if (!p->semistochastic || w->imp_distance[iw] >= 1) {
       double hii;
@@ -1111,12 +1126,12 @@ static int move_uniform2_mt(const orc_sys *s, orc_walk *w, const orc_step_params
   }
   int st = 0;
   for (int64_t iw = 0; iw < n0 && !st; iw++) {
-    for (int64_t c = 0; c < nchild[iw]; c++) {
-      const double wj = cw[off[iw] + c];
+    for (int64_t c = 0; c < spc * nchild[iw]; c++) {
+      const double wj = cw[spc * off[iw] + c];
       if (wj != 0) {
         int64_t k = w->nwalk++;
         if (w->nwalk > w->mwalk) { st = 1; break; }
-        w->up[k] = cu[off[iw] + c]; w->dn[k] = cd[off[iw] + c]; w->wt[k] = wj;
+        w->up[k] = cu[spc * off[iw] + c]; w->dn[k] = cd[spc * off[iw] + c]; w->wt[k] = wj;
         if (w->imp_distance[iw] == -2) w->imp_distance[k] = p->c_t_initiator ? 1 : 2;
         else w->imp_distance[k] = (int8_t)((w->imp_distance[iw] < 126 ? w->imp_distance[iw] : 126) + 1);
         if (p->semistochastic && w->imp_distance[iw] == 0) w->imp_distance[k] = -1;
@@ -1156,15 +1171,19 @@ static void search_list_and_update(orc_walk *w, int64_t n, double acc[7]) {
  * run_type 'none'.  Population control (2880-2901) stays with the caller. */
 static int walk_step_sys(const orc_sys *s, orc_walk *w, const orc_step_params *p, double out[16]);
 int orc_walk_step(const orc_chem *c, orc_walk *w, const orc_step_params *p, double out[16]) {
-  orc_sys y = {c, NULL, NULL};
+  orc_sys y = {c, NULL, NULL, NULL};
+  return walk_step_sys(&y, w, p, out);
+}
+int orc_walk_step_heatbath(const orc_chem *c, const orc_hb *hb, orc_walk *w, const orc_step_params *p, double out[16]) {
+  orc_sys y = {c, NULL, NULL, hb};
   return walk_step_sys(&y, w, p, out);
 }
 int orc_walk_step_hubbard(const orc_hub *h, orc_walk *w, const orc_step_params *p, double out[16]) {
-  orc_sys y = {NULL, NULL, h};
+  orc_sys y = {NULL, NULL, h, NULL};
   return walk_step_sys(&y, w, p, out);
 }
 int orc_walk_step_heg(const orc_heg *h, orc_walk *w, const orc_step_params *p, double out[16]) {
-  orc_sys y = {NULL, h, NULL};
+  orc_sys y = {NULL, h, NULL, NULL};
   return walk_step_sys(&y, w, p, out);
 }
 static double orc_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }

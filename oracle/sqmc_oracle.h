@@ -152,6 +152,8 @@ typedef struct {
 orc_walk *orc_walk_new(int64_t mwalk);
 void orc_walk_free(orc_walk *w);
 int  orc_walk_step(const orc_chem *s, orc_walk *w, const orc_step_params *p, double out[16]);
+/* the same with proposal_method fast_heatbath: every child may add TWO walkers (do_walk.f90:3604-3611, add_walker 7584-7697) */
+int  orc_walk_step_heatbath(const orc_chem *c, const orc_hb *hb, orc_walk *w, const orc_step_params *p, double out[16]);
 /* n > 1: the COUNTER-discipline step runs its spawn loop, sort and permutations on n OpenMP threads (bit-identical results):
  * the all-host-cores CPU baseline of SURVEY section 8d(ii) */
 void orc_set_threads(int n);

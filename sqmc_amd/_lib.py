@@ -12,7 +12,7 @@ RNG_REPLAY, RNG_COUNTER = 0, 1
 _LIB = None
 
 EXPORTS = [
-    "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_init_heg", "sqmc_gpu_init_hubbard", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_projector",
+    "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_init_heg", "sqmc_gpu_init_hubbard", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_heatbath_tables", "sqmc_gpu_propose_heatbath_batch", "sqmc_gpu_set_projector",
     "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
     "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_annihilate", "sqmc_gpu_det_owner", "sqmc_gpu_set_owner_hash", "sqmc_gpu_shard_config",
     "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init", "sqmc_gpu_comm_size",
@@ -371,6 +371,35 @@ class GpuChem:
             self.L.sqmc_gpu_free(q)
         return rc, ix, vl
 
+    def set_heatbath_tables(self, tabs):
+        """tabs: dict with the reference's arrays in the reference's (Fortran, column-major) order -- see sqmc_heatbath_tables"""
+        t = HeatbathTables()
+        keep = []
+        def put(name, arr, dt):
+            a = np.ascontiguousarray(arr, dt).reshape(-1); keep.append(a)
+            setattr(t, name, a.ctypes.data_as(C.c_void_p))
+        t.norb = int(tabs["norb"])
+        put("one", tabs["one"], np.float64); put("two", tabs["two"], np.float64)
+        put("three_same", tabs["three_same"], np.float64); put("three_opp", tabs["three_opp"], np.float64)
+        put("j3_same", tabs["j3_same"], np.int32); put("j3_opp", tabs["j3_opp"], np.int32)
+        put("q3_same", tabs["q3_same"], np.float64); put("q3_opp", tabs["q3_opp"], np.float64)
+        t.size_same, t.size_opp = int(tabs["size_same"]), int(tabs["size_opp"])
+        put("four_same", tabs["four_same"], np.float32); put("four_opp", tabs["four_opp"], np.float32)
+        put("j4_same", tabs["j4_same"], np.int32); put("j4_opp", tabs["j4_opp"], np.int32)
+        put("q4_same", tabs["q4_same"], np.float32); put("q4_opp", tabs["q4_opp"], np.float32)
+        put("htot_same", tabs["htot_same"], np.float64); put("htot_opp", tabs["htot_opp"], np.float64)
+        self.L.sqmc_gpu_set_heatbath_tables.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(self.L.sqmc_gpu_set_heatbath_tables(self.h, C.byref(t)))
+
+    def propose_heatbath_batch(self, tau, up, dn, seeds):
+        u, d = _u64(up), _u64(dn)
+        s = np.ascontiguousarray(seeds, np.int32).reshape(-1)
+        n = len(u)
+        ju, jd, wj, sa = np.zeros(2 * n, np.uint64), np.zeros(2 * n, np.uint64), np.zeros(2 * n), np.zeros(4 * n, np.int32)
+        self.L.sqmc_gpu_propose_heatbath_batch.argtypes = [C.c_void_p, C.c_int64, C.c_double] + [C.c_void_p] * 7
+        _chk(self.L.sqmc_gpu_propose_heatbath_batch(self.h, n, float(tau), _p(u), _p(d), _p(s), _p(ju), _p(jd), _p(wj), _p(sa)))
+        return ju.reshape(n, 2), jd.reshape(n, 2), wj.reshape(n, 2), sa.reshape(n, 4)
+
     def propose_batch(self, tau, up, dn, seeds):
         u, d = _u64(up), _u64(dn)
         s = np.ascontiguousarray(seeds, np.int32).reshape(-1)
@@ -394,6 +423,14 @@ class GpuChem:
             self.L.sqmc_gpu_free(ptr)
             return a
         return take(pu, C.c_uint64, np.uint64), take(pd, C.c_uint64, np.uint64), take(pn, C.c_double, np.float64), take(pe, C.c_double, np.float64)
+
+
+class HeatbathTables(C.Structure):
+    """sqmc_heatbath_tables of include/sqmc_gpu.h"""
+    _fields_ = [("norb", C.c_int32), ("reserved", C.c_int32), ("one", C.c_void_p), ("two", C.c_void_p), ("three_same", C.c_void_p), ("three_opp", C.c_void_p),
+                ("j3_same", C.c_void_p), ("j3_opp", C.c_void_p), ("q3_same", C.c_void_p), ("q3_opp", C.c_void_p), ("size_same", C.c_int64), ("size_opp", C.c_int64),
+                ("four_same", C.c_void_p), ("four_opp", C.c_void_p), ("j4_same", C.c_void_p), ("j4_opp", C.c_void_p), ("q4_same", C.c_void_p), ("q4_opp", C.c_void_p),
+                ("htot_same", C.c_void_p), ("htot_opp", C.c_void_p)]
 
 
 class SpmvPlan:

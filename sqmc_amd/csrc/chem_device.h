@@ -42,6 +42,18 @@ struct ChemTab {
   unsigned short c2[(SQ_MAXORB + 2) * (SQ_MAXORB + 2)];   // only the first c2_stride^2 entries are used/staged
 };
 
+// efficient heat-bath proposal tables on the device (heatbath_device.h): 0-based, last index fastest
+struct HbDev {
+  int on, norb, npairs;
+  const double *one;                     // [norb]                      one_orbital_probabilities
+  const double *two;                     // [2 norb][2 norb]            two_orbital_probabilities
+  const double *three_same, *three_opp;  // [norb][norb][norb], normalised over the last index
+  const int *j3_same, *j3_opp; const double *q3_same, *q3_opp;          // alias tables of the first hole (J 1-based as in the reference)
+  const float *four_same, *four_opp; const int *j4_same, *j4_opp; const float *q4_same, *q4_opp;     // [same_index - 1] / [opposite_index - 1], single precision as the reference stores them
+  const double *htot_same;               // [npairs][norb]
+  const double *htot_opp;                // [norb][norb][norb]
+};
+
 #define SQ_BINOM_STRIDE 68              // C(c, i) for every i <= 64, + 3 entries the 4-wide rounds of colex_rank may touch
 struct ChemDev {                        // pointers into HBM, passed by value
   const ChemTab *tab; int tab_words;
@@ -51,6 +63,7 @@ struct ChemDev {                        // pointers into HBM, passed by value
   // HCI heat-bath table (chemistry.f90:900-993)
   const int *hb_r, *hb_s; const double *hb_absH; const long long *pq_ind; const int *pq_count;
   double max_double;
+  HbDev hb;                             // proposal_method fast_heatbath (hb.on) instead of uniform2
 };
 
 // 32-bit words of a ChemTab that are in use: header + the used part of combine_2 only (norb=26:

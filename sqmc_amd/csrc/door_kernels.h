@@ -58,6 +58,18 @@ __global__ void __launch_bounds__(TPB) k_build_ham(ChemDev dev, const u64 *__res
   if (!pass && live) counts[i] = cnt;
 }
 
+__global__ void __launch_bounds__(TPB) k_propose_heatbath_batch(ChemDev dev, const u64 *up, const u64 *dn, const u64 *state_in, u64 *ju, u64 *jd,
+                                                                double *wj, u64 *state_out, long long n, double tau) {
+  __shared__ ChemTab t;
+  stage_tab(&t, dev.tab, dev.tab_words);
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  Rng g; g.mode = 0; g.x = state_in[i];
+  u64 a[2], b[2]; double w[2];
+  propose_heatbath(t, dev.integrals, dev.hb, g, tau, up[i], dn[i], a, b, w);
+  for (int k = 0; k < 2; k++) { ju[2 * i + k] = a[k]; jd[2 * i + k] = b[k]; wj[2 * i + k] = w[k]; }
+  state_out[i] = g.x;
+}
 __global__ void __launch_bounds__(TPB) k_propose_batch(ChemDev dev, const u64 *up, const u64 *dn, const u64 *state_in, u64 *ju, u64 *jd,
                                                        double *wj, u64 *state_out, long long n, double tau) {
   __shared__ ChemTab t;
@@ -70,4 +82,21 @@ __global__ void __launch_bounds__(TPB) k_propose_batch(ChemDev dev, const u64 *u
   double w = 0.0;
   if (level > 0) w = proposal_weight(t, dev.integrals, tau, up[i], dn[i], a, b, level, prob);
   ju[i] = a; jd[i] = b; wj[i] = w; state_out[i] = g.x;
+}
+
+// ---- host helpers of sqmc_gpu_set_heatbath_tables (templates: outside the extern "C" block)
+// column-major (i,j,k) of extent n^3 -> [i][j][k] with k fastest
+template <typename T>
+static std::vector<T> hb_transpose3(const T *src, int n) {
+  std::vector<T> out((size_t)n * n * n);
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) for (int k = 0; k < n; k++) out[((size_t)i * n + j) * n + k] = src[(size_t)i + (size_t)n * ((size_t)j + (size_t)n * k)];
+  return out;
+}
+template <typename T>
+static int hb_upload(sqmc_gpu_ctx *c, int slot, const T *host, size_t count, const T **dev) {
+  hipFree(c->d_hbt[slot]); c->d_hbt[slot] = nullptr;
+  HIPCHK(hipMalloc(&c->d_hbt[slot], (count + 1) * sizeof(T)));
+  HIPCHK(hipMemcpy(c->d_hbt[slot], host, count * sizeof(T), hipMemcpyHostToDevice));
+  *dev = (const T *)c->d_hbt[slot];
+  return SQMC_OK;
 }

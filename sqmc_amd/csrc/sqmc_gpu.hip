@@ -30,6 +30,7 @@
 #include <algorithm>
 #include "../../include/sqmc_gpu.h"
 #include "chem_device.h"
+#include "heatbath_device.h"
 #include "scan_sort.h"
 #include "bucket_partition.h"
 
@@ -121,6 +122,7 @@ struct sqmc_gpu_ctx {
   hipStream_t st;
   ChemTab htab; ChemTab *d_tab; double *d_ints; ChemDev dev;
   int *d_hb_r, *d_hb_s; double *d_hb_absH; long long *d_pq_ind; int *d_pq_count;
+  void *d_hbt[16];                     // device copies of the efficient heat-bath tables (sqmc_gpu_set_heatbath_tables)
   long long mwalk, nwalk;
   WalkArr w, m;                        // walkers (main + appended spawns), merge results
   u64 *d_nchild; u64 *d_child_off; double *d_wchild; u64 *d_child_state;
@@ -365,6 +367,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
     hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done); hipFree(c->d_segoff);
   }
   hipFree(c->d_binom); hipFree(c->d_grow);
+  for (int q = 0; q < 16; q++) hipFree(c->d_hbt[q]);
   comm_release(c);
   hipFree(c->d_tab); hipFree(c->d_ints); hipFree(c->d_hb_r); hipFree(c->d_hb_s); hipFree(c->d_hb_absH); hipFree(c->d_pq_ind); hipFree(c->d_pq_count);
   hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x); hipFree(c->d_prj_xs[0]); hipFree(c->d_prj_xs[1]); hipFree(c->d_prj_y);
@@ -585,7 +588,7 @@ static OwnerOut shard_owner_out(sqmc_gpu_ctx *c) {
 // what does not change from step to step about the short-list (bucket) tail
 static inline bool bucket_static_ok(const sqmc_gpu_ctx *c, const StepP &p) {
   static const int bucket_env = getenv("SQMC_ANNEAL_ITEMS") ? 0 : (getenv("SQMC_BUCKET") ? atoi(getenv("SQMC_BUCKET")) : 1);      // a forced tile shape asks for the radix tail's kernel
-  return bucket_env && c->pack && p.semi && c->rng_mode == SQMC_RNG_COUNTER && !c->d_grow && c->comm == nullptr;
+  return bucket_env && c->pack && p.semi && c->rng_mode == SQMC_RNG_COUNTER && !c->d_grow && c->comm == nullptr && !c->dev.hb.on;      // heat-bath children take two slots each: radix tail
 }
 static inline long long bucket_count(long long nall) {
   static const long long bk_target = getenv("SQMC_BUCKET_TARGET") ? atoll(getenv("SQMC_BUCKET_TARGET")) : BK_TARGET;
@@ -858,7 +861,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     const int other = c->scan_flip ^ 1;
     fa.scan_state = c->d_scan_state + (long long)other * c->cap_tiles; fa.scan_ticket = c->d_scan_ticket + other;
     fa.n_scan_words = c->scan_used[other]; fa.n_tickets = 1; c->scan_used[other] = 0;
-    fa.n_children = nall - n0;
+    fa.n_children = (nall - n0) / (c->dev.hb.on ? 2 : 1);      // children, not walker slots
   }
   const bool fin_in_gate = c->pipeline_next && p.semi && use_mail;     // the next step's gate kernel does the final sums in its first block
   TBEG(estimate, st);
@@ -937,6 +940,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   if (c->mwalk <= 0 || c->nwalk <= 0) return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0");
   if (c->d_grow) return fail(SQMC_ERR_BAD_ARG, "context is configured for sharded steps: use sqmc_gpu_shard_begin/pack/finish");
   if (sp->semistochastic && (c->n_imp <= 0 || !c->d_prj_ptr)) return fail(SQMC_ERR_BAD_ARG, "semistochastic step without projector");
+  if (c->dev.hb.on && c->rng_mode == SQMC_RNG_REPLAY) return fail(SQMC_ERR_UNSUPPORTED, "the efficient heat-bath proposal runs in the COUNTER discipline only");
   if (!c->d_ct_up) return fail(SQMC_ERR_BAD_ARG, "C(T) table not set");
   hipStream_t st = c->st;
   StepP p; p.tau = sp->tau; p.e_trial = sp->e_trial; p.rfi = sp->reweight_factor_inv; p.r_init = sp->r_initiator; p.min_wt = sp->min_wt;
@@ -1003,12 +1007,13 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     if (wr < 0) { u64 v; HIPCHK(hipMemcpy(&v, &c->d_sc->n_children, 8, hipMemcpyDeviceToHost)); nch = (long long)v; }
     else nch = (long long)c->h_mail->n_children;
   } else { u64 v; HIPCHK(hipMemcpyAsync(&v, &c->d_sc->n_children, 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); nch = (long long)v; }
-  if (n0 + nch > M) {
+  const long long spc = c->dev.hb.on ? 2 : 1;          // walker slots per child (fast_heatbath: two)
+  if (n0 + spc * nch > M) {
     hipStreamSynchronize(st); hipStreamSynchronize(st2); hipStreamSynchronize(c->st3);
     hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
     return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
   }
-  const long long nall = n0 + nch;
+  const long long nall = n0 + spc * nch;
   return step_tail(c, p, n0, nall, !(c->side_pending && c->head_hii_joined), out);       // nothing ran on the side streams when the tail does that work itself and the H_ii came out of k_spawn
 }
 

@@ -291,7 +291,8 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   if (mail && blockIdx.x == 0 && threadIdx.x == 0) {      // the host sizes the sort from this while the kernel runs
     mail->n_children = (u64)nchildren; __threadfence_system(); mail->cnt_seq = cnt_seq;
   }
-  if (c0 >= nchildren || n0 + nchildren > cap_all) return;
+  const long long spc = dev.hb.on ? 2 : 1;             // walker slots per child: the heat-bath proposal may return a single AND a double
+  if (c0 >= nchildren || n0 + spc * nchildren > cap_all) return;
   const bool part = ba.B > 0 && (int)blockIdx.x < ba.nsb;                  // rows beyond the room the host provided: the tail will see that and use its own partition
   if (part) bucket_partition_stage(s_spl, s_wcnt, keys, n0, ba.B);     // resident keys [0, n0) of the same array the children's keys go to; a barrier follows below
   PROF(1);
@@ -332,6 +333,12 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
     const u32 pflg = w.flg[ip]; const double wch = wchild[ip];     // needed at the end: fetched in the same round trip
     u64 ju, jd; double prob;
     PROF(3);
+    if (dev.hb.on) {                    // proposal_method fast_heatbath: both slots of the child are written (weight 0: no walker), do_walk.f90:3604-3611
+      u64 ju2[2], jd2[2]; double wj2[2];
+      propose_heatbath(t, dev.integrals, dev.hb, g, p.tau, iu, id, ju2, jd2, wj2);
+      spawn_emit(dev, w, keys, vals, n0, 2 * c, pflg, ju2[0], jd2[0], wch * wj2[0], p, invalid_key, pack, oo);
+      spawn_emit(dev, w, keys, vals, n0, 2 * c + 1, pflg, ju2[1], jd2[1], wch * wj2[1], p, invalid_key, pack, oo);
+    } else {
     const int level = propose_any(t, g, iu, id, ju, jd, prob);
     PROF(4);
     double wj = 0.0;
@@ -340,6 +347,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
       wj = wch * wj;
     }
     ckey = spawn_emit(dev, w, keys, vals, n0, c, pflg, ju, jd, wj, p, invalid_key, pack, oo);
+    }
   }
   if (part) bucket_partition_block(s_spl, s_wcnt, active && ckey != invalid_key, (u32)ckey, (ckey << 32) | (u64)(n0 + c), (long long)blockIdx.x, ba);
   PROF(5);

@@ -16,7 +16,7 @@ module sqmc_gpu_mod
   public :: sqmc_gpu_hci_connections, sqmc_gpu_free, sqmc_gpu_set_timing, sqmc_gpu_get_timing
   public :: sqmc_gpu_det_owner, sqmc_gpu_shard_config, sqmc_gpu_shard_begin, sqmc_gpu_shard_pack, sqmc_gpu_shard_finish
   public :: sqmc_gpu_annihilate, sqmc_gpu_build_spmv_plan, sqmc_gpu_hci_connections_slice
-  public :: sqmc_gpu_comm_unique_id, sqmc_gpu_comm_init, sqmc_gpu_comm_size, sqmc_gpu_set_owner_hash, sqmc_gpu_tail_stats, sqmc_gpu_shard_step, sqmc_gpu_shard_run
+  public :: sqmc_gpu_comm_unique_id, sqmc_gpu_comm_init, sqmc_gpu_comm_size, sqmc_gpu_set_owner_hash, sqmc_gpu_tail_stats, sqmc_gpu_set_heatbath_tables, sqmc_gpu_propose_heatbath_batch, sqmc_heatbath_tables, sqmc_gpu_shard_step, sqmc_gpu_shard_run
   public :: sqmc_gpu_check
 
   integer(c_int), parameter, public :: SQMC_RNG_REPLAY = 0, SQMC_RNG_COUNTER = 1
@@ -58,6 +58,20 @@ module sqmc_gpu_mod
     integer(c_int32_t) :: reserved
   end type
 
+  ! the tables of setup_efficient_heatbath (chemistry.f90:1002-1225) as the reference holds them: c_loc of its module arrays
+  type, bind(C) :: sqmc_heatbath_tables
+    integer(c_int32_t) :: norb, reserved
+    type(c_ptr) :: one_orbital_probabilities, two_orbital_probabilities
+    type(c_ptr) :: three_orbital_probabilities_same_spin, three_orbital_probabilities_opposite_spin
+    type(c_ptr) :: J_three_orbital_probabilities_same_spin, J_three_orbital_probabilities_opposite_spin
+    type(c_ptr) :: q_three_orbital_probabilities_same_spin, q_three_orbital_probabilities_opposite_spin
+    integer(c_int64_t) :: size_same, size_opposite
+    type(c_ptr) :: four_orbital_probabilities_same_spin, four_orbital_probabilities_opposite_spin
+    type(c_ptr) :: J_four_orbital_probabilities_same_spin, J_four_orbital_probabilities_opposite_spin
+    type(c_ptr) :: q_four_orbital_probabilities_same_spin, q_four_orbital_probabilities_opposite_spin
+    type(c_ptr) :: Htot_same, Htot_opposite
+  end type
+
   type, bind(C) :: sqmc_popctl
     real(c_double) :: tau_sav, tau, tau_prev, e_trial, e_est, w_abs_gen_target, w_abs_gen
     real(c_double) :: r_initiator_sav, r_initiator, initiator_rescale_power, population_control_exponent
@@ -91,6 +105,15 @@ module sqmc_gpu_mod
     end function
     integer(c_int) function sqmc_gpu_tail_stats(ctx, bucket_steps, bucket_retries) bind(C, name='sqmc_gpu_tail_stats')
       import; type(c_ptr), value :: ctx; integer(c_int64_t), intent(out) :: bucket_steps, bucket_retries
+    end function
+    integer(c_int) function sqmc_gpu_set_heatbath_tables(ctx, t) bind(C, name='sqmc_gpu_set_heatbath_tables')
+      import; type(c_ptr), value :: ctx; type(sqmc_heatbath_tables), intent(in) :: t
+    end function
+    integer(c_int) function sqmc_gpu_propose_heatbath_batch(ctx, n, tau, up, dn, seeds, det_j_up, det_j_dn, weight_j, seeds_after) &
+        bind(C, name='sqmc_gpu_propose_heatbath_batch')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n; real(c_double), value :: tau
+      integer(c_int64_t), intent(in) :: up(*), dn(*); integer(c_int32_t), intent(in) :: seeds(*)
+      integer(c_int64_t), intent(out) :: det_j_up(*), det_j_dn(*); real(c_double), intent(out) :: weight_j(*); integer(c_int32_t), intent(out) :: seeds_after(*)
     end function
     integer(c_int) function sqmc_gpu_comm_size(ctx, nranks) bind(C, name='sqmc_gpu_comm_size')
       import; type(c_ptr), value :: ctx; integer(c_int32_t), intent(out) :: nranks

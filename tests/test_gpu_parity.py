@@ -1504,3 +1504,90 @@ def test_bucket_tail_variants_are_bit_exact(env, expect):
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+# ------------------------------------------------------------------ efficient heat-bath proposal
+@pytest.fixture(scope="module")
+def c2_10e(oracle):
+    """the shipped C2 cc-pVDZ integrals with 10 electrons: the synthetic system on which the reference's own check accepts
+    fast_heatbath (tests/golden/README_heatbath.md)"""
+    from conftest import FCIDUMP
+    return oracle.ChemSystem(FCIDUMP, 10, 5, "d2h", time_sym=False, hf_mode=0)
+
+
+@pytest.mark.parametrize("time_sym", [False, True])
+def test_heatbath_proposals_bit_exact(oracle, c2_10e, time_sym):
+    """off_diagonal_move_chem_efficient_heatbath (chemistry.f90:5086-5347): 10^4 proposals, both slots of each (the single AND
+    double return included), determinants, weights and the RNG state after -- GPU kernel against the oracle, with the tables
+    handed over in the reference's own array layout; without and with time-reversal symmetry (the second pathway through
+    proposal_prob_efficient_heatbath, 5350-5549)."""
+    from conftest import FCIDUMP
+    sysm = c2_10e if not time_sym else oracle.ChemSystem(FCIDUMP, 10, 5, "d2h", time_sym=True, z=1, hf_mode=0)
+    hb = oracle.HeatBath(sysm)
+    assert hb.unbiased
+    g = gpu_ctx_from_oracle(sysm)
+    g.set_heatbath_tables(hb.fortran_arrays())
+    rng = np.random.default_rng(10)
+    cu, cd, _ = sysm.connected(sysm.hf_up, sysm.hf_dn, with_elems=False)
+    n = 10000
+    up = np.concatenate((np.full(1500, sysm.hf_up, np.uint64), np.resize(cu, 3500), _random_dets(rng, 26, 5, n - 5000)))
+    dn = np.concatenate((np.full(1500, sysm.hf_dn, np.uint64), np.resize(cd, 3500), _random_dets(rng, 26, 5, n - 5000)))
+    if time_sym:                                     # representatives only (up <= dn), as the walk holds them
+        sw = up > dn
+        up[sw], dn[sw] = dn[sw].copy(), up[sw].copy()
+    seeds = rng.integers(0, 4096, size=(n, 4)).astype(np.int32); seeds[:, 3] |= 1
+    tau = 0.0045
+    pju, pjd, wj, sa = g.propose_heatbath_batch(tau, up, dn, seeds)
+    g.close()
+    L = oracle.lib()
+    r = oracle.Rng()
+    two = moves = 0
+    for i in range(n):
+        L.orc_setrn(C.byref(r), (C.c_int * 4)(*seeds[i]))
+        ju, jd, w, lev, nd = (C.c_uint64 * 2)(), (C.c_uint64 * 2)(), (C.c_double * 2)(), (C.c_int * 2)(), C.c_int()
+        nn = L.orc_off_diagonal_move_chem_heatbath(sysm.h, hb.h, C.byref(r), tau, int(up[i]), int(dn[i]), ju, jd, w, lev, C.byref(nd))
+        assert [r.l[k] for k in range(4)] == list(sa[i]), i
+        for k in range(2):
+            assert w[k] == wj[i, k], (i, k, w[k], wj[i, k])
+            if w[k] != 0.0:
+                moves += 1
+                assert (ju[k], jd[k]) == (int(pju[i, k]), int(pjd[i, k])), (i, k)
+        two += (nn == 2 and w[0] != 0.0 and w[1] != 0.0)
+    hb.close()
+    assert moves > n // 3 and two > 20
+
+
+def test_heatbath_walk_trajectory_bit_exact(oracle, c2_10e):
+    """A semistochastic walk with proposal_method fast_heatbath (two walker slots per child, do_walk.f90:3604-3611 ->
+    add_walker 7584-7697) in the COUNTER discipline: 120 steps, walkers, weights and flags equal the oracle's."""
+    sysm = c2_10e
+    hb = oracle.HeatBath(sysm)
+    su = oracle.setup_walk(sysm, 100, 1000, 0.1)
+    g = gpu_ctx_from_oracle(sysm, rng_mode=1, seed=SEED, mwalk=400000)
+    g.set_heatbath_tables(hb.fortran_arrays())
+    g.set_projector(su.prj_counts, su.prj_indices, su.prj_values)
+    g.set_ct_table(su.ct_up, su.ct_dn, su.ct_num, su.ct_den)
+    wk = oracle.initial_walkers(su, 50)
+    g.upload_walkers(wk)
+    ow = oracle.OracleWalk(sysm, su, wk, 400000, SEED, rng_mode=1, heatbath=hb)
+    pc = oracle.PopControl(su.tau, su.e_trial0, 8000)
+    w_abs = float(np.abs(wk["wt"]).sum())
+    try:
+        for it in range(120):
+            r = pc.pre_step(w_abs)
+            if r != 1.0:
+                ow.scale_projector(r); g.scale_projector(r)
+            st, oc = ow.step(pc.params())
+            og = g.step(pc.params())
+            assert st == 0 and og[5] == oc[5] and og[7] == oc[7] and og[15] == oc[15], (it, og, oc)
+            assert _sums_close(og, oc), (it, [(k, og[k], oc[k]) for k in range(16) if og[k] != oc[k]])
+            r = pc.post_step(oc)
+            if r != 1.0:
+                ow.scale_projector(r); g.scale_projector(r)
+            w_abs = oc[1]
+        wg, wc = g.download_walkers(), ow.walkers()
+    finally:
+        g.close(); ow.close(); hb.close()
+    for k in ("up", "dn", "imp_distance", "initiator"):
+        assert np.array_equal(wg[k], wc[k]), k
+    assert np.array_equal(wg["wt"], wc["wt"]) and len(wg["up"]) > 3000
