@@ -334,6 +334,14 @@ int sqmc_gpu_hci_connections(sqmc_gpu_ctx *ctx, int64_t n_ref, const uint64_t *r
 int sqmc_gpu_hci_connections_slice(sqmc_gpu_ctx *ctx, int64_t n_ref, const uint64_t *ref_up, const uint64_t *ref_dn,
                                    const double *coeffs, double eps, int diag_mode, int32_t slice, int32_t n_slices, int64_t *out_n,
                                    uint64_t **out_up, uint64_t **out_dn, double **out_e_mix_num, double **out_e_mix_den);
+/* replaces: second_order_pt (hci.f90:1100-1182), the deterministic Epstein-Nesbet correction of a variational wavefunction:
+ * delta_e = sum_a (sum_i H_ai c_i)^2 / (E_var - H_aa) over the connected determinants outside the variational space, the inner
+ * sum screened by |H_ai c_i| >= eps_pt; n_connections = connected determinants visited (the reference prints it).  Everything
+ * stays on the device; n_slices > 1 does the connected space in parts of the determinant range.  Needs sqmc_gpu_set_hb_tables
+ * (chem) like the generator.  For a time-symmetrised wavefunction pass the determinant-basis expansion, as the reference does
+ * (convert_time_symmetrized_to_dets, hci.f90:4365-4564) on a context initialised with time_sym = 0. */
+int sqmc_gpu_hci_pt2(sqmc_gpu_ctx *ctx, int64_t n_var, const uint64_t *var_up, const uint64_t *var_dn, const double *coeffs, double e_var,
+                     double eps_pt, int32_t n_slices, double *delta_e, int64_t *n_connections);
 void sqmc_gpu_free(void *p);
 
 /* HIP-event timing on the library's streams.  level 0 off; 1 = only the k_spawn launch

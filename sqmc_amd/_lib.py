@@ -18,7 +18,7 @@ EXPORTS = [
     "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init", "sqmc_gpu_comm_size",
     "sqmc_gpu_shard_step", "sqmc_gpu_shard_run", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_tail_stats", "sqmc_gpu_spmv_prepare",
     "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_build_spmv_plan", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
-    "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_hci_connections_slice", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
+    "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_hci_connections_slice", "sqmc_gpu_hci_pt2", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
 ]
 
 
@@ -425,6 +425,15 @@ class GpuChem:
         return take(pu, C.c_uint64, np.uint64), take(pd, C.c_uint64, np.uint64), take(pn, C.c_double, np.float64), take(pe, C.c_double, np.float64)
 
 
+def _gpuchem_hci_pt2(self, up, dn, coeffs, e_var, eps_pt, n_slices=1):
+    """sqmc_gpu_hci_pt2: (delta_E, number of connected determinants), everything on the device"""
+    u, d, c = _u64(up), _u64(dn), _f64(coeffs)
+    de, nc = C.c_double(), C.c_int64()
+    self.L.sqmc_gpu_hci_pt2.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p]
+    _chk(self.L.sqmc_gpu_hci_pt2(self.h, len(u), _p(u), _p(d), _p(c), float(e_var), float(eps_pt), int(n_slices), C.byref(de), C.byref(nc)))
+    return de.value, nc.value
+
+
 class HeatbathTables(C.Structure):
     """sqmc_heatbath_tables of include/sqmc_gpu.h"""
     _fields_ = [("norb", C.c_int32), ("reserved", C.c_int32), ("one", C.c_void_p), ("two", C.c_void_p), ("three_same", C.c_void_p), ("three_opp", C.c_void_p),
@@ -467,3 +476,6 @@ class SpmvPlan:
         if self.h:
             self.L.sqmc_gpu_spmv_free(self.h)
             self.h = None
+
+
+GpuChem.hci_pt2 = _gpuchem_hci_pt2

@@ -9,6 +9,29 @@ __global__ void __launch_bounds__(TPB) k_ham_batch(ChemDev dev, const u64 *iu, c
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i < n) h[i] = h_any(t, dev.integrals, iu[i], id[i], ju[i], jd[i]);
 }
+// second_order_pt's sum (hci.f90:1140-1175): one term per deduplicated connection that is NOT in the variational space (binary
+// search on its sorted determinant ranks), num^2 / (E_var - H_aa); grid-stride, one partial sum per block (fixed tree)
+__global__ void __launch_bounds__(TPB) k_pt2_terms(ChemDev dev, const u64 *__restrict__ cu, const u64 *__restrict__ cd, const double *__restrict__ num, long long n,
+                                                   const u64 *__restrict__ vkeys, long long nv, double e_var, double *__restrict__ partial) {
+  __shared__ ChemTab t;
+  stage_tab(&t, dev.tab, dev.tab_words);
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+    const u64 u = cu[i], d = cd[i];
+    const u64 key = det_key(dev, u, d);
+    long long lo = 0, hi = nv;                         // first variational rank >= key
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (vkeys[mid] < key) lo = mid + 1; else hi = mid; }
+    if (lo < nv && vkeys[lo] == key) continue;         // inside the variational space
+    const double haa = h_any(t, dev.integrals, u, d, u, d);
+    const double x = num[i];
+    acc += x * x / (e_var - haa);
+  }
+  __shared__ double red[TPB / 64];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { double v = 0.0; for (int q = 0; q < TPB / 64; q++) v += red[q]; partial[blockIdx.x] = v; }
+}
 __global__ void __launch_bounds__(TPB) k_ham_chem_batch(ChemDev dev, const u64 *iu, const u64 *id, const u64 *ju, const u64 *jd, double *h, long long n) {
   __shared__ ChemTab t;
   stage_tab(&t, dev.tab, dev.tab_words);

@@ -169,6 +169,8 @@ struct sqmc_gpu_ctx {
 };
 
 #include "walk_kernels.h"
+#define SPAWN_LAUNCH(HB_, ...) do { if (HB_) hipLaunchKernelGGL(k_spawn<1>, __VA_ARGS__); else hipLaunchKernelGGL(k_spawn<0>, __VA_ARGS__); } while (0)
+#define SPAWN_LAUNCH_EXT(HB_, ...) do { if (HB_) hipExtLaunchKernelGGL(k_spawn<1>, __VA_ARGS__); else hipExtLaunchKernelGGL(k_spawn<0>, __VA_ARGS__); } while (0)
 #include "bucket_kernels.h"
 #include "door_kernels.h"
 #include "hci_kernels.h"
@@ -640,19 +642,17 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   //      host mailbox as soon as it starts.
   HIPCHK(hipEventRecord(c->e_fork, st));
   // pipelined head: the diagonal elements of the determinants the last step created depend on nothing the host still has to
-  // decide: they are computed now, beside the scan and k_spawn -- by a kernel on the side stream (default), or by spare blocks of
-  // k_spawn itself (SQMC_HII_IN_SPAWN=1: no cross-stream join, but the extra LDS costs k_spawn its occupancy: 122 against 110 us
-  // per step at 10^5 walkers).  Death/clone later finds them cached.
+  // decide: a kernel on the side stream computes them now, beside the scan and k_spawn; death/clone later finds them cached.
+  // (Doing this in spare blocks of k_spawn instead saves the cross-stream join but costs k_spawn its occupancy through the extra
+  // LDS: 122 against 110 us per step at 10^5 walkers, and 35 % more spawn time at 10^6-10^7 -- taken out again.)
   static const bool no_early = getenv("SQMC_NO_EARLY_HII") != nullptr;
-  static const bool hii_in_spawn = getenv("SQMC_HII_IN_SPAWN") != nullptr;
   const bool early = dev_n && !c->d_grow && !no_early;
-  const int hii_blocks = (early && hii_in_spawn) ? nblk(n0) : 0;
-  if (early && !hii_in_spawn) {
+  if (early) {
     HIPCHK(hipStreamWaitEvent(c->st2, c->e_fork, 0));
     hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, c->st2, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc, 1);
     HIPCHK(hipEventRecord(c->e_join, c->st2));          // a tail that does death/clone itself still has to wait for these
   }
-  c->head_hii = early; c->head_hii_joined = early && hii_in_spawn;
+  c->head_hii = early; c->head_hii_joined = false;
   *cseq = ++c->cnt_seq;
   const OwnerOut oo = shard_owner_out(c);
   // short lists: k_spawn groups its children by key range as it emits them (the bucket tail then needs no partition kernel).
@@ -675,11 +675,11 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   const long long nfree = dev_n ? M : M - n0;          // dev_n: nothing is known about the count but that it is >= 0
   if (nfree > 0) {
     if (s0)
-      hipExtLaunchKernelGGL(k_spawn, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + hii_blocks + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, nblk(nfree), hii_blocks);
+      SPAWN_LAUNCH_EXT(c->dev.hb.on, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
+                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, nblk(nfree));
     else
-      hipLaunchKernelGGL(k_spawn, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + hii_blocks + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, nblk(nfree), hii_blocks);
+      SPAWN_LAUNCH(c->dev.hb.on, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, nblk(nfree));
   } else if (s0) { hipEventRecord(s0, st); hipEventRecord(s1, st); }
   HIPCHK(hipGetLastError());
   return SQMC_OK;
@@ -978,11 +978,11 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     cseq = ++c->cnt_seq;
     if (M > n0) {
       if (t_spawn >= 0)
-        hipExtLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->ev0[t_spawn], c->ev1[t_spawn], 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{}, PrjPre{}, nblk(M - n0), 0);
+        SPAWN_LAUNCH_EXT(c->dev.hb.on, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->ev0[t_spawn], c->ev1[t_spawn], 0, c->dev, c->w, c->d_child_off, c->d_wchild,
+                              c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{}, PrjPre{}, nblk(M - n0));
       else
-        hipLaunchKernelGGL(k_spawn, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{}, PrjPre{}, nblk(M - n0), 0);
+        SPAWN_LAUNCH(c->dev.hb.on, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                           n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{}, PrjPre{}, nblk(M - n0));
     } else if (t_spawn >= 0) { hipEventRecord(c->ev0[t_spawn], st); hipEventRecord(c->ev1[t_spawn], st); }
   } else {
     int r = enqueue_head(c, p, step, n0, false, t_gate_scan >= 0 ? c->ev0[t_gate_scan] : nullptr, t_gate_scan >= 0 ? c->ev1[t_gate_scan] : nullptr,

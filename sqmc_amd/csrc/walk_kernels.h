@@ -238,11 +238,12 @@ extern "C" int sqmc_gpu_debug_prof(unsigned long long *out) { return (int)hipMem
 #define PROF(K)
 #endif
 // one thread per child proposal; parent found by binary search in the child offsets
+// HB: proposal_method fast_heatbath (two walker slots per child) -- a kernel of its own, so that the uniform proposal keeps its registers
+template <int HB>
 __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
                                                const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
                                                long long n0_arg, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc,
-                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo, BucketArgs ba, FinArgs fin, PrjPre pp, int extra0,
-                                               int hii_blocks) {
+                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo, BucketArgs ba, FinArgs fin, PrjPre pp, int extra0) {
   // Blocks from extra0 on do not spawn.  Steps whose child offsets came out of the bucket tail have no scan launch to carry the
   // last step's final sums: block extra0 does them (it runs beside the spawning blocks; nothing it touches is read by them).
   // The blocks behind it multiply the deterministic projector into last step's deterministic weights, one wavefront per row:
@@ -251,16 +252,8 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
     const int xb = (int)blockIdx.x - extra0;
     if (fin.on && xb == 0) { finish_all(fin, const_cast<DevScalars *>(sc)); return; }
     if (n_on_device && sc->retry) return;
-    // behind the finishing block: hii_blocks blocks that fill in the H_ii of the determinants the last step created (what the
-    // death/clone of this step's tail needs; nothing the spawning blocks read), then the rows of the projector
     const int hb0 = xb - (fin.on ? 1 : 0);
-    if (hb0 < hii_blocks) {
-      __shared__ ChemTab th;
-      stage_tab(&th, dev.tab, dev.tab_words);
-      diag_block(th, dev, w.up, w.dn, w.wt, w.flg, w.me, (long long)sc->nwalk, p, const_cast<DevScalars *>(sc), 1, (long long)hb0);
-      return;
-    }
-    const int row = (hb0 - hii_blocks) * (TPB / 64) + (int)(threadIdx.x >> 6);
+    const int row = hb0 * (TPB / 64) + (int)(threadIdx.x >> 6);
     if (pp.n_imp > 0 && row < pp.n_imp) prj_row_product(pp, row);
     return;
   }
@@ -291,7 +284,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   if (mail && blockIdx.x == 0 && threadIdx.x == 0) {      // the host sizes the sort from this while the kernel runs
     mail->n_children = (u64)nchildren; __threadfence_system(); mail->cnt_seq = cnt_seq;
   }
-  const long long spc = dev.hb.on ? 2 : 1;             // walker slots per child: the heat-bath proposal may return a single AND a double
+  const long long spc = HB ? 2 : 1;             // walker slots per child: the heat-bath proposal may return a single AND a double
   if (c0 >= nchildren || n0 + spc * nchildren > cap_all) return;
   const bool part = ba.B > 0 && (int)blockIdx.x < ba.nsb;                  // rows beyond the room the host provided: the tail will see that and use its own partition
   if (part) bucket_partition_stage(s_spl, s_wcnt, keys, n0, ba.B);     // resident keys [0, n0) of the same array the children's keys go to; a barrier follows below
@@ -333,7 +326,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
     const u32 pflg = w.flg[ip]; const double wch = wchild[ip];     // needed at the end: fetched in the same round trip
     u64 ju, jd; double prob;
     PROF(3);
-    if (dev.hb.on) {                    // proposal_method fast_heatbath: both slots of the child are written (weight 0: no walker), do_walk.f90:3604-3611
+    if (HB) {                    // proposal_method fast_heatbath: both slots of the child are written (weight 0: no walker), do_walk.f90:3604-3611
       u64 ju2[2], jd2[2]; double wj2[2];
       propose_heatbath(t, dev.integrals, dev.hb, g, p.tau, iu, id, ju2, jd2, wj2);
       spawn_emit(dev, w, keys, vals, n0, 2 * c, pflg, ju2[0], jd2[0], wch * wj2[0], p, invalid_key, pack, oo);

@@ -4,7 +4,8 @@
 !> sqmc_gpu_build_spmv_plan for generate_sparse_ham_chem_upper_triangular, sqmc_gpu_spmv_apply for
 !> the matvec inside the Davidson iteration -- and the host logic (list bookkeeping, the small
 !> Krylov problem) written here.  Tables come from a deck written by sqmc_amd.host.dump_hci_deck.
-!>   usage: example_hci <deck>
+!>   usage: example_hci <deck> [eps_pt]      with eps_pt: the Epstein-Nesbet correction of state 1 (second_order_pt,
+!>   hci.f90:1100-1182) in one call, sqmc_gpu_hci_pt2, on the basis the deck's context works in
 module hci_host_tools
   use iso_c_binding
   implicit none
@@ -110,7 +111,8 @@ program example_hci
   character(len=512) :: deck
   integer :: u, it, ns, nsched, i, j, k, itc, niter, iters, ist
   integer(c_int64_t) :: hdr(18), n, n_old, n_new, n_conn, nnz, q
-  real(c_double) :: max_double, eps, tol
+  real(c_double) :: max_double, eps, tol, eps_pt, delta_e
+  character(len=64) :: arg2
   real(c_double), allocatable :: sched(:)
   integer(c_int32_t), allocatable, target :: prod(:), osym(:), c2(:), hb_r(:), hb_s(:), pq_count(:)
   integer(c_int64_t), allocatable :: pq_ind(:)
@@ -123,8 +125,12 @@ program example_hci
   type(sqmc_chem_cfg) :: cfg
   logical :: converged
 
-  if (command_argument_count() < 1) stop 'usage: example_hci <deck>'
+  if (command_argument_count() < 1) stop 'usage: example_hci <deck> [eps_pt]'
   call get_command_argument(1, deck)
+  eps_pt = 0
+  if (command_argument_count() >= 2) then
+    call get_command_argument(2, arg2); read(arg2, *) eps_pt
+  endif
   open(newunit=u, file=trim(deck), access='stream', form='unformatted', status='old')
   read(u) hdr
   if (hdr(1) /= int(z'68636930', c_int64_t)) stop 'not an hci deck'
@@ -264,6 +270,12 @@ program example_hci
     old_energy = energy
   enddo
   write(6, '(a,i10,10es26.17)') 'fortran hci:', n, energy
+  if (eps_pt > 0) then
+    allocate(coeffs(n)); coeffs = wts(:, 1)
+    call sqmc_gpu_check(sqmc_gpu_hci_pt2(gpu, n, up, dn, coeffs, energy(1), eps_pt, 1_c_int32_t, delta_e, n_conn), 'hci_pt2')
+    write(6, '(a,i12,2es26.17)') 'fortran pt2:', n_conn, delta_e, energy(1) + delta_e
+    deallocate(coeffs)
+  endif
   call sqmc_gpu_check(sqmc_gpu_finalize(gpu), 'finalize')
 
 contains

@@ -1036,10 +1036,17 @@ def hci_pt2(host, g, up, dn, coeffs, e_var, eps_pt, n_slices=1):
     """Deterministic Epstein-Nesbet second-order correction, second_order_pt (hci.f90:1100-1182):
     delta_E = sum over determinants a outside the variational space of
     (sum_i H_ai c_i)^2 / (E_var - H_aa), the inner sum screened by |H_ai c_i| >= eps_pt.
-    Connections, their dedup-sum and the diagonal elements all come from the GPU.  n_slices > 1
-    does the connected space in that many slices of the determinant-key range (exact: every
-    connected determinant lives in one slice), for spaces whose connections do not fit one call.
+    One library call (sqmc_gpu_hci_pt2): connections, their dedup-sum, the membership search, the
+    diagonal elements and the reduction all stay on the device.  n_slices > 1 does the connected
+    space in that many slices of the determinant-key range (exact: every connected determinant
+    lives in one slice), for spaces whose connections do not fit one call.
     Returns (delta_E, number of connected determinants)."""
+    return g.hci_pt2(up, dn, coeffs, e_var, eps_pt, n_slices)
+
+
+def hci_pt2_by_doors(host, g, up, dn, coeffs, e_var, eps_pt, n_slices=1):
+    """The same sum assembled on the host from the batch doors (connections, then H_aa); kept as
+    the cross-check of sqmc_gpu_hci_pt2 in the tests."""
     up, dn = np.ascontiguousarray(up, np.uint64), np.ascontiguousarray(dn, np.uint64)
     delta, n_conn = 0.0, 0
     for sl in range(n_slices):

@@ -719,6 +719,9 @@ def test_hci_pt2_matches_oracle_and_reference_run(oracle, c2_hci):
     # the connected space in 7 slices of the key range: same determinants, same sums
     d_sl, n_sl = H.hci_pt2(h, g, up, dn, w[:, 0], float(e[0]), 2e-5, n_slices=7)
     assert n_sl == n_gpu and abs(d_sl - d_gpu) < 1e-14
+    # the one-call entry against the same sum assembled from the batch doors on the host
+    d_doors, n_doors = H.hci_pt2_by_doors(h, g, up, dn, w[:, 0], float(e[0]), 2e-5, n_slices=3)
+    assert n_doors == n_gpu and abs(d_doors - d_gpu) < 1e-14
     up, dn, w, e, hist = H.hci_variational(h, g, 1e-4, eps_sched=(2e-4, 2e-4), n_states=1)
     g.close()
     # the reference converts to the determinant basis before PT (hci.f90:648-659): 6.56 M connections there
@@ -1163,10 +1166,17 @@ def test_fortran_host_hci(tmp_path):
     g.close()
     deck = str(tmp_path / "c2_hci.deck")
     H.dump_hci_deck(deck, h, hb, 1e-3, eps_sched=(2e-3, 2e-3), n_states=2)
-    out = subprocess.run([exe, deck], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([exe, deck, "2e-5"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     last = [l for l in out.stdout.splitlines() if l.startswith("fortran hci:")][0].split()
     assert int(last[2]) == 12776
+    # the PT stage through the same module (sqmc_gpu_hci_pt2) against the Python host on its own wavefunction
+    pt = [l for l in out.stdout.splitlines() if l.startswith("fortran pt2:")][0].split()
+    g = h.gpu(); g.set_hb_tables(*hb)
+    up, dn, w, e, hist = H.hci_variational(h, g, 1e-3, eps_sched=(2e-3, 2e-3), n_states=2)
+    d_py, n_py = H.hci_pt2(h, g, up, dn, w[:, 0], float(e[0]), 2e-5)
+    g.close()
+    assert int(pt[2]) == n_py and abs(float(pt[3]) - d_py) < 1e-8 and d_py < -1e-3
     assert abs(float(last[3]) - (-75.719473642)) < 2e-9 and abs(float(last[4]) - (-75.631097209)) < 2e-9
     its = [l for l in out.stdout.splitlines() if l.startswith("Iteration")]
     assert [int(l.split("ndets=")[1].split()[0]) for l in its] == [1, 650, 3767, 11787, 12705, 12776]
