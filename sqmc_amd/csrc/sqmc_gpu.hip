@@ -169,8 +169,8 @@ struct sqmc_gpu_ctx {
 };
 
 #include "walk_kernels.h"
-#define SPAWN_LAUNCH(HB_, ...) do { if (HB_) hipLaunchKernelGGL(k_spawn<1>, __VA_ARGS__); else hipLaunchKernelGGL(k_spawn<0>, __VA_ARGS__); } while (0)
-#define SPAWN_LAUNCH_EXT(HB_, ...) do { if (HB_) hipExtLaunchKernelGGL(k_spawn<1>, __VA_ARGS__); else hipExtLaunchKernelGGL(k_spawn<0>, __VA_ARGS__); } while (0)
+#define SPAWN_LAUNCH(HB_, FUSE_, ...) do { if (HB_) hipLaunchKernelGGL((k_spawn<1, 1>), __VA_ARGS__); else if (FUSE_) hipLaunchKernelGGL((k_spawn<0, 1>), __VA_ARGS__); else hipLaunchKernelGGL((k_spawn<0, 0>), __VA_ARGS__); } while (0)
+#define SPAWN_LAUNCH_EXT(HB_, FUSE_, ...) do { if (HB_) hipExtLaunchKernelGGL((k_spawn<1, 1>), __VA_ARGS__); else if (FUSE_) hipExtLaunchKernelGGL((k_spawn<0, 1>), __VA_ARGS__); else hipExtLaunchKernelGGL((k_spawn<0, 0>), __VA_ARGS__); } while (0)
 #include "bucket_kernels.h"
 #include "door_kernels.h"
 #include "hci_kernels.h"
@@ -673,12 +673,13 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
     c->head_ba = hb;
   }
   const long long nfree = dev_n ? M : M - n0;          // dev_n: nothing is known about the count but that it is >= 0
+  const int spawn_fuse = (hb.B > 0 || spawn_fin.on || pp.n_imp > 0) ? 1 : 0;
   if (nfree > 0) {
     if (s0)
-      SPAWN_LAUNCH_EXT(c->dev.hb.on, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
+      SPAWN_LAUNCH_EXT(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
                             c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, nblk(nfree));
     else
-      SPAWN_LAUNCH(c->dev.hb.on, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+      SPAWN_LAUNCH(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
                          n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, nblk(nfree));
   } else if (s0) { hipEventRecord(s0, st); hipEventRecord(s1, st); }
   HIPCHK(hipGetLastError());
@@ -978,10 +979,10 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     cseq = ++c->cnt_seq;
     if (M > n0) {
       if (t_spawn >= 0)
-        SPAWN_LAUNCH_EXT(c->dev.hb.on, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->ev0[t_spawn], c->ev1[t_spawn], 0, c->dev, c->w, c->d_child_off, c->d_wchild,
+        SPAWN_LAUNCH_EXT(c->dev.hb.on, 0, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->ev0[t_spawn], c->ev1[t_spawn], 0, c->dev, c->w, c->d_child_off, c->d_wchild,
                               c->d_child_state, c->d_keys, c->d_vals, n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{}, PrjPre{}, nblk(M - n0));
       else
-        SPAWN_LAUNCH(c->dev.hb.on, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+        SPAWN_LAUNCH(c->dev.hb.on, 0, dim3(nblk(M - n0)), dim3(TPB), 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
                            n0, M, p, mode, seed, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, cseq, c->pack, 0, OwnerOut{nullptr, nullptr, 0, 0}, BucketArgs{}, FinArgs{}, PrjPre{}, nblk(M - n0));
     } else if (t_spawn >= 0) { hipEventRecord(c->ev0[t_spawn], st); hipEventRecord(c->ev1[t_spawn], st); }
   } else {

@@ -239,7 +239,9 @@ extern "C" int sqmc_gpu_debug_prof(unsigned long long *out) { return (int)hipMem
 #endif
 // one thread per child proposal; parent found by binary search in the child offsets
 // HB: proposal_method fast_heatbath (two walker slots per child) -- a kernel of its own, so that the uniform proposal keeps its registers
-template <int HB>
+// FUSE: the short-list extras (children grouped by key range for the bucket tail, the block with the final sums, the projector rows);
+//       large populations run FUSE = 0, whose register and LDS budget is the plain spawn's (7 waves per SIMD)
+template <int HB, int FUSE>
 __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
                                                const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
                                                long long n0_arg, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc,
@@ -248,7 +250,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   // last step's final sums: block extra0 does them (it runs beside the spawning blocks; nothing it touches is read by them).
   // The blocks behind it multiply the deterministic projector into last step's deterministic weights, one wavefront per row:
   // the part of the projection that needs nothing the host still has to decide (E_T enters in the tail, bucket_kernels.h).
-  if ((int)blockIdx.x >= extra0) {
+  if (FUSE && (int)blockIdx.x >= extra0) {
     const int xb = (int)blockIdx.x - extra0;
     if (fin.on && xb == 0) { finish_all(fin, const_cast<DevScalars *>(sc)); return; }
     if (n_on_device && sc->retry) return;
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   }
   const long long spc = HB ? 2 : 1;             // walker slots per child: the heat-bath proposal may return a single AND a double
   if (c0 >= nchildren || n0 + spc * nchildren > cap_all) return;
-  const bool part = ba.B > 0 && (int)blockIdx.x < ba.nsb;                  // rows beyond the room the host provided: the tail will see that and use its own partition
+  const bool part = FUSE && ba.B > 0 && (int)blockIdx.x < ba.nsb;                  // rows beyond the room the host provided: the tail will see that and use its own partition
   if (part) bucket_partition_stage(s_spl, s_wcnt, keys, n0, ba.B);     // resident keys [0, n0) of the same array the children's keys go to; a barrier follows below
   PROF(1);
   while (whi - wlo > SPAWN_WIN) {

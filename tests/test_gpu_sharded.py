@@ -58,19 +58,51 @@ def _run(world, tmp_path, port, system="c2", **kw):
     return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
 
 
-def test_one_rank_sharded_equals_single_rank_step(tmp_path):
-    """With one rank the sharded pipeline (bucket -> exchange -> unpack) must reproduce the
-    single-rank step exactly."""
-    res = _run(1, tmp_path, 29541)[0]
+def _single_rank_worker(outdir, bucket, w_target=None, nsteps=None):
+    W_TARGET, NSTEPS = w_target or globals()["W_TARGET"], nsteps or globals()["NSTEPS"]
+    os.environ["SQMC_BUCKET"] = str(bucket)        # read once per process, hence a process of its own
+    sys.path.insert(0, ROOT)
+    import sqmc_amd
     from sqmc_amd import host as H
+    sqmc_amd.set_device(0)
     hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
     ref = H.GpuWalk(hst, W_TARGET, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
     outs = np.array([ref.step().copy() for _ in range(NSTEPS)])
     wk = ref.g.download_walkers()
+    np.savez(os.path.join(outdir, "single%d.npz" % bucket), outs=outs, tail=np.array(ref.g.tail_stats()), **wk)
     ref.close()
+
+
+def _single_rank_radix_tail(tmp_path, w_target=None, nsteps=None):
+    """the plain single-rank walk on the radix tail (the tail the sharded step runs), in a process of its own"""
+    import torch.multiprocessing as mp
+    pr = mp.get_context("spawn").Process(target=_single_rank_worker, args=(str(tmp_path), 0, w_target, nsteps))
+    pr.start(); pr.join(600)
+    assert pr.exitcode == 0
+    return np.load(os.path.join(str(tmp_path), "single0.npz"))
+
+
+def test_one_rank_sharded_equals_single_rank_step(tmp_path):
+    """With one rank the sharded pipeline (bucket -> exchange -> unpack) must reproduce the
+    single-rank step: bit for bit against the single-rank step on the same tail (the radix tail, the
+    one the sharded step uses); against the short-list tail the estimator sums come out of another
+    reduction tree, E_T follows them, and the weights agree to rounding."""
+    import torch.multiprocessing as mp
+    res = _run(1, tmp_path, 29541)[0]
+    ctx = mp.get_context("spawn")
+    for bucket in (0, 1):
+        pr = ctx.Process(target=_single_rank_worker, args=(str(tmp_path), bucket))
+        pr.start(); pr.join(600)
+        assert pr.exitcode == 0
+    wk = np.load(os.path.join(str(tmp_path), "single0.npz"))
+    assert tuple(wk["tail"]) == (0, 0)
     assert np.array_equal(res["up"], wk["up"]) and np.array_equal(res["dn"], wk["dn"])
     assert np.array_equal(res["wt"], wk["wt"]) and np.array_equal(res["initiator"], wk["initiator"])
-    assert np.allclose(res["outs"], outs, rtol=1e-12, atol=1e-12)
+    assert np.allclose(res["outs"], wk["outs"], rtol=1e-12, atol=1e-12)
+    wb = np.load(os.path.join(str(tmp_path), "single1.npz"))
+    assert wb["tail"][0] > NSTEPS // 2
+    assert np.array_equal(res["up"], wb["up"]) and np.array_equal(res["dn"], wb["dn"]) and np.array_equal(res["initiator"], wb["initiator"])
+    assert np.allclose(res["wt"], wb["wt"], rtol=1e-11, atol=0) and np.allclose(res["outs"], wb["outs"], rtol=1e-11, atol=1e-11)
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -195,12 +227,7 @@ def test_in_library_pipelined_run_matches_plain_walk(tmp_path):
     assert p.exitcode == 0
     res = np.load(os.path.join(str(tmp_path), "inlib_long.npz"))
     assert int(res["reached"][0]) == 2
-    from sqmc_amd import host as H
-    hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
-    ref = H.GpuWalk(hst, w_target, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
-    outs = np.array([ref.step().copy() for _ in range(nsteps)])
-    wk = ref.g.download_walkers()
-    ref.close()
+    wk = _single_rank_radix_tail(tmp_path, w_target, nsteps); outs = wk["outs"]
     assert np.array_equal(res["up"], wk["up"]) and np.array_equal(res["dn"], wk["dn"])
     assert np.array_equal(res["wt"], wk["wt"])
     assert np.allclose(res["outs"], outs, rtol=1e-12, atol=1e-12)
@@ -216,12 +243,7 @@ def test_in_library_rccl_exchange_single_rank(tmp_path):
     p.start(); p.join(600)
     assert p.exitcode == 0
     res = np.load(os.path.join(str(tmp_path), "inlib.npz"))
-    from sqmc_amd import host as H
-    hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
-    ref = H.GpuWalk(hst, W_TARGET, w_begin=W_BEGIN, seed=SEED, mwalk=400000)
-    outs = np.array([ref.step().copy() for _ in range(NSTEPS)])
-    wk = ref.g.download_walkers()
-    ref.close()
+    wk = _single_rank_radix_tail(tmp_path); outs = wk["outs"]
     assert np.array_equal(res["up"], wk["up"]) and np.array_equal(res["dn"], wk["dn"])
     assert np.array_equal(res["wt"], wk["wt"])
     assert np.allclose(res["outs"], outs, rtol=1e-12, atol=1e-12)
