@@ -227,8 +227,12 @@ def main():
                 return None, None
             k = tr["kernels"][kern]
             return k["hbm_bytes_calibrated"], {"fetch_x1": k["hbm_bytes_x1"], "fetch_x2": k["hbm_bytes_x2"], "calibrated": k["hbm_bytes_calibrated"],
+                                               "profiled_kernel": k.get("kernel", "")[:60],
                                                "source": os.path.relpath(TRAFFIC_JSON, ROOT), "commit": tr.get("commit")}
 
+        tail = walk.g.tail_stats()
+        # which annihilation kernel the timed launches were: the short-list tail's (one block per key range) or the radix tail's
+        dom_name = "k_anneal_bucket" if (dom == "k_anneal" and tail[0] - tail[1] > (args.steps + args.warmup) // 2) else dom
         line = {
             "metric": "walker-steps/sec", "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if sharded else "weak",
@@ -240,8 +244,8 @@ def main():
                        "occupied_dets_per_step": n_avg, "spawns_per_step": s_avg, "spawns_per_s": spawn_all / dt,
                        "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": parallelism,
                        "rccl_ranks": rccl_ranks, "devices": min(world, ndev),
-                       "short_list_tail": dict(zip(("bucket_steps", "rerun_through_radix_tail"), walk.g.tail_stats()))},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                       "short_list_tail": dict(zip(("bucket_steps", "rerun_through_radix_tail"), tail))},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic_of(dom)[0], "traffic_detail": traffic_of(dom)[1], "ms_per_launch": dom_ms,
                          "algorithmic_bytes_per_launch": dom_bytes,
                          "other_kernels": {"k_spawn": {"ms_per_launch": spawn_ms, "algorithmic_bytes_per_launch": 26.0 * s_avg + 34.0 * n_avg,
