@@ -155,6 +155,7 @@ def main():
         if multi:
             parallelism = "replicas x%d (sharded path unavailable)" % world
     sharded = isinstance(walk, H.ShardedWalk)
+    slowest = None
 
     if sharded and not walk.in_library:
         for _ in range(args.equil + args.warmup):
@@ -187,6 +188,7 @@ def main():
         dt = time.perf_counter() - t0
         nwalk_sum, spawn_sum = float(totals[5]) / (world if sharded else 1), float(totals[15])      # sharded: nwalk is the global count
         e_num, e_den = float((stats[:, 3] * np.sign(stats[:, 2])).sum()), float(np.abs(stats[:, 2]).sum())
+        slowest = walk.g.slowest_steps()                   # wall clock of the slowest timed steps: host jitter, reruns
         timers_timed = walk.g.timing()                     # mean ms per k_spawn / k_anneal launch over the K timed steps
         spawn_ms = dict(timers_timed).get("spawn", float('nan'))
         walk.g.set_timing(2)                                # informational stage breakdown from an untimed tail
@@ -244,7 +246,8 @@ def main():
                        "occupied_dets_per_step": n_avg, "spawns_per_step": s_avg, "spawns_per_s": spawn_all / dt,
                        "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": parallelism,
                        "rccl_ranks": rccl_ranks, "devices": min(world, ndev),
-                       "short_list_tail": dict(zip(("bucket_steps", "rerun_through_radix_tail"), tail))},
+                       "short_list_tail": dict(zip(("bucket_steps", "rerun_through_radix_tail"), tail)),
+                       "slowest_steps_us": slowest},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic_of(dom)[0], "traffic_detail": traffic_of(dom)[1], "ms_per_launch": dom_ms,
                          "algorithmic_bytes_per_launch": dom_bytes,

@@ -263,6 +263,9 @@ int sqmc_gpu_shard_run(sqmc_gpu_ctx *ctx, sqmc_popctl *pc, int64_t nsteps, doubl
 /* How many steps took the short-list tail (block-local partition + one annihilation kernel per key range, no global sort) and
  * how many of those had to be re-run through the radix tail because a key range outgrew its block (diagnostics, tests). */
 int sqmc_gpu_tail_stats(sqmc_gpu_ctx *ctx, int64_t *bucket_steps, int64_t *bucket_retries);
+/* diagnostics: wall-clock time (microseconds) and index of the four slowest steps of the last sqmc_gpu_run / sqmc_gpu_shard_run
+ * call -- a step that waited for the host (scheduling, a rerun through the radix tail) stands out here */
+int sqmc_gpu_slowest_steps(sqmc_gpu_ctx *ctx, double us[4], int64_t step[4]);
 int sqmc_gpu_get_rng(sqmc_gpu_ctx *ctx, int32_t seed[4]);
 int sqmc_gpu_set_rng(sqmc_gpu_ctx *ctx, const int32_t seed[4]);
 

@@ -116,6 +116,79 @@ __device__ __forceinline__ u64 bk_lookback_wide(u64 *__restrict__ state, int b, 
   if (tid == 0) atomicExch((unsigned long long *)&state[b], SCAN_ST_INC | (excl + tot));
   return excl;
 }
+// ---- H_ii of one determinant by 16 lanes (chemistry, no time symmetry).  h_diag (chem_device.h) is three running sums -- one-body,
+// exchange, direct -- of ~50 integrals; a lane on its own pays one L2 round trip per group of four.  Here every term of a sum has its
+// place in the reference's order (closed form from the electron indices), the 16 lanes fetch all terms at once into LDS, and one
+// lane per sum adds them up in that order: the same value bit for bit, one round trip instead of ~25.
+#define BK_HG 16
+#define BK_HG_TERMS 112            // LDS doubles per group: BK_CAP_T / (BK_AT / BK_HG)
+#define BK_HG_TASKS 6              // tasks per lane at the cap
+static_assert(BK_HG_TERMS * (BK_AT / BK_HG) <= BK_CAP_T, "the groups share the weight array");
+__device__ __forceinline__ int bk_nth_orb(u64 x, int n) { for (int k = 0; k < n; k++) x &= x - 1; return ctz64(x); }     // 0-based orbital of the n-th electron
+__device__ __forceinline__ bool bk_hii_group_ok(const ChemTab &t) {
+  const int nup = t.nup, ndn = t.ndn, nuu = nup * (nup - 1) / 2, ndd = ndn * (ndn - 1) / 2, nud = nup * ndn;
+  return t.sys_type == 0 && !t.time_sym && (nup + ndn) + (nuu + ndd) + (nuu + nud + ndd) <= BK_HG_TERMS && (nup + ndn) + nuu + ndd + nud <= BK_HG * BK_HG_TASKS;
+}
+// all threads of the block call this together (two barriers inside); sg: the group's BK_HG_TERMS doubles; g: lane inside the group
+__device__ __forceinline__ double bk_hii_group16(const ChemTab &t, const double *__restrict__ ints, u64 up, u64 dn, bool valid, double *sg, int g) {
+  const int nup = t.nup, ndn = t.ndn, n1 = t.norb + 1;
+  const bool same = (dn == up);
+  const int nuu = nup * (nup - 1) / 2, ndd = ndn * (ndn - 1) / 2, nud = nup * ndn;
+  const int L_e1 = same ? nup : nup + ndn, L_ex = nuu + (same ? 0 : ndd), L_di = nuu + nud + ndd;
+  const int o_ex = L_e1, o_di = L_e1 + L_ex;
+  const int ntask = valid ? (nup + ndn) + nuu + ndd + nud : 0;
+  int p0[BK_HG_TASKS], p1[BK_HG_TASKS], x0[BK_HG_TASKS], x1[BK_HG_TASKS];
+#pragma unroll
+  for (int m = 0; m < BK_HG_TASKS; m++) {
+    int k = g + BK_HG * m;
+    p0[m] = -1; p1[m] = -1; x0[m] = 0; x1[m] = 0;
+    if (k >= ntask) continue;
+    if (k < nup) {                                   // one-body, up electron k
+      const int i = bk_nth_orb(up, k) + 1;
+      p0[m] = k; x0[m] = integral_index(t, i, i, n1, n1);
+    } else if (k < nup + ndn) {                      // one-body, dn electron
+      const int b = k - nup;
+      if (!same) { const int i = bk_nth_orb(dn, b) + 1; p0[m] = nup + b; x0[m] = integral_index(t, i, i, n1, n1); }
+    } else if (k < nup + ndn + nuu) {                // up-up pair (a < a2): an exchange and a direct term
+      int r = k - nup - ndn, a = 0;
+      while (r >= nup - 1 - a) { r -= nup - 1 - a; a++; }
+      const int a2 = a + 1 + r, i0 = bk_nth_orb(up, a), j0 = bk_nth_orb(up, a2);
+      const int Bc = __popcll(dn & ((1ull << i0) - 1ull));
+      const int base = a * (nup - 1 + ndn) - a * (a - 1) / 2 + Bc * (ndn - 1) - Bc * (Bc - 1) / 2;
+      p0[m] = o_ex + a * (nup - 1) - a * (a - 1) / 2 + (a2 - a - 1); x0[m] = integral_index(t, i0 + 1, j0 + 1, j0 + 1, i0 + 1);
+      p1[m] = o_di + base + (a2 - a - 1);                            x1[m] = integral_index(t, i0 + 1, i0 + 1, j0 + 1, j0 + 1);
+    } else if (k < nup + ndn + nuu + ndd) {          // dn-dn pair (b < b2): direct always, exchange unless the strings are equal
+      int r = k - nup - ndn - nuu, b = 0;
+      while (r >= ndn - 1 - b) { r -= ndn - 1 - b; b++; }
+      const int b2 = b + 1 + r, i0 = bk_nth_orb(dn, b), j0 = bk_nth_orb(dn, b2);
+      const int A = __popcll(up & ((2ull << i0) - 1ull));              // up electrons at orbitals <= i0 come first
+      const int base = A * (nup - 1 + ndn) - A * (A - 1) / 2 + b * (ndn - 1) - b * (b - 1) / 2;
+      if (!same) { p0[m] = o_ex + nuu + b * (ndn - 1) - b * (b - 1) / 2 + (b2 - b - 1); x0[m] = integral_index(t, i0 + 1, j0 + 1, j0 + 1, i0 + 1); }
+      p1[m] = o_di + base + (b2 - b - 1); x1[m] = integral_index(t, i0 + 1, i0 + 1, j0 + 1, j0 + 1);
+    } else {                                         // up-dn pair: one direct term
+      const int r = k - nup - ndn - nuu - ndd, a = r / ndn, b = r - a * ndn;
+      const int i0 = bk_nth_orb(up, a), j0 = bk_nth_orb(dn, b);
+      const int Bc = __popcll(dn & ((1ull << i0) - 1ull));
+      const int base = a * (nup - 1 + ndn) - a * (a - 1) / 2 + Bc * (ndn - 1) - Bc * (Bc - 1) / 2;
+      p1[m] = o_di + base + (nup - 1 - a) + b; x1[m] = integral_index(t, i0 + 1, i0 + 1, j0 + 1, j0 + 1);
+    }
+  }
+  double v0[BK_HG_TASKS], v1[BK_HG_TASKS];
+#pragma unroll
+  for (int m = 0; m < BK_HG_TASKS; m++) { v0[m] = (p0[m] >= 0) ? ints[x0[m]] : 0.0; v1[m] = (p1[m] >= 0) ? ints[x1[m]] : 0.0; }
+#pragma unroll
+  for (int m = 0; m < BK_HG_TASKS; m++) { if (p0[m] >= 0) sg[p0[m]] = v0[m]; if (p1[m] >= 0) sg[p1[m]] = v1[m]; }
+  __syncthreads();
+  double acc = 0.0;
+  if (valid) {
+    if (g == 0) { for (int q = 0; q < L_e1; q++) acc = acc + sg[q]; if (same) acc = acc * 2.0; }
+    else if (g == 1) { for (int q = 0; q < L_ex; q++) acc = acc - sg[o_ex + q]; if (same) acc = acc * 2.0; }
+    else if (g == 2) { for (int q = 0; q < L_di; q++) acc = acc + sg[o_di + q]; }
+  }
+  const double e1 = __shfl(acc, 0, BK_HG), ex = __shfl(acc, 1, BK_HG), di = __shfl(acc, 2, BK_HG);
+  __syncthreads();
+  return e1 + (ex + di) + t.nuclear;
+}
 // elements one thread handles per phase at the caps (loops are unrolled to these so that all loads of a phase are in flight)
 #define BK_PER_ROWS ((BK_CAP_ROWS + BK_AT - 1) / BK_AT)
 #define BK_PER_S ((BK_CAP_S + BK_AT - 1) / BK_AT)
@@ -126,18 +199,21 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
                                                          const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 hmask,
                                                          const double *__restrict__ cnum, const double *__restrict__ cden,
                                                          double *__restrict__ partials, double *__restrict__ wabs_part, long long n0, long long nch, StepP p,
-                                                         u64 invalid_key, u64 seed, u64 step, DevScalars *sc, BucketArgs ba, GateOut go, FusedSide fs) {
+                                                         u64 invalid_key, u64 seed, u64 step, DevScalars *sc, BucketArgs ba, GateOut go, FusedSide fs, ChemDev dev) {
   // ---- LDS: the whole bucket lives here
   __shared__ u64 sw[BK_CAP_S], sw2[BK_CAP_S];            // sort words of the spawns (double buffer)
   __shared__ u32 rk[BK_CAP_R];                            // keys of the residents
   __shared__ double s_w[BK_CAP_T]; __shared__ u32 s_f[BK_CAP_T];   // weight / flags by SOURCE: residents [0, R), sorted spawns [R, R + S); later the merged walker of a run, at its head
   __shared__ u32 m2s[BK_CAP_T];                           // merged order -> source (| BK_STOP at the first slot of a run)
   __shared__ unsigned short rnk[BK_CAP_T];               // sort: rank inside its digit; later: keep code of a merged slot
-  __shared__ u32 scratch[(BK_AT / 64) * 1024];            // rows of the gather (offset u16 + base u32), then the digit counters of the sort
+  __shared__ __align__(16) u32 scratch[(BK_AT / 64) * 1024];   // rows of the gather (offset u16 + base u32), then the digit counters of the sort, then child counts [0, T) + the Slater-Condon tables [4096, ...)
+  __shared__ unsigned short s_hq[BK_CAP_T]; __shared__ int s_hqn;      // kept walkers of this bucket that have no H_ii yet (position inside the bucket's output)
+  static_assert(sizeof(ChemTab) <= ((BK_AT / 64) * 1024 - 4096) * 4 && BK_CAP_T <= 4096, "the tables share the idle sort counters with the child counts");
+  ChemTab *s_tab = (ChemTab *)(scratch + 4096);
   __shared__ u32 s_tile; __shared__ u32 s_kmin, s_kmax;
   __shared__ double s_red[BK_AT / 64][NSTAT + 2];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) s_tile = atomicAdd(ba.ticket, 1u);
+  if (tid == 0) { s_tile = atomicAdd(ba.ticket, 1u); s_hqn = 0; }
   __syncthreads();
   const int b = (int)s_tile, B = ba.B, nsb = ba.nsb;
   const long long r_lo = ((long long)b * n0) / B, r_hi = ((long long)(b + 1) * n0) / B;
@@ -375,6 +451,9 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
       } else s_rank[q] = 0xFFFFFFFFu;
     }
     __syncthreads();                                 // ranks and child prefixes are read row-wise below
+    // the determinants this step creates get their H_ii at the end of this kernel (no kernel of its own on a side stream, nothing to
+    // join): the tables travel to the idle counters while the look-back waits for its predecessors
+    stage_tab(s_tab, dev.tab, dev.tab_words);
     ex_glob = bk_lookback_wide(ba.state, b, tot);
     if (tid == 0 && b == B - 1) {
       const u64 all = ex_glob + tot, npos = all & 0xFFFFFull, ndet = (all >> 20) & 0x3FFFFull;
@@ -419,6 +498,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
       const double en = en_[z], ed = ed_[z];
       o.up[q0] = up_[z]; o.dn[q0] = dn_[z]; o.wt[q0] = wt; o.flg[q0] = fl;
       o.me[q0] = me_[z]; o.en[q0] = en; o.ed[q0] = ed;
+      if (me_[z] > 1e50 && !(p.semi && d < 1)) s_hq[atomicAdd(&s_hqn, 1)] = (unsigned short)(r_[z] & 0xFFFu);      // k_diag's rule (walk_kernels.h): death/clone will want H_ii
       if (go.on) {
         u64 nc; double wc;
         gate_children(wt, go.cutoff, seed, go.step_next, key_[z], nc, wc);
@@ -438,6 +518,31 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     }
   }
   BPROF(8);
+  // ---- H_ii of the new determinants: 16 lanes per determinant, 32 determinants per pass (chemistry); any other system, one
+  //      thread per determinant
+  __syncthreads();
+  {
+    const int nq = s_hqn;
+    const long long base = (long long)(ex_glob & 0xFFFFFull);
+    if (bk_hii_group_ok(*s_tab)) {
+      const int G = tid / BK_HG, g = tid % BK_HG;
+      double *sg = s_w + G * BK_HG_TERMS;            // the weights were last read by the compaction
+      for (int k0 = 0; k0 < nq; k0 += BK_AT / BK_HG) {
+        const int k = k0 + G; const bool valid = k < nq;
+        const long long q0 = valid ? base + (long long)s_hq[k] : 0;
+        const u64 u = valid ? o.up[q0] : 0ull, dd = valid ? o.dn[q0] : 0ull;
+        const double v = bk_hii_group16(*s_tab, dev.integrals, u, dd, valid, sg, g);
+        if (valid && g == 0) o.me[q0] = v;
+      }
+    } else {
+      for (int k = tid; k < nq; k += BK_AT) {
+        const long long q0 = base + (long long)s_hq[k];
+        const u64 u = o.up[q0], dd = o.dn[q0];
+        o.me[q0] = h_any(*s_tab, dev.integrals, u, dd, u, dd);
+      }
+    }
+  }
+  BPROF(11);
   // block sums: the 13 estimator pieces and the two pre-merge sums
 #pragma unroll
   for (int k = 0; k < NSTAT + 2; k++) {

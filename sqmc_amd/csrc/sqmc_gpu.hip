@@ -160,6 +160,9 @@ struct sqmc_gpu_ctx {
   double *d_prj_y; const double *head_prj_x; bool head_y_done;      // A x of the pipelined head's spare k_spawn blocks, the x it used
   double *d_prj_xs[2]; int xs_cur; bool xs_valid;      // snapshots of the deterministic-space weights by row, written by the bucket tail for the NEXT step's projection (two: one is read while the other is written)
   bool side_pending;          // death/clone and the projection of this step have not been launched as kernels: the bucket tail does them itself, any other tail must launch them first
+  double slow_us[4]; long long slow_step[4];      // the slowest steps of the last run_steps call (wall clock; host jitter shows up here)
+  bool tail_fills_hii;        // the tail that enqueues the next head is a bucket tail: it computes the H_ii of the determinants it creates itself
+  bool fork_valid;            // e_fork was recorded behind the last tail (a head behind a bucket tail forks nothing and skips it)
   bool head_hii, head_hii_joined;     // the pipelined head fills the missing H_ii of this step's walkers (joined: inside k_spawn itself, nothing to wait for)
   bool head_offsets_done;     // the bucket tail of the step before wrote this step's child offsets and total (no scan launch in the head)
   double last_wabs;           // sum |w| after the last step (bounds the next step's child count)
@@ -640,19 +643,24 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   //      bench.py reports, taken from the kernel's own start/stop timestamps).  It is launched
   //      over the whole free capacity with a device-side child count and posts that count to the
   //      host mailbox as soon as it starts.
-  HIPCHK(hipEventRecord(c->e_fork, st));
+  const bool tail_fills = dev_n && c->tail_fills_hii && !c->d_grow;
+  c->tail_fills_hii = false;
+  if (!tail_fills) HIPCHK(hipEventRecord(c->e_fork, st));
+  c->fork_valid = !tail_fills;
   // pipelined head: the diagonal elements of the determinants the last step created depend on nothing the host still has to
   // decide: a kernel on the side stream computes them now, beside the scan and k_spawn; death/clone later finds them cached.
   // (Doing this in spare blocks of k_spawn instead saves the cross-stream join but costs k_spawn its occupancy through the extra
   // LDS: 122 against 110 us per step at 10^5 walkers, and 35 % more spawn time at 10^6-10^7 -- taken out again.)
   static const bool no_early = getenv("SQMC_NO_EARLY_HII") != nullptr;
-  const bool early = dev_n && !c->d_grow && !no_early;
+  // Behind a bucket tail there is nothing to fill: that kernel computes the H_ii of the determinants it creates, and the step
+  // runs on one stream (no fork, no join: every cross-stream wait costs 5-12 us on the critical path at 10^5 walkers).
+  const bool early = dev_n && !c->d_grow && !no_early && !tail_fills;
   if (early) {
     HIPCHK(hipStreamWaitEvent(c->st2, c->e_fork, 0));
     hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, c->st2, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc, 1);
     HIPCHK(hipEventRecord(c->e_join, c->st2));          // a tail that does death/clone itself still has to wait for these
   }
-  c->head_hii = early; c->head_hii_joined = false;
+  c->head_hii = early || tail_fills; c->head_hii_joined = tail_fills;
   *cseq = ++c->cnt_seq;
   const OwnerOut oo = shard_owner_out(c);
   // short lists: k_spawn groups its children by key range as it emits them (the bucket tail then needs no partition kernel).
@@ -698,6 +706,7 @@ static void drop_head(sqmc_gpu_ctx *c) {
 // death/clone (k_diag) and the deterministic projection as kernels of their own: on the two side streams, forked at e_fork and
 // joined by e_join / e_join3 -- or, `serial`, on the main stream (a tail that found them still pending)
 static int launch_side_kernels(sqmc_gpu_ctx *c, const StepP &p, long long n0, bool serial) {
+  if (!serial && !c->fork_valid) { HIPCHK(hipEventRecord(c->e_fork, c->st)); c->fork_valid = true; }      // the head forked nothing: the side streams start behind what is enqueued so far
   hipStream_t st2 = serial ? c->st : c->st2;
   if (!serial) HIPCHK(hipStreamWaitEvent(st2, c->e_fork, 0));
   TBEG(diag, st2);
@@ -824,7 +833,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       static const bool no_fs = getenv("SQMC_NO_FUSED_SIDE") != nullptr;
       if (c->pipeline_next && p.semi && !no_fs) c->head_prj_x = fs.x_out;      // the head enqueued below may multiply the projector into it
 #define BUCKET_ARGS c->w, c->m, (const u64 *)c->d_keys, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, \
-                    n0, nall - n0, p, c->invalid_key, seed, step, c->d_sc, ba, go, fs
+                    n0, nall - n0, p, c->invalid_key, seed, step, c->d_sc, ba, go, fs, c->dev
       if (t_anneal >= 0) hipExtLaunchKernelGGL(k_anneal_bucket, dim3(nb), dim3(BK_AT), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, BUCKET_ARGS);
       else hipLaunchKernelGGL(k_anneal_bucket, dim3(nb), dim3(BK_AT), 0, st, BUCKET_ARGS);
 #undef BUCKET_ARGS
@@ -876,6 +885,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     if (!mail_in_gate) hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(64), 0, st, c->d_sc, c->d_mail, seq);
     else { memset(&fa, 0, sizeof(fa)); fa.on = 3; fa.mail = c->d_mail; fa.seq = seq; fa.expect_nimp = -1; }
   }
+  c->tail_fills_hii = bucket && c->pipeline_next;
   if (c->pipeline_next) {
     // the next step's gate + scan + spawn go out now, behind k_finish: the GPU runs on while the host
     // reads this step's sums and does its population control.  nall bounds the new walker count.
@@ -975,7 +985,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     hipLaunchKernelGGL(k_replay_prepass, dim3(1), dim3(64), 0, st, c->d_tab, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_child_off,
                        c->d_child_state, n0, M - n0, p, c->d_sc);
     if (t_gate_scan >= 0) hipEventRecord(c->ev1[t_gate_scan], st);
-    HIPCHK(hipEventRecord(c->e_fork, st));
+    HIPCHK(hipEventRecord(c->e_fork, st)); c->fork_valid = true;
     cseq = ++c->cnt_seq;
     if (M > n0) {
       if (t_spawn >= 0)
@@ -1023,6 +1033,8 @@ typedef int (*step_fn)(sqmc_gpu_ctx *, const sqmc_step_params *, double *);
 static int run_steps(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats, double totals[16], step_fn one_step) {
   if (!c || !pc || !totals || nsteps < 0) return fail(SQMC_ERR_BAD_ARG, "bad argument");
   for (int k = 0; k < 16; k++) totals[k] = 0.0;
+  for (int k = 0; k < 4; k++) { c->slow_us[k] = 0.0; c->slow_step[k] = -1; }
+  struct timespec ts_prev; clock_gettime(CLOCK_MONOTONIC, &ts_prev);
   for (int64_t it = 0; it < nsteps; it++) {
     // do_walk.f90:2175-2184
     if (pc->reached_w_abs_gen == 0) {
@@ -1047,6 +1059,11 @@ static int run_steps(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *s
     if (r) { drop_head(c); return r; }
     if (stats) memcpy(stats + it * 16, out, sizeof(out));
     for (int k = 0; k < 16; k++) totals[k] += out[k];
+    {
+      struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+      double us = 1e6 * (double)(ts.tv_sec - ts_prev.tv_sec) + 1e-3 * (double)(ts.tv_nsec - ts_prev.tv_nsec); long long wh = it; ts_prev = ts;
+      for (int k = 0; k < 4; k++) if (us > c->slow_us[k]) { std::swap(us, c->slow_us[k]); std::swap(wh, c->slow_step[k]); }
+    }
     // do_walk.f90:2880-2923
     pc->istep++;
     const double w_abs_gen = out[1], e_den_gen = out[2], e_num_gen = out[3];
@@ -1070,6 +1087,11 @@ static int run_steps(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *s
     }
     pc->tau_prev = pc->tau; pc->w_abs_gen = w_abs_gen;
   }
+  return SQMC_OK;
+}
+int sqmc_gpu_slowest_steps(sqmc_gpu_ctx *c, double us[4], int64_t step[4]) {
+  if (!c || !us || !step) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  for (int k = 0; k < 4; k++) { us[k] = c->slow_us[k]; step[k] = c->slow_step[k]; }
   return SQMC_OK;
 }
 int sqmc_gpu_run(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *stats, double totals[16]) {

@@ -1,10 +1,10 @@
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "trajectory or bucket or pipelin"  > gpurun_out/t_sel.log 2>&1; echo "pytest rc=$?" >> gpurun_out/t_sel.log
+tail -4 gpurun_out/t_sel.log
+grep -q "rc=0" gpurun_out/t_sel.log && \
 timeout -k 10 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/b_1e5_drv.log 2>&1 && \
 timeout -k 10 120 python bench.py --steps 300 --warmup 50 --no-cpu-baseline > gpurun_out/b_1e5.log 2>&1 && \
-timeout -k 10 120 python bench.py --steps 300 --warmup 50 --no-cpu-baseline > gpurun_out/b_1e5_b.log 2>&1 && \
 timeout -k 10 120 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline > gpurun_out/b_1e5_c.log 2>&1 && \
-timeout -k 10 200 python bench.py --steps 100 --warmup 20 --target 1e6 --no-cpu-baseline > gpurun_out/b_1e6.log 2>&1 && \
-timeout -k 10 300 python bench.py --steps 30 --warmup 10 --target 1e7 --no-cpu-baseline > gpurun_out/b_1e7.log 2>&1 && \
-timeout -k 10 200 python bench.py --steps 100 --warmup 20 --system heg --target 1e6 --no-cpu-baseline > gpurun_out/b_heg.log 2>&1
+timeout -k 10 200 python bench.py --steps 100 --warmup 20 --system hubbard --target 1e5 --no-cpu-baseline > gpurun_out/b_hub.log 2>&1
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob("gpurun_out/b_*.log")):
