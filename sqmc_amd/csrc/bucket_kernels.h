@@ -282,8 +282,77 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
   }
   __syncthreads();
   BPROF(2);
-  // ---- stable LDS radix sort of the spawn words on key - kmin
+  // ---- sort of the spawn words.  Short resident lists (always, at the sizes the host picks): ONE stable counting pass on the GAP of
+  //      a spawn -- the number of residents with key <= its own, found by binary search -- then every spawn ranks itself among the
+  //      spawns of its gap by (key, creation order).  A gap holds a handful of spawns (those between two neighbouring residents), or
+  //      many with one key (the heavy determinants: the loop below reads LDS at one address per step, a broadcast).  The time does
+  //      not depend on how wide the bucket's key range is (the key-digit sort took 2-4 passes), and the gap IS the merge position.
   u64 *sa = sw, *sb = sw2;
+  const bool gap_sort = R <= 1023;
+  unsigned short *gs = (unsigned short *)m2s, *gst = gs + BK_CAP_S;     // gap of the spawn at a sorted position; first sorted position of a gap (R + 2 entries) -- m2s is idle until the merged order is written
+  static_assert((BK_CAP_S + 1026) * 2 <= BK_CAP_T * 4, "gap tables fit the merged-order array");
+  if (gap_sort) {
+    unsigned short *gp = s_hq;                            // gap by creation order (the H_ii queue is idle until the compaction)
+    u32(*wcnt)[1024] = (u32(*)[1024])scratch;
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int chunk = ((S + BK_AT - 1) / BK_AT) * 64;
+    for (int d = tid; d < (BK_AT / 64) * 1024; d += BK_AT) scratch[d] = 0;
+    for (int j = tid; j < S; j += BK_AT) {
+      const u32 k = (u32)(sa[j] >> 32);
+      int lo = 0, hi = R;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (rk[mid] <= k) lo = mid + 1; else hi = mid; }
+      gp[j] = (unsigned short)lo;
+    }
+    __syncthreads();
+    {
+      const int beg = wv * chunk, end = (beg + chunk < S) ? beg + chunk : S;
+      for (int base = beg; base < end; base += 64) {
+        const int idx = base + lane; const bool valid = idx < end;
+        const u32 dig = valid ? (u32)gp[idx] : 0u;
+        u64 same = __ballot(valid);
+#pragma unroll
+        for (int q = 0; q < 10; q++) { const u64 m = __ballot((dig >> q) & 1); same &= ((dig >> q) & 1) ? m : ~m; }
+        const u32 rank = (u32)__popcll(same & lt), cnt = (u32)__popcll(same);
+        u32 prev = 0;
+        if (valid) prev = wcnt[wv][dig];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) wcnt[wv][dig] = prev + cnt;
+        __builtin_amdgcn_wave_barrier();
+        if (valid) rnk[idx] = (unsigned short)(prev + rank);
+      }
+    }
+    __syncthreads();
+    {
+      u32 t2[2]; u64 sum = 0;
+#pragma unroll
+      for (int q = 0; q < 2; q++) { const int d = tid * 2 + q; u32 s2 = 0; for (int v = 0; v < BK_AT / 64; v++) s2 += wcnt[v][d]; t2[q] = s2; sum += s2; }
+      u64 tt; u32 ex = (u32)bk_block_excl_scan(sum, &tt);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int d = tid * 2 + q; u32 a2 = ex;
+        if (d <= R) gst[d] = (unsigned short)ex;
+        for (int v = 0; v < BK_AT / 64; v++) { const u32 cn = wcnt[v][d]; wcnt[v][d] = a2; a2 += cn; }
+        ex += t2[q];
+      }
+      if (tid == 0) gst[R + 1] = (unsigned short)S;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < S; idx += BK_AT) {
+      const u32 dig = (u32)gp[idx];
+      const u32 pos = wcnt[idx / chunk][dig] + rnk[idx];
+      sb[pos] = sa[idx]; gs[pos] = (unsigned short)dig;
+    }
+    __syncthreads();
+    for (int j = tid; j < S; j += BK_AT) {              // inside the gap: by key, then by creation order (the word's low half)
+      const u64 mine = sb[j];
+      const int g0 = (int)gs[j], a2 = (int)gst[g0], e2 = (int)gst[g0 + 1];
+      int less = 0;
+      if (e2 - a2 > 1) for (int i = a2; i < e2; i++) less += (sb[i] < mine) ? 1 : 0;
+      sa[a2 + less] = mine;
+    }
+    __syncthreads();
+  } else {
+  // wide resident lists: stable LDS radix sort of the spawn words on key - kmin
   {
     const u32 kmin = s_kmin, span = s_kmax - kmin;
     int nbits = 0; while (nbits < 32 && (span >> nbits)) nbits++;
@@ -328,6 +397,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
       u64 *tp = sa; sa = sb; sb = tp;
     }
   }
+  }
   BPROF(3);
   // ---- records by source, all requested before any is used.  With fs.on the block also does what the side-stream kernels
   //      did: death/clone (do_walk.f90:3743-3793) of the residents outside the deterministic space as their weights arrive ...
@@ -371,6 +441,28 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
   double wabs = 0.0, cnt = 0.0;
   for (int x = tid; x < T; x += BK_AT) { wabs += fabs(s_w[x]); cnt += 1.0; }
   // ---- merged order: a resident goes behind the spawns with smaller keys, a spawn behind the residents with keys <= its own
+  if (gap_sort) {
+    // both are known from the sort: gst[i + 1] spawns lie in the gaps 0..i, i.e. in front of resident i; the spawn at sorted
+    // position j lies behind gs[j] residents.  (The tables live in the array the merged order goes to: read first, then write.)
+    u32 rp_[BK_PER_R], cp_[BK_PER_S]; u32 ce_[BK_PER_S];
+#pragma unroll
+    for (int q = 0; q < BK_PER_R; q++) { const int i = tid + q * BK_AT; rp_[q] = (i < R) ? (u32)i + (u32)gst[i + 1] : 0u; }
+#pragma unroll
+    for (int q = 0; q < BK_PER_S; q++) {
+      const int j = tid + q * BK_AT; cp_[q] = 0; ce_[q] = 0;
+      if (j < S) {
+        const u32 k = (u32)(sa[j] >> 32); const int g0 = (int)gs[j];
+        const bool on_resident = g0 > 0 && rk[g0 - 1] == k;
+        const bool head = !on_resident && (j == 0 || (u32)(sa[j - 1] >> 32) != k);
+        cp_[q] = (u32)(j + g0); ce_[q] = (head ? BK_STOP : 0u) | (u32)(R + j);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < BK_PER_R; q++) { const int i = tid + q * BK_AT; if (i < R) m2s[rp_[q]] = BK_STOP | (u32)i; }
+#pragma unroll
+    for (int q = 0; q < BK_PER_S; q++) { const int j = tid + q * BK_AT; if (j < S) m2s[cp_[q]] = ce_[q]; }
+  } else {
   for (int i = tid; i < R; i += BK_AT) {
     const u32 k = rk[i];
     int lo = 0, hi = S;                                                    // spawns with key < k
@@ -384,6 +476,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     const bool on_resident = lo > 0 && rk[lo - 1] == k;
     const bool head = !on_resident && (j == 0 || (u32)(sa[j - 1] >> 32) != k);
     m2s[j + lo] = (head ? BK_STOP : 0u) | (u32)(R + j);
+  }
   }
   __syncthreads();
   BPROF(5);

@@ -34,11 +34,13 @@ t0 = a[:, 0].min()
 names = ["ticket+rows issue", "rows scan", "gather words", "sort", "records", "merge order", "fold+round", "chunk scan", "lookback", "compaction", "sums"]
 print("buckets", nb, "kernel span %.1f us" % ((a[:, 10].max() - t0) / 100.0))
 print("start skew: mean %.1f max %.1f us" % ((a[:, 0] - t0).mean() / 100.0, (a[:, 0] - t0).max() / 100.0))
-seq = [0, 1, 2, 3, 4, 5, 6, 9, 8, 10]            # stamp 7 sits right behind 9
-names = ["rows (loads + scan)", "gather words", "LDS sort", "records", "merge order", "fold + round + gate count", "chunk scan + look-back", "compaction", "block sums"]
+seq = [0, 1, 2, 3, 4, 5, 6, 9, 8, 11, 10]        # stamp 7 sits right behind 9
+names = ["rows (loads + scan)", "gather words", "LDS sort", "records", "merge order", "fold + round + gate count", "chunk scan + look-back", "compaction", "H_ii of new determinants", "block sums"]
 for k in range(1, len(seq)):
     d = (a[:, seq[k]] - a[:, seq[k - 1]]) / 100.0
     print("%-28s mean %6.2f  max %6.2f us" % (names[k - 1], d.mean(), d.max()))
+d = (a[:, 10] - a[:, 0]) / 100.0
+print("bucket life: mean %.1f max %.1f us; end skew mean %.1f" % (d.mean(), d.max(), (a[:, 10].max() - a[:, 10]).mean() / 100.0))
 w.close()
 os.environ.pop("SQMC_EXTRA_CFLAGS")
 sqmc_amd.build_library(force=True)
