@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(BK_T) k_bucket_partition(const u64 *__restrict
   const long long c = (long long)blockIdx.x * BK_T + threadIdx.x;
   u64 word = 0; u32 key = 0; bool valid = false;
   if (c < nch) word = keys[n0 + c];
-  bucket_partition_stage(spl, wcnt, keys, n0, ba.B);
+  bucket_partition_stage(spl, wcnt, keys, n0, ba);
   if (c < nch) { key = (u32)(word >> 32); valid = (u64)key != invalid_key; }
   __syncthreads();
   bucket_partition_block(spl, wcnt, valid, key, word, (long long)blockIdx.x, ba);
@@ -58,9 +58,11 @@ __device__ __forceinline__ void bk_fold(double &wt, int &ini, int &d, double w2,
 // build with -DBUCKET_PROF (tools/bucket_prof.py): wall-clock stamps (100 MHz) of every bucket at the phase boundaries
 __device__ unsigned long long g_bprof[16 * 1024];
 #define BPROF(K) do { if (threadIdx.x == 0 && b < 1024) g_bprof[b * 16 + (K)] = wall_clock64(); } while (0)
+#define BPROF_VAL(K, V) do { if (threadIdx.x == 0 && b < 1024) g_bprof[b * 16 + (K)] = (unsigned long long)(V); } while (0)
 extern "C" int sqmc_gpu_debug_bprof(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bprof), sizeof(g_bprof)); }
 #else
 #define BPROF(K)
+#define BPROF_VAL(K, V)
 #endif
 // block-wide exclusive scan for the BK_AT threads of the annihilation kernel (total in every thread)
 #define BK_AT 512                      // threads of k_anneal_bucket: one block per CU, so the block itself has to keep the memory pipes busy
@@ -120,27 +122,32 @@ __device__ __forceinline__ u64 bk_lookback_wide(u64 *__restrict__ state, int b, 
 // exchange, direct -- of ~50 integrals; a lane on its own pays one L2 round trip per group of four.  Here every term of a sum has its
 // place in the reference's order (closed form from the electron indices), the 16 lanes fetch all terms at once into LDS, and one
 // lane per sum adds them up in that order: the same value bit for bit, one round trip instead of ~25.
-#define BK_HG 16
-#define BK_HG_TERMS 112            // LDS doubles per group: BK_CAP_T / (BK_AT / BK_HG)
-#define BK_HG_TASKS 6              // tasks per lane at the cap
-static_assert(BK_HG_TERMS * (BK_AT / BK_HG) <= BK_CAP_T, "the groups share the weight array");
+// HG lanes per determinant: 8 (64 determinants per pass) when its terms fit 56 doubles -- up to 4 + 4 electrons --, else 16
+#define BK_HG_TERMS(HG) (BK_CAP_T / (BK_AT / (HG)))            // LDS doubles per group: the groups share the weight array (112 at HG = 16)
+#define BK_HG_TASKS 6                                           // tasks per lane at the cap of HG = 16; 12 at HG = 8
 __device__ __forceinline__ int bk_nth_orb(u64 x, int n) { for (int k = 0; k < n; k++) x &= x - 1; return ctz64(x); }     // 0-based orbital of the n-th electron
-__device__ __forceinline__ bool bk_hii_group_ok(const ChemTab &t) {
+__device__ __forceinline__ int bk_hii_group_lanes(const ChemTab &t) {          // 0: no group form for this system
   const int nup = t.nup, ndn = t.ndn, nuu = nup * (nup - 1) / 2, ndd = ndn * (ndn - 1) / 2, nud = nup * ndn;
-  return t.sys_type == 0 && !t.time_sym && (nup + ndn) + (nuu + ndd) + (nuu + nud + ndd) <= BK_HG_TERMS && (nup + ndn) + nuu + ndd + nud <= BK_HG * BK_HG_TASKS;
+  const int terms = (nup + ndn) + (nuu + ndd) + (nuu + nud + ndd), tasks = (nup + ndn) + nuu + ndd + nud;
+  if (t.sys_type != 0 || t.time_sym) return 0;
+  if (terms <= BK_HG_TERMS(8) && tasks <= 8 * 2 * BK_HG_TASKS) return 8;
+  if (terms <= BK_HG_TERMS(16) && tasks <= 16 * BK_HG_TASKS) return 16;
+  return 0;
 }
-// all threads of the block call this together (two barriers inside); sg: the group's BK_HG_TERMS doubles; g: lane inside the group
-__device__ __forceinline__ double bk_hii_group16(const ChemTab &t, const double *__restrict__ ints, u64 up, u64 dn, bool valid, double *sg, int g) {
+// all threads of the block call this together (two barriers inside); sg: the group's BK_HG_TERMS(HG) doubles; g: lane inside the group
+template <int HG>
+__device__ __forceinline__ double bk_hii_group(const ChemTab &t, const double *__restrict__ ints, u64 up, u64 dn, bool valid, double *sg, int g) {
+  constexpr int NTASK = BK_HG_TASKS * 16 / HG;
   const int nup = t.nup, ndn = t.ndn, n1 = t.norb + 1;
   const bool same = (dn == up);
   const int nuu = nup * (nup - 1) / 2, ndd = ndn * (ndn - 1) / 2, nud = nup * ndn;
   const int L_e1 = same ? nup : nup + ndn, L_ex = nuu + (same ? 0 : ndd), L_di = nuu + nud + ndd;
   const int o_ex = L_e1, o_di = L_e1 + L_ex;
   const int ntask = valid ? (nup + ndn) + nuu + ndd + nud : 0;
-  int p0[BK_HG_TASKS], p1[BK_HG_TASKS], x0[BK_HG_TASKS], x1[BK_HG_TASKS];
+  int p0[NTASK], p1[NTASK], x0[NTASK], x1[NTASK];
 #pragma unroll
-  for (int m = 0; m < BK_HG_TASKS; m++) {
-    int k = g + BK_HG * m;
+  for (int m = 0; m < NTASK; m++) {
+    int k = g + HG * m;
     p0[m] = -1; p1[m] = -1; x0[m] = 0; x1[m] = 0;
     if (k >= ntask) continue;
     if (k < nup) {                                   // one-body, up electron k
@@ -173,11 +180,11 @@ __device__ __forceinline__ double bk_hii_group16(const ChemTab &t, const double 
       p1[m] = o_di + base + (nup - 1 - a) + b; x1[m] = integral_index(t, i0 + 1, i0 + 1, j0 + 1, j0 + 1);
     }
   }
-  double v0[BK_HG_TASKS], v1[BK_HG_TASKS];
+  double v0[NTASK], v1[NTASK];
 #pragma unroll
-  for (int m = 0; m < BK_HG_TASKS; m++) { v0[m] = (p0[m] >= 0) ? ints[x0[m]] : 0.0; v1[m] = (p1[m] >= 0) ? ints[x1[m]] : 0.0; }
+  for (int m = 0; m < NTASK; m++) { v0[m] = (p0[m] >= 0) ? ints[x0[m]] : 0.0; v1[m] = (p1[m] >= 0) ? ints[x1[m]] : 0.0; }
 #pragma unroll
-  for (int m = 0; m < BK_HG_TASKS; m++) { if (p0[m] >= 0) sg[p0[m]] = v0[m]; if (p1[m] >= 0) sg[p1[m]] = v1[m]; }
+  for (int m = 0; m < NTASK; m++) { if (p0[m] >= 0) sg[p0[m]] = v0[m]; if (p1[m] >= 0) sg[p1[m]] = v1[m]; }
   __syncthreads();
   double acc = 0.0;
   if (valid) {
@@ -185,9 +192,24 @@ __device__ __forceinline__ double bk_hii_group16(const ChemTab &t, const double 
     else if (g == 1) { for (int q = 0; q < L_ex; q++) acc = acc - sg[o_ex + q]; if (same) acc = acc * 2.0; }
     else if (g == 2) { for (int q = 0; q < L_di; q++) acc = acc + sg[o_di + q]; }
   }
-  const double e1 = __shfl(acc, 0, BK_HG), ex = __shfl(acc, 1, BK_HG), di = __shfl(acc, 2, BK_HG);
+  const double e1 = __shfl(acc, 0, HG), ex = __shfl(acc, 1, HG), di = __shfl(acc, 2, HG);
   __syncthreads();
   return e1 + (ex + di) + t.nuclear;
+}
+#define BK_HQ_DETS (BK_CAP_T * 2 / 16)                       // determinants whose (up, dn) wait in LDS for the H_ii phase
+// sum over the wavefront by DPP row shifts and row broadcasts (lane 63 holds it): 6 steps of two 32-bit moves and an add
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double bk_dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bk_wave_sum_lane63(double v) {
+  v += bk_dpp_f64<0x111, 0xf>(v); v += bk_dpp_f64<0x112, 0xf>(v); v += bk_dpp_f64<0x114, 0xf>(v); v += bk_dpp_f64<0x118, 0xf>(v);     // row_shr 1, 2, 4, 8: prefix inside rows of 16
+  v += bk_dpp_f64<0x142, 0xa>(v);                                                                                                    // row_bcast 15 into rows 1 and 3
+  v += bk_dpp_f64<0x143, 0xc>(v);                                                                                                    // row_bcast 31 into rows 2 and 3
+  return v;
 }
 // elements one thread handles per phase at the caps (loops are unrolled to these so that all loads of a phase are in flight)
 #define BK_PER_ROWS ((BK_CAP_ROWS + BK_AT - 1) / BK_AT)
@@ -205,18 +227,19 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
   __shared__ u32 rk[BK_CAP_R];                            // keys of the residents
   __shared__ double s_w[BK_CAP_T]; __shared__ u32 s_f[BK_CAP_T];   // weight / flags by SOURCE: residents [0, R), sorted spawns [R, R + S); later the merged walker of a run, at its head
   __shared__ u32 m2s[BK_CAP_T];                           // merged order -> source (| BK_STOP at the first slot of a run)
-  __shared__ unsigned short rnk[BK_CAP_T];               // sort: rank inside its digit; later: keep code of a merged slot
+  __shared__ __align__(16) unsigned short rnk[BK_CAP_T];               // sort: rank inside its digit; later: keep code of a merged slot
   __shared__ __align__(16) u32 scratch[(BK_AT / 64) * 1024];   // rows of the gather (offset u16 + base u32), then the digit counters of the sort, then child counts [0, T) + the Slater-Condon tables [4096, ...)
   __shared__ unsigned short s_hq[BK_CAP_T]; __shared__ int s_hqn;      // kept walkers of this bucket that have no H_ii yet (position inside the bucket's output)
   static_assert(sizeof(ChemTab) <= ((BK_AT / 64) * 1024 - 4096) * 4 && BK_CAP_T <= 4096, "the tables share the idle sort counters with the child counts");
   ChemTab *s_tab = (ChemTab *)(scratch + 4096);
+  u64 *s_hdet = (u64 *)rnk;                               // (up, dn) of the first BK_HQ_DETS queued determinants: the keep codes are idle once the ranks exist
   __shared__ u32 s_tile; __shared__ u32 s_kmin, s_kmax;
   __shared__ double s_red[BK_AT / 64][NSTAT + 2];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) { s_tile = atomicAdd(ba.ticket, 1u); s_hqn = 0; }
   __syncthreads();
   const int b = (int)s_tile, B = ba.B, nsb = ba.nsb;
-  const long long r_lo = ((long long)b * n0) / B, r_hi = ((long long)(b + 1) * n0) / B;
+  const long long r_lo = bk_bound(ba, b, n0), r_hi = bk_bound(ba, b + 1, n0);
   const int R = (int)(r_hi - r_lo);
   BPROF(0);
   // key range of the bucket (the sort only looks at the bits that vary inside it)
@@ -281,7 +304,8 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     for (int q = 0; q < BK_PER_S; q++) { const int j = tid + q * BK_AT; if (j < S) sw[j] = wv_[q]; }
   }
   __syncthreads();
-  BPROF(2);
+  BPROF(2); BPROF_VAL(12, S); BPROF_VAL(13, R);
+  if (tid == 0 && ba.scount) { ba.scount[b] = (u32)S; if (b == 0) ba.scount[B] = (u32)n0; }
   // ---- sort of the spawn words.  Short resident lists (always, at the sizes the host picks): ONE stable counting pass on the GAP of
   //      a spawn -- the number of residents with key <= its own, found by binary search -- then every spawn ranks itself among the
   //      spawns of its gap by (key, creation order).  A gap holds a handful of spawns (those between two neighbouring residents), or
@@ -437,6 +461,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     for (int q = 0; q < BK_PER_S; q++) { const int j = tid + q * BK_AT; if (j < S) { s_w[R + j] = sw_[q]; s_f[R + j] = (u32)sf_[q]; } }
   }
   __syncthreads();
+  BPROF(4);
   // ---- sums over the pre-merge list (do_walk.f90:2347-2349), after death/clone and projection as the reference takes them
   double wabs = 0.0, cnt = 0.0;
   for (int x = tid; x < T; x += BK_AT) { wabs += fabs(s_w[x]); cnt += 1.0; }
@@ -591,7 +616,11 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
       const double en = en_[z], ed = ed_[z];
       o.up[q0] = up_[z]; o.dn[q0] = dn_[z]; o.wt[q0] = wt; o.flg[q0] = fl;
       o.me[q0] = me_[z]; o.en[q0] = en; o.ed[q0] = ed;
-      if (me_[z] > 1e50 && !(p.semi && d < 1)) s_hq[atomicAdd(&s_hqn, 1)] = (unsigned short)(r_[z] & 0xFFFu);      // k_diag's rule (walk_kernels.h): death/clone will want H_ii
+      if (me_[z] > 1e50 && !(p.semi && d < 1)) {                   // k_diag's rule (walk_kernels.h): death/clone will want H_ii
+        const int slot = atomicAdd(&s_hqn, 1);
+        s_hq[slot] = (unsigned short)(r_[z] & 0xFFFu);
+        if (slot < BK_HQ_DETS) { s_hdet[2 * slot] = up_[z]; s_hdet[2 * slot + 1] = dn_[z]; }
+      }
       if (go.on) {
         u64 nc; double wc;
         gate_children(wt, go.cutoff, seed, go.step_next, key_[z], nc, wc);
@@ -611,37 +640,43 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     }
   }
   BPROF(8);
-  // ---- H_ii of the new determinants: 16 lanes per determinant, 32 determinants per pass (chemistry); any other system, one
-  //      thread per determinant
+  // ---- H_ii of the new determinants: 8 or 16 lanes per determinant (chemistry); any other system, one thread per determinant
   __syncthreads();
   {
     const int nq = s_hqn;
     const long long base = (long long)(ex_glob & 0xFFFFFull);
-    if (bk_hii_group_ok(*s_tab)) {
-      const int G = tid / BK_HG, g = tid % BK_HG;
-      double *sg = s_w + G * BK_HG_TERMS;            // the weights were last read by the compaction
-      for (int k0 = 0; k0 < nq; k0 += BK_AT / BK_HG) {
-        const int k = k0 + G; const bool valid = k < nq;
-        const long long q0 = valid ? base + (long long)s_hq[k] : 0;
-        const u64 u = valid ? o.up[q0] : 0ull, dd = valid ? o.dn[q0] : 0ull;
-        const double v = bk_hii_group16(*s_tab, dev.integrals, u, dd, valid, sg, g);
-        if (valid && g == 0) o.me[q0] = v;
-      }
-    } else {
+    const int hg = bk_hii_group_lanes(*s_tab);
+#define BK_HII_PASSES(HG)                                                                                          \
+    {                                                                                                              \
+      const int G = tid / HG, g = tid % HG;                                                                        \
+      double *sg = s_w + G * BK_HG_TERMS(HG);            /* the weights were last read by the compaction */        \
+      for (int k0 = 0; k0 < nq; k0 += BK_AT / HG) {                                                                \
+        const int k = k0 + G; const bool valid = k < nq;                                                           \
+        const long long q0 = valid ? base + (long long)s_hq[k] : 0;                                                \
+        u64 u = 0, dd = 0;                                                                                         \
+        if (valid) { if (k < BK_HQ_DETS) { u = s_hdet[2 * k]; dd = s_hdet[2 * k + 1]; } else { u = o.up[q0]; dd = o.dn[q0]; } }   \
+        const double v = bk_hii_group<HG>(*s_tab, dev.integrals, u, dd, valid, sg, g);                             \
+        if (valid && g == 0) o.me[q0] = v;                                                                         \
+      }                                                                                                            \
+    }
+    if (hg == 8) BK_HII_PASSES(8)
+    else if (hg == 16) BK_HII_PASSES(16)
+    else {
       for (int k = tid; k < nq; k += BK_AT) {
         const long long q0 = base + (long long)s_hq[k];
         const u64 u = o.up[q0], dd = o.dn[q0];
         o.me[q0] = h_any(*s_tab, dev.integrals, u, dd, u, dd);
       }
     }
+#undef BK_HII_PASSES
   }
   BPROF(11);
   // block sums: the 13 estimator pieces and the two pre-merge sums
 #pragma unroll
   for (int k = 0; k < NSTAT + 2; k++) {
     double v = (k < NSTAT) ? st[k] : (k == NSTAT ? wabs : cnt);
-    for (int q = 32; q > 0; q >>= 1) v += __shfl_down(v, q, 64);
-    if (lane == 0) s_red[wv][k] = v;
+    v = bk_wave_sum_lane63(v);
+    if (lane == 63) s_red[wv][k] = v;
   }
   __syncthreads();
   if (tid < NSTAT + 2) {

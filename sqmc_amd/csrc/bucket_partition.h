@@ -27,7 +27,48 @@ struct BucketArgs {
   unsigned short *segoff;              // nsb rows of B+1 group offsets
   u64 *state; u32 *ticket;             // look-back over the buckets
   int force_retry;                     // tests: behave as if a bucket did not fit
+  // Where the buckets begin in the sorted resident list.  frac == null: at b n0 / B (equal numbers of residents).  Otherwise at
+  // frac[b] n0 / 2^32: boundaries that equalise residents + spawns per bucket as measured two steps back (the spawns crowd on
+  // the heavy determinants: with equal residents the fullest bucket held 3x the mean, and every bucket waits for it).
+  const u32 *frac;
+  u32 *scount;                         // out, B + 1 words: spawns of every bucket, then n0 -- what the next boundaries are made from
+  const u32 *frac_prev; u32 *frac_out; // k_spawn's spare block: boundaries for the step after this one from scount and the boundaries it was counted with
 };
+#define BK_REBAL_MAXB 256
+#define BK_REBAL_UNIFORM 0.125         // share of the equal-residents boundaries in the blend (no bucket narrower than 1/8 of its equal share)
+__device__ __forceinline__ long long bk_bound(const BucketArgs &ba, int b, long long n0) {
+  if (b <= 0) return 0;
+  if (b >= ba.B) return n0;
+  return ba.frac ? (long long)(((u64)ba.frac[b] * (u64)n0) >> 32) : ((long long)b * n0) / ba.B;
+}
+// one block of BK_T threads: new boundaries such that every bucket holds the same number of residents + spawns, if the spawns
+// fall as they did when scount was taken (piecewise-constant density inside the old buckets); reads everything before it writes
+__device__ __forceinline__ void bk_rebalance_block(const u32 *__restrict__ fprev, const u32 *__restrict__ scount, int B, u32 *__restrict__ fout) {
+  __shared__ double s_fr[BK_REBAL_MAXB + 1], s_pre[BK_REBAL_MAXB + 1];
+  const int tid = threadIdx.x;
+  const double n0 = (double)scount[B];
+  for (int b = tid; b <= B; b += BK_T) s_fr[b] = (b == 0) ? 0.0 : (b == B ? 1.0 : (fprev ? (double)fprev[b] * (1.0 / 4294967296.0) : (double)b / (double)B));
+  __syncthreads();
+  if (tid == 0) {                      // 256 additions beside a kernel that runs for tens of microseconds
+    double acc = 0.0;
+    for (int b = 0; b < B; b++) { s_pre[b] = acc; acc += (s_fr[b + 1] - s_fr[b]) * n0 + (double)scount[b]; }
+    s_pre[B] = acc;
+  }
+  __syncthreads();
+  const double total = s_pre[B];
+  for (int j = tid; j < B; j += BK_T) {
+    if (j == 0) { fout[0] = 0u; continue; }
+    const double target = total * (double)j / (double)B;
+    int lo = 0, hi = B;                 // s_pre[lo] <= target < s_pre[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pre[mid] <= target) lo = mid; else hi = mid; }
+    const double width = s_pre[lo + 1] - s_pre[lo];
+    const double x = width > 0.0 ? (target - s_pre[lo]) / width : 0.0;
+    const double bal = s_fr[lo] + x * (s_fr[lo + 1] - s_fr[lo]);
+    double v = (1.0 - BK_REBAL_UNIFORM) * bal + BK_REBAL_UNIFORM * (double)j / (double)B;
+    v = v * 4294967296.0;
+    fout[j] = v >= 4294967295.0 ? 4294967295u : (u32)v;
+  }
+}
 
 // ------------------------------------------------------------------------------------------------ partition
 // The 256 children of one block, grouped by bucket (stable) behind the block's row of group offsets.  spl[b] (b >= 1) = first
@@ -67,7 +108,8 @@ __device__ __forceinline__ void bucket_partition_block(const u32 *__restrict__ s
   if (valid) ba.words[blk * BK_T + wcnt[wv][bkt] + rank] = word;
 }
 // splitters and zeroed counters of a partition block (no barrier inside: the caller synchronises once before partitioning)
-__device__ __forceinline__ void bucket_partition_stage(u32 *__restrict__ spl, u32 (*__restrict__ wcnt)[BK_MAXB], const u64 *__restrict__ rkeys, long long n0, int B) {
-  for (int b = threadIdx.x; b < B; b += BK_T) spl[b] = b ? (u32)(rkeys[((long long)b * n0) / B] >> 32) : 0u;      // first key of bucket b
+__device__ __forceinline__ void bucket_partition_stage(u32 *__restrict__ spl, u32 (*__restrict__ wcnt)[BK_MAXB], const u64 *__restrict__ rkeys, long long n0, const BucketArgs &ba) {
+  const int B = ba.B;
+  for (int b = threadIdx.x; b < B; b += BK_T) spl[b] = b ? (u32)(rkeys[bk_bound(ba, b, n0)] >> 32) : 0u;      // first key of bucket b
   for (int d = threadIdx.x; d < (BK_T / 64) * BK_MAXB; d += BK_T) (&wcnt[0][0])[d] = 0;
 }

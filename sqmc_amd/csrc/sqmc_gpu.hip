@@ -157,6 +157,9 @@ struct sqmc_gpu_ctx {
   int scan_flip, scan_used[2];   // gate-fused heads: look-back set of the next head scan, and how many words of each set its last scan may have touched
   bool residents_sorted;      // the walker arrays are known to be in (up, dn) order: true after every finished step and after an upload (which refuses unsorted lists)
   unsigned short *d_segoff; long long segoff_cap;      // bucket tail: group offsets of the partition blocks
+  u32 *d_bfrac, *d_bscount;   // bucket boundaries (two sets of BK_MAXB + 1 fractions of n0: even / odd steps) and the spawns the last bucket tail counted per bucket
+  int frac_B[2], scount_B;    // the bucket count each was made for / counted with (0: not valid)
+  bool scount_frac;           // the counts were taken with adaptive boundaries (those of the counting step's parity)
   double *d_prj_y; const double *head_prj_x; bool head_y_done;      // A x of the pipelined head's spare k_spawn blocks, the x it used
   double *d_prj_xs[2]; int xs_cur; bool xs_valid;      // snapshots of the deterministic-space weights by row, written by the bucket tail for the NEXT step's projection (two: one is read while the other is written)
   bool side_pending;          // death/clone and the projection of this step have not been launched as kernels: the bucket tail does them itself, any other tail must launch them first
@@ -248,6 +251,9 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
     c->cap_ftiles = std::max<long long>(nblk(M) + 1, BK_MAXB + 1);
     c->segoff_cap = ((std::min<long long>(M, 1ll << 20) + BK_T - 1) / BK_T + 1) * (BK_MAXB + 1);
     HIPCHK(hipMalloc(&c->d_segoff, c->segoff_cap * sizeof(unsigned short)));
+    HIPCHK(hipMalloc(&c->d_bfrac, 2 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMalloc(&c->d_bscount, (BK_MAXB + 1) * sizeof(u32)));
+    HIPCHK(hipMemset(c->d_bfrac, 0, 2 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMemset(c->d_bscount, 0, (BK_MAXB + 1) * sizeof(u32)));
+    c->frac_B[0] = c->frac_B[1] = 0; c->scount_B = 0; c->scount_frac = false;
     HIPCHK(hipMalloc(&c->d_fstate, 2 * c->cap_ftiles * 8)); HIPCHK(hipMalloc(&c->d_fticket, 4));
     HIPCHK(hipMemset(c->d_fstate, 0, 2 * c->cap_ftiles * 8)); HIPCHK(hipMemset(c->d_fticket, 0, 4));
     c->n_partial_blocks = std::max(nblk(M), BK_MAXB);
@@ -369,7 +375,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
     free_walk(c->w); free_walk(c->m);
     hipFree(c->d_nchild); hipFree(c->d_child_off); hipFree(c->d_wchild); hipFree(c->d_child_state);
     hipFree(c->d_keys); hipFree(c->d_keys_alt); hipFree(c->d_vals); hipFree(c->d_vals_alt); hipFree(c->d_hist); hipFree(c->d_rowtot);
-    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done); hipFree(c->d_segoff);
+    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done); hipFree(c->d_segoff); hipFree(c->d_bfrac); hipFree(c->d_bscount);
   }
   hipFree(c->d_binom); hipFree(c->d_grow);
   for (int q = 0; q < 16; q++) hipFree(c->d_hbt[q]);
@@ -675,6 +681,19 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
       long long B = bucket_count(est); if (B > n_known / 2) B = n_known / 2;
       if (B >= 1) {
         hb.B = (int)B; hb.words = c->d_flags; hb.segoff = c->d_segoff; hb.state = c->d_fstate; hb.ticket = c->d_fticket;
+        hb.scount = c->d_bscount;
+        // boundaries that follow the spawns: this step partitions with the set of its parity if that was made for B buckets; a spare
+        // block of its k_spawn makes the other set (for the next step) from the counts of the bucket tail that has just been enqueued
+        static const bool no_rebal = getenv("SQMC_BUCKET_UNIFORM") != nullptr;
+        const int par = (int)(step & 1);
+        if (!no_rebal && B <= BK_REBAL_MAXB && n_known >= 16 * B) {
+          if (c->frac_B[par] == (int)B) hb.frac = c->d_bfrac + par * (BK_MAXB + 1);
+          if (c->scount_B == (int)B) {
+            hb.frac_prev = c->scount_frac ? c->d_bfrac + (par ^ 1) * (BK_MAXB + 1) : (const u32 *)nullptr;
+            hb.frac_out = c->d_bfrac + (par ^ 1) * (BK_MAXB + 1);
+            c->frac_B[par ^ 1] = (int)B;
+          }
+        }
         hb.nsb = (int)std::min<long long>(std::min<long long>(c->segoff_cap / (B + 1), M / BK_T), BK_CAP_ROWS);      // rows there is room for
       }
     }
@@ -684,10 +703,10 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   const int spawn_fuse = (hb.B > 0 || spawn_fin.on || pp.n_imp > 0) ? 1 : 0;
   if (nfree > 0) {
     if (s0)
-      SPAWN_LAUNCH_EXT(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
+      SPAWN_LAUNCH_EXT(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + (hb.frac_out ? 1 : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
                             c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, nblk(nfree));
     else
-      SPAWN_LAUNCH(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+      SPAWN_LAUNCH(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + (hb.frac_out ? 1 : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
                          n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, nblk(nfree));
   } else if (s0) { hipEventRecord(s0, st); hipEventRecord(s1, st); }
   HIPCHK(hipGetLastError());
@@ -765,6 +784,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
         if (nsb <= BK_CAP_ROWS && (n0 + B - 1) / B <= BK_CAP_R && nsb * (B + 1) <= c->segoff_cap && nsb * BK_T <= M) {
           bucket = true;
           ba.B = (int)B; ba.nsb = (int)nsb; ba.words = c->d_flags; ba.segoff = c->d_segoff; ba.state = c->d_fstate; ba.ticket = c->d_fticket;
+          ba.scount = c->d_bscount;
           hipLaunchKernelGGL(k_bucket_partition, dim3((unsigned)nsb), dim3(BK_T), 0, st, (const u64 *)c->d_keys, n0, nch, c->invalid_key, ba);
         }
       }
@@ -839,7 +859,8 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
 #undef BUCKET_ARGS
       c->bk_steps++;
       c->head_offsets_done = (go.child_off != nullptr);
-    } else if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 3) ANNEAL_LAUNCH(3); else ANNEAL_LAUNCH(4);
+      c->scount_B = ba.B; c->scount_frac = (ba.frac != nullptr);
+    } else { c->scount_B = 0; if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 3) ANNEAL_LAUNCH(3); else ANNEAL_LAUNCH(4); }
 #undef ANNEAL_LAUNCH
 #undef ANNEAL_ARGS
     if (fuse_gate && go.keys == c->d_keys_alt) std::swap(c->d_keys, c->d_keys_alt);      // the next step's spawn kernel appends its keys behind the walkers'
@@ -916,6 +937,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed); std::swap(c->w.irk, c->m.irk);
       if (fuse_gate) std::swap(c->d_keys, c->d_keys_alt);
       c->pipeline_next = false; c->bk_retries++; c->head_offsets_done = false;
+      c->frac_B[0] = c->frac_B[1] = 0; c->scount_B = 0;                 // boundaries are learnt anew
       { static const int hold = getenv("SQMC_BUCKET_HOLDOFF") ? atoi(getenv("SQMC_BUCKET_HOLDOFF")) : 8; c->bk_holdoff = hold; }
       return SQMC_INTERNAL_RETRY;
     }

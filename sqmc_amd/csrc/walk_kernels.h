@@ -255,6 +255,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
     if (fin.on && xb == 0) { finish_all(fin, const_cast<DevScalars *>(sc)); return; }
     if (n_on_device && sc->retry) return;
     const int hb0 = xb - (fin.on ? 1 : 0);
+    if (ba.frac_out && (int)blockIdx.x == (int)gridDim.x - 1) { bk_rebalance_block(ba.frac_prev, ba.scount, ba.B, ba.frac_out); return; }      // the last spare block
     const int row = hb0 * (TPB / 64) + (int)(threadIdx.x >> 6);
     if (pp.n_imp > 0 && row < pp.n_imp) prj_row_product(pp, row);
     return;
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   const long long spc = HB ? 2 : 1;             // walker slots per child: the heat-bath proposal may return a single AND a double
   if (c0 >= nchildren || n0 + spc * nchildren > cap_all) return;
   const bool part = FUSE && ba.B > 0 && (int)blockIdx.x < ba.nsb;                  // rows beyond the room the host provided: the tail will see that and use its own partition
-  if (part) bucket_partition_stage(s_spl, s_wcnt, keys, n0, ba.B);     // resident keys [0, n0) of the same array the children's keys go to; a barrier follows below
+  if (part) bucket_partition_stage(s_spl, s_wcnt, keys, n0, ba);     // resident keys [0, n0) of the same array the children's keys go to; a barrier follows below
   PROF(1);
   while (whi - wlo > SPAWN_WIN) {
     const long long stepw = (whi - wlo + TPB - 1) / TPB, probe = wlo + (long long)threadIdx.x * stepw;

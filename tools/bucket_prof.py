@@ -39,6 +39,17 @@ names = ["rows (loads + scan)", "gather words", "LDS sort", "records", "merge or
 for k in range(1, len(seq)):
     d = (a[:, seq[k]] - a[:, seq[k - 1]]) / 100.0
     print("%-28s mean %6.2f  max %6.2f us" % (names[k - 1], d.mean(), d.max()))
+srt = (a[:, 3] - a[:, 2]) / 100.0
+order = np.argsort(-srt)[:6]
+print("slowest sorts: " + ", ".join("%.1f us (S %d R %d, started %.1f)" % (srt[i], a[i, 12], a[i, 13], (a[i, 0] - t0) / 100.0) for i in order))
+life = (a[:, 10] - a[:, 0]) / 100.0
+order = np.argsort(-(a[:, 6] - a[:, 0]))[:6]
+print("latest to publish: " + ", ".join("%.1f us after its start (S %d R %d)" % ((a[i, 6] - a[i, 0]) / 100.0, a[i, 12], a[i, 13]) for i in order))
+print("S: mean %.0f max %d; R mean %.0f min %d max %d; T max %d" % (a[:, 12].mean(), a[:, 12].max(), a[:, 13].mean(), a[:, 13].min(), a[:, 13].max(), (a[:, 12] + a[:, 13]).max()))
+ids = np.nonzero(np.array(buf, dtype=np.int64).reshape(1024, 16)[:, 0] != old[:, 0])[0]
+top = np.argsort(-(a[:, 12] + a[:, 13]))[:8]
+print("fullest buckets (id: R + S): " + ", ".join("%d: %d + %d" % (ids[i], a[i, 13], a[i, 12]) for i in top))
+print("first buckets (id: R + S): " + ", ".join("%d: %d + %d" % (ids[i], a[i, 13], a[i, 12]) for i in range(6)))
 d = (a[:, 10] - a[:, 0]) / 100.0
 print("bucket life: mean %.1f max %.1f us; end skew mean %.1f" % (d.mean(), d.max(), (a[:, 10].max() - a[:, 10]).mean() / 100.0))
 w.close()
