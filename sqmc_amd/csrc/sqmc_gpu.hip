@@ -180,6 +180,7 @@ struct sqmc_gpu_ctx {
 #include "bucket_kernels.h"
 #include "door_kernels.h"
 #include "hci_kernels.h"
+#include "hbuild_kernels.h"
 #include "spmv_kernels.h"
 
 // ================================================================================ ABI

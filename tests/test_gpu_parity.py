@@ -341,6 +341,40 @@ def test_hci_time_sym_hamiltonian_builder(oracle, c2_hci):
     assert abs(w[0] - (-75.654492433)) < 5e-9       # HCI iteration 1 energy of the reference-pinned oracle run
 
 
+def _ham_builder_worker(outdir, time_sym, allpairs):
+    import os, sys
+    if allpairs:
+        os.environ["SQMC_HAM_ALLPAIRS"] = "1"           # read once per process
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from conftest import FCIDUMP
+    from sqmc_amd import host as H
+    h = H.ChemHost(FCIDUMP, 8, 4, "d2h", time_sym=bool(time_sym), z=1, hf_symmetry=1)
+    g = h.gpu()
+    g.set_hb_tables(*h.hb_tables(g))
+    up, dn, w, e, hist = H.hci_variational(h, g, 1e-3, eps_sched=(2e-3, 2e-3), n_states=1, max_iters=3)
+    order = H.sort_dets(up, dn)
+    rc, ix, vl = g.build_sparse_ham(up[order], dn[order])
+    g.close()
+    np.savez(os.path.join(outdir, "ham_%d_%d.npz" % (time_sym, allpairs)), up=up[order], dn=dn[order], rc=rc, ix=ix, vl=vl)
+
+
+@pytest.mark.parametrize("time_sym", [0, 1])
+def test_string_group_hamiltonian_builder_equals_all_pairs(tmp_path, time_sym):
+    """generate_sparse_ham_chem_upper_triangular two ways on a ~10^4-determinant HCI space: candidates from the alpha/beta
+    string groups (hbuild_kernels.h, the default) against every pair tested (k_build_ham, SQMC_HAM_ALLPAIRS=1): the same rows,
+    the same column order, the same bits -- with and without time-reversal symmetrisation (whose second source, the
+    spin-flipped partner, finds some pairs twice)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    for allpairs in (0, 1):
+        pr = ctx.Process(target=_ham_builder_worker, args=(str(tmp_path), time_sym, allpairs))
+        pr.start(); pr.join(600)
+        assert pr.exitcode == 0
+    a = np.load(str(tmp_path / ("ham_%d_0.npz" % time_sym))); b = np.load(str(tmp_path / ("ham_%d_1.npz" % time_sym)))
+    assert len(a["up"]) > 3000 and np.array_equal(a["up"], b["up"]) and np.array_equal(a["dn"], b["dn"])
+    assert np.array_equal(a["rc"], b["rc"]) and np.array_equal(a["ix"], b["ix"]) and np.array_equal(a["vl"], b["vl"])
+
+
 def test_fortran_host_example():
     """The Fortran iso_c_binding host (sqmc_amd/fortran/example_spmv.f90) runs against the library."""
     import os, subprocess
