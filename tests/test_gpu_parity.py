@@ -619,6 +619,31 @@ def test_walk_deck_end_to_end(tmp_path):
     assert abs(r2["energy"] - r1["energy"]) < 5 * (r1["energy_err"] + r2["energy_err"]) + 1e-3
 
 
+def test_survey_walk_deck_statistical_pin():
+    """The one external walk observable on file: BASELINE.md section 2's reference smoke run of
+    tests/golden/C2_r1.24253_i_walk_survey printed Energy= -75.71813(81) after four 100-step blocks.  Four independent seeds
+    of the same deck and schedule on the GPU path: same set-up figures (1002 deterministic determinants, tau, ~16,400
+    occupied).  Four blocks are less than one autocorrelation time, so single runs scatter by 2.6 mHa (eight seeds on file,
+    profiles/r02_survey_walk_pin.txt: mean -75.72859, scatter 0.0026); their mean must agree with this geometry's near-FCI
+    HCI+PT2 total, -75.72854, and must not be the smoke value, which lies 4 sigma of a single run above it (a run that
+    measured before its population had equilibrated).  The test fails if the walk drifts to either side."""
+    import io, os
+    from conftest import FCIDUMP
+    from sqmc_amd.walk_run import parse_walk_deck, run_walk
+    text = open(os.path.join(os.path.dirname(__file__), "golden", "C2_r1.24253_i_walk_survey")).read()
+    es = []
+    for k in range(4):
+        deck = parse_walk_deck(text)
+        deck["irand_seed"][1][3] = (deck["irand_seed"][1][3] + 2 * k) % 10000
+        r = run_walk(deck, FCIDUMP, out=io.StringIO())
+        assert r["n_imp"] == 1002 and abs(r["tau"] - 0.005314) < 1e-6 and 15800 < r["nwalk_av"] < 17000
+        assert abs(r["energy"] - (-75.72854)) < 4 * 0.0026, (k, r["energy"], r["energy_err"])
+        es.append(r["energy"])
+    mean = float(np.mean(es))
+    assert abs(mean - (-75.72854)) < 3 * 0.0026 / 2, (mean, es)              # three standard errors of a four-run mean
+    assert mean - (-75.71813) < -0.005, (mean, es)
+
+
 @pytest.mark.parametrize("deckname,lo,hi", [("heg14_i_walk", 58.270, 58.280), ("hubbard4x4_i_walk", -12.5, -10.0)])
 def test_walk_decks_of_the_other_systems(deckname, lo, hi):
     """Walk decks for the electron gas (the system of the reference's e2e fixtures, whose HCI total
