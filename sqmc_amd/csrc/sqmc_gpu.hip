@@ -1074,7 +1074,7 @@ static int run_steps(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *s
     sp.reached_w_abs_gen = pc->reached_w_abs_gen; sp.reserved = 0;
     // pipelined head: once the target population has been reached tau and r_initiator stay put, and the head of a step
     // (gate, scan, spawn) depends on nothing else that this step's sums could change
-    c->pipeline_next = ((one_step == (step_fn)sqmc_gpu_step || (one_step == (step_fn)sqmc_gpu_shard_step && c->comm2 != nullptr)) && it + 1 < nsteps &&
+    c->pipeline_next = ((one_step == (step_fn)sqmc_gpu_step || (one_step == (step_fn)sqmc_gpu_shard_step && c->comm != nullptr && !getenv("SQMC_SHARD_NO_PIPELINE"))) && it + 1 < nsteps &&
                         pc->reached_w_abs_gen == 2 && c->rng_mode != SQMC_RNG_REPLAY && !getenv("SQMC_NO_PIPELINE"));
     double out[16];
     int r = one_step(c, &sp, out);
