@@ -337,6 +337,12 @@ int sqmc_gpu_hci_connections(sqmc_gpu_ctx *ctx, int64_t n_ref, const uint64_t *r
 int sqmc_gpu_hci_connections_slice(sqmc_gpu_ctx *ctx, int64_t n_ref, const uint64_t *ref_up, const uint64_t *ref_dn,
                                    const double *coeffs, double eps, int diag_mode, int32_t slice, int32_t n_slices, int64_t *out_n,
                                    uint64_t **out_up, uint64_t **out_dn, double **out_e_mix_num, double **out_e_mix_den);
+/* replaces: the optional arguments core_up/dn, virt_up/dn, active_only of find_important_connected_dets_chem
+ * (chemistry.f90:6840-6846, 6926-6947, 7087-7108) as get_next_det_list, second_order_pt and do_pt pass them down
+ * (hci.f90:150-182, 386-389, 786-798, 914-920).  mode 0: no masks; 1: only determinants inside the active space (every core
+ * orbital occupied, every virtual orbital empty); 2: only determinants outside it.  State of the context: applies to
+ * sqmc_gpu_hci_connections(_slice) and sqmc_gpu_hci_pt2 until changed.  Chemistry only. */
+int sqmc_gpu_hci_set_active_space(sqmc_gpu_ctx *ctx, uint64_t core_up, uint64_t core_dn, uint64_t virt_up, uint64_t virt_dn, int32_t mode);
 /* replaces: second_order_pt (hci.f90:1100-1182), the deterministic Epstein-Nesbet correction of a variational wavefunction:
  * delta_e = sum_a (sum_i H_ai c_i)^2 / (E_var - H_aa) over the connected determinants outside the variational space, the inner
  * sum screened by |H_ai c_i| >= eps_pt; n_connections = connected determinants visited (the reference prints it).  Everything

@@ -182,6 +182,11 @@ class ChemSystem:
         assert n <= cap
         return cu[:n], cd[:n], el[:n]
 
+    def set_active_space(self, core_up, core_dn, virt_up, virt_dn, mode):
+        """masks of find_important_connected_dets_chem: mode 0 none, 1 inside the active space only, 2 outside only"""
+        lib().orc_set_active_space.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
+        lib().orc_set_active_space(self.h, int(core_up), int(core_dn), int(virt_up), int(virt_dn), int(mode))
+
     def important_connected(self, up, dn, eps, cap=400000):
         self.setup_hb()
         cu = np.zeros(cap, np.uint64); cd = np.zeros(cap, np.uint64); el = np.zeros(cap)

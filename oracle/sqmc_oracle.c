@@ -431,7 +431,16 @@ void orc_chem_setup_hb(orc_chem *s) {
   free(all);
 }
 
-/* chemistry.f90:6819-7159 with matrix_elements present, no active-space masks, no eps_big */
+/* chemistry.f90:6926-6947 and 7087-7108: the optional core / virtual masks.  Returns 1 when the new determinant is to be skipped. */
+static int active_space_skip(const orc_chem *s, det_t nu, det_t nd) {
+  if (!s->as_mode) return 0;
+  const int outside = ((s->as_core_up & nu) != s->as_core_up) || ((s->as_core_dn & nd) != s->as_core_dn) || (s->as_virt_up & nu) != 0 || (s->as_virt_dn & nd) != 0;
+  return s->as_mode == 1 ? outside : !outside;
+}
+void orc_set_active_space(orc_chem *s, det_t core_up, det_t core_dn, det_t virt_up, det_t virt_dn, int mode) {
+  s->as_mode = mode; s->as_core_up = core_up; s->as_core_dn = core_dn; s->as_virt_up = virt_up; s->as_virt_dn = virt_dn;
+}
+/* chemistry.f90:6819-7159 with matrix_elements present; active-space masks as set by orc_set_active_space; no eps_big */
 int orc_find_important_connected_dets_chem(const orc_chem *s, det_t up, det_t dn, double eps,
                                            det_t *cu, det_t *cd, double *el, int cap) {
   const double sqrt2 = sqrt(2.0), sqrt2inv = 1.0 / sqrt2;
@@ -447,6 +456,7 @@ int orc_find_important_connected_dets_chem(const orc_chem *s, det_t up, det_t dn
       if (s->orbsym[pe] != s->orbsym[r]) continue;
       det_t nu_ = up, nd_ = dn;
       if (isup) nu_ = (up & ~BIT(pe - 1)) | BIT(r - 1); else nd_ = (dn & ~BIT(pe - 1)) | BIT(r - 1);
+      if (active_space_skip(s, nu_, nd_)) continue;
       if (s->time_sym) {
         if (nu_ == nd_ && s->z < 0) continue;
         if (up == nd_ && dn == nu_) continue;
@@ -485,6 +495,7 @@ int orc_find_important_connected_dets_chem(const orc_chem *s, det_t up, det_t dn
       if (q <= n) nu_ &= ~BIT(q - 1); else nd_ &= ~BIT(q - n - 1);
       if (r <= n) nu_ |= BIT(r - 1); else nd_ |= BIT(r - n - 1);
       if (t <= n) nu_ |= BIT(t - 1); else nd_ |= BIT(t - n - 1);
+      if (active_space_skip(s, nu_, nd_)) continue;
       if (s->time_sym) {
         if (nu_ == nd_ && s->z < 0) continue;
         if (up == nd_ && dn == nu_) continue;

@@ -60,6 +60,9 @@ typedef struct {
   int *hb_r, *hb_s; double *hb_absH;
   int64_t *pq_ind; int *pq_count; int n_pq;
   double max_double;
+  /* active-space masks of find_important_connected_dets_chem (chemistry.f90:6840-6846, 6926-6947): as_mode 0 = none,
+   * 1 = only determinants inside the active space (core fully occupied, virtuals empty), 2 = only those outside it */
+  int as_mode; det_t as_core_up, as_core_dn, as_virt_up, as_virt_dn;
 } orc_chem;
 
 /* hf_mode: 0 = first nup/ndn orbitals (walk decks), 1 = auto HF of symmetry
@@ -105,6 +108,7 @@ double orc_hb_proposal_prob(const orc_chem *c, const orc_hb *h, det_t iu, det_t 
 /* connections */
 int orc_find_connected_dets_chem(const orc_chem *s, det_t up, det_t dn, det_t *cu, det_t *cd,
                                  double *elems, int cap);
+void orc_set_active_space(orc_chem *s, det_t core_up, det_t core_dn, det_t virt_up, det_t virt_dn, int mode);
 int orc_find_important_connected_dets_chem(const orc_chem *s, det_t up, det_t dn, double eps,
                                            det_t *cu, det_t *cd, double *elems, int cap);
 

@@ -18,7 +18,7 @@ EXPORTS = [
     "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init", "sqmc_gpu_comm_size",
     "sqmc_gpu_shard_step", "sqmc_gpu_shard_run", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_tail_stats", "sqmc_gpu_slowest_steps", "sqmc_gpu_spmv_prepare",
     "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_build_spmv_plan", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
-    "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_hci_connections_slice", "sqmc_gpu_hci_pt2", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
+    "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_hci_connections_slice", "sqmc_gpu_hci_pt2", "sqmc_gpu_hci_set_active_space", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
 ]
 
 
@@ -432,6 +432,12 @@ class GpuChem:
         return take(pu, C.c_uint64, np.uint64), take(pd, C.c_uint64, np.uint64), take(pn, C.c_double, np.float64), take(pe, C.c_double, np.float64)
 
 
+def _gpuchem_hci_set_active_space(self, core_up, core_dn, virt_up, virt_dn, mode):
+    """masks of the HCI generator: mode 0 none, 1 inside the active space only, 2 outside only"""
+    self.L.sqmc_gpu_hci_set_active_space.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32]
+    _chk(self.L.sqmc_gpu_hci_set_active_space(self.h, int(core_up), int(core_dn), int(virt_up), int(virt_dn), int(mode)))
+
+
 def _gpuchem_hci_pt2(self, up, dn, coeffs, e_var, eps_pt, n_slices=1):
     """sqmc_gpu_hci_pt2: (delta_E, number of connected determinants), everything on the device"""
     u, d, c = _u64(up), _u64(dn), _f64(coeffs)
@@ -486,3 +492,4 @@ class SpmvPlan:
 
 
 GpuChem.hci_pt2 = _gpuchem_hci_pt2
+GpuChem.hci_set_active_space = _gpuchem_hci_set_active_space

@@ -603,3 +603,12 @@ __device__ __forceinline__ int propose_any(const ChemTab &t, Rng &g, u64 iu, u64
   if (t.sys_type == 2) return propose_hubbard(t, g, iu, id, ju, jd, prob);
   return propose_uniform(t, g, iu, id, ju, jd, prob);
 }
+
+// active-space masks of find_important_connected_dets_chem (chemistry.f90:6840-6846, 6926-6947, 7087-7108): mode 0 none, 1 only the
+// determinants inside the active space (core orbitals all occupied, virtual orbitals all empty), 2 only those outside it
+struct ActiveSpace { int mode; u64 core_up, core_dn, virt_up, virt_dn; };
+__device__ __forceinline__ bool active_space_skip(const ActiveSpace &a, u64 nu, u64 nd) {
+  if (!a.mode) return false;
+  const bool outside = ((a.core_up & nu) != a.core_up) || ((a.core_dn & nd) != a.core_dn) || (a.virt_up & nu) != 0 || (a.virt_dn & nd) != 0;
+  return a.mode == 1 ? outside : !outside;
+}

@@ -10,7 +10,7 @@
 __global__ void __launch_bounds__(TPB) k_hci_gen(ChemDev dev, const u64 *__restrict__ rup, const u64 *__restrict__ rdn, const double *__restrict__ coef,
                                                  double eps_var, int diag_mode, long long n_ref, int pass, u64 *__restrict__ counts,
                                                  const u64 *__restrict__ offs, u64 *__restrict__ ou, u64 *__restrict__ od,
-                                                 double *__restrict__ onum, double *__restrict__ oden, u64 key_lo, u64 key_hi) {
+                                                 double *__restrict__ onum, double *__restrict__ oden, u64 key_lo, u64 key_hi, ActiveSpace as) {
   __shared__ ChemTab t;
   __shared__ unsigned char s_lut[HEG_LUT_MAX];        // plane wave (kx,ky,kz) -> orbital id, 0 = not in the basis (find_orb_id, heg.f90:752-771)
   stage_tab(&t, dev.tab, dev.tab_words);
@@ -84,6 +84,7 @@ __global__ void __launch_bounds__(TPB) k_hci_gen(ChemDev dev, const u64 *__restr
         const int r = ctz64(h) + 1;
         u64 nu = up, nd = dn;
         if (!sp) nu = (up & ~bit64(pe - 1)) | bit64(r - 1); else nd = (dn & ~bit64(pe - 1)) | bit64(r - 1);
+        if (active_space_skip(as, nu, nd)) continue;
         if (t.time_sym) { if (nu == nd && t.z < 0) continue; if (up == nd && dn == nu) continue; }
         double mel = h_single(t, dev.integrals, up, dn, nu, nd);
         if (fabs(mel) < eps) continue;
@@ -123,6 +124,7 @@ __global__ void __launch_bounds__(TPB) k_hci_gen(ChemDev dev, const u64 *__restr
             if (q <= n) nu &= ~bit64(q - 1); else nd &= ~bit64(q - n - 1);
             if (r <= n) nu |= bit64(r - 1); else nd |= bit64(r - n - 1);
             if (s <= n) nu |= bit64(s - 1); else nd |= bit64(s - n - 1);
+            if (active_space_skip(as, nu, nd)) continue;
             if (t.time_sym) { if (nu == nd && t.z < 0) continue; if (up == nd && dn == nu) continue; }
             double mel = 0.0;
             if (pass) {

@@ -164,6 +164,7 @@ struct sqmc_gpu_ctx {
   double *d_prj_xs[2]; int xs_cur; bool xs_valid;      // snapshots of the deterministic-space weights by row, written by the bucket tail for the NEXT step's projection (two: one is read while the other is written)
   bool side_pending;          // death/clone and the projection of this step have not been launched as kernels: the bucket tail does them itself, any other tail must launch them first
   double slow_us[4]; long long slow_step[4];      // the slowest steps of the last run_steps call (wall clock; host jitter shows up here)
+  ActiveSpace as;             // masks of the HCI generator (sqmc_gpu_hci_set_active_space); mode 0 = none
   bool tail_fills_hii;        // the tail that enqueues the next head is a bucket tail: it computes the H_ii of the determinants it creates itself
   bool fork_valid;            // e_fork was recorded behind the last tail (a head behind a bucket tail forks nothing and skips it)
   bool head_hii, head_hii_joined;     // the pipelined head fills the missing H_ii of this step's walkers (joined: inside k_spawn itself, nothing to wait for)

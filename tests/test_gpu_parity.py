@@ -139,6 +139,47 @@ def test_hci_connections_match_oracle(oracle, c2_walk, c2_hci, which, eps):
     assert np.allclose(gden, [den[k] for k in ks], rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("which", ["hci", "walk"])
+def test_hci_connections_active_space_masks(oracle, c2_walk, c2_hci, which):
+    """The core / virtual masks of find_important_connected_dets_chem (chemistry.f90:6840-6846, 6926-6947, 7087-7108; built by
+    hci.f90:150-182 from n_var_e_up/dn and n_var_orbs): generator restricted to the active space (mode 1) and to its
+    complement (mode 2), GPU against oracle; the two modes partition what the unmasked generator finds.  Active space here:
+    the lowest up/dn orbital frozen (core), the last 8 orbitals virtual."""
+    sysm = c2_walk if which == "walk" else c2_hci
+    g = gpu_ctx_from_oracle(sysm)
+    r, s_, a, pi, pc = sysm.hb_tables()
+    g.set_hb_tables(r, s_, a, pi, pc, sysm.s.max_double)
+    norb = 26
+    core = 1                                   # orbital 1
+    virt = ((1 << norb) - 1) ^ ((1 << (norb - 8)) - 1)
+    cu, cd, el = sysm.important_connected(sysm.hf_up, sysm.hf_dn, 1e-2)
+    keys = sorted(set(zip(cu.tolist(), cd.tolist())))[:30]
+    ref_up = np.array([k[0] for k in keys], np.uint64); ref_dn = np.array([k[1] for k in keys], np.uint64)
+    coef = np.linspace(1.0, 0.05, len(keys)) * np.where(np.arange(len(keys)) % 2 == 0, -1, 1)
+    eps = 3e-4
+    got = {}
+    for mode in (0, 1, 2):
+        g.hci_set_active_space(core, core, virt, virt, mode)
+        sysm.set_active_space(core, core, virt, virt, mode)
+        gu, gd, gnum, gden = g.hci_connections(ref_up, ref_dn, coef, eps)
+        acc = {}
+        for u, d, c in zip(ref_up.tolist(), ref_dn.tolist(), coef.tolist()):
+            xu, xd, xe = sysm.important_connected(u, d, eps / abs(c))
+            for p, q, h in zip(xu.tolist(), xd.tolist(), xe.tolist()):
+                acc[(p, q)] = acc.get((p, q), 0.0) + h * c
+        ks = sorted(acc)
+        assert [k[0] for k in ks] == gu.tolist() and [k[1] for k in ks] == gd.tolist(), mode
+        assert np.allclose(gnum, [acc[k] for k in ks], rtol=1e-12, atol=1e-15)
+        got[mode] = dict(zip(zip(gu.tolist(), gd.tolist()), gnum.tolist()))
+    sysm.set_active_space(0, 0, 0, 0, 0)
+    g.close()
+    refs = set(keys)
+    inside = set(got[1]) - refs; outside = set(got[2]) - refs; everything = set(got[0]) - refs
+    assert inside and outside and not (inside & outside) and (inside | outside) == everything
+    for k in everything:                       # a connection's sum splits by SOURCE: each (reference, connection) pair goes to exactly one mode
+        assert abs(got[0][k] - (got[1].get(k, 0.0) + got[2].get(k, 0.0))) < 1e-12
+
+
 def _run_pair(oracle, sysm, setup, rng_mode, nsteps, w_begin, w_target, mwalk=400000, n_equil=10**9, e_trial=-75.72):
     g = gpu_ctx_from_oracle(sysm, rng_mode=rng_mode, seed=SEED, mwalk=mwalk)
     g.set_projector(setup.prj_counts, setup.prj_indices, setup.prj_values)
