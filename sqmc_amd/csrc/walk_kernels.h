@@ -245,22 +245,25 @@ template <int HB, int FUSE>
 __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64 *__restrict__ child_off, const double *__restrict__ wchild,
                                                const u64 *__restrict__ child_state, u64 *__restrict__ keys, u32 *__restrict__ vals,
                                                long long n0_arg, long long cap_all, StepP p, int mode, u64 seed, u64 step, u64 invalid_key, const DevScalars *sc,
-                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo, BucketArgs ba, FinArgs fin, PrjPre pp, int extra0) {
-  // Blocks from extra0 on do not spawn.  Steps whose child offsets came out of the bucket tail have no scan launch to carry the
-  // last step's final sums: block extra0 does them (it runs beside the spawning blocks; nothing it touches is read by them).
-  // The blocks behind it multiply the deterministic projector into last step's deterministic weights, one wavefront per row:
-  // the part of the projection that needs nothing the host still has to decide (E_T enters in the tail, bucket_kernels.h).
-  if (FUSE && (int)blockIdx.x >= extra0) {
-    const int xb = (int)blockIdx.x - extra0;
+                                               HostMail *mail, u64 cnt_seq, int pack, int n_on_device, OwnerOut oo, BucketArgs ba, FinArgs fin, PrjPre pp, int n_extra) {
+  // The first n_extra blocks do not spawn (they come first in the grid so that they run beside the spawning blocks from the start:
+  // behind them they waited for the thousands of empty blocks a capacity-sized grid has, and the kernel for them -- 32 against
+  // 20 us).  Steps whose child offsets came out of the bucket tail have no scan launch to carry the last step's final sums:
+  // block 0 does them (nothing it touches is read by the spawning blocks).  The blocks behind it multiply the deterministic
+  // projector into last step's deterministic weights, one wavefront per row: the part of the projection that needs nothing
+  // the host still has to decide (E_T enters in the tail, bucket_kernels.h).  The last of them makes the next bucket boundaries.
+  if (FUSE && (int)blockIdx.x < n_extra) {
+    const int xb = (int)blockIdx.x;
     if (fin.on && xb == 0) { finish_all(fin, const_cast<DevScalars *>(sc)); return; }
     if (n_on_device && sc->retry) return;
     const int hb0 = xb - (fin.on ? 1 : 0);
-    if (ba.frac_out && (int)blockIdx.x == (int)gridDim.x - 1) { bk_rebalance_block(ba.frac_prev, ba.scount, ba.B, ba.frac_out); return; }      // the last spare block
+    if (ba.frac_out && xb == n_extra - 1) { bk_rebalance_block(ba.frac_prev, ba.scount, ba.B, ba.frac_out); return; }      // the last spare block
     const int row = hb0 * (TPB / 64) + (int)(threadIdx.x >> 6);
     if (pp.n_imp > 0 && row < pp.n_imp) prj_row_product(pp, row);
     return;
   }
   if (n_on_device && sc->retry) return;                                 // see k_gate
+  const unsigned bx = blockIdx.x - (FUSE ? (unsigned)n_extra : 0u);      // index among the spawning blocks
   const long long n0 = n_on_device ? (long long)sc->nwalk : n0_arg;     // pipelined head: launched before the host learnt the walker count
   // the grid covers the free capacity of the walker arrays; the number of children is read from
   // device memory so that the launch does not wait for the host to learn it
@@ -275,7 +278,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   // (one round trip per level instead of log2(n0) dependent loads), then every thread finishes
   // inside a 1024-entry LDS window (global search only if it runs past it).  The first probe, the
   // table staging and the child count do not depend on each other: they are issued together.
-  const long long c0 = (long long)blockIdx.x * TPB;
+  const long long c0 = (long long)bx * TPB;
   long long wlo = 0, whi = n0;                       // invariant: child_off[wlo] <= c0, answer for c0 in [wlo, whi)
   u64 pv = 0;
   if (whi - wlo > SPAWN_WIN) {
@@ -284,12 +287,12 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   }
   stage_tab(&t, dev.tab, dev.tab_words);
   const long long nchildren = (long long)sc->n_children;
-  if (mail && blockIdx.x == 0 && threadIdx.x == 0) {      // the host sizes the sort from this while the kernel runs
+  if (mail && bx == 0 && threadIdx.x == 0) {      // the host sizes the sort from this while the kernel runs
     mail->n_children = (u64)nchildren; __threadfence_system(); mail->cnt_seq = cnt_seq;
   }
   const long long spc = HB ? 2 : 1;             // walker slots per child: the heat-bath proposal may return a single AND a double
   if (c0 >= nchildren || n0 + spc * nchildren > cap_all) return;
-  const bool part = FUSE && ba.B > 0 && (int)blockIdx.x < ba.nsb;                  // rows beyond the room the host provided: the tail will see that and use its own partition
+  const bool part = FUSE && ba.B > 0 && (int)bx < ba.nsb;                  // rows beyond the room the host provided: the tail will see that and use its own partition
   if (part) bucket_partition_stage(s_spl, s_wcnt, keys, n0, ba);     // resident keys [0, n0) of the same array the children's keys go to; a barrier follows below
   PROF(1);
   while (whi - wlo > SPAWN_WIN) {
@@ -345,7 +348,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
     ckey = spawn_emit(dev, w, keys, vals, n0, c, pflg, ju, jd, wj, p, invalid_key, pack, oo);
     }
   }
-  if (part) bucket_partition_block(s_spl, s_wcnt, active && ckey != invalid_key, (u32)ckey, (ckey << 32) | (u64)(n0 + c), (long long)blockIdx.x, ba);
+  if (part) bucket_partition_block(s_spl, s_wcnt, active && ckey != invalid_key, (u32)ckey, (ckey << 32) | (u64)(n0 + c), (long long)bx, ba);
   PROF(5);
 }
 
