@@ -243,10 +243,12 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
   const int R = (int)(r_hi - r_lo);
   BPROF(0);
   // key range of the bucket (the sort only looks at the bits that vary inside it)
-  if (tid == 0) s_kmin = b ? (u32)(rkeys[r_lo] >> 32) : 0u;
-  if (tid == 64) s_kmax = (b + 1 < B) ? (u32)(rkeys[r_hi] >> 32) - 1u : (u32)invalid_key;
+  if (tid == 0) s_kmin = b ? (ba.kb ? ba.kb[b] : (u32)(rkeys[r_lo] >> 32)) : 0u;
+  if (tid == 64) s_kmax = (b + 1 < B) ? (ba.kb ? ba.kb[b + 1] : (u32)(rkeys[r_hi] >> 32)) - 1u : (u32)invalid_key;
   unsigned short *seg_lo = (unsigned short *)scratch; u32 *seg_base = scratch + (BK_CAP_ROWS / 2 + 4);     // u16 x ROWS, then u32 x (ROWS + 1)
-  bool fits = nsb <= BK_CAP_ROWS && R <= BK_CAP_R;
+  // (key boundaries: the first and the last walker of the whole list get special treatment below and are looked for in the first
+  //  and the last bucket -- which equal-residents boundaries never leave empty; here an empty one sends the step to the radix tail)
+  bool fits = nsb <= BK_CAP_ROWS && R <= BK_CAP_R && !(ba.kb && (b == 0 || b == B - 1) && R == 0);
   // ---- rows: where the bucket's children lie in every partition block.  Thread t owns rows [t C, (t+1) C): all loads first.
   //      The residents' keys are requested in the same round trip.
   u32 rk_reg[BK_PER_R];

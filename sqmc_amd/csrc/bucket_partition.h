@@ -27,47 +27,113 @@ struct BucketArgs {
   unsigned short *segoff;              // nsb rows of B+1 group offsets
   u64 *state; u32 *ticket;             // look-back over the buckets
   int force_retry;                     // tests: behave as if a bucket did not fit
-  // Where the buckets begin in the sorted resident list.  frac == null: at b n0 / B (equal numbers of residents).  Otherwise at
-  // frac[b] n0 / 2^32: boundaries that equalise residents + spawns per bucket as measured two steps back (the spawns crowd on
-  // the heavy determinants: with equal residents the fullest bucket held 3x the mean, and every bucket waits for it).
-  const u32 *frac;
+  // Where the buckets begin.  kb == null: at the residents at positions b n0 / B (equal numbers of residents).  Otherwise bucket b
+  // holds the keys [kb[b], kb[b+1]): boundaries that equalise the cost of a bucket, residents + 1.7 spawns, as measured one bucket
+  // step back (the spawns crowd on the heavy determinants: with equal residents the fullest bucket held 3x the mean, and every
+  // bucket waits for it).  Keys, not positions: a determinant keeps its key, while its position moves with every birth and death
+  // in front of it.
+  const u32 *kb;
+  u32 *pos;                            // positions of kb in this step's resident list (B + 1): a spare block of k_spawn finds them, the tail reads them
   u32 *scount;                         // out, B + 1 words: spawns of every bucket, then n0 -- what the next boundaries are made from
-  const u32 *frac_prev; u32 *frac_out; // k_spawn's spare block: boundaries for the step after this one from scount and the boundaries it was counted with
+  const u32 *kb_prev; u32 *kb_out;     // k_spawn's spare block: the next boundaries from scount and the boundaries it was counted with (null: equal residents)
 };
 #define BK_REBAL_MAXB 256
-#define BK_REBAL_UNIFORM 0.125         // share of the equal-residents boundaries in the blend (no bucket narrower than 1/8 of its equal share)
+#define BK_REBAL_SPAWN_COST 1.2        // a spawn against a resident in a bucket's cost.  Its time to publish fits 7.1 + 0.0101 S + 0.0059 R us over the
+                                       // buckets of a step, i.e. 1.7; the smaller weight keeps the residents of spawn-poor ranges below the gap sort's 1023
 __device__ __forceinline__ long long bk_bound(const BucketArgs &ba, int b, long long n0) {
   if (b <= 0) return 0;
   if (b >= ba.B) return n0;
-  return ba.frac ? (long long)(((u64)ba.frac[b] * (u64)n0) >> 32) : ((long long)b * n0) / ba.B;
+  return ba.kb ? (long long)ba.pos[b] : ((long long)b * n0) / ba.B;
 }
-// one block of BK_T threads: new boundaries such that every bucket holds the same number of residents + spawns, if the spawns
-// fall as they did when scount was taken (piecewise-constant density inside the old buckets); reads everything before it writes
-__device__ __forceinline__ void bk_rebalance_block(const u32 *__restrict__ fprev, const u32 *__restrict__ scount, int B, u32 *__restrict__ fout) {
-  __shared__ double s_fr[BK_REBAL_MAXB + 1], s_pre[BK_REBAL_MAXB + 1];
-  const int tid = threadIdx.x;
-  const double n0 = (double)scount[B];
-  for (int b = tid; b <= B; b += BK_T) s_fr[b] = (b == 0) ? 0.0 : (b == B ? 1.0 : (fprev ? (double)fprev[b] * (1.0 / 4294967296.0) : (double)b / (double)B));
+// first resident position whose key is >= k (rkeys: key << 32 | index, ascending); two searches at once: their loads are independent
+__device__ __forceinline__ void bk_lower_bound2(const u64 *__restrict__ rkeys, long long n0, u32 k1, u32 k2, bool do1, bool do2, long long &p1, long long &p2) {
+  long long lo1 = 0, hi1 = do1 ? n0 : 0, lo2 = 0, hi2 = do2 ? n0 : 0;
+  while (lo1 < hi1 || lo2 < hi2) {
+    const long long m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
+    const u64 v1 = (lo1 < hi1) ? rkeys[m1] : 0ull, v2 = (lo2 < hi2) ? rkeys[m2] : 0ull;
+    if (lo1 < hi1) { if ((u32)(v1 >> 32) < k1) lo1 = m1 + 1; else hi1 = m1; }
+    if (lo2 < hi2) { if ((u32)(v2 >> 32) < k2) lo2 = m2 + 1; else hi2 = m2; }
+  }
+  p1 = lo1; p2 = lo2;
+}
+// One block of BK_T threads beside the spawning blocks of k_spawn: (1) where this step's boundaries lie in this step's resident
+// list; (2) the next boundaries: every bucket the same cost, if residents and spawns fall as they did when scount was taken,
+// evenly over the KEY range of each bucket of then.  (Evenly over its residents does not work: most spawns land on
+// determinants nobody occupies, whole key ranges of them, and die there by the initiator rule -- a bucket can hold 2000 spawns
+// in a range its 650 residents only line the edges of.)  If the new boundaries would overfill a block with residents, or leave
+// the first or the last bucket without any, equal-residents boundaries are written instead.
+__device__ __forceinline__ void bk_rebalance_block(const BucketArgs &ba, const u64 *__restrict__ rkeys, long long n0) {
+  __shared__ double s_pre[BK_REBAL_MAXB + 1]; __shared__ u32 s_pp[BK_REBAL_MAXB + 1], s_kk[BK_REBAL_MAXB + 1], s_kn[BK_REBAL_MAXB + 1], s_pn[BK_REBAL_MAXB + 1];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, B = ba.B;
+  if (tid == 0) s_bad = 0;
+  for (int j = tid; j <= B; j += BK_T) {
+    long long p1 = 0, p2 = 0;
+    const bool inner = j > 0 && j < B;
+    bk_lower_bound2(rkeys, n0, (inner && ba.kb) ? ba.kb[j] : 0u, (inner && ba.kb_out && ba.kb_prev) ? ba.kb_prev[j] : 0u, inner && ba.kb != nullptr,
+                    inner && ba.kb_out != nullptr && ba.kb_prev != nullptr, p1, p2);
+    if (ba.kb) ba.pos[j] = (j == 0) ? 0u : (j == B ? (u32)n0 : (u32)p1);
+    if (ba.kb_out) {
+      const u32 pp = (j == 0) ? 0u : (j == B ? (u32)n0 : (ba.kb_prev ? (u32)p2 : (u32)(((long long)j * n0) / B)));
+      s_pp[j] = pp;
+      s_kk[j] = (j == 0) ? 0u : (j == B ? (u32)(rkeys[n0 - 1] >> 32) + 1u : (ba.kb_prev ? ba.kb_prev[j] : (u32)(rkeys[pp] >> 32)));
+    }
+  }
+  if (!ba.kb_out) return;
   __syncthreads();
   if (tid == 0) {                      // 256 additions beside a kernel that runs for tens of microseconds
     double acc = 0.0;
-    for (int b = 0; b < B; b++) { s_pre[b] = acc; acc += (s_fr[b + 1] - s_fr[b]) * n0 + (double)scount[b]; }
+    for (int b = 0; b < B; b++) { s_pre[b] = acc; acc += (double)(s_pp[b + 1] - s_pp[b]) + BK_REBAL_SPAWN_COST * (double)ba.scount[b]; }
     s_pre[B] = acc;
   }
   __syncthreads();
   const double total = s_pre[B];
-  for (int j = tid; j < B; j += BK_T) {
-    if (j == 0) { fout[0] = 0u; continue; }
-    const double target = total * (double)j / (double)B;
-    int lo = 0, hi = B;                 // s_pre[lo] <= target < s_pre[hi]
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pre[mid] <= target) lo = mid; else hi = mid; }
-    const double width = s_pre[lo + 1] - s_pre[lo];
-    const double x = width > 0.0 ? (target - s_pre[lo]) / width : 0.0;
-    const double bal = s_fr[lo] + x * (s_fr[lo + 1] - s_fr[lo]);
-    double v = (1.0 - BK_REBAL_UNIFORM) * bal + BK_REBAL_UNIFORM * (double)j / (double)B;
-    v = v * 4294967296.0;
-    fout[j] = v >= 4294967295.0 ? 4294967295u : (u32)v;
+  for (int j = tid; j <= B; j += BK_T) {
+    u32 kn = (j == 0) ? 0u : s_kk[B];
+    if (j > 0 && j < B) {
+      const double target = total * (double)j / (double)B;
+      int lo = 0, hi = B;               // s_pre[lo] <= target < s_pre[hi]
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pre[mid] <= target) lo = mid; else hi = mid; }
+      // inside bucket lo of then: its residents where they are today, its spawns evenly over its key range.  Cost up to resident p
+      // (exclusive) = (p - p_lo) + d (key(p) - K_lo); the boundary goes behind the last resident that cost still admits, then on
+      // into the gap behind it as far as the spawn density allows
+      const double r = target - s_pre[lo];
+      const u32 p_lo = s_pp[lo], p_hi = s_pp[lo + 1], K_lo = s_kk[lo], K_hi = s_kk[lo + 1];
+      const double d = (K_hi > K_lo) ? BK_REBAL_SPAWN_COST * (double)ba.scount[lo] / (double)(K_hi - K_lo) : 0.0;
+      u32 a = p_lo, e = p_hi;           // residents [p_lo, a) are admitted, [e, p_hi) are not
+      while (a < e) {
+        const u32 m = (a + e) >> 1;
+        const u32 km = (u32)(rkeys[m] >> 32);
+        const double f = (double)(m - p_lo) + d * (double)(km > K_lo ? km - K_lo : 0u);
+        if (f <= r) a = m + 1; else e = m;
+      }
+      if (a == p_lo) kn = K_lo + (d > 0.0 ? (u32)(r / d) : 0u);                      // in front of the bucket's first resident
+      else {
+        const u32 kp = (u32)(rkeys[a - 1] >> 32);
+        const double f = (double)(a - 1 - p_lo) + d * (double)(kp > K_lo ? kp - K_lo : 0u);
+        kn = kp + 1u + (d > 0.0 ? (u32)((r - f) / d) : 0u);
+      }
+      const u32 cap_k = (a < p_hi) ? (u32)(rkeys[a] >> 32) : K_hi;                   // not past the first resident that was not admitted
+      if (kn > cap_k) kn = cap_k;
+    }
+    s_kn[j] = kn;
   }
+  __syncthreads();
+  for (int j = tid; j <= B; j += BK_T) {      // where the new boundaries lie in today's list: what the blocks would have to hold
+    long long p1 = 0, p2 = 0;
+    const bool inner = j > 0 && j < B;
+    bk_lower_bound2(rkeys, n0, s_kn[j], 0u, inner, false, p1, p2);
+    s_pn[j] = (j == 0) ? 0u : (j == B ? (u32)n0 : (u32)p1);
+    if (inner && s_kn[j] <= s_kn[j - 1]) s_bad = 1;
+  }
+  __syncthreads();
+  for (int j = tid; j < B; j += BK_T) {
+    const u32 r = s_pn[j + 1] - s_pn[j];
+    if (r > 1000u || ((j == 0 || j == B - 1) && r == 0u)) s_bad = 1;
+  }
+  __syncthreads();
+  const bool bad = s_bad != 0;
+  for (int j = tid; j < B; j += BK_T) ba.kb_out[j] = (j == 0) ? 0u : (bad ? (u32)(rkeys[((long long)j * n0) / B] >> 32) : s_kn[j]);
 }
 
 // ------------------------------------------------------------------------------------------------ partition
@@ -110,6 +176,6 @@ __device__ __forceinline__ void bucket_partition_block(const u32 *__restrict__ s
 // splitters and zeroed counters of a partition block (no barrier inside: the caller synchronises once before partitioning)
 __device__ __forceinline__ void bucket_partition_stage(u32 *__restrict__ spl, u32 (*__restrict__ wcnt)[BK_MAXB], const u64 *__restrict__ rkeys, long long n0, const BucketArgs &ba) {
   const int B = ba.B;
-  for (int b = threadIdx.x; b < B; b += BK_T) spl[b] = b ? (u32)(rkeys[bk_bound(ba, b, n0)] >> 32) : 0u;      // first key of bucket b
+  for (int b = threadIdx.x; b < B; b += BK_T) spl[b] = b ? (ba.kb ? ba.kb[b] : (u32)(rkeys[((long long)b * n0) / B] >> 32)) : 0u;      // first key of bucket b
   for (int d = threadIdx.x; d < (BK_T / 64) * BK_MAXB; d += BK_T) (&wcnt[0][0])[d] = 0;
 }

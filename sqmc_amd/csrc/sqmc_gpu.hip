@@ -157,9 +157,9 @@ struct sqmc_gpu_ctx {
   int scan_flip, scan_used[2];   // gate-fused heads: look-back set of the next head scan, and how many words of each set its last scan may have touched
   bool residents_sorted;      // the walker arrays are known to be in (up, dn) order: true after every finished step and after an upload (which refuses unsorted lists)
   unsigned short *d_segoff; long long segoff_cap;      // bucket tail: group offsets of the partition blocks
-  u32 *d_bfrac, *d_bscount;   // bucket boundaries (two sets of BK_MAXB + 1 fractions of n0: even / odd steps) and the spawns the last bucket tail counted per bucket
-  int frac_B[2], scount_B;    // the bucket count each was made for / counted with (0: not valid)
-  bool scount_frac;           // the counts were taken with adaptive boundaries (those of the counting step's parity)
+  u32 *d_bkb, *d_bpos, *d_bscount;   // bucket boundaries (three sets of BK_MAXB + 1 keys: in use, counted with, being made), their positions in this step's list, the spawns the last bucket tail counted per bucket
+  int kb_B[3], scount_B;      // the bucket count each set was made for / the counts were taken with (0: not valid)
+  int kb_next, scount_buf, head_kb_use;   // set the next bucket head partitions with; set the counts were taken with; set the enqueued head uses (-1: equal-residents boundaries)
   double *d_prj_y; const double *head_prj_x; bool head_y_done;      // A x of the pipelined head's spare k_spawn blocks, the x it used
   double *d_prj_xs[2]; int xs_cur; bool xs_valid;      // snapshots of the deterministic-space weights by row, written by the bucket tail for the NEXT step's projection (two: one is read while the other is written)
   bool side_pending;          // death/clone and the projection of this step have not been launched as kernels: the bucket tail does them itself, any other tail must launch them first
@@ -253,9 +253,9 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
     c->cap_ftiles = std::max<long long>(nblk(M) + 1, BK_MAXB + 1);
     c->segoff_cap = ((std::min<long long>(M, 1ll << 20) + BK_T - 1) / BK_T + 1) * (BK_MAXB + 1);
     HIPCHK(hipMalloc(&c->d_segoff, c->segoff_cap * sizeof(unsigned short)));
-    HIPCHK(hipMalloc(&c->d_bfrac, 2 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMalloc(&c->d_bscount, (BK_MAXB + 1) * sizeof(u32)));
-    HIPCHK(hipMemset(c->d_bfrac, 0, 2 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMemset(c->d_bscount, 0, (BK_MAXB + 1) * sizeof(u32)));
-    c->frac_B[0] = c->frac_B[1] = 0; c->scount_B = 0; c->scount_frac = false;
+    HIPCHK(hipMalloc(&c->d_bkb, 3 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMalloc(&c->d_bpos, (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMalloc(&c->d_bscount, (BK_MAXB + 1) * sizeof(u32)));
+    HIPCHK(hipMemset(c->d_bkb, 0, 3 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMemset(c->d_bpos, 0, (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMemset(c->d_bscount, 0, (BK_MAXB + 1) * sizeof(u32)));
+    c->kb_B[0] = c->kb_B[1] = c->kb_B[2] = 0; c->scount_B = 0; c->kb_next = c->scount_buf = c->head_kb_use = -1;
     HIPCHK(hipMalloc(&c->d_fstate, 2 * c->cap_ftiles * 8)); HIPCHK(hipMalloc(&c->d_fticket, 4));
     HIPCHK(hipMemset(c->d_fstate, 0, 2 * c->cap_ftiles * 8)); HIPCHK(hipMemset(c->d_fticket, 0, 4));
     c->n_partial_blocks = std::max(nblk(M), BK_MAXB);
@@ -377,7 +377,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
     free_walk(c->w); free_walk(c->m);
     hipFree(c->d_nchild); hipFree(c->d_child_off); hipFree(c->d_wchild); hipFree(c->d_child_state);
     hipFree(c->d_keys); hipFree(c->d_keys_alt); hipFree(c->d_vals); hipFree(c->d_vals_alt); hipFree(c->d_hist); hipFree(c->d_rowtot);
-    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done); hipFree(c->d_segoff); hipFree(c->d_bfrac); hipFree(c->d_bscount);
+    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done); hipFree(c->d_segoff); hipFree(c->d_bkb); hipFree(c->d_bpos); hipFree(c->d_bscount);
   }
   hipFree(c->d_binom); hipFree(c->d_grow);
   for (int q = 0; q < 16; q++) hipFree(c->d_hbt[q]);
@@ -684,32 +684,37 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
       if (B >= 1) {
         hb.B = (int)B; hb.words = c->d_flags; hb.segoff = c->d_segoff; hb.state = c->d_fstate; hb.ticket = c->d_fticket;
         hb.scount = c->d_bscount;
-        // boundaries that follow the spawns: this step partitions with the set of its parity if that was made for B buckets; a spare
-        // block of its k_spawn makes the other set (for the next step) from the counts of the bucket tail that has just been enqueued
+        hb.nsb = (int)std::min<long long>(std::min<long long>(c->segoff_cap / (B + 1), M / BK_T), BK_CAP_ROWS);      // rows there is room for
+        // boundaries that follow the spawns: this head partitions with the set the last head's spare block made (if it was made for
+        // B buckets); its own spare block makes the next set from the counts of the bucket tail that has just been enqueued
         static const bool no_rebal = getenv("SQMC_BUCKET_UNIFORM") != nullptr;
-        const int par = (int)(step & 1);
+        c->head_kb_use = -1;
         if (!no_rebal && B <= BK_REBAL_MAXB && n_known >= 16 * B) {
-          if (c->frac_B[par] == (int)B) hb.frac = c->d_bfrac + par * (BK_MAXB + 1);
+          const int use = (c->kb_next >= 0 && c->kb_B[c->kb_next] == (int)B) ? c->kb_next : -1;
+          if (use >= 0) { hb.kb = c->d_bkb + use * (BK_MAXB + 1); hb.pos = c->d_bpos; }
+          c->head_kb_use = use;
           if (c->scount_B == (int)B) {
-            hb.frac_prev = c->scount_frac ? c->d_bfrac + (par ^ 1) * (BK_MAXB + 1) : (const u32 *)nullptr;
-            hb.frac_out = c->d_bfrac + (par ^ 1) * (BK_MAXB + 1);
-            c->frac_B[par ^ 1] = (int)B;
+            const int prev = (c->scount_buf >= 0 && c->kb_B[c->scount_buf] == (int)B) ? c->scount_buf : -1;
+            int out = 0; while (out == use || out == prev) out++;
+            hb.kb_prev = prev >= 0 ? c->d_bkb + prev * (BK_MAXB + 1) : (const u32 *)nullptr;
+            hb.kb_out = c->d_bkb + out * (BK_MAXB + 1);
+            c->kb_B[out] = (int)B; c->kb_next = out;
           }
         }
-        hb.nsb = (int)std::min<long long>(std::min<long long>(c->segoff_cap / (B + 1), M / BK_T), BK_CAP_ROWS);      // rows there is room for
       }
     }
+    { static const bool dbg = getenv("SQMC_DEBUG_KB") != nullptr; if (dbg && (step % 50) == 0) fprintf(stderr, "head step %llu: B %d kb %p kb_out %p kb_prev %p scount_B %d kb_next %d use %d est %lld n_known %lld holdoff %d\n", (unsigned long long)step, hb.B, (void *)hb.kb, (void *)hb.kb_out, (void *)hb.kb_prev, c->scount_B, c->kb_next, c->head_kb_use, c->last_nall, dev_n ? c->nwalk : n0, c->bk_holdoff); }
     c->head_ba = hb;
   }
   const long long nfree = dev_n ? M : M - n0;          // dev_n: nothing is known about the count but that it is >= 0
   const int spawn_fuse = (hb.B > 0 || spawn_fin.on || pp.n_imp > 0) ? 1 : 0;
   if (nfree > 0) {
     if (s0)
-      SPAWN_LAUNCH_EXT(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + (hb.frac_out ? 1 : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + (hb.frac_out ? 1 : 0));
+      SPAWN_LAUNCH_EXT(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
+                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0));
     else
-      SPAWN_LAUNCH(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + (hb.frac_out ? 1 : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + (hb.frac_out ? 1 : 0));
+      SPAWN_LAUNCH(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0));
   } else if (s0) { hipEventRecord(s0, st); hipEventRecord(s1, st); }
   HIPCHK(hipGetLastError());
   return SQMC_OK;
@@ -861,7 +866,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
 #undef BUCKET_ARGS
       c->bk_steps++;
       c->head_offsets_done = (go.child_off != nullptr);
-      c->scount_B = ba.B; c->scount_frac = (ba.frac != nullptr);
+      c->scount_B = ba.B; c->scount_buf = ba.kb ? c->head_kb_use : -1;
     } else { c->scount_B = 0; if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 3) ANNEAL_LAUNCH(3); else ANNEAL_LAUNCH(4); }
 #undef ANNEAL_LAUNCH
 #undef ANNEAL_ARGS
@@ -939,7 +944,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed); std::swap(c->w.irk, c->m.irk);
       if (fuse_gate) std::swap(c->d_keys, c->d_keys_alt);
       c->pipeline_next = false; c->bk_retries++; c->head_offsets_done = false;
-      c->frac_B[0] = c->frac_B[1] = 0; c->scount_B = 0;                 // boundaries are learnt anew
+      c->kb_B[0] = c->kb_B[1] = c->kb_B[2] = 0; c->scount_B = 0; c->kb_next = c->scount_buf = -1;      // boundaries are learnt anew
       { static const int hold = getenv("SQMC_BUCKET_HOLDOFF") ? atoi(getenv("SQMC_BUCKET_HOLDOFF")) : 8; c->bk_holdoff = hold; }
       return SQMC_INTERNAL_RETRY;
     }
@@ -1113,6 +1118,15 @@ static int run_steps(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *s
   }
   return SQMC_OK;
 }
+#ifdef BUCKET_PROF
+extern "C" int sqmc_gpu_debug_buckets(sqmc_gpu_ctx *c, unsigned int *kb3, unsigned int *pos, unsigned int *scount, int *state) {
+  hipStreamSynchronize(c->st);
+  hipMemcpy(kb3, c->d_bkb, 3 * (BK_MAXB + 1) * 4, hipMemcpyDeviceToHost); hipMemcpy(pos, c->d_bpos, (BK_MAXB + 1) * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(scount, c->d_bscount, (BK_MAXB + 1) * 4, hipMemcpyDeviceToHost);
+  state[0] = c->kb_next; state[1] = c->scount_buf; state[2] = c->head_kb_use; state[3] = c->scount_B; state[4] = c->kb_B[0]; state[5] = c->kb_B[1]; state[6] = c->kb_B[2];
+  return 0;
+}
+#endif
 int sqmc_gpu_slowest_steps(sqmc_gpu_ctx *c, double us[4], int64_t step[4]) {
   if (!c || !us || !step) return fail(SQMC_ERR_BAD_ARG, "null argument");
   for (int k = 0; k < 4; k++) { us[k] = c->slow_us[k]; step[k] = c->slow_step[k]; }

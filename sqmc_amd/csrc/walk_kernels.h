@@ -257,7 +257,10 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
     if (fin.on && xb == 0) { finish_all(fin, const_cast<DevScalars *>(sc)); return; }
     if (n_on_device && sc->retry) return;
     const int hb0 = xb - (fin.on ? 1 : 0);
-    if (ba.frac_out && xb == n_extra - 1) { bk_rebalance_block(ba.frac_prev, ba.scount, ba.B, ba.frac_out); return; }      // the last spare block
+    if ((ba.kb || ba.kb_out) && xb == n_extra - 1) {      // the last spare block: bucket boundaries (bucket_partition.h)
+      bk_rebalance_block(ba, keys, n_on_device ? (long long)sc->nwalk : n0_arg);
+      return;
+    }
     const int row = hb0 * (TPB / 64) + (int)(threadIdx.x >> 6);
     if (pp.n_imp > 0 && row < pp.n_imp) prj_row_product(pp, row);
     return;

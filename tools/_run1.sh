@@ -12,3 +12,4 @@ for f in sorted(glob.glob("gpurun_out/b_*.log")):
         if l.startswith("{"):
             d=json.loads(l); print(f, d["steps"], round(d["ms_per_step"]*1000,1), "us", d["config"]["short_list_tail"], d["config"].get("slowest_steps_us"), {k:round(v*1000,1) for k,v in d["roofline"]["stage_ms_per_step"].items()})
 PY
+timeout -k 10 400 python tools/bucket_prof.py > gpurun_out/bprof.log 2>&1; tail -19 gpurun_out/bprof.log

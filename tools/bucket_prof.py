@@ -49,6 +49,7 @@ print("S: mean %.0f max %d; R mean %.0f min %d max %d; T max %d" % (a[:, 12].mea
 ids = np.nonzero(np.array(buf, dtype=np.int64).reshape(1024, 16)[:, 0] != old[:, 0])[0]
 top = np.argsort(-(a[:, 12] + a[:, 13]))[:8]
 print("fullest buckets (id: R + S): " + ", ".join("%d: %d + %d" % (ids[i], a[i, 13], a[i, 12]) for i in top))
+np.save(os.path.join(ROOT, "gpurun_out", "bprof_rs.npy"), np.stack([ids, a[:, 13], a[:, 12], (a[:, 6] - a[:, 0]), (a[:, 3] - a[:, 2]), (a[:, 6] - a[:, 5])], axis=1))
 print("first buckets (id: R + S): " + ", ".join("%d: %d + %d" % (ids[i], a[i, 13], a[i, 12]) for i in range(6)))
 d = (a[:, 10] - a[:, 0]) / 100.0
 print("bucket life: mean %.1f max %.1f us; end skew mean %.1f" % (d.mean(), d.max(), (a[:, 10].max() - a[:, 10]).mean() / 100.0))
