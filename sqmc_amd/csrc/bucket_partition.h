@@ -36,6 +36,8 @@ struct BucketArgs {
   u32 *pos;                            // positions of kb in this step's resident list (B + 1): a spare block of k_spawn finds them, the tail reads them
   u32 *scount;                         // out, B + 1 words: spawns of every bucket, then n0 -- what the next boundaries are made from
   const u32 *kb_prev; u32 *kb_out;     // k_spawn's spare block: the next boundaries from scount and the boundaries it was counted with (null: equal residents)
+  const u32 *pos_prev;                 // where kb_prev lay in the list scount was taken from (the pos of that step)
+  const u32 *hint; u32 *hint_out;      // about where kb lies in today's list (found when it was made) / the same for kb_out
 };
 #define BK_REBAL_MAXB 256
 #define BK_REBAL_SPAWN_COST 1.2        // a spawn against a resident in a bucket's cost.  Its time to publish fits 7.1 + 0.0101 S + 0.0059 R us over the
@@ -45,16 +47,18 @@ __device__ __forceinline__ long long bk_bound(const BucketArgs &ba, int b, long 
   if (b >= ba.B) return n0;
   return ba.kb ? (long long)ba.pos[b] : ((long long)b * n0) / ba.B;
 }
-// first resident position whose key is >= k (rkeys: key << 32 | index, ascending); two searches at once: their loads are independent
-__device__ __forceinline__ void bk_lower_bound2(const u64 *__restrict__ rkeys, long long n0, u32 k1, u32 k2, bool do1, bool do2, long long &p1, long long &p2) {
-  long long lo1 = 0, hi1 = do1 ? n0 : 0, lo2 = 0, hi2 = do2 ? n0 : 0;
-  while (lo1 < hi1 || lo2 < hi2) {
-    const long long m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
-    const u64 v1 = (lo1 < hi1) ? rkeys[m1] : 0ull, v2 = (lo2 < hi2) ? rkeys[m2] : 0ull;
-    if (lo1 < hi1) { if ((u32)(v1 >> 32) < k1) lo1 = m1 + 1; else hi1 = m1; }
-    if (lo2 < hi2) { if ((u32)(v2 >> 32) < k2) lo2 = m2 + 1; else hi2 = m2; }
-  }
-  p1 = lo1; p2 = lo2;
+// first resident position whose key is >= k (rkeys: key << 32 | index, ascending), looked for around `hint` first: the list
+// changes by a fraction of a percent from step to step, so a boundary found yesterday is within a few hundred places today
+__device__ __forceinline__ long long bk_lower_bound_near(const u64 *__restrict__ rkeys, long long n0, u32 k, long long hint) {
+  const long long W = 384;
+  long long lo = hint - W < 0 ? 0 : hint - W, hi = hint + W > n0 ? n0 : hint + W;
+  if (lo > hi) lo = hi;
+  const u64 vlo = (lo > 0 && lo < n0) ? rkeys[lo] : 0ull, vhi = (hi > 0 && hi < n0) ? rkeys[hi - 1] : 0ull;      // both in flight
+  if (lo > 0 && (lo >= n0 || (u32)(vlo >> 32) >= k)) lo = 0;
+  if (hi < n0 && hi > 0 && (u32)(vhi >> 32) < k) hi = n0;
+  if (hi == 0) hi = n0;
+  while (lo < hi) { const long long m = (lo + hi) >> 1; if ((u32)(rkeys[m] >> 32) < k) lo = m + 1; else hi = m; }
+  return lo;
 }
 // One block of BK_T threads beside the spawning blocks of k_spawn: (1) where this step's boundaries lie in this step's resident
 // list; (2) the next boundaries: every bucket the same cost, if residents and spawns fall as they did when scount was taken,
@@ -68,16 +72,16 @@ __device__ __forceinline__ void bk_rebalance_block(const BucketArgs &ba, const u
   const int tid = threadIdx.x, B = ba.B;
   if (tid == 0) s_bad = 0;
   for (int j = tid; j <= B; j += BK_T) {
-    long long p1 = 0, p2 = 0;
     const bool inner = j > 0 && j < B;
-    bk_lower_bound2(rkeys, n0, (inner && ba.kb) ? ba.kb[j] : 0u, (inner && ba.kb_out && ba.kb_prev) ? ba.kb_prev[j] : 0u, inner && ba.kb != nullptr,
-                    inner && ba.kb_out != nullptr && ba.kb_prev != nullptr, p1, p2);
-    if (ba.kb) ba.pos[j] = (j == 0) ? 0u : (j == B ? (u32)n0 : (u32)p1);
+    if (ba.kb) ba.pos[j] = (j == 0) ? 0u : (j == B ? (u32)n0 : (u32)bk_lower_bound_near(rkeys, n0, ba.kb[j], ba.hint ? (long long)ba.hint[j] : n0 / 2));
     if (ba.kb_out) {
-      const u32 pp = (j == 0) ? 0u : (j == B ? (u32)n0 : (ba.kb_prev ? (u32)p2 : (u32)(((long long)j * n0) / B)));
-      s_pp[j] = pp;
-      s_kk[j] = (j == 0) ? 0u : (j == B ? (u32)(rkeys[n0 - 1] >> 32) + 1u : (ba.kb_prev ? ba.kb_prev[j] : (u32)(rkeys[pp] >> 32)));
+      // the boundaries of then, where they lay then: the residents they held are the ones the spawns were counted beside
+      long long pp = (j == 0) ? 0 : (j == B ? n0 : ((ba.kb_prev && ba.pos_prev) ? (long long)ba.pos_prev[j] : ((long long)j * n0) / B));
+      if (pp > n0) pp = n0;
+      s_pp[j] = (u32)pp;
+      s_kk[j] = (j == 0) ? 0u : (j == B ? (u32)(rkeys[n0 - 1] >> 32) + 1u : ((ba.kb_prev && ba.pos_prev) ? ba.kb_prev[j] : (u32)(rkeys[pp < n0 ? pp : n0 - 1] >> 32)));
     }
+    (void)inner;
   }
   if (!ba.kb_out) return;
   __syncthreads();
@@ -115,17 +119,12 @@ __device__ __forceinline__ void bk_rebalance_block(const BucketArgs &ba, const u
       }
       const u32 cap_k = (a < p_hi) ? (u32)(rkeys[a] >> 32) : K_hi;                   // not past the first resident that was not admitted
       if (kn > cap_k) kn = cap_k;
-    }
+      s_pn[j] = a;                       // kn lies in (key(a - 1), key(a)]: a is its place in today's list
+    } else s_pn[j] = (j == 0) ? 0u : (u32)n0;
     s_kn[j] = kn;
   }
   __syncthreads();
-  for (int j = tid; j <= B; j += BK_T) {      // where the new boundaries lie in today's list: what the blocks would have to hold
-    long long p1 = 0, p2 = 0;
-    const bool inner = j > 0 && j < B;
-    bk_lower_bound2(rkeys, n0, s_kn[j], 0u, inner, false, p1, p2);
-    s_pn[j] = (j == 0) ? 0u : (j == B ? (u32)n0 : (u32)p1);
-    if (inner && s_kn[j] <= s_kn[j - 1]) s_bad = 1;
-  }
+  for (int j = tid + 1; j < B; j += BK_T) if (s_kn[j] <= s_kn[j - 1] || s_pn[j] < s_pn[j - 1]) s_bad = 1;
   __syncthreads();
   for (int j = tid; j < B; j += BK_T) {
     const u32 r = s_pn[j + 1] - s_pn[j];
@@ -133,7 +132,10 @@ __device__ __forceinline__ void bk_rebalance_block(const BucketArgs &ba, const u
   }
   __syncthreads();
   const bool bad = s_bad != 0;
-  for (int j = tid; j < B; j += BK_T) ba.kb_out[j] = (j == 0) ? 0u : (bad ? (u32)(rkeys[((long long)j * n0) / B] >> 32) : s_kn[j]);
+  for (int j = tid; j < B; j += BK_T) {
+    ba.kb_out[j] = (j == 0) ? 0u : (bad ? (u32)(rkeys[((long long)j * n0) / B] >> 32) : s_kn[j]);
+    if (ba.hint_out) ba.hint_out[j] = bad ? (u32)(((long long)j * n0) / B) : s_pn[j];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ partition

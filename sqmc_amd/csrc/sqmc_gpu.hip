@@ -157,6 +157,7 @@ struct sqmc_gpu_ctx {
   int scan_flip, scan_used[2];   // gate-fused heads: look-back set of the next head scan, and how many words of each set its last scan may have touched
   bool residents_sorted;      // the walker arrays are known to be in (up, dn) order: true after every finished step and after an upload (which refuses unsorted lists)
   unsigned short *d_segoff; long long segoff_cap;      // bucket tail: group offsets of the partition blocks
+  u32 *d_bhint; int pos_flip, scount_pos;      // where each boundary set lay when it was made (3 x BK_MAXB + 1); which of the two d_bpos halves this step writes / the counts were taken with
   u32 *d_bkb, *d_bpos, *d_bscount;   // bucket boundaries (three sets of BK_MAXB + 1 keys: in use, counted with, being made), their positions in this step's list, the spawns the last bucket tail counted per bucket
   int kb_B[3], scount_B;      // the bucket count each set was made for / the counts were taken with (0: not valid)
   int kb_next, scount_buf, head_kb_use;   // set the next bucket head partitions with; set the counts were taken with; set the enqueued head uses (-1: equal-residents boundaries)
@@ -253,8 +254,8 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
     c->cap_ftiles = std::max<long long>(nblk(M) + 1, BK_MAXB + 1);
     c->segoff_cap = ((std::min<long long>(M, 1ll << 20) + BK_T - 1) / BK_T + 1) * (BK_MAXB + 1);
     HIPCHK(hipMalloc(&c->d_segoff, c->segoff_cap * sizeof(unsigned short)));
-    HIPCHK(hipMalloc(&c->d_bkb, 3 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMalloc(&c->d_bpos, (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMalloc(&c->d_bscount, (BK_MAXB + 1) * sizeof(u32)));
-    HIPCHK(hipMemset(c->d_bkb, 0, 3 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMemset(c->d_bpos, 0, (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMemset(c->d_bscount, 0, (BK_MAXB + 1) * sizeof(u32)));
+    HIPCHK(hipMalloc(&c->d_bkb, 3 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMalloc(&c->d_bpos, 2 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMalloc(&c->d_bhint, 3 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMemset(c->d_bhint, 0, 3 * (BK_MAXB + 1) * sizeof(u32))); c->pos_flip = 0; c->scount_pos = 0; HIPCHK(hipMalloc(&c->d_bscount, (BK_MAXB + 1) * sizeof(u32)));
+    HIPCHK(hipMemset(c->d_bkb, 0, 3 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMemset(c->d_bpos, 0, 2 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMemset(c->d_bscount, 0, (BK_MAXB + 1) * sizeof(u32)));
     c->kb_B[0] = c->kb_B[1] = c->kb_B[2] = 0; c->scount_B = 0; c->kb_next = c->scount_buf = c->head_kb_use = -1;
     HIPCHK(hipMalloc(&c->d_fstate, 2 * c->cap_ftiles * 8)); HIPCHK(hipMalloc(&c->d_fticket, 4));
     HIPCHK(hipMemset(c->d_fstate, 0, 2 * c->cap_ftiles * 8)); HIPCHK(hipMemset(c->d_fticket, 0, 4));
@@ -377,7 +378,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
     free_walk(c->w); free_walk(c->m);
     hipFree(c->d_nchild); hipFree(c->d_child_off); hipFree(c->d_wchild); hipFree(c->d_child_state);
     hipFree(c->d_keys); hipFree(c->d_keys_alt); hipFree(c->d_vals); hipFree(c->d_vals_alt); hipFree(c->d_hist); hipFree(c->d_rowtot);
-    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done); hipFree(c->d_segoff); hipFree(c->d_bkb); hipFree(c->d_bpos); hipFree(c->d_bscount);
+    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done); hipFree(c->d_segoff); hipFree(c->d_bkb); hipFree(c->d_bhint); hipFree(c->d_bpos); hipFree(c->d_bscount);
   }
   hipFree(c->d_binom); hipFree(c->d_grow);
   for (int q = 0; q < 16; q++) hipFree(c->d_hbt[q]);
@@ -691,19 +692,19 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
         c->head_kb_use = -1;
         if (!no_rebal && B <= BK_REBAL_MAXB && n_known >= 16 * B) {
           const int use = (c->kb_next >= 0 && c->kb_B[c->kb_next] == (int)B) ? c->kb_next : -1;
-          if (use >= 0) { hb.kb = c->d_bkb + use * (BK_MAXB + 1); hb.pos = c->d_bpos; }
+          if (use >= 0) { c->pos_flip ^= 1; hb.kb = c->d_bkb + use * (BK_MAXB + 1); hb.pos = c->d_bpos + c->pos_flip * (BK_MAXB + 1); hb.hint = c->d_bhint + use * (BK_MAXB + 1); }
           c->head_kb_use = use;
           if (c->scount_B == (int)B) {
             const int prev = (c->scount_buf >= 0 && c->kb_B[c->scount_buf] == (int)B) ? c->scount_buf : -1;
             int out = 0; while (out == use || out == prev) out++;
             hb.kb_prev = prev >= 0 ? c->d_bkb + prev * (BK_MAXB + 1) : (const u32 *)nullptr;
-            hb.kb_out = c->d_bkb + out * (BK_MAXB + 1);
+            hb.kb_out = c->d_bkb + out * (BK_MAXB + 1); hb.hint_out = c->d_bhint + out * (BK_MAXB + 1);
+            hb.pos_prev = prev >= 0 ? c->d_bpos + c->scount_pos * (BK_MAXB + 1) : (const u32 *)nullptr;
             c->kb_B[out] = (int)B; c->kb_next = out;
           }
         }
       }
     }
-    { static const bool dbg = getenv("SQMC_DEBUG_KB") != nullptr; if (dbg && (step % 50) == 0) fprintf(stderr, "head step %llu: B %d kb %p kb_out %p kb_prev %p scount_B %d kb_next %d use %d est %lld n_known %lld holdoff %d\n", (unsigned long long)step, hb.B, (void *)hb.kb, (void *)hb.kb_out, (void *)hb.kb_prev, c->scount_B, c->kb_next, c->head_kb_use, c->last_nall, dev_n ? c->nwalk : n0, c->bk_holdoff); }
     c->head_ba = hb;
   }
   const long long nfree = dev_n ? M : M - n0;          // dev_n: nothing is known about the count but that it is >= 0
@@ -866,7 +867,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
 #undef BUCKET_ARGS
       c->bk_steps++;
       c->head_offsets_done = (go.child_off != nullptr);
-      c->scount_B = ba.B; c->scount_buf = ba.kb ? c->head_kb_use : -1;
+      c->scount_B = ba.B; c->scount_buf = ba.kb ? c->head_kb_use : -1; c->scount_pos = c->pos_flip;
     } else { c->scount_B = 0; if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 3) ANNEAL_LAUNCH(3); else ANNEAL_LAUNCH(4); }
 #undef ANNEAL_LAUNCH
 #undef ANNEAL_ARGS
