@@ -179,8 +179,14 @@ def main():
     else:
         # equilibration + warmup (untimed), then EXACTLY --steps timed steps inside sqmc_gpu_run
         walk.run(args.equil, keep_stats=False)
+        walk.g.set_timing(0 if os.environ.get('SQMC_BENCH_NO_EVENTS') else 1)           # HIP events around the k_spawn / k_anneal launches only (every 8th step), accumulated from here on
+        # A host that walks in blocks calls sqmc_gpu_run once per block; with chained runs the last step of a call enqueues the head
+        # of the first step of the next one, as every step does for its successor.  Warm-up and timed region are two such calls: the K
+        # timed steps then are K tails and K heads (the last one enqueues -- and the closing fence waits for -- the head of a step
+        # after the region, as the warm-up's last step did for the region's first).  SQMC_BENCH_NO_CHAIN=1: the first timed step starts cold.
+        chain = not sharded and not os.environ.get('SQMC_BENCH_NO_CHAIN')
+        if chain: walk.g.set_chained_runs(True)
         walk.run(args.warmup, keep_stats=False)
-        walk.g.set_timing(0 if os.environ.get('SQMC_BENCH_NO_EVENTS') else 1)           # HIP events around the k_spawn / k_anneal launches only, accumulated over the timed steps
         fence()
         t0 = time.perf_counter()
         stats, totals = walk.run(args.steps, keep_stats=True)
@@ -189,7 +195,8 @@ def main():
         nwalk_sum, spawn_sum = float(totals[5]) / (world if sharded else 1), float(totals[15])      # sharded: nwalk is the global count
         e_num, e_den = float((stats[:, 3] * np.sign(stats[:, 2])).sum()), float(np.abs(stats[:, 2]).sum())
         slowest = walk.g.slowest_steps()                   # wall clock of the slowest timed steps: host jitter, reruns
-        timers_timed = walk.g.timing()                     # mean ms per k_spawn / k_anneal launch over the K timed steps
+        if chain: walk.g.set_chained_runs(False)          # forgets the head the last timed step enqueued
+        timers_timed = walk.g.timing()                     # mean ms per k_spawn / k_anneal launch (warm-up and timed steps)
         spawn_ms = dict(timers_timed).get("spawn", float('nan'))
         walk.g.set_timing(2)                                # informational stage breakdown from an untimed tail
         walk.run(20, keep_stats=False)
@@ -247,7 +254,7 @@ def main():
                        "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": parallelism,
                        "rccl_ranks": rccl_ranks, "devices": min(world, ndev),
                        "short_list_tail": dict(zip(("bucket_steps", "rerun_through_radix_tail"), tail)),
-                       "slowest_steps_us": slowest},
+                       "slowest_steps_us": slowest, "chained_runs": bool(not sharded and not os.environ.get('SQMC_BENCH_NO_CHAIN'))},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic_of(dom)[0], "traffic_detail": traffic_of(dom)[1], "ms_per_launch": dom_ms,
                          "algorithmic_bytes_per_launch": dom_bytes,

@@ -263,6 +263,13 @@ int sqmc_gpu_shard_run(sqmc_gpu_ctx *ctx, sqmc_popctl *pc, int64_t nsteps, doubl
 /* How many steps took the short-list tail (block-local partition + one annihilation kernel per key range, no global sort) and
  * how many of those had to be re-run through the radix tail because a key range outgrew its block (diagnostics, tests). */
 int sqmc_gpu_tail_stats(sqmc_gpu_ctx *ctx, int64_t *bucket_steps, int64_t *bucket_retries);
+/* A host that runs the walk in blocks (nstep steps, then its block statistics: do_walk.f90:2171 inside the iblk loop, 2086-3300)
+ * calls sqmc_gpu_run once per block.  With chained runs on, the last step of a call enqueues the head (gate, child offsets, spawn)
+ * of the first step of the NEXT call behind its own tail, as every other step of the call does for its successor, so the GPU keeps
+ * working while the host does its block bookkeeping (the first step of a call costs 0.135 instead of 0.075 ms otherwise).  The
+ * head is forgotten, at the cost of one stream synchronisation, if anything but a step with the same tau / cutoff / mode comes
+ * next (walkers uploaded or downloaded, projector rescaled, RNG reset, chaining switched off, finalize).  Single-GPU steps only. */
+int sqmc_gpu_set_chained_runs(sqmc_gpu_ctx *ctx, int32_t on);
 /* diagnostics: wall-clock time (microseconds) and index of the four slowest steps of the last sqmc_gpu_run / sqmc_gpu_shard_run
  * call -- a step that waited for the host (scheduling, a rerun through the radix tail) stands out here */
 int sqmc_gpu_slowest_steps(sqmc_gpu_ctx *ctx, double us[4], int64_t step[4]);

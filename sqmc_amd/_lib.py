@@ -16,7 +16,7 @@ EXPORTS = [
     "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
     "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_annihilate", "sqmc_gpu_det_owner", "sqmc_gpu_set_owner_hash", "sqmc_gpu_shard_config",
     "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init", "sqmc_gpu_comm_size",
-    "sqmc_gpu_shard_step", "sqmc_gpu_shard_run", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_tail_stats", "sqmc_gpu_slowest_steps", "sqmc_gpu_spmv_prepare",
+    "sqmc_gpu_shard_step", "sqmc_gpu_shard_run", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_tail_stats", "sqmc_gpu_slowest_steps", "sqmc_gpu_set_chained_runs", "sqmc_gpu_spmv_prepare",
     "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_build_spmv_plan", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
     "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_hci_connections_slice", "sqmc_gpu_hci_pt2", "sqmc_gpu_hci_set_active_space", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
 ]
@@ -308,6 +308,11 @@ class GpuChem:
         self.L.sqmc_gpu_tail_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _chk(self.L.sqmc_gpu_tail_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def set_chained_runs(self, on):
+        """sqmc_gpu_set_chained_runs: keep the step pipeline primed across run() calls (block-structured hosts)"""
+        self.L.sqmc_gpu_set_chained_runs.argtypes = [C.c_void_p, C.c_int32]
+        _chk(self.L.sqmc_gpu_set_chained_runs(self.h, 1 if on else 0))
 
     def slowest_steps(self):
         """[(microseconds, step index)] of the four slowest steps of the last run() call"""

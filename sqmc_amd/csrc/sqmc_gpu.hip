@@ -152,6 +152,7 @@ struct sqmc_gpu_ctx {
   hipStream_t st3; hipEvent_t e_join3;                   // third stream: the deterministic projection (it touches the deterministic-space walkers only, death/clone all the others)
   // pipelined head (sqmc_gpu_run, COUNTER discipline, target population reached): gate + scan + spawn of step n+1 are
   // enqueued right behind k_finish of step n, before the host has read step n's sums
+  bool chained_runs;          // sqmc_gpu_set_chained_runs: the last step of a run call enqueues the head of the first step of the next call
   bool pipeline_next, head_ready; StepP head_p; u64 head_cseq; hipEvent_t hev[4];
   bool owner_ready;           // this step's k_spawn already wrote the owner key of every child (sharded steps)
   int scan_flip, scan_used[2];   // gate-fused heads: look-back set of the next head scan, and how many words of each set its last scan may have touched
@@ -175,6 +176,9 @@ struct sqmc_gpu_ctx {
   int bk_holdoff;             // steps for which the bucket tail stays off (after a bucket overflowed or came close)
   long long bk_steps, bk_retries;
 };
+// a head enqueued for a step that is not going to be the next thing that happens (chained runs): forget it
+static void abandon_head(sqmc_gpu_ctx *c);
+
 
 #include "walk_kernels.h"
 #define SPAWN_LAUNCH(HB_, FUSE_, ...) do { if (HB_) hipLaunchKernelGGL((k_spawn<1, 1>), __VA_ARGS__); else if (FUSE_) hipLaunchKernelGGL((k_spawn<0, 1>), __VA_ARGS__); else hipLaunchKernelGGL((k_spawn<0, 0>), __VA_ARGS__); } while (0)
@@ -372,6 +376,7 @@ int sqmc_gpu_init_hubbard(const sqmc_hubbard_cfg *cfg, sqmc_gpu_ctx **out) {
 
 static void comm_release(sqmc_gpu_ctx *c);
 int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
+  abandon_head(c);
   if (!c) return SQMC_OK;
   hipStreamSynchronize(c->st);
   if (c->mwalk > 0) {
@@ -411,6 +416,7 @@ int sqmc_gpu_set_hb_tables(sqmc_gpu_ctx *c, int64_t n_hb, const int32_t *r, cons
 }
 
 int sqmc_gpu_set_projector(sqmc_gpu_ctx *c, int64_t n_imp, int64_t nnz, const int64_t *rc, const int64_t *idx, const double *val) {
+  abandon_head(c);
   if (!c) return fail(SQMC_ERR_BAD_ARG, "null ctx");
   long long chk = 0; for (long long i = 0; i < n_imp; i++) chk += rc[i];
   if (chk != nnz) return fail(SQMC_ERR_BAD_ARG, "sum(row_counts) != nnz");
@@ -430,6 +436,7 @@ int sqmc_gpu_set_projector(sqmc_gpu_ctx *c, int64_t n_imp, int64_t nnz, const in
   return SQMC_OK;
 }
 int sqmc_gpu_scale_projector(sqmc_gpu_ctx *c, double ratio) {
+  abandon_head(c);
   if (!c || !c->d_prj_val) return fail(SQMC_ERR_BAD_ARG, "no projector");
   hipLaunchKernelGGL(k_scale, dim3(nblk(c->prj_nnz)), dim3(TPB), 0, c->st, c->d_prj_val, c->prj_nnz, ratio);
   HIPCHK(hipGetLastError());
@@ -437,6 +444,7 @@ int sqmc_gpu_scale_projector(sqmc_gpu_ctx *c, double ratio) {
 }
 
 int sqmc_gpu_set_ct_table(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, const uint64_t *dn, const double *num, const double *den) {
+  abandon_head(c);
   if (!c) return fail(SQMC_ERR_BAD_ARG, "null ctx");
   for (long long i = 1; i < n; i++)
     if (!(up[i - 1] < up[i] || (up[i - 1] == up[i] && dn[i - 1] < dn[i]))) return fail(SQMC_ERR_BAD_ARG, "C(T) list must be strictly sorted by (up,dn)");
@@ -464,6 +472,7 @@ int sqmc_gpu_set_ct_table(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, const 
 
 int sqmc_gpu_upload_walkers(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, const uint64_t *dn, const double *wt, const int8_t *impd,
                             const int8_t *init, const int8_t *psign, const double *me, const double *en, const double *ed) {
+  abandon_head(c);
   if (!c || c->mwalk <= 0) return fail(SQMC_ERR_BAD_ARG, "context has no walker arrays (mwalk=0)");
   if (n > c->mwalk) return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
   const u64 lim = c->htab.orb_mask;
@@ -493,6 +502,7 @@ int sqmc_gpu_upload_walkers(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, cons
 int sqmc_gpu_num_walkers(sqmc_gpu_ctx *c, int64_t *n) { if (!c || !n) return SQMC_ERR_BAD_ARG; *n = c->nwalk; return SQMC_OK; }
 int sqmc_gpu_download_walkers(sqmc_gpu_ctx *c, int64_t cap, int64_t *n, uint64_t *up, uint64_t *dn, double *wt, int8_t *impd, int8_t *init,
                               double *me, double *en, double *ed) {
+  abandon_head(c);
   if (!c || !n) return fail(SQMC_ERR_BAD_ARG, "null");
   HIPCHK(hipStreamSynchronize(c->st));
   *n = c->nwalk;
@@ -524,6 +534,7 @@ int sqmc_gpu_get_rng(sqmc_gpu_ctx *c, int32_t seed[4]) {
   return SQMC_OK;
 }
 int sqmc_gpu_set_rng(sqmc_gpu_ctx *c, const int32_t seed[4]) {
+  abandon_head(c);
   if (!c) return SQMC_ERR_BAD_ARG;
   u64 x = (((u64)seed[0] << 36) + ((u64)seed[1] << 24) + ((u64)seed[2] << 12) + (u64)(2 * (seed[3] / 2) + 1)) & SQ_MASK48;
   HIPCHK(hipStreamSynchronize(c->st)); HIPCHK(hipMemcpy(&c->d_sc->lcg, &x, 8, hipMemcpyHostToDevice));
@@ -533,6 +544,7 @@ int sqmc_gpu_set_rng(sqmc_gpu_ctx *c, const int32_t seed[4]) {
 
 static void collect_timers(sqmc_gpu_ctx *c);
 int sqmc_gpu_set_timing(sqmc_gpu_ctx *c, int on) {
+  abandon_head(c);
   if (!c) return SQMC_ERR_BAD_ARG;
   hipStreamSynchronize(c->st); hipStreamSynchronize(c->st2); hipStreamSynchronize(c->st3); c->timers_pending = false;
   c->timing = on; c->tsteps = 0; c->nt = 0;
@@ -727,6 +739,12 @@ static void drop_head(sqmc_gpu_ctx *c) {
   hipStreamSynchronize(c->st);
   hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
   c->scan_used[0] = c->scan_used[1] = 0;
+}
+static void abandon_head(sqmc_gpu_ctx *c) {
+  if (!c || !c->head_ready) return;
+  drop_head(c);                          // waits for its kernels (they wrote scratch only: keys, child offsets, spawn records, partition rows) and re-zeroes the scan words
+  c->head_ba.B = 0; c->head_offsets_done = false; c->head_y_done = false; c->head_hii = false; c->head_hii_joined = false; c->head_prj_x = nullptr;
+  c->side_pending = false; c->xs_valid = false; c->tail_fills_hii = false; c->fork_valid = false;
 }
 // sort -> merge -> round -> compact/estimate -> readback; shared by the single-rank step and
 // the sharded step (where the spawns behind slot n0 arrived from other ranks)
@@ -996,6 +1014,10 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   if (c->timing >= 2 && c->nt < NTIMERS) { t_gate_scan = c->nt++; c->tname[t_gate_scan] = "gate_scan"; }
   if (kernel_events_on(c, step) && c->nt < NTIMERS) { t_spawn = c->nt++; c->tname[t_spawn] = "spawn"; }
   u64 cseq;
+  if (c->head_ready) {                 // chained runs: the caller came back with other parameters than it left with
+    const StepP &h0 = c->head_p;
+    if (h0.tau != p.tau || h0.cutoff != p.cutoff || h0.semi != p.semi || h0.cti != p.cti || mode == SQMC_RNG_REPLAY) abandon_head(c);
+  }
   const bool from_head = c->head_ready;
   if (c->head_ready) {
     // gate + scan + spawn of this step already run behind k_finish of the last one (pipelined head):
@@ -1081,7 +1103,7 @@ static int run_steps(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *s
     sp.reached_w_abs_gen = pc->reached_w_abs_gen; sp.reserved = 0;
     // pipelined head: once the target population has been reached tau and r_initiator stay put, and the head of a step
     // (gate, scan, spawn) depends on nothing else that this step's sums could change
-    c->pipeline_next = ((one_step == (step_fn)sqmc_gpu_step || (one_step == (step_fn)sqmc_gpu_shard_step && c->comm != nullptr && !getenv("SQMC_SHARD_NO_PIPELINE"))) && it + 1 < nsteps &&
+    c->pipeline_next = ((one_step == (step_fn)sqmc_gpu_step || (one_step == (step_fn)sqmc_gpu_shard_step && c->comm != nullptr && !getenv("SQMC_SHARD_NO_PIPELINE"))) && (it + 1 < nsteps || (c->chained_runs && one_step == (step_fn)sqmc_gpu_step)) &&
                         pc->reached_w_abs_gen == 2 && c->rng_mode != SQMC_RNG_REPLAY && !getenv("SQMC_NO_PIPELINE"));
     double out[16];
     int r = one_step(c, &sp, out);
@@ -1128,6 +1150,12 @@ extern "C" int sqmc_gpu_debug_buckets(sqmc_gpu_ctx *c, unsigned int *kb3, unsign
   return 0;
 }
 #endif
+int sqmc_gpu_set_chained_runs(sqmc_gpu_ctx *c, int32_t on) {
+  if (!c) return fail(SQMC_ERR_BAD_ARG, "null argument");
+  c->chained_runs = on != 0;
+  if (!on) abandon_head(c);
+  return SQMC_OK;
+}
 int sqmc_gpu_slowest_steps(sqmc_gpu_ctx *c, double us[4], int64_t step[4]) {
   if (!c || !us || !step) return fail(SQMC_ERR_BAD_ARG, "null argument");
   for (int k = 0; k < 4; k++) { us[k] = c->slow_us[k]; step[k] = c->slow_step[k]; }
@@ -1153,6 +1181,7 @@ __global__ void __launch_bounds__(TPB) k_spawn_keys(ChemDev dev, WalkArr w, u64 
 // parity tests use to put hand-built collision cases through k_merge.
 int sqmc_gpu_annihilate(sqmc_gpu_ctx *c, const sqmc_step_params *sp, int64_t n_spawn, const uint64_t *up, const uint64_t *dn, const double *wt,
                         const int8_t *impd, const int8_t *init, double out[16]) {
+  abandon_head(c);
   if (!c || !sp || !out || n_spawn < 0) return fail(SQMC_ERR_BAD_ARG, "bad argument");
   if (n_spawn > 0 && (!up || !dn || !wt || !impd || !init)) return fail(SQMC_ERR_BAD_ARG, "null spawn array");
   if (c->mwalk <= 0 || c->nwalk <= 0) return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0");

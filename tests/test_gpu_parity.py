@@ -574,6 +574,42 @@ def test_heg_matrix_elements_and_proposals_bit_exact(oracle, heg14):
     assert nz > n // 10
 
 
+def test_chained_runs_walk_the_same_trajectory():
+    """sqmc_gpu_set_chained_runs: a block-structured host (one sqmc_gpu_run per block) keeps the step pipeline primed across
+    its calls -- the last step of a call enqueues the head of the first step of the next.  The walk must be the one an
+    unchained host walks, bit for bit; a pending head must be forgotten when something else comes next (a download, a
+    projector rescale, other step parameters), and switching chaining off must leave nothing behind."""
+    from conftest import FCIDUMP
+    from sqmc_amd import host as H
+    hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+    def fresh():
+        return H.GpuWalk(hst, 2e4, seed=SEED, mwalk=400000)
+    a = fresh(); a.run(340, keep_stats=False); wa = a.g.download_walkers(); a.close()
+    b = fresh(); b.run(300, keep_stats=False)
+    assert b.pc.reached == 2
+    b.g.set_chained_runs(True)
+    sb = [b.run(n, keep_stats=True)[0] for n in (7, 1, 13, 19)]
+    mid = b.g.download_walkers()                       # a pending head is forgotten here ...
+    b.g.set_chained_runs(False)
+    wb = b.g.download_walkers()
+    assert all(np.array_equal(mid[k], wb[k]) for k in ("up", "dn", "wt"))
+    for k in ("up", "dn", "wt", "initiator", "imp_distance"):
+        assert np.array_equal(wa[k], wb[k]), k
+    # ... and when the caller comes back with another tau: the step must run as if nothing had been enqueued
+    b.g.set_chained_runs(True)
+    b.run(5, keep_stats=False)
+    c = fresh(); c.run(345, keep_stats=False)
+    for w_ in (b, c):
+        w_.pc.tau_sav *= 0.5; w_.pc.tau = w_.pc.tau_prev = w_.pc.tau_sav
+        w_.g.scale_projector(0.5)
+    b.run(6, keep_stats=False); c.run(6, keep_stats=False)
+    b.g.set_chained_runs(False)
+    wb2, wc2 = b.g.download_walkers(), c.g.download_walkers()
+    b.close(); c.close()
+    for k in ("up", "dn", "wt"):
+        assert np.array_equal(wb2[k], wc2[k]), k
+
+
 @pytest.mark.parametrize("rng_mode,nsteps", [(0, 60), (1, 120)])
 def test_heg_walk_trajectory_bit_exact(oracle, heg14, heg_setup, rng_mode, nsteps):
     """BASELINE.json configs[3] system (14-electron 3D HEG) at a size the oracle runs: the same
