@@ -262,6 +262,7 @@ def run_walk(deck, fcidump="FCIDUMP", out=sys.stdout, walkalize=None, max_equil_
     e_blk_prev = 1e300
     n_walker_steps, t_steps = 0.0, 0.0
     announced_reached = False
+    g.set_chained_runs(True)          # one sqmc_gpu_run per block: the last step of a block enqueues the head of the next block's first step
     while iblkk <= ntimes * nblk_eq + nblk:
         in_equil = iblkk <= ntimes * nblk_eq
         if (nblk_eq == 1 or iblkk % nblk_eq == 1) and iblkk <= ntimes * nblk_eq + 1:
@@ -316,6 +317,7 @@ def run_walk(deck, fcidump="FCIDUMP", out=sys.stdout, walkalize=None, max_equil_
                 ntimes += 1
         w_abs_blk_prev, w_perm_blk_prev, e_blk_prev = w_abs_blk, w_perm_blk, e_blk
         iblkk += 1
+    g.set_chained_runs(False)
     passes = float(nstep) * nblk
     p("e_genabs_ave, e_genabs_err, e_blkabs_ave, e_blkabs_err=%12.4E%12.4E%12.4E%12.4E" % (st.e_genabs_ave, st.e_genabs_err, st.e_blkabs_ave, st.e_blkabs_err))
     ratio_n = st.nwalk_cum / st.nwalk_before_cum if st.nwalk_before_cum else 0.0
