@@ -188,9 +188,20 @@ __device__ __forceinline__ double bk_hii_group(const ChemTab &t, const double *_
   __syncthreads();
   double acc = 0.0;
   if (valid) {
-    if (g == 0) { for (int q = 0; q < L_e1; q++) acc = acc + sg[q]; if (same) acc = acc * 2.0; }
-    else if (g == 1) { for (int q = 0; q < L_ex; q++) acc = acc - sg[o_ex + q]; if (same) acc = acc * 2.0; }
-    else if (g == 2) { for (int q = 0; q < L_di; q++) acc = acc + sg[o_di + q]; }
+    // one lane per sum, terms in the reference's order; eight LDS reads are requested before the first of them is added (the
+    // additions stay sequential, the reads need not wait for one another: 28 dependent read-add pairs were 1.7 of this phase's 7 us)
+    const int o = (g == 0) ? 0 : (g == 1 ? o_ex : o_di), L = (g == 0) ? L_e1 : (g == 1 ? L_ex : (g == 2 ? L_di : 0));
+    const double sgn = (g == 1) ? -1.0 : 1.0;
+    int q = 0;
+    for (; q + 8 <= L; q += 8) {
+      double a_[8];
+#pragma unroll
+      for (int z = 0; z < 8; z++) a_[z] = sg[o + q + z];
+#pragma unroll
+      for (int z = 0; z < 8; z++) acc = acc + sgn * a_[z];
+    }
+    for (; q < L; q++) acc = acc + sgn * sg[o + q];
+    if (same && g < 2) acc = acc * 2.0;
   }
   const double e1 = __shfl(acc, 0, HG), ex = __shfl(acc, 1, HG), di = __shfl(acc, 2, HG);
   __syncthreads();
@@ -644,8 +655,10 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
   BPROF(8);
   // ---- H_ii of the new determinants: 8 or 16 lanes per determinant (chemistry); any other system, one thread per determinant
   __syncthreads();
+  BPROF(14);
   {
     const int nq = s_hqn;
+    BPROF_VAL(15, nq);
     const long long base = (long long)(ex_glob & 0xFFFFFull);
     const int hg = bk_hii_group_lanes(*s_tab);
 #define BK_HII_PASSES(HG)                                                                                          \
@@ -661,7 +674,11 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
         if (valid && g == 0) o.me[q0] = v;                                                                         \
       }                                                                                                            \
     }
-    if (hg == 8) BK_HII_PASSES(8)
+    // few determinants (a bucket creates 13 on average at the bench size, 28 at most): more lanes each -- the phase is the latency
+    // of one lane's decode + fetch + sum chain, and a lane with 2 tasks is through sooner than one with 5
+    if (hg == 8 && nq <= BK_AT / 32) BK_HII_PASSES(32)
+    else if (hg == 8 && nq <= BK_AT / 16) BK_HII_PASSES(16)
+    else if (hg == 8) BK_HII_PASSES(8)
     else if (hg == 16) BK_HII_PASSES(16)
     else {
       for (int k = tid; k < nq; k += BK_AT) {

@@ -45,6 +45,8 @@ print("slowest sorts: " + ", ".join("%.1f us (S %d R %d, started %.1f)" % (srt[i
 life = (a[:, 10] - a[:, 0]) / 100.0
 order = np.argsort(-(a[:, 6] - a[:, 0]))[:6]
 print("latest to publish: " + ", ".join("%.1f us after its start (S %d R %d)" % ((a[i, 6] - a[i, 0]) / 100.0, a[i, 12], a[i, 13]) for i in order))
+print("H_ii phase: wait for the block's last compaction thread mean %.2f max %.2f us; the passes mean %.2f max %.2f us; determinants per bucket mean %.0f max %d" % (
+    ((a[:, 14] - a[:, 8]) / 100.0).mean(), ((a[:, 14] - a[:, 8]) / 100.0).max(), ((a[:, 11] - a[:, 14]) / 100.0).mean(), ((a[:, 11] - a[:, 14]) / 100.0).max(), a[:, 15].mean(), a[:, 15].max()))
 print("S: mean %.0f max %d; R mean %.0f min %d max %d; T max %d" % (a[:, 12].mean(), a[:, 12].max(), a[:, 13].mean(), a[:, 13].min(), a[:, 13].max(), (a[:, 12] + a[:, 13]).max()))
 ids = np.nonzero(np.array(buf, dtype=np.int64).reshape(1024, 16)[:, 0] != old[:, 0])[0]
 top = np.argsort(-(a[:, 12] + a[:, 13]))[:8]
