@@ -17,8 +17,12 @@ sqmc_amd.build_library(force=True)
 from sqmc_amd import host as H
 
 target = float(sys.argv[1]) if len(sys.argv) > 1 else 1e5
-hst = H.ChemHost(os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP"), 8, 4, "d2h")
-w = H.GpuWalk(hst, target, seed=(1346, 5634, 6635, 4361))
+if os.environ.get("SQMC_PROF_SYSTEM") == "hubbard":
+    hst = H.HubbardHost(4, 4, True, 8, 8, 1.0, 4.0)
+    w = H.GpuWalk(hst, target, seed=(1346, 5634, 6635, 4361), w_begin=min(target, 1e4), n_truncate_trial_wf=20, size_deterministic=500, tau_multiplier=0.5)
+else:
+    hst = H.ChemHost(os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP"), 8, 4, "d2h")
+    w = H.GpuWalk(hst, target, seed=(1346, 5634, 6635, 4361))
 w.run(500, keep_stats=False)
 L = sqmc_amd.load_library()
 buf = (C.c_uint64 * (16 * 1024))()
