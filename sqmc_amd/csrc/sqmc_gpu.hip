@@ -101,7 +101,8 @@ struct DevScalars {
   int err;                 // SQMC_ERR_* raised on device
   int retry;               // the bucket tail met a bucket that does not fit its block: nothing of this step's tail counts, the host re-runs it (sticky: only the host clears it)
   double stats[16];
-  double red[8];           // sharded steps: what the ranks all-reduce -- the seven global sums and the collective status (256^code summed over ranks)
+  double red[8];           // sharded steps: the all-reduced seven global sums and the collective status (256^code summed over ranks, + 1 per rank whose bucket tail gave up)
+  double redl[8];          // this rank's contribution to red (kept: a step whose tail some rank has to re-run is all-reduced twice)
   unsigned int bk_fill, pad2;   // bucket tail: fill of the fullest bucket this step, per mille of the LDS caps
 };
 // status of a step summed over ranks as 256^code: the highest code any rank raised (codes 1..5, at most 255 ranks: exact in a double)
@@ -614,7 +615,8 @@ static OwnerOut shard_owner_out(sqmc_gpu_ctx *c) {
 // what does not change from step to step about the short-list (bucket) tail
 static inline bool bucket_static_ok(const sqmc_gpu_ctx *c, const StepP &p) {
   static const int bucket_env = getenv("SQMC_ANNEAL_ITEMS") ? 0 : (getenv("SQMC_BUCKET") ? atoi(getenv("SQMC_BUCKET")) : 1);      // a forced tile shape asks for the radix tail's kernel
-  return bucket_env && c->pack && p.semi && c->rng_mode == SQMC_RNG_COUNTER && !c->d_grow && c->comm == nullptr && !c->dev.hb.on;      // heat-bath children take two slots each: radix tail
+  static const bool shard_bucket = !(getenv("SQMC_SHARD_BUCKET") && getenv("SQMC_SHARD_BUCKET")[0] == '0');
+  return bucket_env && c->pack && p.semi && c->rng_mode == SQMC_RNG_COUNTER && (shard_bucket || (!c->d_grow && c->comm == nullptr)) && !c->dev.hb.on;      // heat-bath children take two slots each: radix tail
 }
 static inline long long bucket_count(long long nall) {
   static const long long bk_target = getenv("SQMC_BUCKET_TARGET") ? atoll(getenv("SQMC_BUCKET_TARGET")) : BK_TARGET;
@@ -692,7 +694,7 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
     static const bool no_fuse = getenv("SQMC_BUCKET_NO_SPAWN_FUSION") != nullptr;
     const long long n_known = dev_n ? c->nwalk : n0;                   // dev_n: the walkers of the step that is finishing, not of this one -- close
     const long long est = c->last_nall > 0 ? c->last_nall : 0;
-    if (!no_fuse && bucket_static_ok(c, p) && c->residents_sorted && c->bk_holdoff == 0 && est > 0 && est < merge_min && est < (1ll << 20) && n_known >= 256) {
+    if (!no_fuse && !c->d_grow && bucket_static_ok(c, p) && c->residents_sorted && c->bk_holdoff == 0 && est > 0 && est < merge_min && est < (1ll << 20) && n_known >= 256) {      // sharded steps: the children a rank anneals are not the ones it spawned
       long long B = bucket_count(est); if (B > n_known / 2) B = n_known / 2;
       if (B >= 1) {
         hb.B = (int)B; hb.words = c->d_flags; hb.segoff = c->d_segoff; hb.state = c->d_fstate; hb.ticket = c->d_fticket;
@@ -814,7 +816,8 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
           hipLaunchKernelGGL(k_bucket_partition, dim3((unsigned)nsb), dim3(BK_T), 0, st, (const u64 *)c->d_keys, n0, nch, c->invalid_key, ba);
         }
       }
-      if (bucket) ba.force_retry = (force_every > 0 && (c->bk_steps % force_every) == force_every - 1) ? 1 : 0;
+      static const int force_rank = getenv("SQMC_BUCKET_FORCE_RETRY_RANK") ? atoi(getenv("SQMC_BUCKET_FORCE_RETRY_RANK")) : -1;      // tests: only this rank of a sharded walk
+      if (bucket) ba.force_retry = (force_every > 0 && (force_rank < 0 || force_rank == c->shard_rank) && (c->bk_steps % force_every) == force_every - 1) ? 1 : 0;
     }
   }
   if (!bucket && c->side_pending) {          // the head counted on the bucket tail for death/clone and the projection: do them now, in line
@@ -950,8 +953,24 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     } else { c->h_sc->tot2 = c->h_mail->tot2; c->h_sc->err = (int)c->h_mail->err; for (int i = 0; i < 16; i++) c->h_sc->stats[i] = c->h_mail->stats[i];
              c->h_sc->retry = (int)c->h_mail->retry; c->h_sc->bk_fill = (unsigned int)c->h_mail->bk_fill; }
   }
-  if (bucket) {
-    if (c->h_sc->retry) {
+  const bool stop_now = !use_mail && c->h_sc->err != 0;      // a collective stop outranks a re-run: every rank returns the status, none reduces again
+  if (bucket && !use_mail && !stop_now && (c->h_sc->retry & 2) && !(c->h_sc->retry & 1)) {
+    // In-library sharded step: ANOTHER rank's bucket tail gave up.  The sums that were just all-reduced contain its unfinished ones:
+    // every rank reduces once more after that rank has re-run its tail -- this rank contributes the same local sums again (redl).
+    const u64 tot2_first = c->h_sc->tot2; double loc[16]; for (int i = 0; i < 16; i++) loc[i] = c->h_sc->stats[i];
+    int rr = comm_allreduce_stats(c); if (rr) return rr;
+    const u64 seq2 = ++c->mail_seq;
+    hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(64), 0, st, c->d_sc, c->d_mail, seq2);
+    int wr = wait_mail(&c->h_mail->seq, seq2, st);
+    if (wr > 0) return fail(SQMC_ERR_HIP, std::string("step failed on the device: ") + hipGetErrorString((hipError_t)wr));
+    if (wr < 0) HIPCHK(hipMemcpy(c->h_sc, c->d_sc, sizeof(DevScalars), hipMemcpyDeviceToHost));
+    else { c->h_sc->err = (int)c->h_mail->err; for (int i = 0; i < 7; i++) c->h_sc->stats[i] = c->h_mail->stats[i]; }
+    for (int i = 7; i < 16; i++) c->h_sc->stats[i] = loc[i];          // the local figures and the walker counts are this rank's own, from its own (valid) tail:
+    c->h_sc->tot2 = tot2_first; c->h_sc->retry = 0;                    // the head enqueued behind it has cleared the device copies since
+    { static const int hold = getenv("SQMC_BUCKET_HOLDOFF") ? atoi(getenv("SQMC_BUCKET_HOLDOFF")) : 8; c->bk_holdoff = hold; }
+  }
+  if (bucket && !stop_now) {
+    if (c->h_sc->retry & 1) {
       // A bucket outgrew its block.  The kernel wrote only the other walker buffer and scratch; the head of the next step,
       // if it was enqueued, saw the flag and did nothing.  Undo the host's bookkeeping and let the caller run the radix tail.
       drop_head(c);

@@ -928,6 +928,8 @@ __device__ __forceinline__ void post_reduced(DevScalars *sc, HostMail *mail, u64
   for (int i = 0; i < 7; i++) sc->stats[i] = sc->red[i];          // the global sums replace the local ones
   for (int i = 0; i < 16; i++) mail->stats[i] = sc->stats[i];
   mail->tot2 = sc->tot2; mail->err = err_decode(sc->red[7]);      // the highest status any rank raised: every rank stops with it
+  mail->retry = (u64)((sc->retry ? 1 : 0) | (fmod(sc->red[7], 256.0) >= 1.0 ? 2 : 0));      // bit 0: this rank's bucket tail gave up, bit 1: some rank's did
+  mail->bk_fill = (u64)sc->bk_fill;
   __threadfence_system();
   mail->seq = seq;
 }
@@ -1010,10 +1012,10 @@ __device__ void finish_step(const double *__restrict__ partials, int nblocks, co
     for (int i = 0; i < 16; i++) sc->stats[i] = o[i];
     sc->nwalk = tot2 & 0xFFFFFFFFull;
     if (expect_nimp >= 0) {      // sharded step: sums and status go through the all-reduce before anything is posted
-      if (!err && (long long)(tot2 >> 32) != expect_nimp) { err = SQMC_ERR_IMP_BROKEN; sc->err = err; }
+      if (!err && !sc->retry && (long long)(tot2 >> 32) != expect_nimp) { err = SQMC_ERR_IMP_BROKEN; sc->err = err; }      // (a tail that gave up has counted nothing)
 #pragma unroll
-      for (int i = 0; i < 7; i++) sc->red[i] = o[i];
-      sc->red[7] = err_encode(err);
+      for (int i = 0; i < 7; i++) sc->redl[i] = o[i];
+      sc->redl[7] = err_encode(err) + (sc->retry ? 1.0 : 0.0);        // a bucket tail that gave up is a status too: every rank has to learn of it
     }
     if (mail) {          // the host's copy goes out from the same registers (finish_all fences and posts the sequence word)
 #pragma unroll

@@ -82,11 +82,12 @@ def _single_rank_radix_tail(tmp_path, w_target=None, nsteps=None):
     return np.load(os.path.join(str(tmp_path), "single0.npz"))
 
 
-def test_one_rank_sharded_equals_single_rank_step(tmp_path):
+def test_one_rank_sharded_equals_single_rank_step(tmp_path, monkeypatch):
     """With one rank the sharded pipeline (bucket -> exchange -> unpack) must reproduce the
     single-rank step: bit for bit against the single-rank step on the same tail (the radix tail, the
     one the sharded step uses); against the short-list tail the estimator sums come out of another
     reduction tree, E_T follows them, and the weights agree to rounding."""
+    monkeypatch.setenv("SQMC_SHARD_BUCKET", "0")      # bit for bit against the single-rank RADIX tail: the sharded step has to run that tail too (the short-list tail sums in another tree)
     import torch.multiprocessing as mp
     res = _run(1, tmp_path, 29541)[0]
     ctx = mp.get_context("spawn")
@@ -215,10 +216,11 @@ def _inlib_long_worker(port, outdir, w_target, nsteps):
     w.close()
 
 
-def test_in_library_pipelined_run_matches_plain_walk(tmp_path):
+def test_in_library_pipelined_run_matches_plain_walk(tmp_path, monkeypatch):
     """sqmc_gpu_shard_run past the point where the target population is reached: from there on the steps are
     pipelined (the annihilation kernel computes the next gate, the next step's scan posts the all-reduced sums).
     One rank over real RCCL must still walk the plain single-rank trajectory, bit for bit."""
+    monkeypatch.setenv("SQMC_SHARD_BUCKET", "0")      # bit for bit against the single-rank RADIX tail: the sharded step has to run that tail too (the short-list tail sums in another tree)
     import torch.multiprocessing as mp
     w_target, nsteps = 4000, 300
     ctx = mp.get_context("spawn")
@@ -233,10 +235,11 @@ def test_in_library_pipelined_run_matches_plain_walk(tmp_path):
     assert np.allclose(res["outs"], outs, rtol=1e-12, atol=1e-12)
 
 
-def test_in_library_rccl_exchange_single_rank(tmp_path):
+def test_in_library_rccl_exchange_single_rank(tmp_path, monkeypatch):
     """sqmc_gpu_comm_init / shard_step / shard_run: the exchanges issued by the library itself on
     an RCCL communicator (one rank is what a one-GPU box can host: every RCCL call still runs).
     Must reproduce the plain single-rank walk exactly."""
+    monkeypatch.setenv("SQMC_SHARD_BUCKET", "0")      # bit for bit against the single-rank RADIX tail: the sharded step has to run that tail too (the short-list tail sums in another tree)
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     p = ctx.Process(target=_inlib_worker, args=(29571, str(tmp_path)))
@@ -329,7 +332,8 @@ def _fake_rccl_lib():
     return so
 
 
-def _inlib_multi_worker(rank, world, port, outdir, fake, w_target=None, nsteps=None, nofuse=False, overlap=False, w_begin=None, mwalk_of_rank=None):
+def _inlib_multi_worker(rank, world, port, outdir, fake, w_target=None, nsteps=None, nofuse=False, overlap=False, w_begin=None, mwalk_of_rank=None, env=None):
+    os.environ.update(env or {})
     import torch                                   # noqa: F401
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -358,7 +362,7 @@ def _inlib_multi_worker(rank, world, port, outdir, fake, w_target=None, nsteps=N
     wk = w.g.download_walkers() if status == 0 else dict(up=np.zeros(0, np.uint64), dn=np.zeros(0, np.uint64), wt=np.zeros(0), imp_distance=np.zeros(0, np.int8))
     owner = w.g.det_owner(wk["up"], wk["dn"], world) if status == 0 else np.zeros(0, np.int32)
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), outs=outs, owner=owner, n_imp_global=w.n_imp_global,
-             reached=np.array([w.pc.reached]), status=np.array([status]), **wk)
+             reached=np.array([w.pc.reached]), status=np.array([status]), tail=np.array(w.g.tail_stats()), **wk)
     w.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -397,6 +401,37 @@ def test_in_library_pipelined_exchange_two_ranks(tmp_path):
     for a, b in zip(runs[0], runs[1]):
         assert np.array_equal(a["outs"], b["outs"])
         assert np.array_equal(a["up"], b["up"]) and np.array_equal(a["dn"], b["dn"]) and np.array_equal(a["wt"], b["wt"])
+
+
+def test_sharded_short_list_tail_when_one_rank_gives_up(tmp_path):
+    """The short-list (bucket) tail inside the sharded in-library step.  A bucket that outgrows its block makes a rank re-run its
+    tail through the radix path -- with a communicator that has to be a collective decision: the flag rides in the status word of
+    the sums' all-reduce, every rank learns of it from the same call, the rank concerned re-runs, and all of them reduce once more
+    (the ranks whose tail was fine contribute the same local sums again).  Here rank 1 alone is made to give up on every third
+    bucket step: the walk must be the one that never gives up (same determinants on the same ranks; weights to rounding: a re-run
+    step sums its estimators in the radix tail's tree), nobody may hang, and only rank 1 may have re-run anything."""
+    import torch.multiprocessing as mp
+    fake = _fake_rccl_lib()
+    ctx = mp.get_context("spawn")
+    runs = []
+    for k, env in enumerate(({}, {"SQMC_BUCKET_FORCE_RETRY": "3", "SQMC_BUCKET_FORCE_RETRY_RANK": "1", "SQMC_BUCKET_HOLDOFF": "1"})):
+        out = os.path.join(str(tmp_path), "run%d" % k); os.makedirs(out)
+        ps = [ctx.Process(target=_inlib_multi_worker, args=(r, 2, 29640 + k, out, fake, 8000, 240), kwargs=dict(env=env)) for r in range(2)]
+        for p in ps: p.start()
+        for p in ps: p.join(300)
+        alive = [p for p in ps if p.is_alive()]
+        for p in alive: p.terminate()
+        assert not alive, "sharded step with a re-run tail did not finish (deadlock?)"
+        assert all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
+        runs.append([np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)])
+    plain, forced = runs
+    assert all(int(r["tail"][0]) > 100 for r in plain) and all(int(r["tail"][1]) == 0 for r in plain)      # the bucket tail ran, nothing was re-run
+    assert int(forced[1]["tail"][1]) >= 10 and int(forced[0]["tail"][1]) == 0
+    for a, b in zip(plain, forced):
+        assert np.array_equal(a["up"], b["up"]) and np.array_equal(a["dn"], b["dn"])
+        assert np.allclose(a["wt"], b["wt"], rtol=1e-10, atol=0) and np.allclose(a["outs"], b["outs"], rtol=1e-10, atol=1e-10)
+    for r in forced[1:]:
+        assert np.array_equal(r["outs"][:, :7], forced[0]["outs"][:, :7])
 
 
 @pytest.mark.parametrize("world,overlap", [(2, False), (3, False), (2, True)])
