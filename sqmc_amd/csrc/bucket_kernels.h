@@ -24,17 +24,21 @@
 // the tail of that step through the radix path and keeps the bucket path off for a while.  COUNTER discipline, packed keys.
 #pragma once
 
+// the boundary block as a kernel of its own (sharded steps: on the side stream, beside the exchange)
+__global__ void __launch_bounds__(BK_T) k_bucket_boundaries(const u64 *__restrict__ keys, long long n0, BucketArgs ba) { bk_rebalance_block(ba, keys, n0); }
 // stand-alone: for spawn lists that did not come out of k_spawn (the annihilation door) or heads launched without it
-__global__ void __launch_bounds__(BK_T) k_bucket_partition(const u64 *__restrict__ keys, long long n0, long long nch, u64 invalid_key, BucketArgs ba) {
+__global__ void __launch_bounds__(BK_T) k_bucket_partition(const u64 *__restrict__ keys, long long n0, long long nch, u64 invalid_key, BucketArgs ba, int n_extra) {
+  if ((int)blockIdx.x < n_extra) { bk_rebalance_block(ba, keys, n0); return; }      // the boundary block, in front (as in k_spawn)
   __shared__ u32 spl[BK_MAXB];
   __shared__ u32 wcnt[BK_T / 64][BK_MAXB];
-  const long long c = (long long)blockIdx.x * BK_T + threadIdx.x;
+  const long long blk = (long long)blockIdx.x - n_extra;
+  const long long c = blk * BK_T + threadIdx.x;
   u64 word = 0; u32 key = 0; bool valid = false;
   if (c < nch) word = keys[n0 + c];
   bucket_partition_stage(spl, wcnt, keys, n0, ba);
   if (c < nch) { key = (u32)(word >> 32); valid = (u64)key != invalid_key; }
   __syncthreads();
-  bucket_partition_block(spl, wcnt, valid, key, word, (long long)blockIdx.x, ba);
+  bucket_partition_block(spl, wcnt, valid, key, word, blk, ba);
 }
 
 // ------------------------------------------------------------------------------------------------ annihilation per bucket

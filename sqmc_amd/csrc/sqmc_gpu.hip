@@ -162,6 +162,7 @@ struct sqmc_gpu_ctx {
   u32 *d_bhint; int pos_flip, scount_pos;      // where each boundary set lay when it was made (3 x BK_MAXB + 1); which of the two d_bpos halves this step writes / the counts were taken with
   u32 *d_bkb, *d_bpos, *d_bscount;   // bucket boundaries (three sets of BK_MAXB + 1 keys: in use, counted with, being made), their positions in this step's list, the spawns the last bucket tail counted per bucket
   int kb_B[3], scount_B;      // the bucket count each set was made for / the counts were taken with (0: not valid)
+  BucketArgs shard_ba;        // sharded steps: the boundaries chosen at the start of the step (their block runs on the side stream)
   int kb_next, scount_buf, head_kb_use;   // set the next bucket head partitions with; set the counts were taken with; set the enqueued head uses (-1: equal-residents boundaries)
   double *d_prj_y; const double *head_prj_x; bool head_y_done;      // A x of the pipelined head's spare k_spawn blocks, the x it used
   double *d_prj_xs[2]; int xs_cur; bool xs_valid;      // snapshots of the deterministic-space weights by row, written by the bucket tail for the NEXT step's projection (two: one is read while the other is written)
@@ -618,6 +619,26 @@ static inline bool bucket_static_ok(const sqmc_gpu_ctx *c, const StepP &p) {
   static const bool shard_bucket = !(getenv("SQMC_SHARD_BUCKET") && getenv("SQMC_SHARD_BUCKET")[0] == '0');
   return bucket_env && c->pack && p.semi && c->rng_mode == SQMC_RNG_COUNTER && (shard_bucket || (!c->d_grow && c->comm == nullptr)) && !c->dev.hb.on;      // heat-bath children take two slots each: radix tail
 }
+// Boundaries that follow the spawns (bucket_partition.h): the partition about to be launched uses the set the last one's boundary
+// block made, if it was made for B buckets; its own boundary block makes the next set from the counts of the last bucket tail.
+// Returns the set in use (-1: equal-residents boundaries).
+static int choose_boundaries(sqmc_gpu_ctx *c, long long B, long long n_known, BucketArgs &hb) {
+  static const bool no_rebal = getenv("SQMC_BUCKET_UNIFORM") != nullptr;
+  int use = -1;
+  if (!no_rebal && B <= BK_REBAL_MAXB && n_known >= 16 * B) {
+    use = (c->kb_next >= 0 && c->kb_B[c->kb_next] == (int)B) ? c->kb_next : -1;
+    if (use >= 0) { c->pos_flip ^= 1; hb.kb = c->d_bkb + use * (BK_MAXB + 1); hb.pos = c->d_bpos + c->pos_flip * (BK_MAXB + 1); hb.hint = c->d_bhint + use * (BK_MAXB + 1); }
+    if (c->scount_B == (int)B) {
+      const int prev = (c->scount_buf >= 0 && c->kb_B[c->scount_buf] == (int)B) ? c->scount_buf : -1;
+      int out = 0; while (out == use || out == prev) out++;
+      hb.kb_prev = prev >= 0 ? c->d_bkb + prev * (BK_MAXB + 1) : (const u32 *)nullptr;
+      hb.kb_out = c->d_bkb + out * (BK_MAXB + 1); hb.hint_out = c->d_bhint + out * (BK_MAXB + 1);
+      hb.pos_prev = prev >= 0 ? c->d_bpos + c->scount_pos * (BK_MAXB + 1) : (const u32 *)nullptr;
+      c->kb_B[out] = (int)B; c->kb_next = out;
+    }
+  }
+  return use;
+}
 static inline long long bucket_count(long long nall) {
   static const long long bk_target = getenv("SQMC_BUCKET_TARGET") ? atoll(getenv("SQMC_BUCKET_TARGET")) : BK_TARGET;
   long long B = (nall + bk_target - 1) / bk_target;
@@ -700,23 +721,7 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
         hb.B = (int)B; hb.words = c->d_flags; hb.segoff = c->d_segoff; hb.state = c->d_fstate; hb.ticket = c->d_fticket;
         hb.scount = c->d_bscount;
         hb.nsb = (int)std::min<long long>(std::min<long long>(c->segoff_cap / (B + 1), M / BK_T), BK_CAP_ROWS);      // rows there is room for
-        // boundaries that follow the spawns: this head partitions with the set the last head's spare block made (if it was made for
-        // B buckets); its own spare block makes the next set from the counts of the bucket tail that has just been enqueued
-        static const bool no_rebal = getenv("SQMC_BUCKET_UNIFORM") != nullptr;
-        c->head_kb_use = -1;
-        if (!no_rebal && B <= BK_REBAL_MAXB && n_known >= 16 * B) {
-          const int use = (c->kb_next >= 0 && c->kb_B[c->kb_next] == (int)B) ? c->kb_next : -1;
-          if (use >= 0) { c->pos_flip ^= 1; hb.kb = c->d_bkb + use * (BK_MAXB + 1); hb.pos = c->d_bpos + c->pos_flip * (BK_MAXB + 1); hb.hint = c->d_bhint + use * (BK_MAXB + 1); }
-          c->head_kb_use = use;
-          if (c->scount_B == (int)B) {
-            const int prev = (c->scount_buf >= 0 && c->kb_B[c->scount_buf] == (int)B) ? c->scount_buf : -1;
-            int out = 0; while (out == use || out == prev) out++;
-            hb.kb_prev = prev >= 0 ? c->d_bkb + prev * (BK_MAXB + 1) : (const u32 *)nullptr;
-            hb.kb_out = c->d_bkb + out * (BK_MAXB + 1); hb.hint_out = c->d_bhint + out * (BK_MAXB + 1);
-            hb.pos_prev = prev >= 0 ? c->d_bpos + c->scount_pos * (BK_MAXB + 1) : (const u32 *)nullptr;
-            c->kb_B[out] = (int)B; c->kb_next = out;
-          }
-        }
+        c->head_kb_use = choose_boundaries(c, B, n_known, hb);
       }
     }
     c->head_ba = hb;
@@ -813,7 +818,15 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
           bucket = true;
           ba.B = (int)B; ba.nsb = (int)nsb; ba.words = c->d_flags; ba.segoff = c->d_segoff; ba.state = c->d_fstate; ba.ticket = c->d_fticket;
           ba.scount = c->d_bscount;
-          hipLaunchKernelGGL(k_bucket_partition, dim3((unsigned)nsb), dim3(BK_T), 0, st, (const u64 *)c->d_keys, n0, nch, c->invalid_key, ba);
+          int n_extra = 0;
+          if (c->d_grow && c->shard_ba.B == (int)B) {          // sharded step: chosen, and computed on the side stream, when the step began
+            ba.kb = c->shard_ba.kb; ba.pos = c->shard_ba.pos; ba.hint = c->shard_ba.hint;
+          } else if (!c->d_grow) {
+            c->head_kb_use = choose_boundaries(c, B, n0, ba);
+            n_extra = (ba.kb || ba.kb_out) ? 1 : 0;
+          } else c->head_kb_use = -1;
+          c->shard_ba.B = 0;
+          hipLaunchKernelGGL(k_bucket_partition, dim3((unsigned)(nsb + n_extra)), dim3(BK_T), 0, st, (const u64 *)c->d_keys, n0, nch, c->invalid_key, ba, n_extra);
         }
       }
       static const int force_rank = getenv("SQMC_BUCKET_FORCE_RETRY_RANK") ? atoi(getenv("SQMC_BUCKET_FORCE_RETRY_RANK")) : -1;      // tests: only this rank of a sharded walk

@@ -1,5 +1,5 @@
 timeout -k 10 1000 python -m pytest tests/test_gpu_sharded.py -m gpu -x -q > gpurun_out/t_sel.log 2>&1; echo "pytest rc=$?" >> gpurun_out/t_sel.log
-tail -25 gpurun_out/t_sel.log
+tail -4 gpurun_out/t_sel.log
 grep -q "rc=0" gpurun_out/t_sel.log && \
 SQMC_BENCH_FORCE_SHARDED=1 timeout -k 10 200 python bench.py --steps 300 --warmup 50 --no-cpu-baseline > gpurun_out/b_sh1.log 2>&1
 python - <<'PY'
