@@ -67,6 +67,8 @@ program example_walk
   pc%semistochastic = 1; pc%reserved = 0; pc%istep = 0; pc%n_equil = 1000000000_c_int64_t
 
   allocate(stats(16, block))
+  ! one sqmc_gpu_run per block: with chained runs the last step of a block enqueues the head of the next block's first step
+  call sqmc_gpu_check(sqmc_gpu_set_chained_runs(gpu, 1_c_int32_t), 'set_chained_runs')
   nblocks = int((nsteps + block - 1) / block)
   done = 0; e_num_all = 0; e_den_all = 0
   write(6, '(a)') '   block     steps        w_abs_gen     nwalk          e_trial      e_block (num/den)'
