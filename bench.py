@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3000, help="timed steps (0.14 ms each at the default size: a short timed region is at the mercy of one host scheduling hiccup)")
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--target", type=float, default=1e5, help="w_abs_gen_target")
-    ap.add_argument("--equil", type=int, default=400, help="untimed equilibration steps before warmup")
+    ap.add_argument("--equil", type=int, default=2000, help="untimed equilibration steps before warmup (2000 steps = 0.15 s of sustained load: the population is at its target after ~300, and the one stall of 60-80 ms this GPU shows 40-75 ms after a process starts loading it -- see DESIGN.md section 9 -- lies behind it)")
     ap.add_argument("--mwalk", type=int, default=0, help="walker capacity of the single-GPU walk (0: the reference's MWALK = 4 (target/min_wt + n_imp))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--system", default="c2", choices=["c2", "heg", "hubbard"], help="c2 = BASELINE.json configs[1] (the metric's config, default); "
