@@ -1,23 +1,26 @@
-// bucket_kernels.h -- the annihilation tail of a semistochastic step for SHORT lists, in two launches instead of ten.
+// bucket_kernels.h -- the annihilation tail of a semistochastic step for SHORT lists, in one launch instead of ten.
 // Textually included by sqmc_gpu.hip behind walk_kernels.h (same translation unit, same types).
 //
 // At 10^5 walkers a step is a chain of dependent launches, not bandwidth: the stable radix sort of the (walkers + spawns)
 // list alone was nine kernels (54 us of a 122 us step) in front of the one-kernel annihilation.  Here the sort never
 // leaves the chip:
 //
-//   k_bucket_partition   one block per 256 children: every child finds its bucket among B key ranges -- the splitters are
-//                        the keys of the resident walkers at positions b n0 / B, which every step leaves sorted, so buckets
-//                        hold equal shares of the residents and (the population moves slowly) nearly equal shares of the
-//                        spawns -- and the block writes its children grouped by bucket (stable counting sort in LDS) with
-//                        the B+1 group offsets.  No counts cross blocks, no atomics, no scan kernel.
-//   k_anneal_bucket      one block per bucket: gathers its children from every partition block (two dependent loads),
-//                        sorts them by key in LDS (stable radix on the bits that vary inside the bucket's key range),
-//                        ranks them against its residents by binary search (residents first on equal keys, spawns in
-//                        creation order: the order of merge_sort2_up_dn, do_walk.f90:5411-5614), folds every run of equal
-//                        determinants with the rules of merge_original_with_spawned2 (5866-6083), rounds small weights
-//                        (reduce_my_walker, 7196-7254), and compacts into the other walker buffer through one decoupled
-//                        look-back over the buckets -- reweighting, C(T) lookup, estimator sums and the next step's gate as
-//                        in k_anneal.
+//   partition            one block per 256 children (inside k_spawn as it emits them, or k_bucket_partition for spawn lists that
+//                        came from elsewhere): every child finds its bucket among B key ranges and the block writes its children
+//                        grouped by bucket (stable counting sort in LDS) with the B+1 group offsets.  No counts cross blocks,
+//                        no atomics, no scan kernel.  The ranges: until boundaries have been learnt, the keys of the resident
+//                        walkers at positions b n0 / B (every step leaves the residents sorted); then boundary keys that
+//                        equalise residents + spawns per bucket, remade every step from the last tail's counts
+//                        (bk_rebalance_block, bucket_partition.h).
+//   k_anneal_bucket      one block per bucket: gathers its children from every partition block (two dependent loads), sorts
+//                        them in LDS -- one stable counting pass on the GAP between residents a child falls into, then a
+//                        ranking inside the gap: the order of merge_sort2_up_dn (do_walk.f90:5411-5614), residents first on
+//                        equal keys, spawns in creation order --, folds every run of equal determinants with the rules of
+//                        merge_original_with_spawned2 (5866-6083), rounds small weights (reduce_my_walker, 7196-7254), and
+//                        compacts into the other walker buffer through one decoupled look-back over the buckets --
+//                        reweighting, C(T) lookup, estimator sums as in k_anneal; the next step's gate AND child offsets (no
+//                        scan launch); death/clone and the projection's last line when the host fused them in (FusedSide);
+//                        H_ii of the determinants it creates.
 //
 // A bucket that does not fit the LDS of its block (a population that moved more than the head-room in one step) raises
 // DevScalars::retry and nothing else: the kernel only ever writes the OTHER walker buffer and scratch, so the host re-runs
