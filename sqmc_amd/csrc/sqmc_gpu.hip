@@ -929,7 +929,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
   fa.scan_state = c->d_scan_state; fa.scan_ticket = c->d_scan_ticket; fa.n_scan_words = (int)(3 * c->cap_tiles);
   fa.mail = use_mail ? c->d_mail : (HostMail *)nullptr; fa.seq = seq; fa.fstate = c->d_fstate; fa.fticket = c->d_fticket; fa.cap_ftiles = c->cap_ftiles;
   fa.n_ftiles = n_ft; fa.on = 1; fa.n_tickets = 3; fa.n_children = -1;
-  fa.expect_nimp = (p.semi && !use_mail) ? c->n_imp_local : -1;      // sharded in-library step: 'locations of my imp broken' must reach every rank
+  fa.expect_nimp = !use_mail ? (p.semi ? c->n_imp_local : -2) : -1;      // sharded in-library step: 'locations of my imp broken' must reach every rank
   if (fuse_gate && use_mail) {       // the finishing block runs beside the next head's scan (look-back set scan_flip): it re-zeroes the other set only
     const int other = c->scan_flip ^ 1;
     fa.scan_state = c->d_scan_state + (long long)other * c->cap_tiles; fa.scan_ticket = c->d_scan_ticket + other;

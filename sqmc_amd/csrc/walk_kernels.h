@@ -1011,8 +1011,8 @@ __device__ void finish_step(const double *__restrict__ partials, int nblocks, co
 #pragma unroll
     for (int i = 0; i < 16; i++) sc->stats[i] = o[i];
     sc->nwalk = tot2 & 0xFFFFFFFFull;
-    if (expect_nimp >= 0) {      // sharded step: sums and status go through the all-reduce before anything is posted
-      if (!err && !sc->retry && (long long)(tot2 >> 32) != expect_nimp) { err = SQMC_ERR_IMP_BROKEN; sc->err = err; }      // (a tail that gave up has counted nothing)
+    if (expect_nimp >= 0 || expect_nimp == -2) {      // sharded step (-2: a plain walk, no deterministic space to check): sums and status go through the all-reduce before anything is posted
+      if (expect_nimp >= 0 && !err && !sc->retry && (long long)(tot2 >> 32) != expect_nimp) { err = SQMC_ERR_IMP_BROKEN; sc->err = err; }      // (a tail that gave up has counted nothing)
 #pragma unroll
       for (int i = 0; i < 7; i++) sc->redl[i] = o[i];
       sc->redl[7] = err_encode(err) + (sc->retry ? 1.0 : 0.0);        // a bucket tail that gave up is a status too: every rank has to learn of it

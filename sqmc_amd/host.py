@@ -695,9 +695,11 @@ class ShardedWalk:
     estimator sums, exactly the three exchanges of the reference's MPI walk."""
 
     def __init__(self, host, w_target, rank, world, w_begin=None, mwalk=None, n_truncate_trial_wf=100, size_deterministic=1000,
-                 tau_multiplier=0.1, e_trial=None, seed=(1346, 5634, 6635, 4361), min_wt=0.5, device_index=0, n_equil_steps=10**9, owner_hash=0):
+                 tau_multiplier=0.1, e_trial=None, seed=(1346, 5634, 6635, 4361), min_wt=0.5, device_index=0, n_equil_steps=10**9, owner_hash=0,
+                 semistochastic=True):
         import torch
         self.rank, self.world, self.min_wt = rank, world, min_wt
+        self.semi = 1 if semistochastic else 0          # 0: semistochastic = f, no deterministic space; join_walker2 is local to a rank (do_walk.f90:2475)
         w_begin = w_begin if w_begin is not None else w_target
         per_rank = w_target / world
         mwalk = mwalk or int(max(6 * (per_rank / min_wt + size_deterministic), 200000))
@@ -705,9 +707,14 @@ class ShardedWalk:
         if owner_hash:
             g.set_owner_hash(owner_hash)       # 1: the reference's get_det_owner (djb_hash), mpi_routines.f90:354-445
         self.setup = s = host.setup_walk(g, n_truncate_trial_wf, size_deterministic, tau_multiplier)
-        g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
+        if self.semi:
+            g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
         g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
         wk = initial_walkers(s, w_begin)
+        if not self.semi:                              # a purely stochastic population
+            wk["imp_distance"] = np.where(wk["imp_distance"] == 0, 1, wk["imp_distance"]).astype(np.int8)
+            keep = ~((wk["wt"] == 0) & (wk["initiator"] < 3))
+            wk = {k: v[keep] for k, v in wk.items()}
         own = g.det_owner(wk["up"], wk["dn"], world) == rank
         mine = {k: v[own] for k, v in wk.items()}
         # global row of every deterministic-space walker this rank owns (both lists sorted by (up,dn))
@@ -724,7 +731,7 @@ class ShardedWalk:
         self.cap = cap
         self.pc = PopControl(s.tau, e_trial if e_trial is not None else s.e_trial0, w_target, n_equil_steps=n_equil_steps)
         self.w_abs = float(np.abs(wk["wt"]).sum())          # global
-        self.n_imp_global = len(s.imp_up)
+        self.n_imp_global = len(s.imp_up) if self.semi else 0
         self.in_library = False
 
     def attach_rccl(self):
@@ -742,7 +749,7 @@ class ShardedWalk:
         """nsteps sharded steps inside the library (sqmc_gpu_shard_run); needs attach_rccl()"""
         if not self.in_library:
             raise RuntimeError("ShardedWalk.run needs attach_rccl(); use step() for the caller-driven exchange")
-        pc = self.pc.to_c(self.w_abs, min_wt=self.min_wt)
+        pc = self.pc.to_c(self.w_abs, min_wt=self.min_wt, semistochastic=self.semi)
         stats, totals = self.g.shard_run(pc, nsteps, keep_stats)
         self.pc.from_c(pc)
         self.w_abs = pc.w_abs_gen
@@ -751,13 +758,13 @@ class ShardedWalk:
     def step(self):
         import torch
         r = self.pc.pre_step(self.w_abs)
-        if r != 1.0:
+        if r != 1.0 and self.semi:
             self.g.scale_projector(r)
-        prm = self.pc.params(min_wt=self.min_wt)
+        prm = self.pc.params(min_wt=self.min_wt, semistochastic=self.semi)
         if self.in_library:
             out = self.g.shard_step(prm)
             r = self.pc.post_step(out)
-            if r != 1.0:
+            if r != 1.0 and self.semi:
                 self.g.scale_projector(r)
             self.w_abs, self.last_local = out[1], out
             return out
@@ -769,7 +776,7 @@ class ShardedWalk:
         local = self.g.shard_finish(prm, self.recv.data_ptr(), nr)
         out = allreduce_step_sums(local, device=self.dev)
         r = self.pc.post_step(out)
-        if r != 1.0:
+        if r != 1.0 and self.semi:
             self.g.scale_projector(r)
         self.w_abs, self.last_local = out[1], local
         return out

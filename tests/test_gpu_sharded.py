@@ -33,6 +33,9 @@ def _worker(rank, world, port, outdir, system="c2", w_begin=None, w_target=None,
         hst = H.HubbardHost(4, 4, True, 8, 8, 1.0, 4.0)
         w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000, n_truncate_trial_wf=20, size_deterministic=500,
                           tau_multiplier=0.5)
+    elif system == "c2_plain":   # semistochastic = f: no deterministic space, join_walker2 local to a rank
+        hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+        w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000, semistochastic=False)
     else:
         hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
         w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000, owner_hash=1 if system == "c2_djb" else 0)
@@ -104,6 +107,60 @@ def test_one_rank_sharded_equals_single_rank_step(tmp_path, monkeypatch):
     assert wb["tail"][0] > NSTEPS // 2
     assert np.array_equal(res["up"], wb["up"]) and np.array_equal(res["dn"], wb["dn"]) and np.array_equal(res["initiator"], wb["initiator"])
     assert np.allclose(res["wt"], wb["wt"], rtol=1e-11, atol=0) and np.allclose(res["outs"], wb["outs"], rtol=1e-11, atol=1e-11)
+
+
+def _single_rank_plain_worker(outdir, w_begin, w_target, nsteps):
+    sys.path.insert(0, ROOT)
+    import sqmc_amd
+    from sqmc_amd import host as H
+    sqmc_amd.set_device(0)
+    hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
+    g = hst.gpu(rng_mode=H.RNG_COUNTER, seed=H.rank_seed(SEED, 0), mwalk=400000)
+    s = hst.setup_walk(g, 100, 1000, 0.1)
+    g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
+    wk = H.initial_walkers(s, w_begin)
+    wk["imp_distance"] = np.where(wk["imp_distance"] == 0, 1, wk["imp_distance"]).astype(np.int8)
+    keep = ~((wk["wt"] == 0) & (wk["initiator"] < 3))
+    wk = {k: v[keep] for k, v in wk.items()}
+    g.upload_walkers(wk)
+    pc = H.PopControl(s.tau, s.e_trial0, w_target, n_equil_steps=10**9)
+    w_abs, outs = float(np.abs(wk["wt"]).sum()), []
+    for _ in range(nsteps):
+        pc.pre_step(w_abs)
+        out = g.step(pc.params(min_wt=0.5, semistochastic=0))
+        pc.post_step(out)
+        w_abs = out[1]; outs.append(out.copy())
+    np.savez(os.path.join(outdir, "plain_single.npz"), outs=np.array(outs), **g.download_walkers())
+    g.close()
+
+
+def test_sharded_plain_walk(tmp_path):
+    """semistochastic = f across ranks (do_walk.f90:2475: join_walker2 is local to a rank; no deterministic space, no projection
+    exchange): one rank must walk the single-rank plain trajectory bit for bit; two ranks must keep the sharding invariants
+    (disjoint ownership, globally unique determinants, identical all-reduced sums) and every walker outside any deterministic
+    space."""
+    import torch.multiprocessing as mp
+    one = os.path.join(str(tmp_path), "one"); os.makedirs(one)
+    res1 = _run(1, one, 29561, system="c2_plain")[0]
+    pr = mp.get_context("spawn").Process(target=_single_rank_plain_worker, args=(one, W_BEGIN, W_TARGET, NSTEPS))
+    pr.start(); pr.join(600)
+    assert pr.exitcode == 0
+    ref = np.load(os.path.join(one, "plain_single.npz"))
+    for k in ("up", "dn", "wt", "initiator", "imp_distance"):
+        assert np.array_equal(res1[k], ref[k]), k
+    assert np.allclose(res1["outs"], ref["outs"], rtol=1e-12, atol=1e-12) and len(ref["up"]) > 2000
+    two = os.path.join(str(tmp_path), "two"); os.makedirs(two)
+    res = _run(2, two, 29562, system="c2_plain")
+    assert np.array_equal(res[1]["outs"][:, :7], res[0]["outs"][:, :7])
+    keys = []
+    for rank, r in enumerate(res):
+        assert np.all(r["owner"] == rank) and np.all(r["imp_distance"] != 0)
+        k = [(int(a), int(b)) for a, b in zip(r["up"], r["dn"])]
+        assert k == sorted(set(k))
+        keys += k
+    assert len(keys) == len(set(keys)) and int(res[0]["outs"][-1][5]) == len(keys)
+    e = res[0]["outs"][10:, 3].sum() / res[0]["outs"][10:, 2].sum()
+    assert -75.85 < e < -75.55
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -332,7 +389,7 @@ def _fake_rccl_lib():
     return so
 
 
-def _inlib_multi_worker(rank, world, port, outdir, fake, w_target=None, nsteps=None, nofuse=False, overlap=False, w_begin=None, mwalk_of_rank=None, env=None):
+def _inlib_multi_worker(rank, world, port, outdir, fake, w_target=None, nsteps=None, nofuse=False, overlap=False, w_begin=None, mwalk_of_rank=None, env=None, plain=False):
     os.environ.update(env or {})
     import torch                                   # noqa: F401
     import torch.distributed as dist
@@ -347,7 +404,7 @@ def _inlib_multi_worker(rank, world, port, outdir, fake, w_target=None, nsteps=N
     from sqmc_amd import host as H
     sqmc_amd.set_device(0)
     hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
-    w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=(mwalk_of_rank or {}).get(rank, 400000))
+    w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=(mwalk_of_rank or {}).get(rank, 400000), semistochastic=not plain)
     w.attach_rccl()
     status, outs = 0, []
     try:
@@ -401,6 +458,29 @@ def test_in_library_pipelined_exchange_two_ranks(tmp_path):
     for a, b in zip(runs[0], runs[1]):
         assert np.array_equal(a["outs"], b["outs"])
         assert np.array_equal(a["up"], b["up"]) and np.array_equal(a["dn"], b["dn"]) and np.array_equal(a["wt"], b["wt"])
+
+
+def test_sharded_plain_walk_in_library(tmp_path):
+    """The plain (semistochastic = f) sharded walk with the exchanges issued by the library (two ranks over the transport
+    double; steps, then the pipelined run): the same walk as with the caller-driven exchanges."""
+    import torch.multiprocessing as mp
+    fake = _fake_rccl_lib()
+    ctx = mp.get_context("spawn")
+    lib = os.path.join(str(tmp_path), "lib"); os.makedirs(lib)
+    ps = [ctx.Process(target=_inlib_multi_worker, args=(r, 2, 29660, lib, fake), kwargs=dict(plain=True)) for r in range(2)]
+    for p in ps: p.start()
+    for p in ps: p.join(300)
+    alive = [p for p in ps if p.is_alive()]
+    for p in alive: p.terminate()
+    assert not alive, "in-library exchange did not finish (deadlock?)"
+    assert all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
+    a = [np.load(os.path.join(lib, "rank%d.npz" % r)) for r in range(2)]
+    host = os.path.join(str(tmp_path), "host"); os.makedirs(host)
+    b = _run(2, host, 29661, system="c2_plain")
+    for x, y in zip(a, b):
+        assert np.array_equal(x["up"], y["up"]) and np.array_equal(x["dn"], y["dn"]) and np.all(x["imp_distance"] != 0)
+        assert np.allclose(x["wt"], y["wt"], rtol=1e-9, atol=0) and np.allclose(x["outs"][:, :7], y["outs"][:, :7], rtol=1e-11, atol=1e-11)
+    assert np.array_equal(a[1]["outs"][:, :7], a[0]["outs"][:, :7])
 
 
 def test_sharded_short_list_tail_when_one_rank_gives_up(tmp_path):

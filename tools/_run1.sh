@@ -1,3 +1,2 @@
-export SQMC_COMMIT=$1
-bash tools/profile_bench.sh r02_bench_1e5 && bash tools/profile_bench.sh r02_bench_1e6 --target 1e6
-ls gpurun_out/r02_bench_1e*
+timeout -k 10 1000 python -m pytest tests/test_gpu_sharded.py -m gpu -x -q > gpurun_out/t_sel.log 2>&1; echo "pytest rc=$?" >> gpurun_out/t_sel.log
+tail -25 gpurun_out/t_sel.log
