@@ -268,7 +268,9 @@ int sqmc_gpu_tail_stats(sqmc_gpu_ctx *ctx, int64_t *bucket_steps, int64_t *bucke
  * of the first step of the NEXT call behind its own tail, as every other step of the call does for its successor, so the GPU keeps
  * working while the host does its block bookkeeping (the first step of a call costs 0.135 instead of 0.075 ms otherwise).  The
  * head is forgotten, at the cost of one stream synchronisation, if anything but a step with the same tau / cutoff / mode comes
- * next (walkers uploaded or downloaded, projector rescaled, RNG reset, chaining switched off, finalize).  Single-GPU steps only. */
+ * next (walkers uploaded or downloaded, projector rescaled, RNG reset, chaining switched off, finalize).  The same holds for a host that
+ * calls sqmc_gpu_step itself, step by step (its own work between steps, as in the reference's loop): with chaining on, every step past the
+ * target population enqueues its successor's head.  Single-GPU steps only. */
 int sqmc_gpu_set_chained_runs(sqmc_gpu_ctx *ctx, int32_t on);
 /* diagnostics: wall-clock time (microseconds) and index of the four slowest steps of the last sqmc_gpu_run / sqmc_gpu_shard_run
  * call -- a step that waited for the host (scheduling, a rerun through the radix tail) stands out here */

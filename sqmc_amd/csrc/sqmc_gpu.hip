@@ -153,6 +153,7 @@ struct sqmc_gpu_ctx {
   hipStream_t st3; hipEvent_t e_join3;                   // third stream: the deterministic projection (it touches the deterministic-space walkers only, death/clone all the others)
   // pipelined head (sqmc_gpu_run, COUNTER discipline, target population reached): gate + scan + spawn of step n+1 are
   // enqueued right behind k_finish of step n, before the host has read step n's sums
+  bool in_run;                // inside sqmc_gpu_run / sqmc_gpu_shard_run (they decide about the pipelined head themselves)
   bool chained_runs;          // sqmc_gpu_set_chained_runs: the last step of a run call enqueues the head of the first step of the next call
   bool pipeline_next, head_ready; StepP head_p; u64 head_cseq; hipEvent_t hev[4];
   bool owner_ready;           // this step's k_spawn already wrote the owner key of every child (sharded steps)
@@ -1039,6 +1040,9 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   p.semi = sp->semistochastic; p.reached = sp->reached_w_abs_gen;
   const long long n0 = c->nwalk, M = c->mwalk;
   const int mode = c->rng_mode; const u64 seed = c->seed64, step = c->step_no;
+  // a host that calls step by step (the reference's own loop does work between steps) and has promised to come back with the
+  // same tau and cutoff (sqmc_gpu_set_chained_runs): this step enqueues the next one's head, as the steps of sqmc_gpu_run do
+  if (!c->in_run) c->pipeline_next = c->chained_runs && sp->reached_w_abs_gen == 2 && mode != SQMC_RNG_REPLAY && !getenv("SQMC_NO_PIPELINE");
   collect_timers(c);
   c->nt = 0;
   hipStream_t st2 = c->st2;
@@ -1118,6 +1122,7 @@ static int run_steps(sqmc_gpu_ctx *c, sqmc_popctl *pc, int64_t nsteps, double *s
   if (!c || !pc || !totals || nsteps < 0) return fail(SQMC_ERR_BAD_ARG, "bad argument");
   for (int k = 0; k < 16; k++) totals[k] = 0.0;
   for (int k = 0; k < 4; k++) { c->slow_us[k] = 0.0; c->slow_step[k] = -1; }
+  struct InRun { sqmc_gpu_ctx *c; InRun(sqmc_gpu_ctx *x) : c(x) { c->in_run = true; } ~InRun() { c->in_run = false; } } in_run_guard(c);
   struct timespec ts_prev; clock_gettime(CLOCK_MONOTONIC, &ts_prev);
   for (int64_t it = 0; it < nsteps; it++) {
     // do_walk.f90:2175-2184

@@ -608,6 +608,18 @@ def test_chained_runs_walk_the_same_trajectory():
     b.close(); c.close()
     for k in ("up", "dn", "wt"):
         assert np.array_equal(wb2[k], wc2[k]), k
+    # a host that calls sqmc_gpu_step itself (population control on its side between the steps): chained, every step past the target
+    # enqueues its successor's head; the walk is the unchained one
+    d, e = fresh(), fresh()
+    d.run(300, keep_stats=False); e.run(300, keep_stats=False)
+    d.g.set_chained_runs(True)
+    od = np.array([d.step().copy() for _ in range(25)]); oe = np.array([e.step().copy() for _ in range(25)])
+    d.g.set_chained_runs(False)
+    wd, we = d.g.download_walkers(), e.g.download_walkers()
+    d.close(); e.close()
+    assert np.array_equal(od, oe)
+    for k in ("up", "dn", "wt"):
+        assert np.array_equal(wd[k], we[k]), k
 
 
 @pytest.mark.parametrize("rng_mode,nsteps", [(0, 60), (1, 120)])
