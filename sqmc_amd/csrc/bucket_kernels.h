@@ -214,6 +214,8 @@ __device__ __forceinline__ double bk_hii_group(const ChemTab &t, const double *_
   __syncthreads();
   return e1 + (ex + di) + t.nuclear;
 }
+#define BK_LONG_RUN 24                 // followers a head folds itself
+#define BK_LONG_MAX 32                 // longer runs a bucket hands to wavefronts (more than that: their heads fold them alone)
 #define BK_HQ_DETS (BK_CAP_T * 2 / 16)                       // determinants whose (up, dn) wait in LDS for the H_ii phase
 // sum over the wavefront by DPP row shifts and row broadcasts (lane 63 holds it): 6 steps of two 32-bit moves and an add
 template <int CTRL, int ROWMASK>
@@ -528,6 +530,43 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
   u32 *s_nc = scratch;                                  // the sort's counters are idle from here on: child count of every kept walker, then its prefix
   // ---- runs: the head folds its followers in merged order, then check_initiator, the discard rule and the rounding;
   //      the merged walker stays at the head's source slot (weight, packed flags); rnk[q] = 1 kept, 0x101 kept in the deterministic space
+  // what follows the fold of a run, for its head at merged slot q (source slot si) and the slot qq behind its last follower
+  auto finish_head = [&](int q, int si, double wt, int ini, int d, int psg, int qq) -> unsigned short {
+    unsigned short keep = 0;
+    {   // check_initiator, do_walk.f90:6838-6872
+      const int dd = d - p.imind > 0 ? d - p.imind : 0;
+      const double thr = p.r_init * ipow_d(dd, p.ipow), aw = fabs(wt);
+      if (ini == 3 && p.r_init >= 0) { if (wt * psg < 1.0) wt = (double)psg; }
+      else if (ini == 2 && ((aw <= thr && d > 0) || ((aw <= p.r_init && !p.cti) && d == -2))) ini = 1;
+      else if (ini < 2 && ((aw > thr && d >= 0) || ((aw > p.r_init || p.cti) && d == -2))) ini = ini + 1;
+    }
+    int dtest = d;
+    if (d == -1) { if (b == B - 1 && qq >= T) dtest = 1; d = 1; }          // 6032-6036 then the last-det test at 6038
+    const bool discard = (((wt == 0.0 && (ini != 3 || p.r_init < 0)) || ini == 0) && dtest >= 1);
+    if (!discard) {
+      if (d >= 1 && fabs(wt) < p.min_wt) {                                // reduce_my_walker, 7196-7254: the draw is keyed by the determinant's rank (its sort key)
+        const u32 kk = (si < R) ? rk[si] : (u32)(sa[si - R] >> 32);
+        Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, (u64)kk);
+        if (rng_draw(g) < (fabs(wt) / p.min_wt)) wt = copysign(p.min_wt, wt); else wt = 0.0;
+      }
+      if (!(wt == 0.0 && d >= 1)) keep = (d == 0) ? 0x101 : 0x1;        // zero weights outside the deterministic space are dropped (7222-7249)
+    }
+    s_w[si] = wt; s_f[si] = pack_flg(d, ini, psg);
+    if (go.child_off && keep) {                                           // the next step's spawn gate: only the child count is needed before the positions are
+      const u32 kk = (si < R) ? rk[si] : (u32)(sa[si - R] >> 32);
+      u64 nc; double wc;
+      gate_children(wt * p.rfi, go.cutoff, seed, go.step_next, (u64)kk, nc, wc);
+      s_nc[q] = (u32)nc;
+    }
+    return keep;
+  };
+  // A head folds its first BK_LONG_RUN followers itself; what is left of a longer run (a heavy determinant: the Neel state of the
+  // 4x4 Hubbard lattice collects ~10^3 spawns of both signs a step, and one thread folding them -- 100 cycles apiece -- kept every
+  // other bucket waiting for 45 us) is handed to a whole wavefront below.
+  __shared__ int s_lq[BK_LONG_MAX], s_lqq[BK_LONG_MAX], s_lini[BK_LONG_MAX], s_ld[BK_LONG_MAX], s_nlong;
+  __shared__ double s_lwt[BK_LONG_MAX];
+  if (tid == 0) s_nlong = 0;
+  __syncthreads();
   for (int q = tid; q < T; q += BK_AT) {
     const u32 e = m2s[q];
     unsigned short keep = 0;
@@ -537,34 +576,95 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
       int ini = flg_init(f0), d = flg_impd(f0); const int psg = flg_psign(f0);
       if (d == -1 && !(b == 0 && q == 0)) d = 1;                          // 5985-5986 (the very first walker keeps -1 until the end)
       int qq = q + 1;
-      for (; qq < T; qq++) { const u32 e2 = m2s[qq]; if (e2 & BK_STOP) break; bk_fold(wt, ini, d, s_w[e2], s_f[e2], p); }
-      {   // check_initiator, do_walk.f90:6838-6872
-        const int dd = d - p.imind > 0 ? d - p.imind : 0;
-        const double thr = p.r_init * ipow_d(dd, p.ipow), aw = fabs(wt);
-        if (ini == 3 && p.r_init >= 0) { if (wt * psg < 1.0) wt = (double)psg; }
-        else if (ini == 2 && ((aw <= thr && d > 0) || ((aw <= p.r_init && !p.cti) && d == -2))) ini = 1;
-        else if (ini < 2 && ((aw > thr && d >= 0) || ((aw > p.r_init || p.cti) && d == -2))) ini = ini + 1;
+      bool more = false;
+      for (; qq < T; qq++) {
+        const u32 e2 = m2s[qq];
+        if (e2 & BK_STOP) break;
+        if (qq - q > BK_LONG_RUN) { more = true; break; }
+        bk_fold(wt, ini, d, s_w[e2], s_f[e2], p);
       }
-      int dtest = d;
-      if (d == -1) { if (b == B - 1 && qq >= T) dtest = 1; d = 1; }          // 6032-6036 then the last-det test at 6038
-      const bool discard = (((wt == 0.0 && (ini != 3 || p.r_init < 0)) || ini == 0) && dtest >= 1);
-      if (!discard) {
-        if (d >= 1 && fabs(wt) < p.min_wt) {                                // reduce_my_walker, 7196-7254: the draw is keyed by the determinant's rank (its sort key)
-          const u32 kk = (si < R) ? rk[si] : (u32)(sa[si - R] >> 32);
-          Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, (u64)kk);
-          if (rng_draw(g) < (fabs(wt) / p.min_wt)) wt = copysign(p.min_wt, wt); else wt = 0.0;
-        }
-        if (!(wt == 0.0 && d >= 1)) keep = (d == 0) ? 0x101 : 0x1;        // zero weights outside the deterministic space are dropped (7222-7249)
-      }
-      s_w[si] = wt; s_f[si] = pack_flg(d, ini, psg);
-      if (go.child_off && keep) {                                           // the next step's spawn gate: only the child count is needed before the positions are
-        const u32 kk = (si < R) ? rk[si] : (u32)(sa[si - R] >> 32);
-        u64 nc; double wc;
-        gate_children(wt * p.rfi, go.cutoff, seed, go.step_next, (u64)kk, nc, wc);
-        s_nc[q] = (u32)nc;
-      }
+      int slot = -1;
+      if (more) { slot = atomicAdd(&s_nlong, 1); if (slot >= BK_LONG_MAX) { slot = -1; for (; qq < T; qq++) { const u32 e2 = m2s[qq]; if (e2 & BK_STOP) break; bk_fold(wt, ini, d, s_w[e2], s_f[e2], p); } } }
+      if (slot >= 0) { s_lq[slot] = q; s_lqq[slot] = qq; s_lwt[slot] = wt; s_lini[slot] = ini; s_ld[slot] = d; }
+      else keep = finish_head(q, si, wt, ini, d, psg, qq);
     }
     rnk[q] = keep;
+  }
+  __syncthreads();
+  {
+    // The rest of a long run, 64 followers at a time by one wavefront.  The reference's pairwise rule is sequential in the weight
+    // (floating-point additions in storage order) and in the initiator flag (which looks at the running weight); both are kept:
+    //   * lane 0 adds the weights one by one and leaves the running weight BEFORE every follower where that follower's own weight
+    //     stood -- 8 cycles apiece, not 100;
+    //   * every lane then knows what its follower does to the initiator flag, a map of {0,1,2,3} to itself (5905-5925): the maximum
+    //     with its own flag if the signs agree, its own flag / 0 / nothing as the running weight is smaller / equal / larger if they
+    //     do not (a permanent initiator keeps its 3 unless r_initiator = -1); the maps are composed in order by a shuffle tree;
+    //   * the distance flag of a run does not depend on the order once no follower can carry 0 (spawns never do): 0 and -2 stay,
+    //     any -2 follower makes -2, else the smallest |d2| (a head still at -1 keeps it).  The one place where the order of the
+    //     flags and the weights meet -- a follower with -1 is not added to a head with 0 (5946) -- depends on the HEAD's 0 only.
+    const int nlong = s_nlong < BK_LONG_MAX ? s_nlong : BK_LONG_MAX;
+    for (int k = wv; k < nlong; k += BK_AT / 64) {
+      const int q = s_lq[k]; int qq = s_lqq[k];
+      double wt = s_lwt[k]; int ini = s_lini[k], d = s_ld[k];
+      const int si = (int)(m2s[q] & ~BK_STOP);
+      const int psg = flg_psign(s_f[si]);
+      const bool keep3 = !(p.r_init == -1.0);                         // a permanent initiator's flag survives a sign change
+      for (;;) {
+        const int idx = qq + lane;
+        const u32 e2 = (idx < T) ? m2s[idx] : BK_STOP;
+        const u64 stops = __ballot((e2 & BK_STOP) != 0);
+        const int n = stops ? (int)__builtin_ctzll(stops) : 64;       // followers in this round: consecutive sorted spawns
+        if (n > 0) {
+          const bool in = lane < n;
+          const int e0 = (int)(__shfl((int)(e2 & ~BK_STOP), 0, 64));
+          const double w2 = in ? s_w[e0 + lane] : 0.0; const u32 f2 = in ? s_f[e0 + lane] : 0u;
+          const int i2 = flg_init(f2), d2 = flg_impd(f2);
+          const u64 skipm = __ballot(in && d == 0 && d2 == -1);          // not added (d stays 0 once it is 0)
+          const bool anym2 = __ballot(in && d2 == -2) != 0ull;
+          int am = (in && d2 != -2) ? (d2 < 0 ? -d2 : d2) : 0x7FFFFFFF;
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) {                                           // running weight in front of every follower, in storage order
+            double run = wt;
+            int z = 0;
+            for (; z + 8 <= n; z += 8) {                             // eight reads in flight, then eight additions in order
+              double a_[8];
+#pragma unroll
+              for (int y = 0; y < 8; y++) a_[y] = s_w[e0 + z + y];
+#pragma unroll
+              for (int y = 0; y < 8; y++) { s_w[e0 + z + y] = run; if (!((skipm >> (z + y)) & 1ull)) run = run + a_[y]; }
+            }
+            for (; z < n; z++) { const double wz = s_w[e0 + z]; s_w[e0 + z] = run; if (!((skipm >> z) & 1ull)) run = run + wz; }
+            wt = run;
+          }
+          __builtin_amdgcn_wave_barrier();
+          const double wb = in ? s_w[e0 + lane] : 0.0;               // the weight this follower met
+          // its map of the initiator flag, two bits per entry (entry x in bits 2x, 2x+1); identity for the idle lanes
+          u32 tab = 0xE4u;                                           // 3,2,1,0
+          if (in) {
+            if (w2 * wb > 0.0) { tab = 0; for (int x = 0; x < 4; x++) tab |= (u32)(x > i2 ? x : i2) << (2 * x); }
+            else if (fabs(wb) < fabs(w2)) { tab = 0; for (int x = 0; x < 4; x++) tab |= (u32)((x != 3 || !keep3) ? i2 : x) << (2 * x); }
+            else if (fabs(wb) == fabs(w2)) { tab = 0; for (int x = 0; x < 4; x++) tab |= (u32)((x != 3 || !keep3) ? 0 : x) << (2 * x); }
+          }
+          for (int o = 1; o < 64; o <<= 1) {                         // lane l: followers l .. l + 2 o - 1 after this round, applied in order
+            const u32 nxt = (u32)__shfl_down((int)tab, o, 64);
+            const int am2 = __shfl_down(am, o, 64);
+            if (lane + o < 64) {
+              u32 c2 = 0;
+              for (int x = 0; x < 4; x++) c2 |= ((nxt >> (2 * ((tab >> (2 * x)) & 3u))) & 3u) << (2 * x);      // nxt after tab
+              tab = c2;
+              am = am2 < am ? am2 : am;
+            }
+          }
+          tab = (u32)__shfl((int)tab, 0, 64); am = __shfl(am, 0, 64);
+          ini = (int)((tab >> (2 * ini)) & 3u);
+          if (d != 0 && d != -2) { if (anym2) d = -2; else if (d != -1 && am < d) d = am; }
+          wt = __shfl(wt, 0, 64);
+          qq += n;
+        }
+        if (stops) break;
+      }
+      if (lane == 0) rnk[q] = finish_head(q, si, wt, ini, d, psg, qq);
+    }
   }
   __syncthreads();
   // ---- rank of every kept walker inside the bucket (lo 16 bits: position, hi: index among the deterministic-space walkers):
