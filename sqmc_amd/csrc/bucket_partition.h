@@ -19,7 +19,8 @@
 // LAST step left them (written by that step's bucket tail into x_out, with every such walker's row in WalkArr::irk).
 struct FusedSide { int on; const double *y; const double *x_in; double *x_out; };      // y = A x_in, row by row, from the spare blocks of k_spawn (PrjPre)
 // the matrix-vector part of the projection, which needs nothing the host still has to decide: computed by spare blocks of k_spawn
-struct PrjPre { int n_imp; const int *ptr, *col; const double *val; const double *x; double *y; };
+struct PrjPre { int n_imp; const int *ptr, *col; const double *val; const double *x; double *y;
+                const int *grow; };      // grow != null (sharded steps): y[i] = row grow[i] of A times x, for the n_imp rows this rank owns
 
 struct BucketArgs {
   int B, nsb;                          // buckets, partition blocks

@@ -163,6 +163,8 @@ struct sqmc_gpu_ctx {
   u32 *d_bhint; int pos_flip, scount_pos;      // where each boundary set lay when it was made (3 x BK_MAXB + 1); which of the two d_bpos halves this step writes / the counts were taken with
   u32 *d_bkb, *d_bpos, *d_bscount;   // bucket boundaries (three sets of BK_MAXB + 1 keys: in use, counted with, being made), their positions in this step's list, the spawns the last bucket tail counted per bucket
   int kb_B[3], scount_B;      // the bucket count each set was made for / the counts were taken with (0: not valid)
+  bool shard_y_used;          // ... and this step is using it
+  bool shard_y_ok;            // in-library sharded step: the pipelined head all-reduced the deterministic weights and its spare blocks multiplied the projector into them (d_prj_y): the step only adds the last line
   BucketArgs shard_ba;        // sharded steps: the boundaries chosen at the start of the step (their block runs on the side stream)
   int kb_next, scount_buf, head_kb_use;   // set the next bucket head partitions with; set the counts were taken with; set the enqueued head uses (-1: equal-residents boundaries)
   double *d_prj_y; const double *head_prj_x; bool head_y_done;      // A x of the pipelined head's spare k_spawn blocks, the x it used
@@ -181,6 +183,7 @@ struct sqmc_gpu_ctx {
 };
 // a head enqueued for a step that is not going to be the next thing that happens (chained runs): forget it
 static void abandon_head(sqmc_gpu_ctx *c);
+static int shard_head_project(sqmc_gpu_ctx *c);      // abi_shard.inc
 
 
 #include "walk_kernels.h"
@@ -657,6 +660,15 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   FinArgs spawn_fin; memset(&spawn_fin, 0, sizeof(spawn_fin));
   PrjPre pp; memset(&pp, 0, sizeof(pp));
   c->head_y_done = false;
+  c->shard_y_ok = false;
+  if (dev_n && c->d_grow && c->comm && !c->comm2 && c->n_imp > 0 && p.semi) {
+    // In-library sharded step (one communicator): the all-reduce of the deterministic weights needs nothing the host still has to
+    // decide either.  It goes in front of k_spawn, whose spare blocks then multiply this rank's rows of the projector into the
+    // result; the step itself only adds the last line.  (Decided by quantities every rank shares: the collectives keep their order.)
+    int rp = shard_head_project(c); if (rp) return rp;
+    pp.n_imp = (int)c->n_imp_local; pp.ptr = c->d_prj_ptr; pp.col = c->d_prj_col; pp.val = c->d_prj_val; pp.x = c->d_xg; pp.y = c->d_prj_y; pp.grow = c->d_grow;
+    c->shard_y_ok = true;
+  }
   if (dev_n && c->head_prj_x && c->n_imp > 0 && !c->d_grow) {       // the tail that enqueues this head is a bucket tail: its deterministic weights, row by row, are this step's x
     pp.n_imp = (int)c->n_imp; pp.ptr = c->d_prj_ptr; pp.col = c->d_prj_col; pp.val = c->d_prj_val; pp.x = c->head_prj_x; pp.y = c->d_prj_y;
     c->head_y_done = true;
@@ -728,7 +740,7 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
     c->head_ba = hb;
   }
   const long long nfree = dev_n ? M : M - n0;          // dev_n: nothing is known about the count but that it is >= 0
-  const int spawn_fuse = (hb.B > 0 || spawn_fin.on || pp.n_imp > 0) ? 1 : 0;
+  const int spawn_fuse = (hb.B > 0 || spawn_fin.on || pp.n_imp > 0 || c->shard_y_ok) ? 1 : 0;
   if (nfree > 0) {
     if (s0)
       SPAWN_LAUNCH_EXT(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
@@ -981,6 +993,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     else { c->h_sc->err = (int)c->h_mail->err; for (int i = 0; i < 7; i++) c->h_sc->stats[i] = c->h_mail->stats[i]; }
     for (int i = 7; i < 16; i++) c->h_sc->stats[i] = loc[i];          // the local figures and the walker counts are this rank's own, from its own (valid) tail:
     c->h_sc->tot2 = tot2_first; c->h_sc->retry = 0;                    // the head enqueued behind it has cleared the device copies since
+    c->shard_y_ok = false;                                             // ... and its projection used weights the other rank had not finished: the step redoes it
     { static const int hold = getenv("SQMC_BUCKET_HOLDOFF") ? atoi(getenv("SQMC_BUCKET_HOLDOFF")) : 8; c->bk_holdoff = hold; }
   }
   if (bucket && !stop_now) {
@@ -995,7 +1008,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       std::swap(c->w.up, c->m.up); std::swap(c->w.dn, c->m.dn); std::swap(c->w.wt, c->m.wt); std::swap(c->w.flg, c->m.flg);
       std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed); std::swap(c->w.irk, c->m.irk);
       if (fuse_gate) std::swap(c->d_keys, c->d_keys_alt);
-      c->pipeline_next = false; c->bk_retries++; c->head_offsets_done = false;
+      c->pipeline_next = false; c->bk_retries++; c->head_offsets_done = false; c->shard_y_ok = false;
       c->kb_B[0] = c->kb_B[1] = c->kb_B[2] = 0; c->scount_B = 0; c->kb_next = c->scount_buf = -1;      // boundaries are learnt anew
       { static const int hold = getenv("SQMC_BUCKET_HOLDOFF") ? atoi(getenv("SQMC_BUCKET_HOLDOFF")) : 8; c->bk_holdoff = hold; }
       return SQMC_INTERNAL_RETRY;

@@ -213,7 +213,8 @@ __device__ __forceinline__ u64 spawn_emit(const ChemDev &dev, const WalkArr &w, 
 __device__ __forceinline__ void prj_row_product(const PrjPre &pp, int row) {
   __shared__ double s_prod[TPB / 64][64];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = pp.ptr[row], e = pp.ptr[row + 1];
+  const int arow = pp.grow ? pp.grow[row] : row;
+  const int b = pp.ptr[arow], e = pp.ptr[arow + 1];
   double y = 0.0;
   for (int base = b; base < e; base += 64) {
     const int k = base + lane;
