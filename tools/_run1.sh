@@ -2,7 +2,7 @@ timeout -k 10 1000 python -m pytest tests/test_gpu_sharded.py -m gpu -x -q > gpu
 tail -12 gpurun_out/t_sel.log
 grep -q "rc=0" gpurun_out/t_sel.log && \
 SQMC_BENCH_FORCE_SHARDED=1 timeout -k 10 200 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline > gpurun_out/b_sh1.log 2>&1 && \
-timeout -k 10 300 python tools/soak_sharded.py 2>&1 | grep "^soak"
+true
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob("gpurun_out/b_sh1.log")):
