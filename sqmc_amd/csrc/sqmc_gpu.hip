@@ -163,6 +163,7 @@ struct sqmc_gpu_ctx {
   u32 *d_bhint; int pos_flip, scount_pos;      // where each boundary set lay when it was made (3 x BK_MAXB + 1); which of the two d_bpos halves this step writes / the counts were taken with
   u32 *d_bkb, *d_bpos, *d_bscount;   // bucket boundaries (three sets of BK_MAXB + 1 keys: in use, counted with, being made), their positions in this step's list, the spawns the last bucket tail counted per bucket
   int kb_B[3], scount_B;      // the bucket count each set was made for / the counts were taken with (0: not valid)
+  bool shard_x_ready, shard_x_used;   // the deterministic weights of the COMING step are all-reduced already (every rank did that behind this step's sums, whether or not it enqueued a head) / this step is using them
   bool shard_y_used;          // ... and this step is using it
   bool shard_y_ok;            // in-library sharded step: the pipelined head all-reduced the deterministic weights and its spare blocks multiplied the projector into them (d_prj_y): the step only adds the last line
   BucketArgs shard_ba;        // sharded steps: the boundaries chosen at the start of the step (their block runs on the side stream)
@@ -667,7 +668,7 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
     // result; the step itself only adds the last line.  (Decided by quantities every rank shares: the collectives keep their order.)
     int rp = shard_head_project(c); if (rp) return rp;
     pp.n_imp = (int)c->n_imp_local; pp.ptr = c->d_prj_ptr; pp.col = c->d_prj_col; pp.val = c->d_prj_val; pp.x = c->d_xg; pp.y = c->d_prj_y; pp.grow = c->d_grow;
-    c->shard_y_ok = true;
+    c->shard_y_ok = true; c->shard_x_ready = true;
   }
   if (dev_n && c->head_prj_x && c->n_imp > 0 && !c->d_grow) {       // the tail that enqueues this head is a bucket tail: its deterministic weights, row by row, are this step's x
     pp.n_imp = (int)c->n_imp; pp.ptr = c->d_prj_ptr; pp.col = c->d_prj_col; pp.val = c->d_prj_val; pp.x = c->head_prj_x; pp.y = c->d_prj_y;
@@ -761,6 +762,7 @@ static void drop_head(sqmc_gpu_ctx *c) {
   c->scan_used[0] = c->scan_used[1] = 0;
 }
 static void abandon_head(sqmc_gpu_ctx *c) {
+  if (c) c->shard_x_ready = false;       // the walkers are about to change under the caller's hands (every rank's: uploads are collective in a sharded walk)
   if (!c || !c->head_ready) return;
   drop_head(c);                          // waits for its kernels (they wrote scratch only: keys, child offsets, spawn records, partition rows) and re-zeroes the scan words
   c->head_ba.B = 0; c->head_offsets_done = false; c->head_y_done = false; c->head_hii = false; c->head_hii_joined = false; c->head_prj_x = nullptr;
@@ -993,7 +995,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     else { c->h_sc->err = (int)c->h_mail->err; for (int i = 0; i < 7; i++) c->h_sc->stats[i] = c->h_mail->stats[i]; }
     for (int i = 7; i < 16; i++) c->h_sc->stats[i] = loc[i];          // the local figures and the walker counts are this rank's own, from its own (valid) tail:
     c->h_sc->tot2 = tot2_first; c->h_sc->retry = 0;                    // the head enqueued behind it has cleared the device copies since
-    c->shard_y_ok = false;                                             // ... and its projection used weights the other rank had not finished: the step redoes it
+    c->shard_y_ok = false; c->shard_x_ready = false;                   // ... and its projection used weights the other rank had not finished: the step redoes it
     { static const int hold = getenv("SQMC_BUCKET_HOLDOFF") ? atoi(getenv("SQMC_BUCKET_HOLDOFF")) : 8; c->bk_holdoff = hold; }
   }
   if (bucket && !stop_now) {
@@ -1008,7 +1010,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       std::swap(c->w.up, c->m.up); std::swap(c->w.dn, c->m.dn); std::swap(c->w.wt, c->m.wt); std::swap(c->w.flg, c->m.flg);
       std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed); std::swap(c->w.irk, c->m.irk);
       if (fuse_gate) std::swap(c->d_keys, c->d_keys_alt);
-      c->pipeline_next = false; c->bk_retries++; c->head_offsets_done = false; c->shard_y_ok = false;
+      c->pipeline_next = false; c->bk_retries++; c->head_offsets_done = false; c->shard_y_ok = false; c->shard_x_ready = false;
       c->kb_B[0] = c->kb_B[1] = c->kb_B[2] = 0; c->scount_B = 0; c->kb_next = c->scount_buf = -1;      // boundaries are learnt anew
       { static const int hold = getenv("SQMC_BUCKET_HOLDOFF") ? atoi(getenv("SQMC_BUCKET_HOLDOFF")) : 8; c->bk_holdoff = hold; }
       return SQMC_INTERNAL_RETRY;

@@ -13,7 +13,7 @@ SEED = (1346, 5634, 6635, 4361)
 NSTEPS, W_BEGIN, W_TARGET = 40, 2000, 20000
 
 
-def _worker(rank, world, port, outdir, system="c2", w_begin=None, w_target=None, nsteps=None):
+def _worker(rank, world, port, outdir, system="c2", w_begin=None, w_target=None, nsteps=None, walk_kw=None):
     W_BEGIN, W_TARGET, NSTEPS = w_begin or globals()["W_BEGIN"], w_target or globals()["W_TARGET"], nsteps or globals()["NSTEPS"]
     import torch                                   # before the HIP library (one libamdhip64 per process)
     import torch.distributed as dist
@@ -38,7 +38,7 @@ def _worker(rank, world, port, outdir, system="c2", w_begin=None, w_target=None,
         w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000, semistochastic=False)
     else:
         hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
-        w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000, owner_hash=1 if system == "c2_djb" else 0)
+        w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=400000, owner_hash=1 if system == "c2_djb" else 0, **(walk_kw or {}))
     outs = []
     for _ in range(NSTEPS):
         outs.append(w.step().copy())
@@ -389,7 +389,7 @@ def _fake_rccl_lib():
     return so
 
 
-def _inlib_multi_worker(rank, world, port, outdir, fake, w_target=None, nsteps=None, nofuse=False, overlap=False, w_begin=None, mwalk_of_rank=None, env=None, plain=False):
+def _inlib_multi_worker(rank, world, port, outdir, fake, w_target=None, nsteps=None, nofuse=False, overlap=False, w_begin=None, mwalk_of_rank=None, env=None, plain=False, walk_kw=None):
     os.environ.update(env or {})
     import torch                                   # noqa: F401
     import torch.distributed as dist
@@ -404,7 +404,7 @@ def _inlib_multi_worker(rank, world, port, outdir, fake, w_target=None, nsteps=N
     from sqmc_amd import host as H
     sqmc_amd.set_device(0)
     hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
-    w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=(mwalk_of_rank or {}).get(rank, 400000), semistochastic=not plain)
+    w = H.ShardedWalk(hst, W_TARGET, rank, world, w_begin=W_BEGIN, seed=SEED, mwalk=(mwalk_of_rank or {}).get(rank, 400000), semistochastic=not plain, **(walk_kw or {}))
     w.attach_rccl()
     status, outs = 0, []
     try:
@@ -580,6 +580,39 @@ def test_in_library_exchange_equals_host_driven_at_tiny_population(tmp_path):
         assert np.allclose(ra["wt"], rb["wt"], rtol=1e-9, atol=0)
         single += int((ra["outs"][:, 15] == 1).sum())
     assert single > 0                        # the case under test really occurred
+
+
+def test_in_library_pipelined_run_with_an_empty_shard(tmp_path):
+    """Four ranks, a deterministic space of two determinants and a handful of walkers: ranks that own no deterministic
+    determinant hold NO walker in some steps of the pipelined sqmc_gpu_shard_run.  Such a rank enqueues no head for the next
+    step, but the all-reduce of the deterministic weights that its peers issue in front of theirs is a collective: it must
+    take part, in the same position between the two all-reduces of the sums, or the ranks fall out of step (a hang, or sums
+    added to weights).  The walk must equal the host-driven one, in which every exchange is issued by every rank by hand."""
+    import torch.multiprocessing as mp
+    fake = _fake_rccl_lib()
+    ctx = mp.get_context("spawn")
+    world = 4
+    kw = dict(w_begin=1.5, w_target=3, nsteps=160, walk_kw=dict(n_truncate_trial_wf=1, size_deterministic=2))
+    a_dir, b_dir = os.path.join(str(tmp_path), "inlib"), os.path.join(str(tmp_path), "host")
+    os.makedirs(a_dir); os.makedirs(b_dir)
+    ps = [ctx.Process(target=_inlib_multi_worker, args=(r, world, 29650, a_dir, fake), kwargs=kw) for r in range(world)]
+    for p in ps: p.start()
+    for p in ps: p.join(300)
+    alive = [p for p in ps if p.is_alive()]
+    for p in alive: p.terminate()
+    assert not alive and all(p.exitcode == 0 for p in ps), [p.exitcode for p in ps]
+    a = [np.load(os.path.join(a_dir, "rank%d.npz" % r)) for r in range(world)]
+    b = _run(world, b_dir, 29651, **kw)
+    assert 0 < int(a[0]["n_imp_global"]) < world
+    empty_in_run = 0
+    for ra, rb in zip(a, b):
+        assert int(ra["reached"][0]) == 2
+        assert np.allclose(ra["outs"][:, :7], rb["outs"][:, :7], rtol=1e-11, atol=1e-13)
+        assert np.array_equal(ra["outs"][:, [5, 7, 15]], rb["outs"][:, [5, 7, 15]])
+        assert np.array_equal(ra["up"], rb["up"]) and np.array_equal(ra["dn"], rb["dn"]) and np.array_equal(ra["imp_distance"], rb["imp_distance"])
+        assert np.allclose(ra["wt"], rb["wt"], rtol=1e-9, atol=0)
+        empty_in_run += int((ra["outs"][80:, 7] == 0).sum())
+    assert empty_in_run > 0                  # the case under test really occurred, in the half walked by sqmc_gpu_shard_run
 
 
 def test_in_library_stop_is_collective(tmp_path):
