@@ -165,6 +165,7 @@ struct sqmc_gpu_ctx {
   int kb_B[3], scount_B;      // the bucket count each set was made for / the counts were taken with (0: not valid)
   bool shard_x_ready, shard_x_used;   // the deterministic weights of the COMING step are all-reduced already (every rank did that behind this step's sums, whether or not it enqueued a head) / this step is using them
   bool shard_y_used;          // ... and this step is using it
+  bool head_sums_ride;        // the all-reduce of the step's sums is the one in front of the pipelined head (they lie behind the weights)
   bool shard_y_ok;            // in-library sharded step: the pipelined head all-reduced the deterministic weights and its spare blocks multiplied the projector into them (d_prj_y): the step only adds the last line
   BucketArgs shard_ba;        // sharded steps: the boundaries chosen at the start of the step (their block runs on the side stream)
   int kb_next, scount_buf, head_kb_use;   // set the next bucket head partitions with; set the counts were taken with; set the enqueued head uses (-1: equal-residents boundaries)
@@ -184,7 +185,7 @@ struct sqmc_gpu_ctx {
 };
 // a head enqueued for a step that is not going to be the next thing that happens (chained runs): forget it
 static void abandon_head(sqmc_gpu_ctx *c);
-static int shard_head_project(sqmc_gpu_ctx *c);      // abi_shard.inc
+static int shard_head_project(sqmc_gpu_ctx *c, bool with_sums, bool empty);      // abi_shard.inc
 
 
 #include "walk_kernels.h"
@@ -666,7 +667,7 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
     // In-library sharded step (one communicator): the all-reduce of the deterministic weights needs nothing the host still has to
     // decide either.  It goes in front of k_spawn, whose spare blocks then multiply this rank's rows of the projector into the
     // result; the step itself only adds the last line.  (Decided by quantities every rank shares: the collectives keep their order.)
-    int rp = shard_head_project(c); if (rp) return rp;
+    int rp = shard_head_project(c, c->head_sums_ride, false); if (rp) return rp;
     pp.n_imp = (int)c->n_imp_local; pp.ptr = c->d_prj_ptr; pp.col = c->d_prj_col; pp.val = c->d_prj_val; pp.x = c->d_xg; pp.y = c->d_prj_y; pp.grow = c->d_grow;
     c->shard_y_ok = true; c->shard_x_ready = true;
   }
@@ -943,7 +944,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
   fa.partials = c->d_partials; fa.nblocks = nb; fa.wabs_part = c->d_wabs_part; fa.nwabs = p.semi ? nb : nbm; fa.mode = mode;
   fa.scan_state = c->d_scan_state; fa.scan_ticket = c->d_scan_ticket; fa.n_scan_words = (int)(3 * c->cap_tiles);
   fa.mail = use_mail ? c->d_mail : (HostMail *)nullptr; fa.seq = seq; fa.fstate = c->d_fstate; fa.fticket = c->d_fticket; fa.cap_ftiles = c->cap_ftiles;
-  fa.n_ftiles = n_ft; fa.on = 1; fa.n_tickets = 3; fa.n_children = -1;
+  fa.n_ftiles = n_ft; fa.on = 1; fa.n_tickets = 3; fa.n_children = -1; fa.red = nullptr;
   fa.expect_nimp = !use_mail ? (p.semi ? c->n_imp_local : -2) : -1;      // sharded in-library step: 'locations of my imp broken' must reach every rank
   if (fuse_gate && use_mail) {       // the finishing block runs beside the next head's scan (look-back set scan_flip): it re-zeroes the other set only
     const int other = c->scan_flip ^ 1;
@@ -957,11 +958,16 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
   TEND(estimate, st);
   HIPCHK(hipGetLastError());
   bool mail_in_gate = false;
+  c->head_sums_ride = false;
   if (!use_mail) {
-    int rr = comm_allreduce_stats(c); if (rr) return rr;      // do_walk.f90:2778-2790: the sums every rank needs
+    // do_walk.f90:2778-2790: the sums every rank needs.  In a pipelined run with one communicator the next step's deterministic weights
+    // are all-reduced straight behind them (enqueue_head): one call carries both (decided by quantities all ranks share)
+    static const bool two_calls = getenv("SQMC_SHARD_SPLIT_ALLREDUCE") != nullptr;
+    c->head_sums_ride = c->pipeline_next && c->d_grow && !c->comm2 && c->n_imp > 0 && p.semi && !two_calls;
+    if (!c->head_sums_ride) { int rr = comm_allreduce_stats(c); if (rr) return rr; }
     mail_in_gate = c->pipeline_next && p.semi;                 // the next step's gate kernel posts them (one launch less)
     if (!mail_in_gate) hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(64), 0, st, c->d_sc, c->d_mail, seq);
-    else { memset(&fa, 0, sizeof(fa)); fa.on = 3; fa.mail = c->d_mail; fa.seq = seq; fa.expect_nimp = -1; }
+    else { memset(&fa, 0, sizeof(fa)); fa.on = 3; fa.mail = c->d_mail; fa.seq = seq; fa.expect_nimp = -1; if (c->head_sums_ride) fa.red = c->d_xg + c->n_imp; }
   }
   c->tail_fills_hii = bucket && c->pipeline_next;
   if (c->pipeline_next) {

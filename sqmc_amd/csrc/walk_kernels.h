@@ -11,6 +11,7 @@ struct FinArgs {
   HostMail *mail; u64 seq; u64 *fstate; u32 *fticket; long long cap_ftiles; int n_ftiles; int on;
   int n_tickets;      // scan tickets behind scan_ticket to reset with the n_scan_words state words (3: all of them)
   long long n_children;   // >= 0: the step's child count from the host (a finish that rides on the NEXT step's scan must not read the scalar that scan writes)
+  const double *red;      // sharded steps: where the all-reduced sums lie when they travelled behind the deterministic weights (null: DevScalars::red)
   long long expect_nimp;  // >= 0: deterministic-space walkers this rank must still hold; anything else raises SQMC_ERR_IMP_BROKEN on the device (sharded steps: the status is all-reduced)
 };
 __device__ void finish_all(const FinArgs &f, DevScalars *sc);
@@ -925,11 +926,12 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
   APROF(5);
 }
 // posts the (all-reduced) scalars of a sharded step to the host mailbox
-__device__ __forceinline__ void post_reduced(DevScalars *sc, HostMail *mail, u64 seq) {
-  for (int i = 0; i < 7; i++) sc->stats[i] = sc->red[i];          // the global sums replace the local ones
+__device__ __forceinline__ void post_reduced(DevScalars *sc, HostMail *mail, u64 seq, const double *red_at = nullptr) {
+  const double *red = red_at ? red_at : sc->red;
+  for (int i = 0; i < 7; i++) sc->stats[i] = red[i];              // the global sums replace the local ones
   for (int i = 0; i < 16; i++) mail->stats[i] = sc->stats[i];
-  mail->tot2 = sc->tot2; mail->err = err_decode(sc->red[7]);      // the highest status any rank raised: every rank stops with it
-  mail->retry = (u64)((sc->retry ? 1 : 0) | (fmod(sc->red[7], 256.0) >= 1.0 ? 2 : 0));      // bit 0: this rank's bucket tail gave up, bit 1: some rank's did
+  mail->tot2 = sc->tot2; mail->err = err_decode(red[7]);          // the highest status any rank raised: every rank stops with it
+  mail->retry = (u64)((sc->retry ? 1 : 0) | (fmod(red[7], 256.0) >= 1.0 ? 2 : 0));      // bit 0: this rank's bucket tail gave up, bit 1: some rank's did
   mail->bk_fill = (u64)sc->bk_fill;
   __threadfence_system();
   mail->seq = seq;
@@ -954,7 +956,7 @@ struct FinExtra {
 };
 __device__ void finish_all(const FinArgs &f, DevScalars *sc) {
   if (f.on == 3) {            // sharded step: the sums were finished and all-reduced by kernels before this one; only the mail is left
-    if (threadIdx.x == 0) post_reduced(sc, f.mail, f.seq);
+    if (threadIdx.x == 0) post_reduced(sc, f.mail, f.seq, f.red);
     __syncthreads();
     return;
   }
