@@ -142,7 +142,7 @@ struct sqmc_gpu_ctx {
   int key_bits; int pack; u64 invalid_key; u64 *d_binom;
   // multi-rank sharding (owner = hash(det) mod shard_n)
   int owner_mode;             // SQMC_OWNER_MIX (default) or SQMC_OWNER_DJB (the reference's get_det_owner, bit for bit)
-  int shard_rank, shard_n; int *d_grow; long long n_imp_local; long long shard_n0, shard_nch;
+  int shard_rank, shard_n; int *d_grow; int *d_ginv; long long n_imp_local; long long shard_n0, shard_nch;
   // in-library exchange over RCCL (sqmc_gpu_comm_init): communicator + device staging
   ncclComm_t comm, comm2; double *d_xg; u64 *d_send, *d_recv; long long xch_cap; u32 *d_cnt_mine, *d_cnt_all; u32 *h_cnt_all, *d_cnt_mail;
   u64 cntall_seq;      // comm2: second communicator (ncclCommSplit) for the all-reduce that runs on the side stream
@@ -393,7 +393,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
     hipFree(c->d_keys); hipFree(c->d_keys_alt); hipFree(c->d_vals); hipFree(c->d_vals_alt); hipFree(c->d_hist); hipFree(c->d_rowtot);
     hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done); hipFree(c->d_segoff); hipFree(c->d_bkb); hipFree(c->d_bhint); hipFree(c->d_bpos); hipFree(c->d_bscount);
   }
-  hipFree(c->d_binom); hipFree(c->d_grow);
+  hipFree(c->d_binom); hipFree(c->d_grow); hipFree(c->d_ginv);
   for (int q = 0; q < 16; q++) hipFree(c->d_hbt[q]);
   comm_release(c);
   hipFree(c->d_tab); hipFree(c->d_ints); hipFree(c->d_hb_r); hipFree(c->d_hb_s); hipFree(c->d_hb_absH); hipFree(c->d_pq_ind); hipFree(c->d_pq_count);
@@ -898,7 +898,8 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       go.on = 1; go.keys = (skey == c->d_keys) ? c->d_keys_alt : c->d_keys;      // never the buffer the kernel reads its sorted words from
       go.nchild = c->d_nchild; go.wchild = c->d_wchild; go.cutoff = p.cutoff; go.step_next = step + 1;
       static const bool no_off = getenv("SQMC_BUCKET_NO_OFFSETS") != nullptr;
-      if (bucket && use_mail && !no_off && c->n_imp < (1ll << 18) && c->last_wabs > 0 && c->last_wabs < 4.0e6) go.child_off = c->d_child_off;     // 24 bits of the look-back word hold the children
+      static const bool no_shard_off = getenv("SQMC_SHARD_NO_OFFSETS") != nullptr;
+      if (bucket && (use_mail || !no_shard_off) && !no_off && c->n_imp < (1ll << 18) && c->last_wabs > 0 && c->last_wabs < 4.0e6) go.child_off = c->d_child_off;     // 24 bits of the look-back word hold the children
     }
 #define ANNEAL_ARGS c->w, c->m, skey, perm, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, n0, nall, p,  \
                     c->invalid_key, c->pack, mode, seed, step, c->d_sc, c->d_fstate, c->d_fstate + c->cap_ftiles, c->d_fticket, go
@@ -952,6 +953,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     fa.n_scan_words = c->scan_used[other]; fa.n_tickets = 1; c->scan_used[other] = 0;
     fa.n_children = (nall - n0) / (c->dev.hb.on ? 2 : 1);      // children, not walker slots
   }
+  if (!use_mail && c->head_offsets_done) fa.n_children = c->shard_nch;      // the bucket tail has written the NEXT step's child count over this step's already
   const bool fin_in_gate = c->pipeline_next && p.semi && use_mail;     // the next step's gate kernel does the final sums in its first block
   TBEG(estimate, st);
   if (!fin_in_gate) hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, fa, c->d_sc);
