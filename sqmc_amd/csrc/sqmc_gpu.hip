@@ -119,6 +119,16 @@ struct HostMail {
 };
 
 #define NTIMERS 32
+// what the block that finishes a step needs (finish_all, walk_kernels.h)
+struct FinArgs {
+  const double *partials; int nblocks; const double *wabs_part; int nwabs; int mode; u64 *scan_state; u32 *scan_ticket; int n_scan_words;
+  HostMail *mail; u64 seq; u64 *fstate; u32 *fticket; long long cap_ftiles; int n_ftiles; int on;
+  int n_tickets;      // scan tickets behind scan_ticket to reset with the n_scan_words state words (3: all of them)
+  long long n_children;   // >= 0: the step's child count from the host (a finish that rides on the NEXT step's scan must not read the scalar that scan writes)
+  const double *red;      // sharded steps: where the all-reduced sums lie when they travelled behind the deterministic weights (null: DevScalars::red)
+  long long expect_nimp;  // >= 0: deterministic-space walkers this rank must still hold; anything else raises SQMC_ERR_IMP_BROKEN on the device (sharded steps: the status is all-reduced)
+};
+
 struct sqmc_gpu_ctx {
   hipStream_t st;
   ChemTab htab; ChemTab *d_tab; double *d_ints; ChemDev dev;
@@ -166,6 +176,7 @@ struct sqmc_gpu_ctx {
   bool shard_x_ready, shard_x_used;   // the deterministic weights of the COMING step are all-reduced already (every rank did that behind this step's sums, whether or not it enqueued a head) / this step is using them
   bool shard_y_used;          // ... and this step is using it
   bool head_sums_ride;        // the all-reduce of the step's sums is the one in front of the pipelined head (they lie behind the weights)
+  FinArgs head_fin;           // ... and the final sums themselves are made by the kernel that gathers the weights
   bool shard_y_ok;            // in-library sharded step: the pipelined head all-reduced the deterministic weights and its spare blocks multiplied the projector into them (d_prj_y): the step only adds the last line
   BucketArgs shard_ba;        // sharded steps: the boundaries chosen at the start of the step (their block runs on the side stream)
   int kb_next, scount_buf, head_kb_use;   // set the next bucket head partitions with; set the counts were taken with; set the enqueued head uses (-1: equal-residents boundaries)
@@ -185,7 +196,7 @@ struct sqmc_gpu_ctx {
 };
 // a head enqueued for a step that is not going to be the next thing that happens (chained runs): forget it
 static void abandon_head(sqmc_gpu_ctx *c);
-static int shard_head_project(sqmc_gpu_ctx *c, bool with_sums, bool empty);      // abi_shard.inc
+static int shard_head_project(sqmc_gpu_ctx *c, bool with_sums, bool empty, const FinArgs *fin = nullptr);      // abi_shard.inc
 
 
 #include "walk_kernels.h"
@@ -667,7 +678,7 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
     // In-library sharded step (one communicator): the all-reduce of the deterministic weights needs nothing the host still has to
     // decide either.  It goes in front of k_spawn, whose spare blocks then multiply this rank's rows of the projector into the
     // result; the step itself only adds the last line.  (Decided by quantities every rank shares: the collectives keep their order.)
-    int rp = shard_head_project(c, c->head_sums_ride, false); if (rp) return rp;
+    int rp = shard_head_project(c, c->head_sums_ride, false, c->head_sums_ride ? &c->head_fin : nullptr); if (rp) return rp;
     pp.n_imp = (int)c->n_imp_local; pp.ptr = c->d_prj_ptr; pp.col = c->d_prj_col; pp.val = c->d_prj_val; pp.x = c->d_xg; pp.y = c->d_prj_y; pp.grow = c->d_grow;
     c->shard_y_ok = true; c->shard_x_ready = true;
   }
@@ -955,17 +966,18 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
   }
   if (!use_mail && c->head_offsets_done) fa.n_children = c->shard_nch;      // the bucket tail has written the NEXT step's child count over this step's already
   const bool fin_in_gate = c->pipeline_next && p.semi && use_mail;     // the next step's gate kernel does the final sums in its first block
+  // Sharded in-library step: do_walk.f90:2778-2790, the sums every rank needs.  In a pipelined run with one communicator the next
+  // step's deterministic weights are all-reduced straight behind them (enqueue_head): one call carries both, and the kernel that
+  // gathers the weights does the final sums in its first block (decided by quantities all ranks share)
+  static const bool two_calls = getenv("SQMC_SHARD_SPLIT_ALLREDUCE") != nullptr;
+  c->head_sums_ride = !use_mail && c->pipeline_next && c->d_grow && !c->comm2 && c->n_imp > 0 && p.semi && !two_calls;
   TBEG(estimate, st);
-  if (!fin_in_gate) hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, fa, c->d_sc);
+  if (c->head_sums_ride) c->head_fin = fa;
+  else if (!fin_in_gate) hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, st, fa, c->d_sc);
   TEND(estimate, st);
   HIPCHK(hipGetLastError());
   bool mail_in_gate = false;
-  c->head_sums_ride = false;
   if (!use_mail) {
-    // do_walk.f90:2778-2790: the sums every rank needs.  In a pipelined run with one communicator the next step's deterministic weights
-    // are all-reduced straight behind them (enqueue_head): one call carries both (decided by quantities all ranks share)
-    static const bool two_calls = getenv("SQMC_SHARD_SPLIT_ALLREDUCE") != nullptr;
-    c->head_sums_ride = c->pipeline_next && c->d_grow && !c->comm2 && c->n_imp > 0 && p.semi && !two_calls;
     if (!c->head_sums_ride) { int rr = comm_allreduce_stats(c); if (rr) return rr; }
     mail_in_gate = c->pipeline_next && p.semi;                 // the next step's gate kernel posts them (one launch less)
     if (!mail_in_gate) hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(64), 0, st, c->d_sc, c->d_mail, seq);

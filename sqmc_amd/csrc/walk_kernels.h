@@ -6,14 +6,7 @@
 
 // Everything k_finish does, as arguments: in the pipelined head the first block of the NEXT step's gate
 // kernel does it (one launch less on the critical path).
-struct FinArgs {
-  const double *partials; int nblocks; const double *wabs_part; int nwabs; int mode; u64 *scan_state; u32 *scan_ticket; int n_scan_words;
-  HostMail *mail; u64 seq; u64 *fstate; u32 *fticket; long long cap_ftiles; int n_ftiles; int on;
-  int n_tickets;      // scan tickets behind scan_ticket to reset with the n_scan_words state words (3: all of them)
-  long long n_children;   // >= 0: the step's child count from the host (a finish that rides on the NEXT step's scan must not read the scalar that scan writes)
-  const double *red;      // sharded steps: where the all-reduced sums lie when they travelled behind the deterministic weights (null: DevScalars::red)
-  long long expect_nimp;  // >= 0: deterministic-space walkers this rank must still hold; anything else raises SQMC_ERR_IMP_BROKEN on the device (sharded steps: the status is all-reduced)
-};
+// (struct FinArgs: sqmc_gpu.hip, in front of the context that keeps one)
 __device__ void finish_all(const FinArgs &f, DevScalars *sc);
 // spawn gate and child count of one walker (COUNTER discipline: the draw is keyed by step and the determinant's rank in
 // (up, dn) order = its sort key `i`, so that it can be taken before the walker's position in the new list is known).  do_walk.f90:3577-3589
