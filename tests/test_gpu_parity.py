@@ -1149,9 +1149,9 @@ def test_error_statuses_match_reference_stops(oracle, c2_walk, c2_setup):
     g.close()
 
 
-@pytest.mark.parametrize("r", ["1.0", "1.6", "2.0"])
+@pytest.mark.parametrize("r", ["1.0", "1.1", "1.2", "1.3", "1.4", "1.6", "1.8", "2.0"])
 def test_binding_curve_geometries_bit_exact(oracle, r):
-    """BASELINE.json configs[2]: other points of the C2 binding curve (different orbital orders and
+    """BASELINE.json configs[2]: every other point of the C2 binding curve (different orbital orders and
     symmetry labels in the FCIDUMP, stretched bonds with a multi-reference Psi_T).  Tables, Psi_T /
     deterministic space from the host path, and a counter-mode trajectory, all against the oracle."""
     import os
