@@ -72,7 +72,6 @@ extern "C" int sqmc_gpu_debug_bprof(unsigned long long *out) { return (int)hipMe
 #define BPROF_VAL(K, V)
 #endif
 // block-wide exclusive scan for the BK_AT threads of the annihilation kernel (total in every thread)
-#define BK_AT 512                      // threads of k_anneal_bucket: one block per CU, so the block itself has to keep the memory pipes busy
 __device__ __forceinline__ u64 bk_block_excl_scan(u64 v, u64 *total) {
   __shared__ u64 wsum[BK_AT / 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -125,95 +124,7 @@ __device__ __forceinline__ u64 bk_lookback_wide(u64 *__restrict__ state, int b, 
   if (tid == 0) atomicExch((unsigned long long *)&state[b], SCAN_ST_INC | (excl + tot));
   return excl;
 }
-// ---- H_ii of one determinant by 16 lanes (chemistry, no time symmetry).  h_diag (chem_device.h) is three running sums -- one-body,
-// exchange, direct -- of ~50 integrals; a lane on its own pays one L2 round trip per group of four.  Here every term of a sum has its
-// place in the reference's order (closed form from the electron indices), the 16 lanes fetch all terms at once into LDS, and one
-// lane per sum adds them up in that order: the same value bit for bit, one round trip instead of ~25.
-// HG lanes per determinant: 8 (64 determinants per pass) when its terms fit 56 doubles -- up to 4 + 4 electrons --, else 16
-#define BK_HG_TERMS(HG) (BK_CAP_T / (BK_AT / (HG)))            // LDS doubles per group: the groups share the weight array (112 at HG = 16)
-#define BK_HG_TASKS 6                                           // tasks per lane at the cap of HG = 16; 12 at HG = 8
-__device__ __forceinline__ int bk_nth_orb(u64 x, int n) { for (int k = 0; k < n; k++) x &= x - 1; return ctz64(x); }     // 0-based orbital of the n-th electron
-__device__ __forceinline__ int bk_hii_group_lanes(const ChemTab &t) {          // 0: no group form for this system
-  const int nup = t.nup, ndn = t.ndn, nuu = nup * (nup - 1) / 2, ndd = ndn * (ndn - 1) / 2, nud = nup * ndn;
-  const int terms = (nup + ndn) + (nuu + ndd) + (nuu + nud + ndd), tasks = (nup + ndn) + nuu + ndd + nud;
-  if (t.sys_type != 0 || t.time_sym) return 0;
-  if (terms <= BK_HG_TERMS(8) && tasks <= 8 * 2 * BK_HG_TASKS) return 8;
-  if (terms <= BK_HG_TERMS(16) && tasks <= 16 * BK_HG_TASKS) return 16;
-  return 0;
-}
-// all threads of the block call this together (two barriers inside); sg: the group's BK_HG_TERMS(HG) doubles; g: lane inside the group
-template <int HG>
-__device__ __forceinline__ double bk_hii_group(const ChemTab &t, const double *__restrict__ ints, u64 up, u64 dn, bool valid, double *sg, int g) {
-  constexpr int NTASK = BK_HG_TASKS * 16 / HG;
-  const int nup = t.nup, ndn = t.ndn, n1 = t.norb + 1;
-  const bool same = (dn == up);
-  const int nuu = nup * (nup - 1) / 2, ndd = ndn * (ndn - 1) / 2, nud = nup * ndn;
-  const int L_e1 = same ? nup : nup + ndn, L_ex = nuu + (same ? 0 : ndd), L_di = nuu + nud + ndd;
-  const int o_ex = L_e1, o_di = L_e1 + L_ex;
-  const int ntask = valid ? (nup + ndn) + nuu + ndd + nud : 0;
-  int p0[NTASK], p1[NTASK], x0[NTASK], x1[NTASK];
-#pragma unroll
-  for (int m = 0; m < NTASK; m++) {
-    int k = g + HG * m;
-    p0[m] = -1; p1[m] = -1; x0[m] = 0; x1[m] = 0;
-    if (k >= ntask) continue;
-    if (k < nup) {                                   // one-body, up electron k
-      const int i = bk_nth_orb(up, k) + 1;
-      p0[m] = k; x0[m] = integral_index(t, i, i, n1, n1);
-    } else if (k < nup + ndn) {                      // one-body, dn electron
-      const int b = k - nup;
-      if (!same) { const int i = bk_nth_orb(dn, b) + 1; p0[m] = nup + b; x0[m] = integral_index(t, i, i, n1, n1); }
-    } else if (k < nup + ndn + nuu) {                // up-up pair (a < a2): an exchange and a direct term
-      int r = k - nup - ndn, a = 0;
-      while (r >= nup - 1 - a) { r -= nup - 1 - a; a++; }
-      const int a2 = a + 1 + r, i0 = bk_nth_orb(up, a), j0 = bk_nth_orb(up, a2);
-      const int Bc = __popcll(dn & ((1ull << i0) - 1ull));
-      const int base = a * (nup - 1 + ndn) - a * (a - 1) / 2 + Bc * (ndn - 1) - Bc * (Bc - 1) / 2;
-      p0[m] = o_ex + a * (nup - 1) - a * (a - 1) / 2 + (a2 - a - 1); x0[m] = integral_index(t, i0 + 1, j0 + 1, j0 + 1, i0 + 1);
-      p1[m] = o_di + base + (a2 - a - 1);                            x1[m] = integral_index(t, i0 + 1, i0 + 1, j0 + 1, j0 + 1);
-    } else if (k < nup + ndn + nuu + ndd) {          // dn-dn pair (b < b2): direct always, exchange unless the strings are equal
-      int r = k - nup - ndn - nuu, b = 0;
-      while (r >= ndn - 1 - b) { r -= ndn - 1 - b; b++; }
-      const int b2 = b + 1 + r, i0 = bk_nth_orb(dn, b), j0 = bk_nth_orb(dn, b2);
-      const int A = __popcll(up & ((2ull << i0) - 1ull));              // up electrons at orbitals <= i0 come first
-      const int base = A * (nup - 1 + ndn) - A * (A - 1) / 2 + b * (ndn - 1) - b * (b - 1) / 2;
-      if (!same) { p0[m] = o_ex + nuu + b * (ndn - 1) - b * (b - 1) / 2 + (b2 - b - 1); x0[m] = integral_index(t, i0 + 1, j0 + 1, j0 + 1, i0 + 1); }
-      p1[m] = o_di + base + (b2 - b - 1); x1[m] = integral_index(t, i0 + 1, i0 + 1, j0 + 1, j0 + 1);
-    } else {                                         // up-dn pair: one direct term
-      const int r = k - nup - ndn - nuu - ndd, a = r / ndn, b = r - a * ndn;
-      const int i0 = bk_nth_orb(up, a), j0 = bk_nth_orb(dn, b);
-      const int Bc = __popcll(dn & ((1ull << i0) - 1ull));
-      const int base = a * (nup - 1 + ndn) - a * (a - 1) / 2 + Bc * (ndn - 1) - Bc * (Bc - 1) / 2;
-      p1[m] = o_di + base + (nup - 1 - a) + b; x1[m] = integral_index(t, i0 + 1, i0 + 1, j0 + 1, j0 + 1);
-    }
-  }
-  double v0[NTASK], v1[NTASK];
-#pragma unroll
-  for (int m = 0; m < NTASK; m++) { v0[m] = (p0[m] >= 0) ? ints[x0[m]] : 0.0; v1[m] = (p1[m] >= 0) ? ints[x1[m]] : 0.0; }
-#pragma unroll
-  for (int m = 0; m < NTASK; m++) { if (p0[m] >= 0) sg[p0[m]] = v0[m]; if (p1[m] >= 0) sg[p1[m]] = v1[m]; }
-  __syncthreads();
-  double acc = 0.0;
-  if (valid) {
-    // one lane per sum, terms in the reference's order; eight LDS reads are requested before the first of them is added (the
-    // additions stay sequential, the reads need not wait for one another: 28 dependent read-add pairs were 1.7 of this phase's 7 us)
-    const int o = (g == 0) ? 0 : (g == 1 ? o_ex : o_di), L = (g == 0) ? L_e1 : (g == 1 ? L_ex : (g == 2 ? L_di : 0));
-    const double sgn = (g == 1) ? -1.0 : 1.0;
-    int q = 0;
-    for (; q + 8 <= L; q += 8) {
-      double a_[8];
-#pragma unroll
-      for (int z = 0; z < 8; z++) a_[z] = sg[o + q + z];
-#pragma unroll
-      for (int z = 0; z < 8; z++) acc = acc + sgn * a_[z];
-    }
-    for (; q < L; q++) acc = acc + sgn * sg[o + q];
-    if (same && g < 2) acc = acc * 2.0;
-  }
-  const double e1 = __shfl(acc, 0, HG), ex = __shfl(acc, 1, HG), di = __shfl(acc, 2, HG);
-  __syncthreads();
-  return e1 + (ex + di) + t.nuclear;
-}
+// (H_ii of one determinant by a group of lanes: hii_group.h -- k_spawn's spare blocks use it too)
 #define BK_LONG_RUN 24                 // followers a head folds itself
 #define BK_LONG_MAX 32                 // longer runs a bucket hands to wavefronts (more than that: their heads fold them alone)
 #define BK_HQ_DETS (BK_CAP_T * 2 / 16)                       // determinants whose (up, dn) wait in LDS for the H_ii phase
@@ -768,11 +679,19 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     BPROF_VAL(15, nq);
     const long long base = (long long)(ex_glob & 0xFFFFFull);
     const int hg = bk_hii_group_lanes(*s_tab);
+    // a pipelined step: the first BK_HQ_DEFER of them are left to spare blocks of the k_spawn that follows (they run beside its spawning
+    // blocks; here they were 5.5 of a bucket's 35 us, at the end of its chain).  Every bucket writes its count, also a zero.
+    int n_def = 0;
+    if (ba.hq_cnt) {
+      n_def = nq < BK_HQ_DEFER ? nq : BK_HQ_DEFER;
+      for (int k = tid; k < n_def; k += BK_AT) ba.hq_pos[b * BK_HQ_DEFER + k] = (u32)(base + (long long)s_hq[k]);
+      if (tid == 0) ba.hq_cnt[b] = (u32)n_def;
+    }
 #define BK_HII_PASSES(HG)                                                                                          \
     {                                                                                                              \
       const int G = tid / HG, g = tid % HG;                                                                        \
       double *sg = s_w + G * BK_HG_TERMS(HG);            /* the weights were last read by the compaction */        \
-      for (int k0 = 0; k0 < nq; k0 += BK_AT / HG) {                                                                \
+      for (int k0 = n_def; k0 < nq; k0 += BK_AT / HG) {                                                            \
         const int k = k0 + G; const bool valid = k < nq;                                                           \
         const long long q0 = valid ? base + (long long)s_hq[k] : 0;                                                \
         u64 u = 0, dd = 0;                                                                                         \
@@ -783,12 +702,13 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     }
     // few determinants (a bucket creates 13 on average at the bench size, 28 at most): more lanes each -- the phase is the latency
     // of one lane's decode + fetch + sum chain, and a lane with 2 tasks is through sooner than one with 5
-    if (hg == 8 && nq <= BK_AT / 32) BK_HII_PASSES(32)
-    else if (hg == 8 && nq <= BK_AT / 16) BK_HII_PASSES(16)
+    if (nq == n_def) { }
+    else if (hg == 8 && nq - n_def <= BK_AT / 32) BK_HII_PASSES(32)
+    else if (hg == 8 && nq - n_def <= BK_AT / 16) BK_HII_PASSES(16)
     else if (hg == 8) BK_HII_PASSES(8)
     else if (hg == 16) BK_HII_PASSES(16)
     else {
-      for (int k = tid; k < nq; k += BK_AT) {
+      for (int k = n_def + tid; k < nq; k += BK_AT) {
         const long long q0 = base + (long long)s_hq[k];
         const u64 u = o.up[q0], dd = o.dn[q0];
         o.me[q0] = h_any(*s_tab, dev.integrals, u, dd, u, dd);

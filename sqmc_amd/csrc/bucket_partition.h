@@ -8,6 +8,7 @@
 #define BK_CAP_S 2560                 // spawns of one bucket
 #define BK_CAP_R 1536                 // residents of one bucket
 #define BK_CAP_T 3584                 // both
+#define BK_HQ_DEFER 64                // deferred H_ii positions per bucket (13 on average at the bench size; the rest is done in the tail)
 #define BK_CAP_ROWS 2560              // partition blocks (256 children each)
 #define BK_MAXB 1024
 #define BK_TARGET 1150                // slots per bucket the host aims at (B = nall / BK_TARGET, at most one block per CU while that holds)
@@ -28,6 +29,10 @@ struct BucketArgs {
   unsigned short *segoff;              // nsb rows of B+1 group offsets
   u64 *state; u32 *ticket;             // look-back over the buckets
   int force_retry;                     // tests: behave as if a bucket did not fit
+  // H_ii of the determinants a bucket creates, deferred to spare blocks of the NEXT step's k_spawn (which runs beside its spawning
+  // blocks instead of at the end of every bucket's chain): bucket b leaves hq_cnt[b] <= BK_HQ_DEFER positions in hq_pos[b * BK_HQ_DEFER ..]
+  u32 *hq_cnt, *hq_pos; int hq_nblk;   // (k_spawn: hq_nblk spare blocks work through the B = hq_B queues)
+  int hq_B;
   // Where the buckets begin.  kb == null: at the residents at positions b n0 / B (equal numbers of residents).  Otherwise bucket b
   // holds the keys [kb[b], kb[b+1]): boundaries that equalise the cost of a bucket, residents + 1.7 spawns, as measured one bucket
   // step back (the spawns crowd on the heavy determinants: with equal residents the fullest bucket held 3x the mean, and every

@@ -33,6 +33,7 @@
 #include "heatbath_device.h"
 #include "scan_sort.h"
 #include "bucket_partition.h"
+#include "hii_group.h"
 
 #define TPB 256
 #define SPAWN_WIN 1024
@@ -171,6 +172,7 @@ struct sqmc_gpu_ctx {
   bool residents_sorted;      // the walker arrays are known to be in (up, dn) order: true after every finished step and after an upload (which refuses unsorted lists)
   unsigned short *d_segoff; long long segoff_cap;      // bucket tail: group offsets of the partition blocks
   u32 *d_bhint; int pos_flip, scount_pos;      // where each boundary set lay when it was made (3 x BK_MAXB + 1); which of the two d_bpos halves this step writes / the counts were taken with
+  u32 *d_hq_cnt, *d_hq_pos; int hii_deferred_B;      // H_ii queues of the buckets (BK_MAXB counts, BK_MAXB x BK_HQ_DEFER positions); > 0: the last tail filled them for the head that follows
   u32 *d_bkb, *d_bpos, *d_bscount;   // bucket boundaries (three sets of BK_MAXB + 1 keys: in use, counted with, being made), their positions in this step's list, the spawns the last bucket tail counted per bucket
   int kb_B[3], scount_B;      // the bucket count each set was made for / the counts were taken with (0: not valid)
   bool shard_x_ready, shard_x_used;   // the deterministic weights of the COMING step are all-reduced already (every rank did that behind this step's sums, whether or not it enqueued a head) / this step is using them
@@ -278,6 +280,7 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
     c->segoff_cap = ((std::min<long long>(M, 1ll << 20) + BK_T - 1) / BK_T + 1) * (BK_MAXB + 1);
     HIPCHK(hipMalloc(&c->d_segoff, c->segoff_cap * sizeof(unsigned short)));
     HIPCHK(hipMalloc(&c->d_bkb, 3 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMalloc(&c->d_bpos, 2 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMalloc(&c->d_bhint, 3 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMemset(c->d_bhint, 0, 3 * (BK_MAXB + 1) * sizeof(u32))); c->pos_flip = 0; c->scount_pos = 0; HIPCHK(hipMalloc(&c->d_bscount, (BK_MAXB + 1) * sizeof(u32)));
+    HIPCHK(hipMalloc(&c->d_hq_cnt, BK_MAXB * sizeof(u32))); HIPCHK(hipMalloc(&c->d_hq_pos, (size_t)BK_MAXB * BK_HQ_DEFER * sizeof(u32))); HIPCHK(hipMemset(c->d_hq_cnt, 0, BK_MAXB * sizeof(u32)));
     HIPCHK(hipMemset(c->d_bkb, 0, 3 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMemset(c->d_bpos, 0, 2 * (BK_MAXB + 1) * sizeof(u32))); HIPCHK(hipMemset(c->d_bscount, 0, (BK_MAXB + 1) * sizeof(u32)));
     c->kb_B[0] = c->kb_B[1] = c->kb_B[2] = 0; c->scount_B = 0; c->kb_next = c->scount_buf = c->head_kb_use = -1;
     HIPCHK(hipMalloc(&c->d_fstate, 2 * c->cap_ftiles * 8)); HIPCHK(hipMalloc(&c->d_fticket, 4));
@@ -402,7 +405,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
     free_walk(c->w); free_walk(c->m);
     hipFree(c->d_nchild); hipFree(c->d_child_off); hipFree(c->d_wchild); hipFree(c->d_child_state);
     hipFree(c->d_keys); hipFree(c->d_keys_alt); hipFree(c->d_vals); hipFree(c->d_vals_alt); hipFree(c->d_hist); hipFree(c->d_rowtot);
-    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done); hipFree(c->d_segoff); hipFree(c->d_bkb); hipFree(c->d_bhint); hipFree(c->d_bpos); hipFree(c->d_bscount);
+    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done); hipFree(c->d_segoff); hipFree(c->d_bkb); hipFree(c->d_bhint); hipFree(c->d_bpos); hipFree(c->d_bscount); hipFree(c->d_hq_cnt); hipFree(c->d_hq_pos);
   }
   hipFree(c->d_binom); hipFree(c->d_grow); hipFree(c->d_ginv);
   for (int q = 0; q < 16; q++) hipFree(c->d_hbt[q]);
@@ -752,15 +755,22 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
     }
     c->head_ba = hb;
   }
+  int hq_blk = 0;
+  if (dev_n && tail_fills && c->hii_deferred_B > 0) {      // the tail left the new determinants' H_ii to this kernel: one spare block per bucket's queue
+    hb.hq_cnt = c->d_hq_cnt; hb.hq_pos = c->d_hq_pos; hb.hq_B = c->hii_deferred_B; hb.hq_nblk = hq_blk = c->hii_deferred_B;
+    c->head_ba.hq_cnt = nullptr; c->head_ba.hq_pos = nullptr; c->head_ba.hq_nblk = 0;      // (the copy the tail takes over describes the partition only)
+  }
+  c->hii_deferred_B = 0;
   const long long nfree = dev_n ? M : M - n0;          // dev_n: nothing is known about the count but that it is >= 0
-  const int spawn_fuse = (hb.B > 0 || spawn_fin.on || pp.n_imp > 0 || c->shard_y_ok) ? 1 : 0;
+  const int spawn_fuse = (hb.B > 0 || spawn_fin.on || pp.n_imp > 0 || c->shard_y_ok || hq_blk > 0) ? 1 : 0;
+  const size_t spawn_lds = (hb.B > 0 || hq_blk > 0) ? BK_PART_LDS : 0;
   if (nfree > 0) {
     if (s0)
-      SPAWN_LAUNCH_EXT(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
-                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0));
+      SPAWN_LAUNCH_EXT(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + hq_blk + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0)), dim3(TPB), spawn_lds, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,
+                            c->d_child_state, c->d_keys, c->d_vals, n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, (spawn_fin.on ? 1 : 0) + hq_blk + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0));
     else
-      SPAWN_LAUNCH(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0)), dim3(TPB), hb.B > 0 ? BK_PART_LDS : 0, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
-                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, (spawn_fin.on ? 1 : 0) + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0));
+      SPAWN_LAUNCH(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + hq_blk + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0)), dim3(TPB), spawn_lds, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
+                         n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, (spawn_fin.on ? 1 : 0) + hq_blk + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0));
   } else if (s0) { hipEventRecord(s0, st); hipEventRecord(s1, st); }
   HIPCHK(hipGetLastError());
   return SQMC_OK;
@@ -856,6 +866,10 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
           hipLaunchKernelGGL(k_bucket_partition, dim3((unsigned)(nsb + n_extra)), dim3(BK_T), 0, st, (const u64 *)c->d_keys, n0, nch, c->invalid_key, ba, n_extra);
         }
       }
+      // pipelined, unsharded: the H_ii of the determinants this tail creates are left to spare blocks of the head's k_spawn (enqueued below)
+      static const bool no_defer = getenv("SQMC_BUCKET_NO_HII_DEFER") != nullptr;
+      c->hii_deferred_B = 0;
+      if (bucket && c->pipeline_next && !c->d_grow && !no_defer && c->rng_mode != SQMC_RNG_REPLAY) { ba.hq_cnt = c->d_hq_cnt; ba.hq_pos = c->d_hq_pos; c->hii_deferred_B = ba.B; }
       static const int force_rank = getenv("SQMC_BUCKET_FORCE_RETRY_RANK") ? atoi(getenv("SQMC_BUCKET_FORCE_RETRY_RANK")) : -1;      // tests: only this rank of a sharded walk
       if (bucket) ba.force_retry = (force_every > 0 && (force_rank < 0 || force_rank == c->shard_rank) && (c->bk_steps % force_every) == force_every - 1) ? 1 : 0;
     }

@@ -247,15 +247,46 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   // block 0 does them (nothing it touches is read by the spawning blocks).  The blocks behind it multiply the deterministic
   // projector into last step's deterministic weights, one wavefront per row: the part of the projection that needs nothing
   // the host still has to decide (E_T enters in the tail, bucket_kernels.h).  The last of them makes the next bucket boundaries.
+  __shared__ ChemTab t;
+  extern __shared__ u32 s_part[];      // BK_PART_LDS bytes when the launch partitions (or its spare blocks compute H_ii), none otherwise (large populations keep their occupancy)
   if (FUSE && (int)blockIdx.x < n_extra) {
     const int xb = (int)blockIdx.x;
     if (fin.on && xb == 0) { finish_all(fin, const_cast<DevScalars *>(sc)); return; }
     if (n_on_device && sc->retry) return;
-    const int hb0 = xb - (fin.on ? 1 : 0);
+    int hb0 = xb - (fin.on ? 1 : 0);
     if ((ba.kb || ba.kb_out) && xb == n_extra - 1) {      // the last spare block: bucket boundaries (bucket_partition.h)
       bk_rebalance_block(ba, keys, n_on_device ? (long long)sc->nwalk : n0_arg);
       return;
     }
+    if (hb0 < ba.hq_nblk) {
+      // H_ii of the determinants the last step's short-list tail created: the buckets left their positions in the new list
+      // (bucket_kernels.h).  One block per bucket, 16 lanes per determinant, terms in the reference's order -- a bucket creates 13 on
+      // average at the bench size, so a block is through after one pass, well inside the spawning blocks' time.  Death/clone of THIS
+      // step's tail reads the values.
+      stage_tab(&t, dev.tab, dev.tab_words);
+      __syncthreads();
+      const int bkt = hb0, cnt = (int)ba.hq_cnt[bkt];
+      if (bk_hii_group_lanes(t)) {
+        const int G = (int)threadIdx.x / 16, g = (int)threadIdx.x % 16;
+        double *sg = (double *)s_part + G * BK_HG_TERMS(16);
+        for (int k0 = 0; k0 < cnt; k0 += TPB / 16) {
+          const int k = k0 + G; const bool valid = k < cnt;
+          const long long q0 = valid ? (long long)ba.hq_pos[bkt * BK_HQ_DEFER + k] : 0;
+          u64 u = 0, dd = 0;
+          if (valid) { u = w.up[q0]; dd = w.dn[q0]; }
+          const double v = bk_hii_group<16>(t, dev.integrals, u, dd, valid, sg, g);
+          if (valid && g == 0) w.me[q0] = v;
+        }
+      } else {
+        for (int k = threadIdx.x; k < cnt; k += TPB) {
+          const long long q0 = (long long)ba.hq_pos[bkt * BK_HQ_DEFER + k];
+          const u64 u = w.up[q0], dd = w.dn[q0];
+          w.me[q0] = h_any(t, dev.integrals, u, dd, u, dd);
+        }
+      }
+      return;
+    }
+    hb0 -= ba.hq_nblk;
     const int row = hb0 * (TPB / 64) + (int)(threadIdx.x >> 6);
     if (pp.n_imp > 0 && row < pp.n_imp) prj_row_product(pp, row);
     return;
@@ -266,10 +297,8 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   // the grid covers the free capacity of the walker arrays; the number of children is read from
   // device memory so that the launch does not wait for the host to learn it
   PROF(0);
-  __shared__ ChemTab t;
   __shared__ u64 s_win[SPAWN_WIN];
   // short lists (ba.B > 0): the block also groups its children by key range for the bucket tail (bucket_kernels.h)
-  extern __shared__ u32 s_part[];      // BK_PART_LDS bytes when the launch partitions, none otherwise (large populations keep their occupancy)
   u32 *s_spl = s_part; u32 (*s_wcnt)[BK_MAXB] = (u32 (*)[BK_MAXB])(s_part + BK_MAXB);
   // Parent of child c = largest i with child_off[i] <= c.  The 256 children of a block have
   // neighbouring parents, so the block narrows [0,n0) for its first child with 256-way splits
