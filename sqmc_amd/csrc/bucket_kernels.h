@@ -38,10 +38,10 @@ __global__ void __launch_bounds__(BK_T) k_bucket_partition(const u64 *__restrict
   const long long c = blk * BK_T + threadIdx.x;
   u64 word = 0; u32 key = 0; bool valid = false;
   if (c < nch) word = keys[n0 + c];
-  bucket_partition_stage(spl, wcnt, keys, n0, ba);
+  bucket_partition_stage(spl, &wcnt[0][0], BK_MAXB, keys, n0, ba);
   if (c < nch) { key = (u32)(word >> 32); valid = (u64)key != invalid_key; }
   __syncthreads();
-  bucket_partition_block(spl, wcnt, valid, key, word, blk, ba);
+  bucket_partition_block(spl, &wcnt[0][0], BK_MAXB, valid, key, word, blk, ba);
 }
 
 // ------------------------------------------------------------------------------------------------ annihilation per bucket

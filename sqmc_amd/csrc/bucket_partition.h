@@ -4,7 +4,8 @@
 #pragma once
 
 #define BK_T 256
-#define BK_PART_LDS ((1 + BK_T / 64) * BK_MAXB * 4)     // dynamic LDS of a kernel that partitions its block's children: splitters + per-wave counters
+#define BK_PART_STRIDE(B) (((B) + 63) & ~63)             // counters per wave of a partitioning block (ws below)
+#define BK_PART_LDS(B) ((1 + BK_T / 64) * BK_PART_STRIDE(B) * 4)     // dynamic LDS of a kernel that partitions its block's children: splitters + per-wave counters, sized by the buckets there are
 #define BK_CAP_S 2560                 // spawns of one bucket
 #define BK_CAP_R 1536                 // residents of one bucket
 #define BK_CAP_T 3584                 // both
@@ -146,8 +147,8 @@ __device__ __forceinline__ void bk_rebalance_block(const BucketArgs &ba, const u
 
 // ------------------------------------------------------------------------------------------------ partition
 // The 256 children of one block, grouped by bucket (stable) behind the block's row of group offsets.  spl[b] (b >= 1) = first
-// key of bucket b, staged by the caller; wcnt = BK_T/64 x BK_MAXB zeroed counters.  Every thread of the block calls it.
-__device__ __forceinline__ void bucket_partition_block(const u32 *__restrict__ spl, u32 (*__restrict__ wcnt)[BK_MAXB], bool valid, u32 key, u64 word, long long blk,
+// key of bucket b, staged by the caller; wcnt = BK_T/64 rows of ws >= B zeroed counters.  Every thread of the block calls it.
+__device__ __forceinline__ void bucket_partition_block(const u32 *__restrict__ spl, u32 *__restrict__ wcnt, int ws, bool valid, u32 key, u64 word, long long blk,
                                                        const BucketArgs &ba) {
   const int B = ba.B, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int bkt = 0;
@@ -162,28 +163,28 @@ __device__ __forceinline__ void bucket_partition_block(const u32 *__restrict__ s
   for (int q = 0; q < nbit; q++) { const u64 m = __ballot((bkt >> q) & 1); same &= ((bkt >> q) & 1) ? m : ~m; }
   const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const u32 rank = (u32)__popcll(same & lt);
-  if (valid && rank == 0) wcnt[wv][bkt] = (u32)__popcll(same);
+  if (valid && rank == 0) wcnt[wv * ws + bkt] = (u32)__popcll(same);
   __syncthreads();
   // group offsets: exclusive scan over the buckets of the four waves' counts; wcnt becomes the base of each wave's share
   constexpr int PER = BK_MAXB / BK_T;
   u32 t4[PER]; u64 sum = 0;
 #pragma unroll
-  for (int q = 0; q < PER; q++) { const int b = tid * PER + q; u32 s = 0; if (b < B) for (int v = 0; v < BK_T / 64; v++) s += wcnt[v][b]; t4[q] = s; sum += s; }
+  for (int q = 0; q < PER; q++) { const int b = tid * PER + q; u32 s = 0; if (b < B) for (int v = 0; v < BK_T / 64; v++) s += wcnt[v * ws + b]; t4[q] = s; sum += s; }
   u64 tot; u32 ex = (u32)block_excl_scan_u64(sum, &tot);
   unsigned short *row = ba.segoff + blk * (B + 1);
 #pragma unroll
   for (int q = 0; q < PER; q++) {
     const int b = tid * PER + q;
-    if (b < B) { row[b] = (unsigned short)ex; u32 a = ex; for (int v = 0; v < BK_T / 64; v++) { const u32 cn = wcnt[v][b]; wcnt[v][b] = a; a += cn; } }
+    if (b < B) { row[b] = (unsigned short)ex; u32 a = ex; for (int v = 0; v < BK_T / 64; v++) { const u32 cn = wcnt[v * ws + b]; wcnt[v * ws + b] = a; a += cn; } }
     ex += t4[q];
   }
   if (tid == 0) row[B] = (unsigned short)tot;
   __syncthreads();
-  if (valid) ba.words[blk * BK_T + wcnt[wv][bkt] + rank] = word;
+  if (valid) ba.words[blk * BK_T + wcnt[wv * ws + bkt] + rank] = word;
 }
 // splitters and zeroed counters of a partition block (no barrier inside: the caller synchronises once before partitioning)
-__device__ __forceinline__ void bucket_partition_stage(u32 *__restrict__ spl, u32 (*__restrict__ wcnt)[BK_MAXB], const u64 *__restrict__ rkeys, long long n0, const BucketArgs &ba) {
+__device__ __forceinline__ void bucket_partition_stage(u32 *__restrict__ spl, u32 *__restrict__ wcnt, int ws, const u64 *__restrict__ rkeys, long long n0, const BucketArgs &ba) {
   const int B = ba.B;
   for (int b = threadIdx.x; b < B; b += BK_T) spl[b] = b ? (ba.kb ? ba.kb[b] : (u32)(rkeys[((long long)b * n0) / B] >> 32)) : 0u;      // first key of bucket b
-  for (int d = threadIdx.x; d < (BK_T / 64) * BK_MAXB; d += BK_T) (&wcnt[0][0])[d] = 0;
+  for (int d = threadIdx.x; d < (BK_T / 64) * ws; d += BK_T) wcnt[d] = 0;
 }

@@ -10,6 +10,8 @@
 #define BK_HG_TERMS(HG) (BK_CAP_T / (BK_AT / (HG)))            // LDS doubles per group: the groups share the weight array (112 at HG = 16)
 #define BK_HG_TASKS 6                                           // tasks per lane at the cap of HG = 16; 12 at HG = 8
 __device__ __forceinline__ int bk_nth_orb(u64 x, int n) { for (int k = 0; k < n; k++) x &= x - 1; return ctz64(x); }     // 0-based orbital of the n-th electron
+__host__ __device__ __forceinline__ int bk_hii_terms_of(int nup, int ndn) { return (nup + ndn) + (nup * (nup - 1) + ndn * (ndn - 1)) + nup * ndn; }      // doubles a group needs for one determinant
+__device__ __forceinline__ int bk_hii_terms(const ChemTab &t) { return bk_hii_terms_of(t.nup, t.ndn); }
 __device__ __forceinline__ int bk_hii_group_lanes(const ChemTab &t) {          // 0: no group form for this system
   const int nup = t.nup, ndn = t.ndn, nuu = nup * (nup - 1) / 2, ndd = ndn * (ndn - 1) / 2, nud = nup * ndn;
   const int terms = (nup + ndn) + (nuu + ndd) + (nuu + nud + ndd), tasks = (nup + ndn) + nuu + ndd + nud;

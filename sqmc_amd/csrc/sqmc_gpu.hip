@@ -763,7 +763,7 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   c->hii_deferred_B = 0;
   const long long nfree = dev_n ? M : M - n0;          // dev_n: nothing is known about the count but that it is >= 0
   const int spawn_fuse = (hb.B > 0 || spawn_fin.on || pp.n_imp > 0 || c->shard_y_ok || hq_blk > 0) ? 1 : 0;
-  const size_t spawn_lds = (hb.B > 0 || hq_blk > 0) ? BK_PART_LDS : 0;
+  const size_t spawn_lds = std::max<size_t>(hb.B > 0 ? (size_t)BK_PART_LDS(hb.B) : 0, hq_blk > 0 ? (size_t)(TPB / 16) * bk_hii_terms_of(c->htab.nup, c->htab.ndn) * 8 : 0);
   if (nfree > 0) {
     if (s0)
       SPAWN_LAUNCH_EXT(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + hq_blk + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0)), dim3(TPB), spawn_lds, st, s0, s1, 0, c->dev, c->w, c->d_child_off, c->d_wchild,

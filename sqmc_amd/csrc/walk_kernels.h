@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   // projector into last step's deterministic weights, one wavefront per row: the part of the projection that needs nothing
   // the host still has to decide (E_T enters in the tail, bucket_kernels.h).  The last of them makes the next bucket boundaries.
   __shared__ ChemTab t;
-  extern __shared__ u32 s_part[];      // BK_PART_LDS bytes when the launch partitions (or its spare blocks compute H_ii), none otherwise (large populations keep their occupancy)
+  extern __shared__ u32 s_part[];      // BK_PART_LDS(B) bytes when the launch partitions (at least 16 x terms doubles when its spare blocks compute H_ii), none otherwise (large populations keep their occupancy)
   if (FUSE && (int)blockIdx.x < n_extra) {
     const int xb = (int)blockIdx.x;
     if (fin.on && xb == 0) { finish_all(fin, const_cast<DevScalars *>(sc)); return; }
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
       const int bkt = hb0, cnt = (int)ba.hq_cnt[bkt];
       if (bk_hii_group_lanes(t)) {
         const int G = (int)threadIdx.x / 16, g = (int)threadIdx.x % 16;
-        double *sg = (double *)s_part + G * BK_HG_TERMS(16);
+        double *sg = (double *)s_part + G * bk_hii_terms(t);
         for (int k0 = 0; k0 < cnt; k0 += TPB / 16) {
           const int k = k0 + G; const bool valid = k < cnt;
           const long long q0 = valid ? (long long)ba.hq_pos[bkt * BK_HQ_DEFER + k] : 0;
@@ -299,7 +299,8 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   PROF(0);
   __shared__ u64 s_win[SPAWN_WIN];
   // short lists (ba.B > 0): the block also groups its children by key range for the bucket tail (bucket_kernels.h)
-  u32 *s_spl = s_part; u32 (*s_wcnt)[BK_MAXB] = (u32 (*)[BK_MAXB])(s_part + BK_MAXB);
+  const int pws = BK_PART_STRIDE(ba.B);
+  u32 *s_spl = s_part; u32 *s_wcnt = s_part + pws;
   // Parent of child c = largest i with child_off[i] <= c.  The 256 children of a block have
   // neighbouring parents, so the block narrows [0,n0) for its first child with 256-way splits
   // (one round trip per level instead of log2(n0) dependent loads), then every thread finishes
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   const long long spc = HB ? 2 : 1;             // walker slots per child: the heat-bath proposal may return a single AND a double
   if (c0 >= nchildren || n0 + spc * nchildren > cap_all) return;
   const bool part = FUSE && ba.B > 0 && (int)bx < ba.nsb;                  // rows beyond the room the host provided: the tail will see that and use its own partition
-  if (part) bucket_partition_stage(s_spl, s_wcnt, keys, n0, ba);     // resident keys [0, n0) of the same array the children's keys go to; a barrier follows below
+  if (part) bucket_partition_stage(s_spl, s_wcnt, pws, keys, n0, ba);     // resident keys [0, n0) of the same array the children's keys go to; a barrier follows below
   PROF(1);
   while (whi - wlo > SPAWN_WIN) {
     const long long stepw = (whi - wlo + TPB - 1) / TPB, probe = wlo + (long long)threadIdx.x * stepw;
@@ -375,7 +376,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
     ckey = spawn_emit(dev, w, keys, vals, n0, c, pflg, ju, jd, wj, p, invalid_key, pack, oo);
     }
   }
-  if (part) bucket_partition_block(s_spl, s_wcnt, active && ckey != invalid_key, (u32)ckey, (ckey << 32) | (u64)(n0 + c), (long long)bx, ba);
+  if (part) bucket_partition_block(s_spl, s_wcnt, pws, active && ckey != invalid_key, (u32)ckey, (ckey << 32) | (u64)(n0 + c), (long long)bx, ba);
   PROF(5);
 }
 
