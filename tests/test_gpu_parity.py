@@ -595,6 +595,10 @@ def test_chained_runs_walk_the_same_trajectory():
     assert all(np.array_equal(mid[k], wb[k]) for k in ("up", "dn", "wt"))
     for k in ("up", "dn", "wt", "initiator", "imp_distance"):
         assert np.array_equal(wa[k], wb[k]), k
+    # the last step of `a` computed the H_ii of the determinants it created inside its tail kernel; `b`'s left them to spare blocks
+    # of the k_spawn of the head that was pending at the download: the same cached values, bit for bit
+    assert np.array_equal(wa["matrix_elements"], wb["matrix_elements"])
+    assert int((wb["matrix_elements"] < 1e50).sum()) > len(wb["up"]) // 2
     # ... and when the caller comes back with another tau: the step must run as if nothing had been enqueued
     b.g.set_chained_runs(True)
     b.run(5, keep_stats=False)
