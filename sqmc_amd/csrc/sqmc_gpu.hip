@@ -957,7 +957,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     TEND(merge, st);
     TBEG(round, st);
     static const bool serial_join = getenv("SQMC_SERIAL_JOIN") != nullptr;
-    if (mode == SQMC_RNG_COUNTER && !serial_join) hipLaunchKernelGGL(k_join_par, dim3(2), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, nall, p, seed, step);
+    if (mode == SQMC_RNG_COUNTER && !serial_join) hipLaunchKernelGGL(k_join_par, dim3(2), dim3(JP_T), 0, st, c->m, c->d_flags, c->d_pos, nall, p, seed, step);
     else hipLaunchKernelGGL(k_join, dim3(1), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, nall, p, mode, seed, step, c->d_sc);
     hipLaunchKernelGGL(k_round, dim3(nblk(nall)), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, c->d_flags2, nall, p, mode, seed, step, c->d_sc, skey, c->pack);
     device_excl_scan_u64(c->d_flags2, c->d_pos2, nall, &c->d_sc->tot2, sw[2], st);

@@ -716,7 +716,8 @@ __global__ void __launch_bounds__(TPB) k_join(WalkArr m, const u64 *__restrict__
 // One lane following every join of the list took 41 ms a step at 10^5 walkers (the whole semistochastic step takes 0.07).
 #define JP_TILE 2048
 #define JP_LV 12                       // 2^JP_LV > JP_TILE + 2
-__global__ void __launch_bounds__(TPB) k_join_par(WalkArr m, const u64 *__restrict__ flags, const u64 *__restrict__ pos, long long n_all, StepP p, u64 seed, u64 step) {
+#define JP_T 1024                      // threads: every phase is a few dependent LDS reads per candidate, so the block wants all the waves a CU can hold
+__global__ void __launch_bounds__(JP_T) k_join_par(WalkArr m, const u64 *__restrict__ flags, const u64 *__restrict__ pos, long long n_all, StepP p, u64 seed, u64 step) {
   __shared__ double s_a[JP_TILE + 2];
   __shared__ u32 s_rk[JP_TILE + 2], s_g[JP_TILE + 2];
   __shared__ unsigned short s_J[JP_LV][JP_TILE + 2];
@@ -724,7 +725,8 @@ __global__ void __launch_bounds__(TPB) k_join_par(WalkArr m, const u64 *__restri
   __shared__ u32 s_cg; __shared__ double s_ctot; __shared__ int s_copen;
   const int pass = (int)blockIdx.x, tid = (int)threadIdx.x;
   const double sgn = pass == 0 ? 1.0 : -1.0;
-  constexpr int PER = JP_TILE / TPB;
+  constexpr int PER = JP_TILE / JP_T;
+  __shared__ int s_wsum[JP_T / 64];
   if (tid == 0) { s_copen = 0; s_cg = 0; s_ctot = 0.0; }
   __syncthreads();
   // phases 2-4 on the candidates 1 .. nc gathered so far (slot 0: the chain the tile before left open)
@@ -735,7 +737,7 @@ __global__ void __launch_bounds__(TPB) k_join_par(WalkArr m, const u64 *__restri
     __syncthreads();
     if (first <= nc) {
       // ---- 2. where the chain that would begin at i ends
-      for (int i = first + tid; i <= nc; i += TPB) {
+      for (int i = first + tid; i <= nc; i += JP_T) {
         double run = s_a[i]; int k = i + 1;
         for (; k <= nc; k++) { run = s_a[k] + run; if (run > p.min_wt) break; }
         s_J[0][i] = (unsigned short)(k <= nc ? k + 1 : END);
@@ -746,7 +748,7 @@ __global__ void __launch_bounds__(TPB) k_join_par(WalkArr m, const u64 *__restri
       // ---- 3. the chains that really begin: reachable from `first`
       int nlv = 1; while ((1 << nlv) < END + 1 && nlv < JP_LV) nlv++;
       for (int l = 1; l < nlv; l++) {
-        for (int i = first + tid; i <= END; i += TPB) s_J[l][i] = s_J[l - 1][s_J[l - 1][i]];
+        for (int i = first + tid; i <= END; i += JP_T) s_J[l][i] = s_J[l - 1][s_J[l - 1][i]];
         __syncthreads();
       }
       if (tid == 0) s_mark[first] = 1;
@@ -754,11 +756,11 @@ __global__ void __launch_bounds__(TPB) k_join_par(WalkArr m, const u64 *__restri
       // (a mark set at this level may or may not be seen by another thread at this level: either way only candidates on the path
       //  are ever marked -- any jump from one of them lands on it -- and the binary expansion of a candidate's distance reaches it)
       for (int l = nlv - 1; l >= 0; l--) {
-        for (int i = first + tid; i <= nc; i += TPB) if (s_mark[i]) { const int t = s_J[l][i]; if (t <= nc) s_mark[t] = 1; }
+        for (int i = first + tid; i <= nc; i += JP_T) if (s_mark[i]) { const int t = s_J[l][i]; if (t <= nc) s_mark[t] = 1; }
         __syncthreads();
       }
       // ---- 4. every real chain once more, with the draws
-      for (int i = first + tid; i <= nc; i += TPB) {
+      for (int i = first + tid; i <= nc; i += JP_T) {
         if (!s_mark[i]) continue;
         double run = s_a[i]; int holder = i, k = i + 1; bool closed = false;
         for (; k <= nc; k++) {
@@ -798,14 +800,26 @@ __global__ void __launch_bounds__(TPB) k_join_par(WalkArr m, const u64 *__restri
         if ((f_[q] & 1ull) && (pass == 0 ? wt > 0.0 : wt < 0.0) && fabs(wt) < p.min_wt && flg_init(fl_[q]) < 3) { a_[q] = fabs(wt); rk_[q] = (u32)(ps_[q] & 0xFFFFFFFFull); cmask |= 1u << q; cnt++; }
       }
     }
-    u64 tot64; const int off = (int)block_excl_scan_u64((u64)cnt, &tot64);
-    if (nc + (int)tot64 > JP_TILE) { process(nc); nc = 0; }
+    int off, tot;                                      // exclusive scan of the threads' counts over the block
+    {
+      const int lane = tid & 63, wv = tid >> 6;
+      int inc = cnt;
+      for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o, 64); if (lane >= o) inc += x; }
+      if (lane == 63) s_wsum[wv] = inc;
+      __syncthreads();
+      int before = 0; tot = 0;
+#pragma unroll
+      for (int v = 0; v < JP_T / 64; v++) { const int x = s_wsum[v]; if (v < wv) before += x; tot += x; }
+      off = before + inc - cnt;
+      __syncthreads();
+    }
+    if (nc + tot > JP_TILE) { process(nc); nc = 0; }
     {
       int o = 1 + nc + off;
 #pragma unroll
       for (int q = 0; q < PER; q++) if (cmask & (1u << q)) { s_a[o] = a_[q]; s_rk[o] = rk_[q]; s_g[o] = (u32)(base + (long long)tid * PER + q); o++; }
     }
-    nc += (int)tot64;
+    nc += tot;
   }
   process(nc);
 }
