@@ -172,6 +172,7 @@ struct sqmc_gpu_ctx {
   bool residents_sorted;      // the walker arrays are known to be in (up, dn) order: true after every finished step and after an upload (which refuses unsorted lists)
   unsigned short *d_segoff; long long segoff_cap;      // bucket tail: group offsets of the partition blocks
   u32 *d_bhint; int pos_flip, scount_pos;      // where each boundary set lay when it was made (3 x BK_MAXB + 1); which of the two d_bpos halves this step writes / the counts were taken with
+  u32 *d_jcnt;                       // plain walks: candidates of join_walker2 per chunk of 2048 walkers (k_join_gather)
   u32 *d_hq_cnt, *d_hq_pos; int hii_deferred_B;      // H_ii queues of the buckets (BK_MAXB counts, BK_MAXB x BK_HQ_DEFER positions); > 0: the last tail filled them for the head that follows
   u32 *d_bkb, *d_bpos, *d_bscount;   // bucket boundaries (three sets of BK_MAXB + 1 keys: in use, counted with, being made), their positions in this step's list, the spawns the last bucket tail counted per bucket
   int kb_B[3], scount_B;      // the bucket count each set was made for / the counts were taken with (0: not valid)
@@ -272,7 +273,7 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
     long long ntiles = (M + RS_TILE - 1) / RS_TILE;
     HIPCHK(hipMalloc(&c->d_hist, ntiles * RS_MAX_RADIX * 4)); HIPCHK(hipMalloc(&c->d_rowtot, RS_MAX_RADIX * 4));
     HIPCHK(hipMalloc(&c->d_flags, M * 8)); HIPCHK(hipMalloc(&c->d_pos, M * 8));
-    HIPCHK(hipMalloc(&c->d_flags2, M * 8)); HIPCHK(hipMalloc(&c->d_pos2, M * 8));
+    HIPCHK(hipMalloc(&c->d_flags2, M * 8)); HIPCHK(hipMalloc(&c->d_pos2, M * 8)); HIPCHK(hipMalloc(&c->d_jcnt, (M / 2048 + 2) * 4));
     c->cap_tiles = (M + SCAN_TILE - 1) / SCAN_TILE + 1;
     HIPCHK(hipMalloc(&c->d_scan_state, 3 * c->cap_tiles * 8)); HIPCHK(hipMalloc(&c->d_scan_ticket, 3 * 4));
     HIPCHK(hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8)); HIPCHK(hipMemset(c->d_scan_ticket, 0, 3 * 4));
@@ -405,7 +406,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
     free_walk(c->w); free_walk(c->m);
     hipFree(c->d_nchild); hipFree(c->d_child_off); hipFree(c->d_wchild); hipFree(c->d_child_state);
     hipFree(c->d_keys); hipFree(c->d_keys_alt); hipFree(c->d_vals); hipFree(c->d_vals_alt); hipFree(c->d_hist); hipFree(c->d_rowtot);
-    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done); hipFree(c->d_segoff); hipFree(c->d_bkb); hipFree(c->d_bhint); hipFree(c->d_bpos); hipFree(c->d_bscount); hipFree(c->d_hq_cnt); hipFree(c->d_hq_pos);
+    hipFree(c->d_flags); hipFree(c->d_pos); hipFree(c->d_flags2); hipFree(c->d_pos2); hipFree(c->d_scan_state); hipFree(c->d_scan_ticket); hipFree(c->d_fstate); hipFree(c->d_fticket); hipFree(c->d_partials); hipFree(c->d_wabs_part); hipFree(c->d_done); hipFree(c->d_segoff); hipFree(c->d_bkb); hipFree(c->d_bhint); hipFree(c->d_bpos); hipFree(c->d_bscount); hipFree(c->d_hq_cnt); hipFree(c->d_hq_pos); hipFree(c->d_jcnt);
   }
   hipFree(c->d_binom); hipFree(c->d_grow); hipFree(c->d_ginv);
   for (int q = 0; q < 16; q++) hipFree(c->d_hbt[q]);
@@ -957,7 +958,12 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     TEND(merge, st);
     TBEG(round, st);
     static const bool serial_join = getenv("SQMC_SERIAL_JOIN") != nullptr;
-    if (mode == SQMC_RNG_COUNTER && !serial_join) hipLaunchKernelGGL(k_join_par, dim3(2), dim3(JP_T), 0, st, c->m, c->d_flags, c->d_pos, nall, p, seed, step);
+    if (mode == SQMC_RNG_COUNTER && !serial_join) {
+      // the arrays of the rounding pass behind it are idle: the chunks' candidates (|w|, draw key | index) and their counts go there
+      const unsigned nchunks = (unsigned)((nall + JP_TILE - 1) / JP_TILE);
+      hipLaunchKernelGGL(k_join_gather, dim3(nchunks), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, nall, p, (double *)c->d_flags2, c->d_pos2, c->d_jcnt);
+      hipLaunchKernelGGL(k_join_par, dim3(2), dim3(JP_T), 0, st, c->m, (const double *)c->d_flags2, (const u64 *)c->d_pos2, (const u32 *)c->d_jcnt, nall, p, seed, step);
+    }
     else hipLaunchKernelGGL(k_join, dim3(1), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, nall, p, mode, seed, step, c->d_sc);
     hipLaunchKernelGGL(k_round, dim3(nblk(nall)), dim3(TPB), 0, st, c->m, c->d_flags, c->d_pos, c->d_flags2, nall, p, mode, seed, step, c->d_sc, skey, c->pack);
     device_excl_scan_u64(c->d_flags2, c->d_pos2, nall, &c->d_sc->tot2, sw[2], st);

@@ -717,19 +717,53 @@ __global__ void __launch_bounds__(TPB) k_join(WalkArr m, const u64 *__restrict__
 #define JP_TILE 2048
 #define JP_LV 12                       // 2^JP_LV > JP_TILE + 2
 #define JP_T 1024                      // threads: every phase is a few dependent LDS reads per candidate, so the block wants all the waves a CU can hold
-__global__ void __launch_bounds__(JP_T) k_join_par(WalkArr m, const u64 *__restrict__ flags, const u64 *__restrict__ pos, long long n_all, StepP p, u64 seed, u64 step) {
+#define JP_CW 1024                     // chunk counts held in LDS at a time
+// step 1 over the whole chip: the candidates of every chunk of JP_TILE walkers, compacted inside the chunk's own slots -- the positive
+// ones from the front, the negative ones from the back (both in list order) -- and their two counts
+__global__ void __launch_bounds__(TPB) k_join_gather(WalkArr m, const u64 *__restrict__ flags, const u64 *__restrict__ pos, long long n_all, StepP p,
+                                                     double *__restrict__ ca, u64 *__restrict__ cb, u32 *__restrict__ counts) {
+  constexpr int PER = JP_TILE / TPB;
+  const int tid = (int)threadIdx.x;
+  const long long cbase = (long long)blockIdx.x * JP_TILE;
+  const long long len = (n_all - cbase < JP_TILE) ? n_all - cbase : JP_TILE;
+  u64 f_[PER], ps_[PER]; double w_[PER]; u32 fl_[PER];
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const long long j = cbase + (long long)tid * PER + q;
+    const bool in = j < n_all;
+    f_[q] = in ? flags[j] : 0ull; w_[q] = in ? m.wt[j] : 0.0; fl_[q] = in ? m.flg[j] : 0u; ps_[q] = in ? pos[j] : 0ull;
+  }
+  unsigned mp = 0, mn = 0; int np_ = 0, nn_ = 0;
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const double wt = w_[q];
+    if ((f_[q] & 1ull) && wt != 0.0 && fabs(wt) < p.min_wt && flg_init(fl_[q]) < 3) { if (wt > 0.0) { mp |= 1u << q; np_++; } else { mn |= 1u << q; nn_++; } }
+  }
+  u64 tot; const u64 ex = block_excl_scan_u64((u64)np_ | ((u64)nn_ << 32), &tot);
+  int op = (int)(ex & 0xFFFFFFFFull), on = (int)(ex >> 32);
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const u64 rec = ((ps_[q] & 0xFFFFFFFFull) << 32) | (u64)(u32)(cbase + (long long)tid * PER + q);       // draw key (rank) | index in the list
+    if (mp & (1u << q)) { ca[cbase + op] = fabs(w_[q]); cb[cbase + op] = rec; op++; }
+    if (mn & (1u << q)) { ca[cbase + len - 1 - on] = fabs(w_[q]); cb[cbase + len - 1 - on] = rec; on++; }
+  }
+  if (tid == 0) counts[blockIdx.x] = (u32)(tot & 0xFFFFull) | ((u32)((tot >> 32) & 0xFFFFull) << 16);
+}
+// steps 2-4: one block per sign works through the chunks' candidates, as many chunks at a time as fit a tile (one round trip a tile)
+__global__ void __launch_bounds__(JP_T) k_join_par(WalkArr m, const double *__restrict__ ca, const u64 *__restrict__ cb, const u32 *__restrict__ counts, long long n_all,
+                                                   StepP p, u64 seed, u64 step) {
   __shared__ double s_a[JP_TILE + 2];
   __shared__ u32 s_rk[JP_TILE + 2], s_g[JP_TILE + 2];
   __shared__ unsigned short s_J[JP_LV][JP_TILE + 2];
   __shared__ unsigned char s_mark[JP_TILE + 2];
+  __shared__ unsigned short s_cn[JP_CW];
   __shared__ u32 s_cg; __shared__ double s_ctot; __shared__ int s_copen;
   const int pass = (int)blockIdx.x, tid = (int)threadIdx.x;
   const double sgn = pass == 0 ? 1.0 : -1.0;
-  constexpr int PER = JP_TILE / JP_T;
-  __shared__ int s_wsum[JP_T / 64];
+  const long long nchunks = (n_all + JP_TILE - 1) / JP_TILE;
   if (tid == 0) { s_copen = 0; s_cg = 0; s_ctot = 0.0; }
   __syncthreads();
-  // phases 2-4 on the candidates 1 .. nc gathered so far (slot 0: the chain the tile before left open)
+  // phases 2-4 on the candidates 1 .. nc (slot 0: the chain the tile before left open)
   auto process = [&](int nc) {
     const int copen = s_copen;
     if (tid == 0) { s_a[0] = s_ctot; s_g[0] = s_cg; s_rk[0] = 0; }
@@ -779,49 +813,29 @@ __global__ void __launch_bounds__(JP_T) k_join_par(WalkArr m, const u64 *__restr
     }
     __syncthreads();
   };
-  int nc = 0;
-  for (long long base = 0; base < n_all; base += JP_TILE) {
-    // ---- 1. the candidates of the next JP_TILE walkers, in order (every thread a contiguous share), behind the ones gathered so
-    //         far; a tile is worked off when the next walkers' candidates might not fit any more
-    double a_[PER]; u32 rk_[PER]; int cnt = 0;
-    unsigned cmask = 0;
-    {
-      u64 f_[PER], ps_[PER]; double w_[PER]; u32 fl_[PER];       // all four loads of all PER walkers in flight together
-#pragma unroll
-      for (int q = 0; q < PER; q++) {
-        const long long j = base + (long long)tid * PER + q;
-        const bool in = j < n_all;
-        f_[q] = in ? flags[j] : 0ull; w_[q] = in ? m.wt[j] : 0.0; fl_[q] = in ? m.flg[j] : 0u; ps_[q] = in ? pos[j] : 0ull;
-      }
-#pragma unroll
-      for (int q = 0; q < PER; q++) {
-        a_[q] = 0.0; rk_[q] = 0;
-        const double wt = w_[q];
-        if ((f_[q] & 1ull) && (pass == 0 ? wt > 0.0 : wt < 0.0) && fabs(wt) < p.min_wt && flg_init(fl_[q]) < 3) { a_[q] = fabs(wt); rk_[q] = (u32)(ps_[q] & 0xFFFFFFFFull); cmask |= 1u << q; cnt++; }
-      }
-    }
-    int off, tot;                                      // exclusive scan of the threads' counts over the block
-    {
-      const int lane = tid & 63, wv = tid >> 6;
-      int inc = cnt;
-      for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o, 64); if (lane >= o) inc += x; }
-      if (lane == 63) s_wsum[wv] = inc;
-      __syncthreads();
-      int before = 0; tot = 0;
-#pragma unroll
-      for (int v = 0; v < JP_T / 64; v++) { const int x = s_wsum[v]; if (v < wv) before += x; tot += x; }
-      off = before + inc - cnt;
+  long long ci = 0, wbase = -JP_CW;
+  while (ci < nchunks) {
+    if (ci >= wbase + JP_CW) {                           // the next JP_CW chunks' counts of this sign
+      wbase = ci;
+      for (int k = tid; k < JP_CW; k += JP_T) { const long long c = wbase + k; const u32 v = (c < nchunks) ? counts[c] : 0u; s_cn[k] = (unsigned short)(pass == 0 ? (v & 0xFFFFu) : (v >> 16)); }
       __syncthreads();
     }
-    if (nc + tot > JP_TILE) { process(nc); nc = 0; }
-    {
-      int o = 1 + nc + off;
-#pragma unroll
-      for (int q = 0; q < PER; q++) if (cmask & (1u << q)) { s_a[o] = a_[q]; s_rk[o] = rk_[q]; s_g[o] = (u32)(base + (long long)tid * PER + q); o++; }
+    // as many chunks as fit the tile (a chunk alone always does); every thread finds the same cj
+    long long cj = ci; int nc = 0;
+    while (cj < nchunks && cj < wbase + JP_CW) { const int v = s_cn[cj - wbase]; if (nc + v > JP_TILE) break; nc += v; cj++; }
+    // ---- 1. their candidates, in list order, in one round trip
+    for (int o = tid; o < nc; o += JP_T) {
+      long long c = ci; int k = o;
+      for (;; c++) { const int v = s_cn[c - wbase]; if (k < v) break; k -= v; }
+      const long long cb0 = c * JP_TILE;
+      const long long len = (n_all - cb0 < JP_TILE) ? n_all - cb0 : JP_TILE;
+      const long long slot = pass == 0 ? cb0 + k : cb0 + len - 1 - k;
+      const u64 rec = cb[slot];
+      s_a[1 + o] = ca[slot]; s_rk[1 + o] = (u32)(rec >> 32); s_g[1 + o] = (u32)rec;
     }
-    nc += tot;
+    process(nc);                                       // (its first barrier also publishes the tile)
+    ci = cj;
   }
-  process(nc);
 }
 
 // C(T) lookup: open-addressed hash (linear probing, load <= 1/2) from the determinant's sort
