@@ -1240,6 +1240,57 @@ def test_non_semistochastic_walk_trajectory_bit_exact(oracle, c2_walk, c2_setup,
     assert small.sum() <= 2                      # at most the unfinished last chain of each sign
 
 
+def test_plain_annihilate_door_with_chains_longer_than_a_tile(oracle, c2_walk, c2_setup):
+    """join_walker2 in the COUNTER discipline is parallel on the GPU (k_join_gather + k_join_par): every candidate follows the
+    chain that would begin at it, the chains that really begin are found by pointer doubling, tile by tile (2048 candidates),
+    an unfinished chain being carried into the next tile.  A hand-made list whose positive candidates are thousands of tiny
+    weights -- chains of ~2500 members that span tiles, carriers that change across a tile boundary -- beside ordinary negative
+    ones, through sqmc_gpu_annihilate with semistochastic = 0, against merge_sort2_up_dn + merge_original_with_spawned2 +
+    join_walker2 of the oracle."""
+    rs = np.random.RandomState(77)
+    main = oracle.initial_walkers(c2_setup, 300)
+    main["imp_distance"] = np.where(main["imp_distance"] == 0, 1, main["imp_distance"]).astype(np.int8)
+    keep = ~((main["wt"] == 0) & (main["initiator"] < 3))
+    main = {k: v[keep] for k, v in main.items()}
+    n0 = len(main["up"])
+    ns = 9000
+    ip = rs.choice(len(c2_setup.ct_up), ns, replace=False)
+    up, dn = c2_setup.ct_up[ip].astype(np.uint64), c2_setup.ct_dn[ip].astype(np.uint64)
+    pos_ = rs.rand(ns) < 0.6
+    wt = np.where(pos_, 2.0e-4 * (1.0 + rs.randint(0, 8, ns)), -rs.choice([0.05, 0.11, 0.2, 0.26, 0.4, 0.45], ns))
+    impd = rs.choice([1, 2, 3, 5], ns).astype(np.int8)
+    init = rs.randint(0, 2, ns).astype(np.int8)
+    prm = dict(tau=c2_setup.tau, e_trial=-75.7, reweight_factor_inv=1.0, r_initiator=-1.0, min_wt=0.5, always_spawn_cutoff_wt=0.5,
+               initiator_power=0, initiator_min_distance=0, c_t_initiator=0, semistochastic=0, reached_w_abs_gen=2)
+    ow = oracle.OracleWalk(c2_walk, c2_setup, main, 50000, list(SEED), rng_mode=1)
+    w = ow.w
+    for k in range(ns):
+        i = n0 + k
+        w.up[i], w.dn[i], w.wt[i], w.imp_distance[i], w.initiator[i] = int(up[k]), int(dn[k]), float(wt[k]), int(impd[k]), int(init[k])
+        w.matrix_elements[i] = w.e_num_walker[i] = w.e_den_walker[i] = 1e51
+    n = n0 + ns
+    p = oracle.StepParams(**prm)
+    L = oracle.lib()
+    L.orc_join_walker2.restype = C.c_int64
+    L.orc_join_walker2.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    L.orc_merge_sort_walkers(ow.h, n)
+    n = L.orc_merge_original_with_spawned2(ow.h, n, C.byref(p))
+    n_merged = n
+    n = L.orc_join_walker2(ow.h, n, C.byref(p))
+    ow.w.nwalk = n
+    ref = ow.walkers(); ow.close()
+    g = gpu_ctx_from_oracle(c2_walk, rng_mode=1, seed=SEED, mwalk=50000)
+    g.set_ct_table(c2_setup.ct_up, c2_setup.ct_dn, c2_setup.ct_num, c2_setup.ct_den)
+    g.upload_walkers(main)
+    out = g.annihilate(prm, dict(up=up, dn=dn, wt=wt, imp_distance=impd, initiator=init))
+    got = g.download_walkers(); g.close()
+    assert len(got["up"]) == n == int(out[5])
+    for k in ("up", "dn", "wt", "imp_distance", "initiator"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert n_merged > 8000 and n < n_merged - 5000                  # thousands of joins happened
+    assert (ref["wt"] > 0.5).sum() >= 1 and int(pos_.sum()) > 2 * 2048     # positive chains closed above min_wt; their members fill more than two tiles
+
+
 def test_shipped_hci_deck_end_to_end(tmp_path):
     """The reference's own input deck C2_v2z_curve/r1.24253/i_1sigma_g, unchanged, through
     `python -m sqmc_amd.run`: deck grammar, hf_symmetry descent, two-state HCI, PT in the
