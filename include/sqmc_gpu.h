@@ -156,6 +156,25 @@ int sqmc_gpu_scale_projector(sqmc_gpu_ctx *ctx, double ratio);
 int sqmc_gpu_set_ct_table(sqmc_gpu_ctx *ctx, int64_t n, const uint64_t *up, const uint64_t *dn,
                           const double *e_num, const double *e_den);
 
+/* hf_to_psit = .true. (input line do_walk.f90:378; "replace HF with psi_T for 1st state"): the step variant in which the first basis
+ * state is the trial wave function, moves to and from it are deterministic and all determinants of C(T) stay in the walker list
+ * (do_walk.f90:1056-1116, 1267-1300, 2272-2320, 2394-2462, 2701-2722, 3574, 3676, 5268-5307, 6484-6833, 7206-7254).
+ * Call after sqmc_gpu_set_ct_table and sqmc_gpu_set_projector, before sqmc_gpu_upload_walkers:
+ *   - the projector is the deterministic-space matrix as generate_sparse_ham_*_upper_triangular builds it with hf_to_psit
+ *     (chemistry.f90:7885-7897, 7926-7933: no first row and column, the (1,1) element stored as 0), times -tau;
+ *   - psit_ct_index[k] (1-based, increasing): where dets_up/dn_psi_t(k), Psi_T in label order (do_walk.f90:1258), lies in the C(T)
+ *     list -- my_locations_of_psit (1849-1886); the first must be 1;  cdet_psi_t[k] its coefficient;
+ *   - diag_elems[n_ct]: H_ii of the C(T) determinants outside the deterministic space, 0 inside (1091-1116);
+ *   - the walker list is [the n_ct determinants of C(T) in order | the survivors outside C(T) in order]: upload takes it so
+ *     (at the start: C(T) alone, do_walk.f90:1267-1300, imp_distance 0 inside the deterministic space and -2 elsewhere) and
+ *     download returns it so.  The deterministic space must lie inside C(T) and only the first state may be a permanent initiator,
+ *     as in the reference's own set-up.
+ * sum_order: 1 = the step's three long sums (first row over C(T), first row over Psi_T, T^-1) through a fixed 64-ary tree;
+ * 0 = left to right as the reference's loops run (one lane: slow).  One rank, COUNTER or REPLAY discipline, uniform proposal.
+ * tests/golden/README_hf_to_psit.md records what parity is defined against (the reference's merge for this variant cannot run as written). */
+int sqmc_gpu_set_hf_to_psit(sqmc_gpu_ctx *ctx, int64_t n_psit, const int64_t *psit_ct_index, const double *cdet_psi_t,
+                            const double *diag_elems, int32_t sum_order);
+
 /* walker SoA of common_walk.f90:5-18.  perm_sign(i) = sign_permanent_initiator of walker i
  * if initiator(i)==3 else 0 (the reference keeps the signs in sorted-walker order,
  * do_walk.f90:1150,2593-2594; here the sign travels with its walker). */

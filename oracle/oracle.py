@@ -472,6 +472,20 @@ class WalkSetup:
     pass
 
 
+def _lowest_in_space(counts, idx, val, guess):
+    """lowest eigenpair of a (small) sparse symmetric matrix in the upper-triangular storage: dense LAPACK below 3000 rows, as the
+    reference's own small cases are handled (real_symmetric_diagonalize, semistoch.f90:1037-1043), Davidson from `guess` above"""
+    n = len(counts)
+    if n > 3000:
+        return davidson_sparse(counts, idx, val, 1, initial_vectors=np.ascontiguousarray(guess).reshape(-1, 1))
+    H = np.zeros((n, n))
+    row = np.repeat(np.arange(n), np.asarray(counts, np.int64))
+    H[row, np.asarray(idx, np.int64) - 1] = val
+    H[np.asarray(idx, np.int64) - 1, row] = val
+    w, v = np.linalg.eigh(H)
+    return w[:1], v[:, :1]
+
+
 def _reps(cu, cd):
     """unique time-reversal representatives (up <= dn) of a list of determinants, sorted"""
     a, b = np.minimum(cu, cd), np.maximum(cu, cd)
@@ -479,7 +493,7 @@ def _reps(cu, cd):
     return np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint64)
 
 
-def setup_walk(sysm, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1, coeffs="eig"):
+def setup_walk(sysm, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1, coeffs="eig", rediagonalize=False):
     """Returns Psi_T, C(T), deterministic space + projector (-tau*H), tau.
     coeffs="eig": lowest eigenvector of H in {HF + connections} (the reference's scheme);
     coeffs="pt1": first-order perturbation coefficients H_i0/(H_00-H_ii), which involve no
@@ -510,6 +524,17 @@ def setup_walk(sysm, n_truncate_trial_wf=100, size_deterministic=1000, tau_multi
     n_i = _truncate_at_csf(c_s, size_deterministic)
     norm = 1.0 / math.sqrt(math.fsum(float(x) * float(x) for x in c_s[:n_t]))
     s.psi_up, s.psi_dn, s.psi_c = up_s[:n_t].copy(), dn_s[:n_t].copy(), c_s[:n_t] * norm
+    if rediagonalize:
+        # "Finally, rediagonalize" (semistoch.f90:575, 706-712): the trial wave function is the lowest eigenvector of H among its own
+        # determinants, in label order -- what the hf_to_psit projector assumes ((H Psi_T)_i = E c_i on every determinant of Psi_T)
+        o = sort_dets(s.psi_up, s.psi_dn)
+        s.psi_up, s.psi_dn = s.psi_up[o], s.psi_dn[o]
+        counts, idx, val = sysm.build_sparse_ham(s.psi_up, s.psi_dn)
+        wr, vr = _lowest_in_space(counts, idx, val, s.psi_c[o])
+        cr = vr[:, 0]
+        if cr[np.argmax(np.abs(cr))] < 0:
+            cr = -cr
+        s.psi_c, s.e_psi_t = cr, float(wr[0])
     o = sort_dets(up_s[:n_i], dn_s[:n_i])
     s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
     lo, hi = sysm.diag_lowest_highest()
@@ -580,9 +605,10 @@ def initial_walkers(s, w_abs_gen_begin, r_initiator=1.0, initiator_power=0):
 class OracleWalk:
     """orc_walk handle fed from numpy arrays."""
 
-    def __init__(self, sysm, setup, walkers, mwalk, seed, rng_mode=0, heatbath=None):
+    def __init__(self, sysm, setup, walkers, mwalk, seed, rng_mode=0, heatbath=None, psit=None, quirks=0, sum_order=1):
         L = lib()
         self.sysm, self.L, self.hb = sysm, L, heatbath          # heatbath: a HeatBath of sysm -> proposal_method fast_heatbath
+        self.q = None                                           # psit: a PsitSetup -> the hf_to_psit step (sqmc_oracle_psit.c)
         self.h = L.orc_walk_new(mwalk)
         self.w = Walk.from_address(self.h)
         self._keep = []
@@ -596,11 +622,12 @@ class OracleWalk:
         signs = walkers["perm_sign"][walkers["initiator"] == 3].astype(np.int8)
         self._set_ptr("sign_perm", signs if len(signs) else np.zeros(1, np.int8), C.c_int8)
         self.w.n_perm = len(signs)
-        self.w.n_imp = len(setup.prj_counts)
-        self.w.nnz = len(setup.prj_values)
-        self._set_ptr("prj_counts", setup.prj_counts.astype(np.int64), C.c_int64)
-        self._set_ptr("prj_indices", setup.prj_indices.astype(np.int64), C.c_int64)
-        self._set_ptr("prj_values", setup.prj_values.astype(np.float64), C.c_double)
+        prj = psit if psit is not None else setup          # hf_to_psit: the matrix without its first row and column
+        self.w.n_imp = len(prj.prj_counts)
+        self.w.nnz = len(prj.prj_values)
+        self._set_ptr("prj_counts", prj.prj_counts.astype(np.int64), C.c_int64)
+        self._set_ptr("prj_indices", prj.prj_indices.astype(np.int64), C.c_int64)
+        self._set_ptr("prj_values", prj.prj_values.astype(np.float64), C.c_double)
         self.w.n_ct = len(setup.ct_up)
         self._set_ptr("ct_up", setup.ct_up, C.c_uint64); self._set_ptr("ct_dn", setup.ct_dn, C.c_uint64)
         self._set_ptr("ct_num", setup.ct_num, C.c_double); self._set_ptr("ct_den", setup.ct_den, C.c_double)
@@ -609,6 +636,20 @@ class OracleWalk:
         L.orc_setrn(C.byref(self.w.rng), sd)
         L.orc_rng_set_mode.argtypes = [C.c_void_p, C.c_int]
         L.orc_rng_set_mode(C.byref(self.w.rng), rng_mode)
+        if psit is not None:
+            L.orc_psit_new.restype = C.c_void_p
+            L.orc_psit_new.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+            L.orc_psit_free.argtypes = [C.c_void_p]
+            L.orc_psit_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            L.orc_psit_n_out.restype = C.c_int64
+            L.orc_psit_n_out.argtypes = [C.c_void_p]
+            L.orc_walk_step_psit.argtypes = [C.c_void_p] * 5
+            L.orc_walk_step_psit_heg.argtypes = [C.c_void_p] * 5
+            lp, cd = np.ascontiguousarray(psit.loc_psit, np.int64), np.ascontiguousarray(psit.cdet, np.float64)
+            de, li = np.ascontiguousarray(psit.diag_elems, np.float64), np.ascontiguousarray(psit.loc_imp, np.int64)
+            assert n == len(de), "the psit walk starts from the C(T) list"
+            self.q = L.orc_psit_new(len(de), len(lp), _p(lp), _p(cd), _p(de), len(li), _p(li))
+            L.orc_psit_set(self.q, quirks, sum_order)
 
     def _set_ptr(self, name, arr, ctype):
         # the C side free()s these in orc_walk_free: hand it malloc'ed copies
@@ -626,6 +667,9 @@ class OracleWalk:
     def step(self, params):
         out = np.zeros(16)
         p = StepParams(**params)
+        if self.q is not None:
+            fn = self.L.orc_walk_step_psit_heg if isinstance(self.sysm, HegSystem) else self.L.orc_walk_step_psit
+            return fn(self.sysm.h, self.h, self.q, C.byref(p), _p(out)), out
         if self.hb is not None:
             self.L.orc_walk_step_heatbath.argtypes = [C.c_void_p] * 5
             return self.L.orc_walk_step_heatbath(self.sysm.h, self.hb.h, self.h, C.byref(p), _p(out)), out
@@ -644,10 +688,90 @@ class OracleWalk:
     def rng_state(self):
         return [self.w.rng.l[i] for i in range(4)]
 
+    def n_outside_ct(self):
+        return int(self.L.orc_psit_n_out(self.q))
+
+    def debug_premerge(self, on=True):
+        self.L.orc_psit_debug.argtypes = [C.c_void_p, C.c_int]
+        self.L.orc_psit_debug(self.q, 1 if on else 0)
+
+    def premerge(self):
+        """the list in front of the merge of the last step (debug_premerge on): residents [0, n0) after death/clone and the projection,
+        then the sorted spawns"""
+        self.L.orc_psit_debug_get.restype = C.c_int64
+        self.L.orc_psit_debug_get.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 6
+        n0 = C.c_int64()
+        z = np.zeros(1, np.uint64)
+        n = self.L.orc_psit_debug_get(self.q, 0, C.byref(n0), _p(z), _p(z), _p(z), _p(z), _p(z))
+        out = dict(up=np.zeros(n, np.uint64), dn=np.zeros(n, np.uint64), wt=np.zeros(n), imp_distance=np.zeros(n, np.int8), initiator=np.zeros(n, np.int8))
+        self.L.orc_psit_debug_get(self.q, n, C.byref(n0), _p(out["up"]), _p(out["dn"]), _p(out["wt"]), _p(out["imp_distance"]), _p(out["initiator"]))
+        return out, int(n0.value)
+
     def close(self):
+        if self.q:
+            self.L.orc_psit_free(self.q)
+            self.q = None
         if self.h:
             self.L.orc_walk_free(self.h)
             self.h = None
+
+
+class PsitSetup:
+    pass
+
+
+def psit_setup(sysm, s):
+    """What hf_to_psit = .true. adds to a walk set-up (reference lines in sqmc_oracle_psit.c):
+    the deterministic-space matrix without its first row and column (generate_sparse_ham_*_upper_triangular with hf_to_psit,
+    chemistry.f90:7885-7897, 7926-7933: the (1,1) element is kept, as 0), Psi_T in label order with the places of its determinants
+    in the walker list (do_walk.f90:1258, 1849-1886), diag_elems (1091-1116), the fixed places of the deterministic space.
+    Stops where the reference silently assumes: deterministic space inside C(T), and the first determinant of C(T), of Psi_T and
+    of the deterministic space being the same one."""
+    q = PsitSetup()
+    ct = {(int(a), int(b)): i for i, (a, b) in enumerate(zip(s.ct_up.tolist(), s.ct_dn.tolist()))}
+    o = sort_dets(s.psi_up, s.psi_dn)
+    pu, pd, q.cdet = s.psi_up[o], s.psi_dn[o], np.array(s.psi_c)[o]
+    q.loc_psit = np.array([ct[(int(a), int(b))] for a, b in zip(pu, pd)], np.int64)
+    q.loc_imp = np.array([ct.get((int(a), int(b)), -1) for a, b in zip(s.imp_up, s.imp_dn)], np.int64)
+    if (q.loc_imp < 0).any():
+        raise ValueError("hf_to_psit: the deterministic space is not contained in C(T)")
+    if q.loc_psit[0] != 0 or q.loc_imp[0] != 0:
+        raise ValueError("hf_to_psit: C(T), Psi_T and the deterministic space do not begin with the same determinant")
+    in_imp = np.zeros(len(s.ct_up), bool)
+    in_imp[q.loc_imp] = True
+    q.in_imp = in_imp
+    q.diag_elems = np.array([0.0 if in_imp[i] else sysm.ham(int(a), int(b), int(a), int(b))
+                             for i, (a, b) in enumerate(zip(s.ct_up.tolist(), s.ct_dn.tolist()))])
+    # rows hold their diagonal first, then the columns j < i (1-based indices): row 1 keeps (1,1) = 0, the others lose column 1
+    cnt, idx, val = [], [], []
+    k = 0
+    for i, c in enumerate(s.prj_counts.tolist()):
+        row = [(int(s.prj_indices[k + j]), float(s.prj_values[k + j])) for j in range(c)]
+        k += c
+        row = [(1, 0.0)] if i == 0 else [(j, v) for (j, v) in row if j != 1]
+        cnt.append(len(row)); idx += [j for j, _ in row]; val += [v for _, v in row]
+    q.prj_counts, q.prj_indices, q.prj_values = np.array(cnt, np.int64), np.array(idx, np.int64), np.array(val)
+    return q
+
+
+def initial_walkers_psit(s, q, w_abs_gen_begin):
+    """do_walk.f90:1245-1329 with hf_to_psit: the deterministic-space determinants (weight 0) and ALL of C(T), where only the first
+    one carries weight; merged (the deterministic-space copy comes first and keeps imp_distance 0, the permanent-initiator flag of
+    the first C(T) determinant survives the merge), then every initiator flag but 3 is set to 2 (1367-1373).  With the
+    deterministic space inside C(T) the list is C(T) itself."""
+    n = len(s.ct_up)
+    cmax, csum = np.max(np.abs(q.cdet)), np.sum(np.abs(q.cdet))
+    wt = np.zeros(n)
+    wt[0] = w_abs_gen_begin / min(w_abs_gen_begin * cmax / csum, 1.0)
+    perm = abs(abs(q.cdet[0]) - cmax) < 1e-3
+    ini = np.full(n, 2, np.int8)
+    psign = np.zeros(n, np.int8)
+    if perm:
+        ini[0], psign[0] = 3, int(np.sign(q.cdet[0]))
+        if wt[0] * psign[0] < 1.0:          # check_initiator inside the merge at 1366
+            wt[0] = psign[0]
+    return dict(up=s.ct_up.copy(), dn=s.ct_dn.copy(), wt=wt, initiator=ini, imp_distance=np.where(q.in_imp, 0, -2).astype(np.int8),
+                perm_sign=psign, matrix_elements=np.full(n, 1e51), e_num=np.full(n, 1e51), e_den=np.full(n, 1e51))
 
 
 class PopControl:
@@ -784,7 +908,7 @@ class HegSystem:
         return self.ham(self.hf_up, self.hf_dn, self.hf_up, self.hf_dn), self.ham(mu, md, mu, md)
 
 
-def setup_walk_heg(hsys, size_deterministic=500, tau_multiplier=0.1, n_truncate_trial_wf=1):
+def setup_walk_heg(hsys, size_deterministic=500, tau_multiplier=0.1, n_truncate_trial_wf=1, rediagonalize=False):
     """HEG walk set-up: Psi_T = the largest-|c| determinants of the ground state in {HF + its
     double excitations} (n_truncate_trial_wf = 1: HF alone, the usual choice for a closed shell),
     deterministic space = the size_deterministic largest, C(T) = connections of Psi_T."""
@@ -803,6 +927,17 @@ def setup_walk_heg(hsys, size_deterministic=500, tau_multiplier=0.1, n_truncate_
     n_t, n_i = _truncate_at_csf(c_s, n_truncate_trial_wf), _truncate_at_csf(c_s, size_deterministic)
     norm = 1.0 / math.sqrt(math.fsum(float(x) * float(x) for x in c_s[:n_t]))
     s.psi_up, s.psi_dn, s.psi_c = up_s[:n_t].copy(), dn_s[:n_t].copy(), c_s[:n_t] * norm
+    if rediagonalize:
+        # "Finally, rediagonalize" (semistoch.f90:575, 706-712): the trial wave function is the lowest eigenvector of H among its own
+        # determinants, in label order -- what the hf_to_psit projector assumes ((H Psi_T)_i = E c_i on every determinant of Psi_T)
+        o = sort_dets(s.psi_up, s.psi_dn)
+        s.psi_up, s.psi_dn = s.psi_up[o], s.psi_dn[o]
+        counts, idx, val = hsys.build_sparse_ham(s.psi_up, s.psi_dn)
+        wr, vr = _lowest_in_space(counts, idx, val, s.psi_c[o])
+        cr = vr[:, 0]
+        if cr[np.argmax(np.abs(cr))] < 0:
+            cr = -cr
+        s.psi_c, s.e_psi_t = cr, float(wr[0])
     o = sort_dets(up_s[:n_i], dn_s[:n_i])
     s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
     lo, hi = hsys.diag_lowest_highest()

@@ -1018,7 +1018,8 @@ int64_t orc_join_walker2(orc_walk *w, int64_t n, const orc_step_params *p) {
 }
 
 /* system dispatch of the walk: 'chem' or 'heg' (do_walk.f90:3599-3633, 3745-3769) */
-typedef struct { const orc_chem *chem; const orc_heg *heg; const orc_hub *hub; const orc_hb *hb; } orc_sys;      /* hb: chem with proposal_method fast_heatbath */
+typedef struct { const orc_chem *chem; const orc_heg *heg; const orc_hub *hub; const orc_hb *hb;      /* hb: chem with proposal_method fast_heatbath */
+                 int psit; det_t first_up, first_dn; } orc_sys;      /* psit: hf_to_psit = .true., the first state is dets_up/dn_psi_t(1) (sqmc_oracle_psit.c) */
 static double sys_diag(const orc_sys *y, det_t u, det_t d) {
   if (y->hub) return orc_hamiltonian_hubbard(y->hub, u, d, u, d);
   return y->chem ? orc_hamiltonian(y->chem, u, d, u, d) : orc_hamiltonian_heg(y->heg, u, d, u, d);
@@ -1033,6 +1034,7 @@ static void sys_move(const orc_sys *y, orc_rng *g, double tau, det_t u, det_t d,
  * (0 ok, 1 nwalk>MWALK, 3 negative diagonal factor after equilibration). */
 static int move_uniform2(const orc_sys *s, orc_walk *w, const orc_step_params *p, int64_t iw, int64_t *attempts) {
   int spawn, use_wt;
+  if (s->psit && w->up[iw] == s->first_up && w->dn[iw] == s->first_dn) return 0;     /* 3574: for the first state all moves are deterministic */
   if (fabs(w->wt[iw]) < p->always_spawn_cutoff_wt) {
     /* COUNTER discipline: the gate's draw is keyed by the determinant's rank in (up, dn) order, like the rounding draw */
     orc_rng_seek(&w->rng, 0, w->key_norb ? orc_det_rank(w->key_norb, w->key_ndn, w->up[iw], w->dn[iw]) : (uint64_t)iw);
@@ -1054,6 +1056,7 @@ static int move_uniform2(const orc_sys *s, orc_walk *w, const orc_step_params *p
       for (int kk = 0; kk < nnew; kk++) {
       ju = ju2[kk]; jd = jd2[kk];
       wj = wchild * wj2[kk];
+      if (s->psit && ju == s->first_up && jd == s->first_dn) wj = 0;      /* 3676 / 7642: no stochastic spawning onto the first state */
       if (wj != 0) {
         int64_t k = w->nwalk++;
         if (w->nwalk > w->mwalk) return 1;
@@ -1182,19 +1185,19 @@ static void search_list_and_update(orc_walk *w, int64_t n, double acc[7]) {
  * run_type 'none'.  Population control (2880-2901) stays with the caller. */
 static int walk_step_sys(const orc_sys *s, orc_walk *w, const orc_step_params *p, double out[16]);
 int orc_walk_step(const orc_chem *c, orc_walk *w, const orc_step_params *p, double out[16]) {
-  orc_sys y = {c, NULL, NULL, NULL};
+  orc_sys y = {c, NULL, NULL, NULL, 0, 0, 0};
   return walk_step_sys(&y, w, p, out);
 }
 int orc_walk_step_heatbath(const orc_chem *c, const orc_hb *hb, orc_walk *w, const orc_step_params *p, double out[16]) {
-  orc_sys y = {c, NULL, NULL, hb};
+  orc_sys y = {c, NULL, NULL, hb, 0, 0, 0};
   return walk_step_sys(&y, w, p, out);
 }
 int orc_walk_step_hubbard(const orc_hub *h, orc_walk *w, const orc_step_params *p, double out[16]) {
-  orc_sys y = {NULL, NULL, h, NULL};
+  orc_sys y = {NULL, NULL, h, NULL, 0, 0, 0};
   return walk_step_sys(&y, w, p, out);
 }
 int orc_walk_step_heg(const orc_heg *h, orc_walk *w, const orc_step_params *p, double out[16]) {
-  orc_sys y = {NULL, h, NULL, NULL};
+  orc_sys y = {NULL, h, NULL, NULL, 0, 0, 0};
   return walk_step_sys(&y, w, p, out);
 }
 static double orc_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
@@ -1585,3 +1588,6 @@ int64_t orc_build_sparse_ham_hubbard(const orc_hub *h, int64_t n, const det_t *u
   *row_counts = rc; *indices = idx; *values = val;
   return nnz;
 }
+
+/* ==================================================================== hf_to_psit step variant */
+#include "sqmc_oracle_psit.c"

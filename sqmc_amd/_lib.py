@@ -13,7 +13,7 @@ _LIB = None
 
 EXPORTS = [
     "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_init_heg", "sqmc_gpu_init_hubbard", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_heatbath_tables", "sqmc_gpu_propose_heatbath_batch", "sqmc_gpu_set_projector",
-    "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
+    "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_set_hf_to_psit", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
     "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_annihilate", "sqmc_gpu_det_owner", "sqmc_gpu_set_owner_hash", "sqmc_gpu_shard_config",
     "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init", "sqmc_gpu_comm_size",
     "sqmc_gpu_shard_step", "sqmc_gpu_shard_run", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_tail_stats", "sqmc_gpu_slowest_steps", "sqmc_gpu_set_chained_runs", "sqmc_gpu_spmv_prepare",
@@ -218,6 +218,13 @@ class GpuChem:
     def set_ct_table(self, up, dn, num, den):
         u, d, n_, e = _u64(up), _u64(dn), _f64(num), _f64(den)
         _chk(self.L.sqmc_gpu_set_ct_table(self.h, len(u), _p(u), _p(d), _p(n_), _p(e)))
+
+    def set_hf_to_psit(self, psit_ct_index, cdet_psi_t, diag_elems, sum_order=1):
+        """hf_to_psit = .true.: after set_projector (matrix without its first row and column) and set_ct_table, before upload_walkers.
+        psit_ct_index: 1-based positions of Psi_T's determinants (label order) in the C(T) list."""
+        ix, cd, de = np.ascontiguousarray(psit_ct_index, np.int64), _f64(cdet_psi_t), _f64(diag_elems)
+        self.L.sqmc_gpu_set_hf_to_psit.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        _chk(self.L.sqmc_gpu_set_hf_to_psit(self.h, len(ix), _p(ix), _p(cd), _p(de), int(sum_order)))
 
     def upload_walkers(self, w):
         arrs = [_u64(w["up"]), _u64(w["dn"]), _f64(w["wt"]), np.ascontiguousarray(w["imp_distance"], np.int8),

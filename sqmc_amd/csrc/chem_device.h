@@ -55,8 +55,17 @@ struct HbDev {
 };
 
 #define SQ_BINOM_STRIDE 68              // C(c, i) for every i <= 64, + 3 entries the 4-wide rounds of colex_rank may touch
+// hf_to_psit = .true. (do_walk.f90:378-386, psit_kernels.h): the walker list is [C(T), fixed | survivors outside C(T)], which is
+// the list sorted by  key' = rank + (determinant outside C(T) ? koff : 0),  koff = number of determinants of the space
+struct PsitDev {
+  u64 koff;                             // 0: off
+  const u64 *hkey; u64 hmask;           // C(T) membership: the open-addressed hash of sqmc_gpu_set_ct_table on the determinant's rank
+  u64 first_up, first_dn;               // dets_up/dn_psi_t(1) = the first state: no stochastic move from it (3574) or onto it (3676, 7642)
+  long long n_ct;
+};
 struct ChemDev {                        // pointers into HBM, passed by value
   const ChemTab *tab; int tab_words;
+  PsitDev ps;
   const u64 *binom;                     // C(c, i) at [c*SQ_BINOM_STRIDE + i], c < 64, i < SQ_BINOM_STRIDE (0 where i > c)
   u64 n_dn_strings;                     // C(norb, ndn)
   const double *integrals;              // 1-based packed

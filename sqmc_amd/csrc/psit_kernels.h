@@ -1,0 +1,202 @@
+// psit_kernels.h -- the step variant hf_to_psit = .true. ("replace the HF state with the trial wave function",
+// do_walk.f90:35, 378-386).  Textually included by sqmc_gpu.hip behind walk_kernels.h.
+//
+// The first basis state is Psi_T instead of its first determinant: moves to and from it are deterministic, everything else stays
+// stochastic, and all n_ct determinants of C(T) stay in the walker list whatever their weights.  The reference keeps three segments
+// -- C(T), the survivors outside C(T), this step's spawns (do_walk.f90:1267-1300, 5268-5307, 6484-6833).  Here the first two are ONE
+// list sorted by  key' = rank + (outside C(T) ? koff : 0):  the C(T) determinants never leave slots [0, n_ct), so every table of the
+// variant (Psi_T locations, deterministic-space locations, e_loc_num/den, diag_elems) is addressed by slot, and sort + annihilation
+// are the unchanged kernels (k_anneal<.,1>).  What is new:
+//
+//   k_gate / k_spawn        slot 0 neither draws nor spawns (3574); a child onto the first determinant has weight 0 (3676, 7642)
+//   k_psit_ct_terms         first row, first column and extra diagonal of the transformed projector over C(T)
+//                           (2285; fast_sparse_matrix_multiply_upper_triangular's degenerate form, more_tools.f90:3656-3662)
+//   k_psit_rows_fin         ... the first row's sum; the Psi_T locations with (1 + tau E_T) c (2286; more_tools.f90:3663-3667)
+//   k_psit_apply            w_i <- w_i - tau dw_i + tau E_T w_i on C(T), + the Psi_T row, + the deterministic-space product (2313-2323)
+//   k_anneal<ITEMS, 1>      merge_my_original_with_spawned3 + reduce_my_walker for everything outside C(T)
+//   k_psit_tinv             T^-1 and its transpose on the Psi_T locations (2394-2442)
+//   k_psit_finish           check_initiator over C(T) without discarding (2444-2462), reweighting (2487), the sums over C(T) and the
+//                           energy estimator, a plain loop over the C(T) slots (2701-2722)
+//
+// Long sums.  Three sums of the step run over thousands of terms left to right in the reference (first row over C(T): n_ct terms;
+// first row over Psi_T and T^-1: n_psit - 1).  seq = 1 keeps that order (one lane; the C(T) row then costs ~0.25 ms).  The default
+// adds the same terms through a fixed 64-ary tree -- chunks of 64 consecutive terms, each added left to right, level by level --
+// a fixed order any implementation can reproduce bit for bit (the tests' CPU restatement does), rounding-level different from the reference.
+//
+// All HBM/latency bound; n_ct = 7.7e4 for C2 cc-pVDZ with a 100-determinant Psi_T: every kernel here is a few microseconds.
+
+// (struct PsitArgs: sqmc_gpu.hip, in front of the context that keeps one)
+#define PSIT_L1 2048          // level-1 sums one wavefront keeps in LDS: sums of up to 64 * PSIT_L1 terms
+#define PSIT_FB 120           // blocks of k_psit_finish (grid-stride)
+
+// Sum of n terms by ONE wavefront through the fixed tree (or left to right by lane 0 if seq); every lane returns it.
+// term(i) must be callable by any lane for 0 <= i < n; s_a: PSIT_L1 + 64 doubles of LDS owned by the wavefront.
+template <class F>
+__device__ __forceinline__ double wave_tree_sum(F term, long long n, double *s_a, int seq) {
+  const int lane = threadIdx.x & 63;
+  double tot = 0.0;
+  if (n <= 0) return 0.0;
+  if (seq) {
+    if (lane == 0) { tot = term(0); for (long long i = 1; i < n; i++) tot = tot + term(i); }
+    return __shfl(tot, 0, 64);
+  }
+  double *s_b = s_a + PSIT_L1;
+  const long long n1 = (n + 63) / 64;
+  if (n1 == 1) {            // a single chunk
+    if (lane == 0) { tot = term(0); for (long long i = 1; i < n; i++) tot = tot + term(i); }
+    return __shfl(tot, 0, 64);
+  }
+  for (long long c = lane; c < n1; c += 64) {
+    const long long b = 64 * c, e = (b + 64 < n) ? b + 64 : n;
+    double s = term(b);
+    for (long long i = b + 1; i < e; i++) s = s + term(i);
+    s_a[c] = s;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int n2 = (int)((n1 + 63) / 64);
+  if (n2 == 1) {
+    if (lane == 0) { tot = s_a[0]; for (int i = 1; i < (int)n1; i++) tot = tot + s_a[i]; }
+    return __shfl(tot, 0, 64);
+  }
+  if (lane < n2) {
+    const int b = 64 * lane, e = (b + 64 < (int)n1) ? b + 64 : (int)n1;
+    double s = s_a[b];
+    for (int i = b + 1; i < e; i++) s = s + s_a[i];
+    s_b[lane] = s;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) { tot = s_b[0]; for (int i = 1; i < n2; i++) tot = tot + s_b[i]; }
+  return __shfl(tot, 0, 64);
+}
+
+// term i of the first row over C(T), more_tools.f90:3657-3660: E_num(1)/E_den(1) w_1, then E_num(i) w_i
+__device__ __forceinline__ double psit_ct_term(const PsitArgs &a, const double *__restrict__ wt, long long i) {
+  return i == 0 ? a.cnum[0] / a.cden[0] * wt[0] : a.cnum[i] * wt[i];
+}
+// One wavefront per 4096 slots of C(T): deltaw of the slots (first column + extra diagonal) and two tree levels of the first row's sum.
+__global__ void __launch_bounds__(64) k_psit_ct_terms(PsitArgs a, const double *__restrict__ wt) {
+  __shared__ double s_t[64][65];
+  __shared__ double s_1[64];
+  const int lane = threadIdx.x;
+  const long long base = (long long)blockIdx.x * 4096;
+  const double w0 = wt[0];
+  for (int r = 0; r < 64; r++) {
+    const long long i = base + 64 * r + lane;
+    double t = 0.0;
+    if (i < a.n_ct) {
+      const double wi = wt[i], num = a.cnum[i];
+      t = (i == 0) ? num / a.cden[0] * wi : num * wi;
+      if (i > 0) { double d = 0.0 + num * w0; d = d + a.diag[i] * wi; a.dw_ct[i] = d; }
+    }
+    s_t[r][lane] = t;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (a.seq) return;                                   // the row's sum is made left to right by k_psit_rows_fin
+  const long long left = a.n_ct - base;                // terms of this tile
+  const int nrow = (int)((left < 4096 ? left : 4096) + 63) / 64;
+  double s = 0.0;
+  if (lane < nrow) {
+    const long long cnt = left - 64 * lane < 64 ? left - 64 * lane : 64;
+    s = s_t[lane][0];
+    for (int k = 1; k < (int)cnt; k++) s = s + s_t[lane][k];
+  }
+  s_1[lane] = s;
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) { double tot = s_1[0]; for (int k = 1; k < nrow; k++) tot = tot + s_1[k]; a.p2[blockIdx.x] = tot; }
+}
+// One block: wave 0 finishes the first row over C(T); wave 1 makes the first row over the Psi_T locations; all threads its first column.
+__global__ void __launch_bounds__(TPB) k_psit_rows_fin(PsitArgs a, const double *__restrict__ wt, double tau, double e_trial) {
+  __shared__ double s_scr[2][PSIT_L1 + 64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double one_plus = 1.0 + tau * e_trial;
+  if (wv == 0) {
+    double tot;
+    if (a.seq) tot = wave_tree_sum([&](long long i) { return psit_ct_term(a, wt, i); }, a.n_ct, s_scr[0], 1);
+    else { const double *p2 = a.p2; tot = wave_tree_sum([&](long long i) { return p2[i]; }, (a.n_ct + 4095) / 4096, s_scr[0], 0); }
+    if (lane == 0) a.dw_ct[0] = 0.0 + tot;
+  } else if (wv == 1) {
+    double tot = 0.0;
+    if (a.n_psit > 1) tot = 0.0 + wave_tree_sum([&](long long i) { return (one_plus * a.cdet[i + 1]) * wt[a.loc_psit[i + 1]]; }, a.n_psit - 1, s_scr[1], a.seq);
+    if (lane == 0) a.dw_ps[0] = tot;
+  }
+  const double v1 = wt[a.loc_psit[0]];
+  for (long long k = 1 + threadIdx.x; k < a.n_psit; k += TPB) a.dw_ps[k] = 0.0 + (one_plus * a.cdet[k]) * v1;
+}
+// do_walk.f90:2313-2323, slot by slot in the reference's order: the C(T) line, then the Psi_T row, then the deterministic-space product
+__global__ void __launch_bounds__(TPB) k_psit_apply(PsitArgs a, double *__restrict__ wt, double tau, double e_trial) {
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= a.n_ct) return;
+  double w = wt[i];
+  w = w - tau * a.dw_ct[i] + tau * e_trial * w;
+  const int k = a.psit_of[i], r = a.imp_of[i];
+  if (k >= 0) w = w + a.dw_ps[k];
+  if (r >= 0) w = w + a.dw_imp[r];
+  wt[i] = w;
+}
+// y = A x of the deterministic space, rows added in the reference's order (prj_row_product); no E_T term in this variant (2262 without 2290)
+__global__ void __launch_bounds__(TPB) k_psit_imp_rows(PrjPre pp) {
+  const int row = (int)blockIdx.x * (TPB / 64) + (int)(threadIdx.x >> 6);
+  if (row < pp.n_imp) prj_row_product(pp, row);
+}
+
+// T^-1 and its transpose on the Psi_T locations after the merge, do_walk.f90:2394-2442 (one block)
+__global__ void __launch_bounds__(TPB) k_psit_tinv(PsitArgs a, double *__restrict__ wt) {
+  __shared__ double s_scr[PSIT_L1 + 64];
+  __shared__ double s_w1;
+  if (threadIdx.x < 64) {
+    double tmp = 0.0;
+    if (a.n_psit > 1) tmp = 0.0 + wave_tree_sum([&](long long i) { return a.cdet[i + 1] * wt[a.loc_psit[i + 1]]; }, a.n_psit - 1, s_scr, a.seq);
+    if (threadIdx.x == 0) {
+      const int l0 = a.loc_psit[0];
+      double w1 = wt[l0];
+      w1 = w1 - tmp; w1 = w1 / a.cdet[0]; w1 = w1 / a.cdet[0];
+      wt[l0] = w1; s_w1 = w1;
+    }
+  }
+  __syncthreads();
+  const double w1 = s_w1;
+  for (long long k = 1 + threadIdx.x; k < a.n_psit; k += TPB) { const int l = a.loc_psit[k]; wt[l] = wt[l] - a.cdet[k] * w1; }
+}
+
+// check_initiator over C(T) (nothing is discarded), the reweighting, and everything the step sums over the C(T) slots
+__global__ void __launch_bounds__(TPB) k_psit_finish(PsitArgs a, double *__restrict__ wt, u32 *__restrict__ flg, StepP p, double *__restrict__ partials2) {
+  double s[NSTAT];
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
+  const double r0 = a.cnum[0] / a.cden[0];
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < a.n_ct; i += (long long)gridDim.x * TPB) {
+    double w = wt[i]; const u32 f = flg[i];
+    int d = flg_impd(f), ini = flg_init(f); const int ps = flg_psign(f);
+    if (!p.cti || i < a.n_perm) {                       // 2447-2461: with c_t_initiator only the first n_permanent_initiator slots are visited
+      const int dd = d - p.imind > 0 ? d - p.imind : 0;
+      const double thr = p.r_init * ipow_d(dd, p.ipow), aw = fabs(w);
+      if (ini == 3 && p.r_init >= 0) { if (w * ps < 1.0) w = (double)ps; }
+      else if (ini == 2 && ((aw <= thr && d > 0) || ((aw <= p.r_init && !p.cti) && d == -2))) ini = 1;
+      else if (ini < 2 && ((aw > thr && d >= 0) || ((aw > p.r_init || p.cti) && d == -2))) ini = ini + 1;
+    }
+    w = w * p.rfi;                                      // 2487
+    wt[i] = w; flg[i] = pack_flg(d, ini, ps);
+    s[0] += w; s[1] += fabs(w); s[8] += w * w;          // 2590-2598
+    if (ini == 3) s[4] += w * ps;
+    if (d == 0 || (d == -2 && p.cti)) s[6] += fabs(w);
+    double e_num, e_den;                                // 2701-2722
+    if (i == 0) { e_num = r0 * w; e_den = w; } else { e_num = a.cnum[i] * w; e_den = a.cden[i] * w; }
+    if (fabs(e_den) < 1e-22) e_den = fabs(e_den);
+    s[2] += e_den; s[3] += e_num; s[9] += e_num * e_num; s[10] += e_den * e_den;
+    s[11] += e_num * copysign(1.0, e_den); s[12] += fabs(e_den); s[5] += e_num * e_den;
+  }
+  __shared__ double red[TPB / 64][NSTAT];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) {
+    double v = s[k];
+    for (int q = 32; q > 0; q >>= 1) v += __shfl_down(v, q, 64);
+    if (lane == 0) red[wv][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NSTAT) {
+    double v = 0.0;
+    for (int q = 0; q < TPB / 64; q++) v += red[q][threadIdx.x];
+    partials2[(long long)blockIdx.x * NSTAT + threadIdx.x] = v;
+  }
+}

@@ -89,6 +89,7 @@ struct StepP {       // device copy of sqmc_step_params + derived values
   double tau, e_trial, rfi, r_init, min_wt, cutoff;
   int ipow, imind, cti, semi, reached;
   int nimp_cap;            // entries of the loc_imp array (set by step_tail): spawn records with made-up flags cannot push an index past it
+  u64 koff = 0; long long nct = 0; // hf_to_psit (0: off): offset of the sort key of a determinant outside C(T), and the length of the C(T) segment
 };
 
 // device-side scalars of a step
@@ -128,6 +129,22 @@ struct FinArgs {
   long long n_children;   // >= 0: the step's child count from the host (a finish that rides on the NEXT step's scan must not read the scalar that scan writes)
   const double *red;      // sharded steps: where the all-reduced sums lie when they travelled behind the deterministic weights (null: DevScalars::red)
   long long expect_nimp;  // >= 0: deterministic-space walkers this rank must still hold; anything else raises SQMC_ERR_IMP_BROKEN on the device (sharded steps: the status is all-reduced)
+  const double *partials2; int nblocks2;      // hf_to_psit: the sums over the C(T) segment (k_psit_finish), added to the tiles' partials
+};
+
+// device tables of the hf_to_psit step variant (psit_kernels.h)
+struct PsitArgs {
+  long long n_ct, n_psit, n_imp;
+  const int *loc_psit;        // [n_psit] slot of dets_psi_t(k) (my_locations_of_psit, do_walk.f90:1849-1886); loc_psit[0] = 0
+  const double *cdet;         // [n_psit] cdet_psi_t in label order
+  const double *diag;         // [n_ct]   diag_elems (do_walk.f90:1091-1116)
+  const int *psit_of;         // [n_ct]   k with loc_psit[k] = slot, or -1
+  const int *imp_of;          // [n_ct]   row of the slot in the deterministic-space matrix, or -1
+  const double *cnum, *cden;  // psi_t_connected_e_loc_num / _den
+  double *dw_ct, *dw_ps, *dw_imp;     // deltaw(n_imp+1 : n_imp+n_ct), deltaw(n_imp+n_ct+1 : ...), deltaw(1 : n_imp)
+  double *p2;                 // first-row sum over C(T): one partial per 4096 terms (two tree levels)
+  int n_perm;                 // n_permanent_initiator (0 or 1: only the first state can be one, do_walk.f90:1276-1292)
+  int seq;
 };
 
 struct sqmc_gpu_ctx {
@@ -196,13 +213,18 @@ struct sqmc_gpu_ctx {
   BucketArgs head_ba; long long last_nall;      // partition already done by the head's k_spawn (B > 0), and the length of the last sorted list (sizes the next one)
   int bk_holdoff;             // steps for which the bucket tail stays off (after a bucket overflowed or came close)
   long long bk_steps, bk_retries;
+  // hf_to_psit (psit_kernels.h)
+  long long dbg_n0, dbg_nall;          // sizes of the last step's list in front of the merge (sqmc_gpu_debug_premerge)
+  bool psit_on; int base_key_bits; PsitArgs psit; int *d_ps_loc, *d_ps_of, *d_ps_impof; double *d_ps_c, *d_ps_diag, *d_ps_dwct, *d_ps_dwps, *d_ps_dwimp, *d_ps_p2, *d_ps_part;
 };
 // a head enqueued for a step that is not going to be the next thing that happens (chained runs): forget it
 static void abandon_head(sqmc_gpu_ctx *c);
+static void psit_off(sqmc_gpu_ctx *c);
 static int shard_head_project(sqmc_gpu_ctx *c, bool with_sums, bool empty, const FinArgs *fin = nullptr);      // abi_shard.inc
 
 
 #include "walk_kernels.h"
+#include "psit_kernels.h"
 #define SPAWN_LAUNCH(HB_, FUSE_, ...) do { if (HB_) hipLaunchKernelGGL((k_spawn<1, 1>), __VA_ARGS__); else if (FUSE_) hipLaunchKernelGGL((k_spawn<0, 1>), __VA_ARGS__); else hipLaunchKernelGGL((k_spawn<0, 0>), __VA_ARGS__); } while (0)
 #define SPAWN_LAUNCH_EXT(HB_, FUSE_, ...) do { if (HB_) hipExtLaunchKernelGGL((k_spawn<1, 1>), __VA_ARGS__); else if (FUSE_) hipExtLaunchKernelGGL((k_spawn<0, 1>), __VA_ARGS__); else hipExtLaunchKernelGGL((k_spawn<0, 0>), __VA_ARGS__); } while (0)
 #include "bucket_kernels.h"
@@ -414,6 +436,8 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   hipFree(c->d_tab); hipFree(c->d_ints); hipFree(c->d_hb_r); hipFree(c->d_hb_s); hipFree(c->d_hb_absH); hipFree(c->d_pq_ind); hipFree(c->d_pq_count);
   hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x); hipFree(c->d_prj_xs[0]); hipFree(c->d_prj_xs[1]); hipFree(c->d_prj_y);
   hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den); hipFree(c->d_ct_hkey); hipFree(c->d_ct_hidx);
+  hipFree(c->d_ps_loc); hipFree(c->d_ps_of); hipFree(c->d_ps_impof); hipFree(c->d_ps_c); hipFree(c->d_ps_diag); hipFree(c->d_ps_dwct); hipFree(c->d_ps_dwps);
+  hipFree(c->d_ps_dwimp); hipFree(c->d_ps_p2); hipFree(c->d_ps_part);
   hipFree(c->d_sc); hipHostFree(c->h_sc); if (c->h_mail) hipHostFree((void *)c->h_mail);
   for (int i = 0; i < NTIMERS; i++) { hipEventDestroy(c->ev0[i]); hipEventDestroy(c->ev1[i]); }
   hipEventDestroy(c->e_fork); hipEventDestroy(c->e_join); hipEventDestroy(c->e_cnt);
@@ -443,6 +467,7 @@ int sqmc_gpu_set_projector(sqmc_gpu_ctx *c, int64_t n_imp, int64_t nnz, const in
   if (!c) return fail(SQMC_ERR_BAD_ARG, "null ctx");
   long long chk = 0; for (long long i = 0; i < n_imp; i++) chk += rc[i];
   if (chk != nnz) return fail(SQMC_ERR_BAD_ARG, "sum(row_counts) != nnz");
+  psit_off(c);
   for (long long k = 0; k < nnz; k++) if (idx[k] < 1 || idx[k] > n_imp) return fail(SQMC_ERR_BAD_ARG, "column index out of range");
   std::vector<int> ptr, col; std::vector<double> v;
   expand_full_csr(n_imp, rc, idx, val, ptr, col, v);
@@ -471,6 +496,7 @@ int sqmc_gpu_set_ct_table(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, const 
   if (!c) return fail(SQMC_ERR_BAD_ARG, "null ctx");
   for (long long i = 1; i < n; i++)
     if (!(up[i - 1] < up[i] || (up[i - 1] == up[i] && dn[i - 1] < dn[i]))) return fail(SQMC_ERR_BAD_ARG, "C(T) list must be strictly sorted by (up,dn)");
+  psit_off(c);
   hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den);
   c->n_ct = n;
   HIPCHK(hipMalloc(&c->d_ct_up, (n + 1) * 8)); HIPCHK(hipMalloc(&c->d_ct_dn, (n + 1) * 8)); HIPCHK(hipMalloc(&c->d_ct_num, (n + 1) * 8)); HIPCHK(hipMalloc(&c->d_ct_den, (n + 1) * 8));
@@ -493,17 +519,93 @@ int sqmc_gpu_set_ct_table(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, const 
   return SQMC_OK;
 }
 
+// hf_to_psit off: the tables it was set up with are about to change
+static void psit_off(sqmc_gpu_ctx *c) {
+  if (!c->psit_on) return;
+  c->psit_on = false; c->dev.ps.koff = 0;
+  c->key_bits = c->base_key_bits; c->invalid_key = (1ull << c->key_bits) - 1ull;
+  c->pack = (c->key_bits <= 32 && !getenv("SQMC_FORCE_UNPACKED")) ? 1 : 0;
+}
+int sqmc_gpu_set_hf_to_psit(sqmc_gpu_ctx *c, int64_t n_psit, const int64_t *psit_ct_index, const double *cdet_psi_t, const double *diag_elems, int32_t sum_order) {
+  abandon_head(c);
+  if (!c || n_psit < 1 || !psit_ct_index || !cdet_psi_t || !diag_elems) return fail(SQMC_ERR_BAD_ARG, "bad argument");
+  if (c->mwalk <= 0) return fail(SQMC_ERR_BAD_ARG, "context has no walker arrays (mwalk=0)");
+  if (c->d_grow || c->comm) return fail(SQMC_ERR_UNSUPPORTED, "hf_to_psit is built for one rank only");
+  if (!c->d_ct_up || c->n_ct < 1) return fail(SQMC_ERR_BAD_ARG, "set the C(T) table first");
+  if (!c->d_prj_ptr || c->n_imp < 1) return fail(SQMC_ERR_BAD_ARG, "set the deterministic-space matrix first");
+  if (sum_order != 0 && sum_order != 1) return fail(SQMC_ERR_BAD_ARG, "sum_order must be 0 (left to right) or 1 (64-ary tree)");
+  if (n_psit - 1 > 64ll * PSIT_L1 || (c->n_ct + 4095) / 4096 > 64ll * PSIT_L1) return fail(SQMC_ERR_UNSUPPORTED, "trial wave function or C(T) too long for the tree sums");
+  if (c->n_ct >= (1ll << 31)) return fail(SQMC_ERR_UNSUPPORTED, "C(T) too long");
+  psit_off(c);
+  const long long n_ct = c->n_ct;
+  std::vector<int> loc(n_psit), of(n_ct, -1);
+  for (long long k = 0; k < n_psit; k++) {
+    const long long q = psit_ct_index[k] - 1;
+    if (q < 0 || q >= n_ct || (k && q <= loc[k - 1])) return fail(SQMC_ERR_BAD_ARG, "psit_ct_index must be increasing 1-based positions in the C(T) list (Psi_T in label order)");
+    loc[k] = (int)q; of[q] = (int)k;
+  }
+  if (loc[0] != 0) return fail(SQMC_ERR_UNSUPPORTED, "hf_to_psit: the first determinant of Psi_T must be the first determinant of C(T) (the reference assumes it: do_walk.f90:2701-2706, 3574)");
+  if (cdet_psi_t[0] == 0.0) return fail(SQMC_ERR_BAD_ARG, "cdet_psi_t(1) = 0");
+  // sort keys get one more bit: a determinant outside C(T) sorts behind every determinant of C(T)
+  u64 total = 0;
+  { auto choose = [&](int n_, int k_) -> long double { long double r = 1; for (int q = 1; q <= k_; q++) r = r * (n_ - k_ + q) / q; return r; };
+    total = (u64)(choose(c->htab.norb, c->htab.nup) * choose(c->htab.norb, c->htab.ndn) + 0.5L); }
+  if (!c->base_key_bits) c->base_key_bits = c->key_bits;
+  if (c->base_key_bits + 1 > 62) return fail(SQMC_ERR_UNSUPPORTED, "determinant space too large for the hf_to_psit sort key");
+  int *d_loc, *d_of, *d_impof; double *d_c, *d_diag, *d_dwct, *d_dwps, *d_dwimp, *d_p2, *d_part;
+  hipFree(c->d_ps_loc); hipFree(c->d_ps_of); hipFree(c->d_ps_impof); hipFree(c->d_ps_c); hipFree(c->d_ps_diag); hipFree(c->d_ps_dwct); hipFree(c->d_ps_dwps);
+  hipFree(c->d_ps_dwimp); hipFree(c->d_ps_p2); hipFree(c->d_ps_part);
+  HIPCHK(hipMalloc(&d_loc, n_psit * 4)); HIPCHK(hipMalloc(&d_of, n_ct * 4)); HIPCHK(hipMalloc(&d_impof, n_ct * 4));
+  HIPCHK(hipMalloc(&d_c, n_psit * 8)); HIPCHK(hipMalloc(&d_diag, n_ct * 8)); HIPCHK(hipMalloc(&d_dwct, n_ct * 8)); HIPCHK(hipMalloc(&d_dwps, n_psit * 8));
+  HIPCHK(hipMalloc(&d_dwimp, (c->n_imp + 1) * 8)); HIPCHK(hipMalloc(&d_p2, ((n_ct + 4095) / 4096 + 1) * 8)); HIPCHK(hipMalloc(&d_part, (size_t)PSIT_FB * NSTAT * 8));
+  HIPCHK(hipMemcpy(d_loc, loc.data(), n_psit * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_of, of.data(), n_ct * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(d_impof, 0xFF, n_ct * 4));                  // filled by the upload (the deterministic-space slots are the walkers with imp_distance 0)
+  HIPCHK(hipMemcpy(d_c, cdet_psi_t, n_psit * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_diag, diag_elems, n_ct * 8, hipMemcpyHostToDevice));
+  c->d_ps_loc = d_loc; c->d_ps_of = d_of; c->d_ps_impof = d_impof; c->d_ps_c = d_c; c->d_ps_diag = d_diag; c->d_ps_dwct = d_dwct; c->d_ps_dwps = d_dwps;
+  c->d_ps_dwimp = d_dwimp; c->d_ps_p2 = d_p2; c->d_ps_part = d_part;
+  PsitArgs &a = c->psit; memset(&a, 0, sizeof(a));
+  a.n_ct = n_ct; a.n_psit = n_psit; a.n_imp = c->n_imp; a.loc_psit = d_loc; a.cdet = d_c; a.diag = d_diag; a.psit_of = d_of; a.imp_of = d_impof;
+  a.cnum = c->d_ct_num; a.cden = c->d_ct_den; a.dw_ct = d_dwct; a.dw_ps = d_dwps; a.dw_imp = d_dwimp; a.p2 = d_p2; a.n_perm = 0; a.seq = sum_order == 0 ? 1 : 0;
+  u64 first[2];
+  HIPCHK(hipMemcpy(&first[0], c->d_ct_up, 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&first[1], c->d_ct_dn, 8, hipMemcpyDeviceToHost));
+  c->dev.ps.koff = total; c->dev.ps.hkey = c->d_ct_hkey; c->dev.ps.hmask = c->ct_mask; c->dev.ps.first_up = first[0]; c->dev.ps.first_dn = first[1]; c->dev.ps.n_ct = n_ct;
+  c->key_bits = c->base_key_bits + 1; c->invalid_key = (1ull << c->key_bits) - 1ull;
+  c->pack = (c->key_bits <= 32 && !getenv("SQMC_FORCE_UNPACKED")) ? 1 : 0;
+  c->psit_on = true; c->nwalk = 0;           // walkers are uploaded anew, in the layout of this variant
+  return SQMC_OK;
+}
+
 int sqmc_gpu_upload_walkers(sqmc_gpu_ctx *c, int64_t n, const uint64_t *up, const uint64_t *dn, const double *wt, const int8_t *impd,
                             const int8_t *init, const int8_t *psign, const double *me, const double *en, const double *ed) {
   abandon_head(c);
   if (!c || c->mwalk <= 0) return fail(SQMC_ERR_BAD_ARG, "context has no walker arrays (mwalk=0)");
   if (n > c->mwalk) return fail(SQMC_ERR_MWALK, "nwalk>MWALK");
   const u64 lim = c->htab.orb_mask;
+  const long long seg = c->psit_on ? c->dev.ps.n_ct : 0;       // hf_to_psit: [C(T) | survivors outside C(T)], each segment in order (do_walk.f90:1267-1300, 6484-6833)
   for (long long i = 0; i < n; i++) {
     if ((up[i] & ~lim) || (dn[i] & ~lim)) return fail(SQMC_ERR_BAD_ARG, "determinant has bits beyond norb");
     if (__builtin_popcountll(up[i]) != c->htab.nup || __builtin_popcountll(dn[i]) != c->htab.ndn)
       return fail(SQMC_ERR_BAD_ARG, "determinant does not hold nup / ndn electrons");
-    if (i && !(up[i - 1] < up[i] || (up[i - 1] == up[i] && dn[i - 1] < dn[i]))) return fail(SQMC_ERR_BAD_ARG, "walkers must be sorted by (up,dn) and unique");
+    if (i && i != seg && !(up[i - 1] < up[i] || (up[i - 1] == up[i] && dn[i - 1] < dn[i]))) return fail(SQMC_ERR_BAD_ARG, "walkers must be sorted by (up,dn) and unique");
+  }
+  if (c->psit_on) {
+    if (n < seg) return fail(SQMC_ERR_BAD_ARG, "hf_to_psit: the walker list begins with ALL determinants of C(T)");
+    std::vector<u64> cu(seg), cd(seg);
+    HIPCHK(hipMemcpy(cu.data(), c->d_ct_up, seg * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(cd.data(), c->d_ct_dn, seg * 8, hipMemcpyDeviceToHost));
+    std::vector<int> impof(seg, -1); int row = 0, n_perm = 0;
+    for (long long i = 0; i < seg; i++) {
+      if (up[i] != cu[i] || dn[i] != cd[i]) return fail(SQMC_ERR_BAD_ARG, "hf_to_psit: the first n_ct walkers must be the C(T) list");
+      if (impd[i] != 0 && impd[i] != -2) return fail(SQMC_ERR_BAD_ARG, "hf_to_psit: a C(T) walker carries imp_distance 0 or -2");
+      if (impd[i] == 0) impof[i] = row++;
+      if (init[i] == 3) { if (i != 0) return fail(SQMC_ERR_UNSUPPORTED, "hf_to_psit: only the first state can be a permanent initiator (do_walk.f90:1276-1292)"); n_perm = 1; }
+    }
+    for (long long i = seg; i < n; i++) {
+      if (impd[i] < 1) return fail(SQMC_ERR_BAD_ARG, "hf_to_psit: a walker outside C(T) carries imp_distance >= 1 (the deterministic space lies inside C(T))");
+      if (init[i] == 3) return fail(SQMC_ERR_UNSUPPORTED, "hf_to_psit: only the first state can be a permanent initiator");
+    }
+    if (row != c->n_imp) return fail(SQMC_ERR_IMP_BROKEN, "number of imp_distance==0 walkers != n_imp");
+    HIPCHK(hipMemcpy(c->d_ps_impof, impof.data(), seg * 4, hipMemcpyHostToDevice));
+    c->psit.n_perm = n_perm;
   }
   HIPCHK(hipMemcpy(c->w.up, up, n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->w.dn, dn, n * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->w.wt, wt, n * 8, hipMemcpyHostToDevice));
@@ -638,7 +740,7 @@ static OwnerOut shard_owner_out(sqmc_gpu_ctx *c) {
 static inline bool bucket_static_ok(const sqmc_gpu_ctx *c, const StepP &p) {
   static const int bucket_env = getenv("SQMC_ANNEAL_ITEMS") ? 0 : (getenv("SQMC_BUCKET") ? atoi(getenv("SQMC_BUCKET")) : 1);      // a forced tile shape asks for the radix tail's kernel
   static const bool shard_bucket = !(getenv("SQMC_SHARD_BUCKET") && getenv("SQMC_SHARD_BUCKET")[0] == '0');
-  return bucket_env && c->pack && p.semi && c->rng_mode == SQMC_RNG_COUNTER && (shard_bucket || (!c->d_grow && c->comm == nullptr)) && !c->dev.hb.on;      // heat-bath children take two slots each: radix tail
+  return bucket_env && c->pack && p.semi && c->rng_mode == SQMC_RNG_COUNTER && (shard_bucket || (!c->d_grow && c->comm == nullptr)) && !c->dev.hb.on && !c->psit_on;      // heat-bath children take two slots each: radix tail; hf_to_psit: radix tail (psit_kernels.h)
 }
 // Boundaries that follow the spawns (bucket_partition.h): the partition about to be launched uses the set the last one's boundary
 // block made, if it was made for B buckets; its own boundary block makes the next set from the counts of the last bucket tail.
@@ -808,7 +910,19 @@ static int launch_side_kernels(sqmc_gpu_ctx *c, const StepP &p, long long n0, bo
   hipStream_t st3 = (p.semi && !no_st3 && !serial) ? c->st3 : st2;
   if (st3 != st2) HIPCHK(hipStreamWaitEvent(st3, c->e_fork, 0));
   TBEG(project, st3);
-  if (p.semi) {
+  if (p.semi && c->psit_on) {
+    // hf_to_psit, do_walk.f90:2262-2323: the deterministic-space product without the E_T term, the first row / column / extra diagonal of
+    // the transformed projector over C(T), the Psi_T locations; then the three updates slot by slot in the reference's order
+    PsitArgs &a = c->psit;
+    hipLaunchKernelGGL(k_prj_gather, dim3(nblk(c->n_imp)), dim3(TPB), 0, st3, c->w.wt, c->d_loc_imp, c->d_prj_x, c->n_imp);
+    PrjPre pp; memset(&pp, 0, sizeof(pp));
+    pp.n_imp = (int)c->n_imp; pp.ptr = c->d_prj_ptr; pp.col = c->d_prj_col; pp.val = c->d_prj_val; pp.x = c->d_prj_x; pp.y = a.dw_imp;
+    hipLaunchKernelGGL(k_psit_imp_rows, dim3(nblk(c->n_imp, TPB / 64)), dim3(TPB), 0, st3, pp);
+    hipLaunchKernelGGL(k_psit_ct_terms, dim3((unsigned)((a.n_ct + 4095) / 4096)), dim3(64), 0, st3, a, (const double *)c->w.wt);
+    hipLaunchKernelGGL(k_psit_rows_fin, dim3(1), dim3(TPB), 0, st3, a, (const double *)c->w.wt, p.tau, p.e_trial);
+    hipLaunchKernelGGL(k_psit_apply, dim3(nblk(a.n_ct)), dim3(TPB), 0, st3, a, c->w.wt, p.tau, p.e_trial);
+    if (st3 != st2) HIPCHK(hipEventRecord(c->e_join3, st3));
+  } else if (p.semi) {
     hipLaunchKernelGGL(k_prj_gather, dim3(nblk(c->n_imp)), dim3(TPB), 0, st3, c->w.wt, c->d_loc_imp, c->d_prj_x, c->n_imp);
     hipLaunchKernelGGL(k_prj_apply, dim3(nblk(c->n_imp, TPB / 64)), dim3(TPB), 0, st3, c->d_prj_ptr, c->d_prj_col, c->d_prj_val, c->d_prj_x, c->d_loc_imp, c->w.wt,
                        c->n_imp, p.e_trial, p.tau);
@@ -842,7 +956,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
   BucketArgs ba; memset(&ba, 0, sizeof(ba));
   bool bucket = false;
   const BucketArgs head_ba = c->head_ba; c->head_ba.B = 0;             // consumed (or ignored) by this tail
-  c->last_nall = nall;
+  c->last_nall = nall; c->dbg_n0 = n0; c->dbg_nall = nall;
   if (allow_bucket && bucket_static_ok(c, p) && c->residents_sorted && nall > n0 && nall < bucket_max && nall < merge_min && n0 >= 64) {
     if (c->bk_holdoff > 0) c->bk_holdoff--;
     else {
@@ -914,11 +1028,12 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     static const int items_env = getenv("SQMC_ANNEAL_ITEMS") ? atoi(getenv("SQMC_ANNEAL_ITEMS")) : 0;
     // small lists want many tiles, large ones short look-back chains; 4 slots per thread spill 31 registers at the 4 waves per SIMD
     // the kernel wants (3: 8), which only pays from ~10^7 slots on (measured: 0.449 against 0.458 ms/step at 2.5e6 slots, 3.44 against 3.35 at 1.7e7)
-    const int items = items_env ? items_env : (nall < (1ll << 20) ? 2 : (nall < (1ll << 23) ? 3 : 4));
+    int items = items_env ? items_env : (nall < (1ll << 20) ? 2 : (nall < (1ll << 23) ? 3 : 4));
+    if (c->psit_on) items = items <= 2 ? 2 : 3;          // the two shapes k_anneal<., 1> is instantiated with
     nb = n_ft = bucket ? ba.B : (int)((nall + (long long)TPB * items - 1) / ((long long)TPB * items));
     // pipelined steps: the kernel also does the next step's gate (keys, child counts, child weights) as it places a walker
     static const bool no_fuse = getenv("SQMC_NO_GATE_FUSION") != nullptr;
-    fuse_gate = c->pipeline_next && c->pack && !no_fuse;
+    fuse_gate = c->pipeline_next && c->pack && !no_fuse && !c->psit_on;
     GateOut go; memset(&go, 0, sizeof(go));
     if (fuse_gate) {
       go.on = 1; go.keys = (skey == c->d_keys) ? c->d_keys_alt : c->d_keys;      // never the buffer the kernel reads its sorted words from
@@ -929,8 +1044,9 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     }
 #define ANNEAL_ARGS c->w, c->m, skey, perm, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, n0, nall, p,  \
                     c->invalid_key, c->pack, mode, seed, step, c->d_sc, c->d_fstate, c->d_fstate + c->cap_ftiles, c->d_fticket, go
-#define ANNEAL_LAUNCH(I) do { if (t_anneal >= 0) hipExtLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, ANNEAL_ARGS); \
-                              else hipLaunchKernelGGL(k_anneal<I>, dim3(nb), dim3(TPB), 0, st, ANNEAL_ARGS); } while (0)
+#define ANNEAL_LAUNCH_(I, P) do { if (t_anneal >= 0) hipExtLaunchKernelGGL((k_anneal<I, P>), dim3(nb), dim3(TPB), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, ANNEAL_ARGS); \
+                                  else hipLaunchKernelGGL((k_anneal<I, P>), dim3(nb), dim3(TPB), 0, st, ANNEAL_ARGS); } while (0)
+#define ANNEAL_LAUNCH(I) ANNEAL_LAUNCH_(I, 0)
     if (bucket) {
       FusedSide fs; memset(&fs, 0, sizeof(fs));
       fs.on = c->side_pending ? 1 : 0; fs.y = c->d_prj_y;
@@ -945,12 +1061,20 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       c->bk_steps++;
       c->head_offsets_done = (go.child_off != nullptr);
       c->scount_B = ba.B; c->scount_buf = ba.kb ? c->head_kb_use : -1; c->scount_pos = c->pos_flip;
-    } else { c->scount_B = 0; if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 3) ANNEAL_LAUNCH(3); else ANNEAL_LAUNCH(4); }
+    } else if (c->psit_on) { c->scount_B = 0; if (items <= 2) ANNEAL_LAUNCH_(2, 1); else ANNEAL_LAUNCH_(3, 1); }      // hf_to_psit: everything outside C(T); the C(T) segment is finished below
+    else { c->scount_B = 0; if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 3) ANNEAL_LAUNCH(3); else ANNEAL_LAUNCH(4); }
+#undef ANNEAL_LAUNCH_
 #undef ANNEAL_LAUNCH
 #undef ANNEAL_ARGS
     if (fuse_gate && go.keys == c->d_keys_alt) std::swap(c->d_keys, c->d_keys_alt);      // the next step's spawn kernel appends its keys behind the walkers'
     std::swap(c->w.up, c->m.up); std::swap(c->w.dn, c->m.dn); std::swap(c->w.wt, c->m.wt); std::swap(c->w.flg, c->m.flg);
     std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed); std::swap(c->w.irk, c->m.irk);
+    if (c->psit_on) {          // do_walk.f90:2394-2462, 2487, 2590-2598, 2701-2722 on the C(T) segment of the NEW list
+      TBEG(psit_fin, st);
+      hipLaunchKernelGGL(k_psit_tinv, dim3(1), dim3(TPB), 0, st, c->psit, c->w.wt);
+      hipLaunchKernelGGL(k_psit_finish, dim3(PSIT_FB), dim3(TPB), 0, st, c->psit, c->w.wt, c->w.flg, p, c->d_ps_part);
+      TEND(psit_fin, st);
+    }
   } else {
     TBEG(merge, st);
     hipLaunchKernelGGL(k_merge, dim3(nbm), dim3(TPB), 0, st, c->w, c->m, skey, perm, c->d_flags, c->d_wabs_part, n0, nall, p, c->invalid_key, c->pack);
@@ -979,6 +1103,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
   fa.scan_state = c->d_scan_state; fa.scan_ticket = c->d_scan_ticket; fa.n_scan_words = (int)(3 * c->cap_tiles);
   fa.mail = use_mail ? c->d_mail : (HostMail *)nullptr; fa.seq = seq; fa.fstate = c->d_fstate; fa.fticket = c->d_fticket; fa.cap_ftiles = c->cap_ftiles;
   fa.n_ftiles = n_ft; fa.on = 1; fa.n_tickets = 3; fa.n_children = -1; fa.red = nullptr;
+  fa.partials2 = (c->psit_on && p.semi) ? c->d_ps_part : (const double *)nullptr; fa.nblocks2 = (c->psit_on && p.semi) ? PSIT_FB : 0;
   fa.expect_nimp = !use_mail ? (p.semi ? c->n_imp_local : -2) : -1;      // sharded in-library step: 'locations of my imp broken' must reach every rank
   if (fuse_gate && use_mail) {       // the finishing block runs beside the next head's scan (look-back set scan_flip): it re-zeroes the other set only
     const int other = c->scan_flip ^ 1;
@@ -1095,11 +1220,18 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   StepP p; p.tau = sp->tau; p.e_trial = sp->e_trial; p.rfi = sp->reweight_factor_inv; p.r_init = sp->r_initiator; p.min_wt = sp->min_wt;
   p.cutoff = sp->always_spawn_cutoff_wt; p.ipow = sp->initiator_power; p.imind = sp->initiator_min_distance; p.cti = sp->c_t_initiator;
   p.semi = sp->semistochastic; p.reached = sp->reached_w_abs_gen;
+  if (c->psit_on) {
+    if (!sp->semistochastic) return fail(SQMC_ERR_BAD_ARG, "hf_to_psit needs a semistochastic step");
+    if (c->dev.hb.on) return fail(SQMC_ERR_UNSUPPORTED, "hf_to_psit with proposal_method fast_heatbath is not built");
+    p.koff = c->dev.ps.koff; p.nct = c->dev.ps.n_ct;
+    if (c->nwalk < p.nct) return fail(SQMC_ERR_BAD_ARG, "hf_to_psit: the walker list does not hold the C(T) segment");
+  }
   const long long n0 = c->nwalk, M = c->mwalk;
   const int mode = c->rng_mode; const u64 seed = c->seed64, step = c->step_no;
   // a host that calls step by step (the reference's own loop does work between steps) and has promised to come back with the
   // same tau and cutoff (sqmc_gpu_set_chained_runs): this step enqueues the next one's head, as the steps of sqmc_gpu_run do
   if (!c->in_run) c->pipeline_next = c->chained_runs && sp->reached_w_abs_gen == 2 && mode != SQMC_RNG_REPLAY && !getenv("SQMC_NO_PIPELINE");
+  if (c->psit_on) c->pipeline_next = false;          // hf_to_psit: the tail's last kernels need E_T-independent sums only, but its head is not pipelined yet
   collect_timers(c);
   c->nt = 0;
   hipStream_t st2 = c->st2;
@@ -1266,7 +1398,9 @@ __global__ void __launch_bounds__(TPB) k_spawn_keys(ChemDev dev, WalkArr w, u64 
   long long k = n0 + (long long)blockIdx.x * TPB + threadIdx.x;
   if (k >= nall) return;
   const SpawnRec r = w.sp[k - n0];
-  put_key(keys, vals, k, (r.wt != 0.0) ? det_key(dev, r.up, r.dn) : invalid_key, pack);
+  u64 key = invalid_key;
+  if (r.wt != 0.0) { key = det_key(dev, r.up, r.dn); if (dev.ps.koff) key = psit_key(dev.ps, key); }
+  put_key(keys, vals, k, key, pack);
 }
 
 // The second half of a step on its own: the caller's spawned walkers (creation order) are appended
@@ -1289,6 +1423,7 @@ int sqmc_gpu_annihilate(sqmc_gpu_ctx *c, const sqmc_step_params *sp, int64_t n_s
   StepP p; p.tau = sp->tau; p.e_trial = sp->e_trial; p.rfi = sp->reweight_factor_inv; p.r_init = sp->r_initiator; p.min_wt = sp->min_wt;
   p.cutoff = sp->always_spawn_cutoff_wt; p.ipow = sp->initiator_power; p.imind = sp->initiator_min_distance; p.cti = sp->c_t_initiator;
   p.semi = sp->semistochastic; p.reached = sp->reached_w_abs_gen;
+  if (c->psit_on) { if (!sp->semistochastic) return fail(SQMC_ERR_BAD_ARG, "hf_to_psit needs a semistochastic step"); p.koff = c->dev.ps.koff; p.nct = c->dev.ps.n_ct; }
   collect_timers(c);
   c->nt = 0;
   HIPCHK(hipStreamSynchronize(st));
@@ -1301,6 +1436,21 @@ int sqmc_gpu_annihilate(sqmc_gpu_ctx *c, const sqmc_step_params *sp, int64_t n_s
   hipLaunchKernelGGL(k_main_keys, dim3(nblk(n0)), dim3(TPB), 0, st, c->dev, c->w.up, c->w.dn, c->d_keys, c->d_vals, n0, c->pack);
   if (n_spawn > 0) hipLaunchKernelGGL(k_spawn_keys, dim3(nblk(n_spawn)), dim3(TPB), 0, st, c->dev, c->w, c->d_keys, c->d_vals, n0, nall, c->invalid_key, c->pack);
   return step_tail(c, p, n0, nall, false, out);
+}
+
+// Debugging aid, not part of the ABI in include/: the list the last semistochastic step (radix tail) stood on in front of its merge.
+// Resident weights after death/clone and the projection (the buffer the annihilation kernel read: the OTHER one now) and the step's
+// spawn records in creation order (weight 0: no walker).
+int sqmc_gpu_debug_premerge(sqmc_gpu_ctx *c, int64_t cap, int64_t *n0, int64_t *n_spawn, double *res_wt, uint64_t *sp_up, uint64_t *sp_dn, double *sp_wt, int8_t *sp_impd, int8_t *sp_init) {
+  if (!c || !n0 || !n_spawn) return SQMC_ERR_BAD_ARG;
+  hipStreamSynchronize(c->st);
+  *n0 = c->dbg_n0; *n_spawn = c->dbg_nall - c->dbg_n0;
+  if (cap < c->dbg_nall) return SQMC_OK;
+  if (hipMemcpy(res_wt, c->m.wt, c->dbg_n0 * 8, hipMemcpyDeviceToHost) != hipSuccess) return SQMC_ERR_HIP;
+  std::vector<SpawnRec> r(*n_spawn);
+  if (*n_spawn > 0 && hipMemcpy(r.data(), c->w.sp, *n_spawn * sizeof(SpawnRec), hipMemcpyDeviceToHost) != hipSuccess) return SQMC_ERR_HIP;
+  for (long long i = 0; i < *n_spawn; i++) { sp_up[i] = r[i].up; sp_dn[i] = r[i].dn; sp_wt[i] = r[i].wt; sp_impd[i] = (int8_t)flg_impd((u32)r[i].flg); sp_init[i] = (int8_t)flg_init((u32)r[i].flg); }
+  return SQMC_OK;
 }
 
 #include "abi_shard.inc"

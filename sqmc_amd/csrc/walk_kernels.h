@@ -4,6 +4,32 @@
 
 // ===================================================================== step kernels
 
+// C(T) lookup: open-addressed hash (linear probing, load <= 1/2) from the determinant's sort
+// key to its row in the C(T) arrays.  Replaces the binary search of
+// binary_search_list_and_update (more_tools.f90:4041-4098): one or two dependent reads
+// instead of log2(n_ct) ~ 17; the 2 MB table is L2-resident.
+#define CT_EMPTY (~0ull)
+__device__ __forceinline__ u64 ct_hash(u64 k) { return sq_mix64(k); }
+__device__ __forceinline__ long long ct_lookup(const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 mask, u64 key) {
+  u64 h = ct_hash(key) & mask;
+  while (true) {
+    const u64 k = hkey[h];
+    if (k == key) return (long long)hidx[h];
+    if (k == CT_EMPTY) return -1;
+    h = (h + 1) & mask;
+  }
+}
+// hf_to_psit: sort key of a determinant that is not known to be a resident of the C(T) segment (a child, a caller's spawn)
+__device__ __forceinline__ u64 psit_key(const PsitDev &ps, u64 rank) {
+  u64 h = ct_hash(rank) & ps.hmask;
+  while (true) {
+    const u64 k = ps.hkey[h];
+    if (k == rank) return rank;
+    if (k == CT_EMPTY) return rank + ps.koff;
+    h = (h + 1) & ps.hmask;
+  }
+}
+
 // Everything k_finish does, as arguments: in the pipelined head the first block of the NEXT step's gate
 // kernel does it (one launch less on the critical path).
 // (struct FinArgs: sqmc_gpu.hip, in front of the context that keeps one)
@@ -38,9 +64,10 @@ __global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict
   if (i == 0) { sc->n_invalid = 0; sc->tot1 = 0; sc->tot2 = 0; sc->err = 0; }   // every writer of these runs after this kernel
   if (i >= n) return;
   const u64 kk = det_key(dev, up[i], dn[i]);
-  put_key(keys, vals, i, kk, pack);      // sort key of the walker itself
+  put_key(keys, vals, i, kk + ((p.koff && i >= p.nct) ? p.koff : 0ull), pack);      // sort key of the walker itself (hf_to_psit: the survivors outside C(T) sort behind C(T))
   u64 nc; double wc;
   gate_children(wt[i], p.cutoff, seed, step, kk, nc, wc);
+  if (p.koff && i == 0) { nc = 0; wc = 0.0; }      // hf_to_psit: all moves of the first state are deterministic (do_walk.f90:3574)
   nchild[i] = nc; wchild[i] = wc;
 }
 
@@ -58,6 +85,7 @@ __global__ void __launch_bounds__(64) k_replay_prepass(const ChemTab *__restrict
   u64 c = 0;
   for (long long i = 0; i < n; i++) {
     double w = wt[i]; bool spawn, use_wt;
+    if (p.koff && i == 0) { nchild[i] = 0; wchild[i] = 0.0; child_off[i] = c; continue; }      // hf_to_psit: the first state neither draws nor spawns (do_walk.f90:3574)
     if (fabs(w) < p.cutoff) { spawn = rng_draw(g) < fabs(w / p.cutoff); use_wt = false; }
     else { spawn = true; use_wt = true; }
     long long nc = 0; double wc = 0.0;
@@ -179,6 +207,7 @@ struct OwnerOut { u64 *okey; u32 *oval; int nranks; int mode; };      // okey ==
 __device__ __forceinline__ u64 spawn_emit(const ChemDev &dev, const WalkArr &w, u64 *__restrict__ keys, u32 *__restrict__ vals, long long n0, long long c,
                                           u32 pf, u64 ju, u64 jd, double wj, const StepP &p, u64 invalid_key, int pack, const OwnerOut &oo) {
   const long long k = n0 + c;
+  if (p.koff && ju == dev.ps.first_up && jd == dev.ps.first_dn) wj = 0.0;      // hf_to_psit: no stochastic spawning onto the first state (do_walk.f90:3676, 7642)
   if (wj != 0.0) {
     const int pd = flg_impd(pf), pi = flg_init(pf);
     int d;
@@ -191,7 +220,8 @@ __device__ __forceinline__ u64 spawn_emit(const ChemDev &dev, const WalkArr &w, 
     // not stored, k_merge supplies them for every slot >= n0
     SpawnRec r; r.up = ju; r.dn = jd; r.wt = wj; r.flg = pack_flg(d, ini, 0);
     w.sp[c] = r;
-    const u64 key = det_key(dev, ju, jd);
+    u64 key = det_key(dev, ju, jd);
+    if (p.koff) key = psit_key(dev.ps, key);
     put_key(keys, vals, k, key, pack);
     if (oo.okey) { oo.okey[c] = (u64)det_owner_any(oo.mode, key, ju, jd, oo.nranks); oo.oval[c] = (u32)c; }
     return key;
@@ -383,7 +413,7 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
 __global__ void __launch_bounds__(TPB) k_main_keys(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, u64 *__restrict__ keys,
                                                    u32 *__restrict__ vals, long long n, int pack) {
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
-  if (i < n) put_key(keys, vals, i, det_key(dev, up[i], dn[i]), pack);
+  if (i < n) put_key(keys, vals, i, det_key(dev, up[i], dn[i]) + ((dev.ps.koff && i >= dev.ps.n_ct) ? dev.ps.koff : 0ull), pack);
 }
 
 // deterministic projection: x = w(loc); y = A x (rows summed in the reference's order);
@@ -485,6 +515,12 @@ __device__ __forceinline__ void stage_slot(const SlotIn &in, double *__restrict_
 }
 // fold the run that starts at in-tile slot idx (if `in` is a head) out of the staged tile; a run that
 // leaves the tile is continued from HBM by the head's wavefront, 64 records per round trip
+// PSIT (hf_to_psit, merge_my_original_with_spawned3, do_walk.f90:6484-6833): a run whose key lies below p.koff belongs to a determinant
+// of C(T) -- always a resident.  Spawns fold into it by the same pairwise rule (6544-6563 = 5897-5950 with the resident's
+// imp_distance, -2 or 0, left alone by the table), but it is never discarded and its initiator test waits until T^-1 has been
+// applied (2394-2462: k_psit_tinv / k_psit_finish).  Everything else -- a survivor outside C(T) (6590-6607), a new determinant
+// (6642-6693) -- folds, is tested and discarded exactly as merge_original_with_spawned2 does it.
+template <int PSIT>
 __device__ __forceinline__ MergedRec fold_slot(const SlotIn &in, const double *__restrict__ s_w, const u32 *__restrict__ s_f, int idx, int tile_slots,
                                                const WalkArr &w, const u64 *__restrict__ skey, const u32 *__restrict__ perm,
                                                long long j, long long n0, long long n_all, const StepP &p, u64 invalid_key, int pack) {
@@ -596,8 +632,9 @@ __device__ __forceinline__ MergedRec fold_slot(const SlotIn &in, const double *_
   }
 #undef MERGE_FOLD
   if (!head) return out;
+  const bool ct_head = PSIT && key < p.koff;
   // check_initiator
-  {
+  if (!ct_head) {
     const int dd = d - p.imind > 0 ? d - p.imind : 0;
     const double thr = p.r_init * ipow_d(dd, p.ipow), aw = fabs(wt);
     if (ini == 3 && p.r_init >= 0) { if (wt * ps < 1.0) wt = (double)ps; }
@@ -606,7 +643,7 @@ __device__ __forceinline__ MergedRec fold_slot(const SlotIn &in, const double *_
   }
   int dtest = d;
   if (d == -1) { if (jj >= n || get_key(skey, jj, pack) == invalid_key) dtest = 1; d = 1; }   // 6032-6036 then the last-det test at 6038
-  const bool discard = (((wt == 0.0 && (ini != 3 || p.r_init < 0)) || ini == 0) && dtest >= 1);
+  const bool discard = !ct_head && (((wt == 0.0 && (ini != 3 || p.r_init < 0)) || ini == 0) && dtest >= 1);
   out.up = h.up; out.dn = h.dn; out.wt = wt; out.flg = pack_flg(d, ini, ps); out.d = d;
   out.me = me; out.en = en; out.ed = ed;
   if (!discard) { out.f = 1ull; if (p.semi && d >= 1 && fabs(wt) < p.min_wt) out.f |= (1ull << 32); }
@@ -621,7 +658,7 @@ __global__ void __launch_bounds__(TPB) k_merge(WalkArr w, WalkArr m, const u64 *
   const SlotIn in = load_slot(w, skey, perm, j, n0, n_all, invalid_key, pack, wabs, cnt);
   stage_slot(in, s_w, s_f, threadIdx.x);
   __syncthreads();
-  const MergedRec r = fold_slot(in, s_w, s_f, threadIdx.x, TPB, w, skey, perm, j, n0, n_all, p, invalid_key, pack);
+  const MergedRec r = fold_slot<0>(in, s_w, s_f, threadIdx.x, TPB, w, skey, perm, j, n0, n_all, p, invalid_key, pack);
   store_wabs(wabs_part, blockIdx.x, wabs, cnt);
   if (j >= n_all) return;
   flags[j] = r.f;
@@ -838,12 +875,7 @@ __global__ void __launch_bounds__(JP_T) k_join_par(WalkArr m, const double *__re
   }
 }
 
-// C(T) lookup: open-addressed hash (linear probing, load <= 1/2) from the determinant's sort
-// key to its row in the C(T) arrays.  Replaces the binary search of
-// binary_search_list_and_update (more_tools.f90:4041-4098): one or two dependent reads
-// instead of log2(n_ct) ~ 17; the 2 MB table is L2-resident.
-#define CT_EMPTY (~0ull)
-__device__ __forceinline__ u64 ct_hash(u64 k) { return sq_mix64(k); }
+// builds the C(T) hash (ct_hash / ct_lookup at the top of this file)
 __global__ void __launch_bounds__(TPB) k_ct_build(ChemDev dev, const u64 *__restrict__ cu, const u64 *__restrict__ cd, long long n,
                                                   u64 *__restrict__ hkey, u32 *__restrict__ hidx, u64 mask) {
   long long i = (long long)blockIdx.x * TPB + threadIdx.x;
@@ -856,19 +888,10 @@ __global__ void __launch_bounds__(TPB) k_ct_build(ChemDev dev, const u64 *__rest
     h = (h + 1) & mask;
   }
 }
-__device__ __forceinline__ long long ct_lookup(const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 mask, u64 key) {
-  u64 h = ct_hash(key) & mask;
-  while (true) {
-    const u64 k = hkey[h];
-    if (k == key) return (long long)hidx[h];
-    if (k == CT_EMPTY) return -1;
-    h = (h + 1) & mask;
-  }
-}
-
 #define NSTAT 13
 __device__ void finish_step(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
-                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words, int n_tickets, long long n_children, HostMail *mail, long long expect_nimp);
+                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words, int n_tickets, long long n_children, HostMail *mail, long long expect_nimp,
+                            const double *__restrict__ partials2 = nullptr, int nblocks2 = 0);
 // compaction into the walker arrays + reweight (2487) + estimator pieces (2573-2684 and
 // binary_search_list_and_update, more_tools.f90:4041-4098) + per-block partial sums
 __global__ void __launch_bounds__(TPB) k_compact(WalkArr m, WalkArr w, const u64 *__restrict__ flags2, const u64 *__restrict__ pos2,
@@ -935,7 +958,10 @@ extern "C" int sqmc_gpu_debug_aprof(unsigned long long *out) { return (int)hipMe
 #else
 #define APROF(K)
 #endif
-template <int ITEMS>
+// PSIT: the hf_to_psit step (fold_slot<1>).  The C(T) segment comes out where it was (its determinants sort first and none is dropped) with
+// the merged weights and flags only: T^-1, the initiator test, the reweighting and every sum over C(T) -- the whole energy estimator,
+// do_walk.f90:2701-2722 -- are k_psit_tinv / k_psit_finish's; the walkers outside C(T) are finished here, without an estimator lookup.
+template <int ITEMS, int PSIT>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) k_anneal(WalkArr w, WalkArr o, const u64 *__restrict__ skey, const u32 *__restrict__ perm, int *__restrict__ loc_imp,
                                                 const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 hmask,
                                                 const double *__restrict__ cnum, const double *__restrict__ cden,
@@ -977,7 +1003,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) r[k] = fold_slot(in[k], s_w, s_f, wv * (64 * ITEMS) + k * 64 + lane, TILE, w, skey, perm, base + (long long)k * 64, n0, n_all, p, invalid_key, pack);
+    for (int k = 0; k < ITEMS; k++) r[k] = fold_slot<PSIT>(in[k], s_w, s_f, wv * (64 * ITEMS) + k * 64 + lane, TILE, w, skey, perm, base + (long long)k * 64, n0, n_all, p, invalid_key, pack);
   }
   APROF(1);
   store_wabs(wabs_part, tile, wabs, cnt);
@@ -1009,7 +1035,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
       if (r[k].f >> 32) {
         double rr;
         if (mode == 0) { const u64 ex1 = ex + inc[k] - r[k].f; rr = (double)lcg_skip(sc->lcg, (ex1 >> 32) + 1) * 3.552713678800500929355621337890625e-15; }
-        else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, key[k]); rr = rng_draw(g); }      // keyed by the determinant's rank = its sort key
+        else { Rng g; g.mode = 1; g.x = sq_counter_key(seed, step, 2, key[k] - (PSIT ? p.koff : 0ull)); rr = rng_draw(g); }      // keyed by the determinant's rank = its sort key (PSIT: only determinants outside C(T) are rounded)
         if (rr < (fabs(r[k].wt) / p.min_wt)) r[k].wt = copysign(p.min_wt, r[k].wt); else r[k].wt = 0.0;
       }
       // reduce_my_walker drops zero weights outside the deterministic space (7222-7249)
@@ -1042,11 +1068,12 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (!(f2[k] & 1ull)) continue;
     const u64 ex2 = ex + inc[k] - f2[k];
     const long long q0 = (long long)(ex2 & 0xFFFFFFFFull);
-    const double wt = r[k].wt * p.rfi;
+    const bool ct_head = PSIT && key[k] < p.koff;
+    const double wt = ct_head ? r[k].wt : r[k].wt * p.rfi;
     const int d = r[k].d, ini = flg_init(r[k].flg), psg = flg_psign(r[k].flg);
     double me = r[k].me, en = r[k].en, ed = r[k].ed;
     if (PARK) { const int q = wv * (64 * ITEMS) + k * 64 + lane; me = s_park[0][q]; en = s_park[PARK ? 1 : 0][q]; ed = s_park[PARK ? 2 : 0][q]; }
-    if (en > 1e50) {
+    if (!PSIT && en > 1e50) {
       const long long q = ct_lookup(hkey, hidx, hmask, key[k]);
       if (q < 0) { en = 0.0; ed = 0.0; } else { en = cnum[q]; ed = cden[q]; }
     }
@@ -1058,11 +1085,12 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
       go.keys[q0] = (key[k] << 32) | (u64)q0; go.nchild[q0] = nc; go.wchild[q0] = wc;
     }
     if (d == 0 && p.semi && (long long)(ex2 >> 32) < p.nimp_cap) loc_imp[ex2 >> 32] = (int)q0;
+    if (ct_head) continue;
     s[0] += wt; s[1] += fabs(wt); s[8] += wt * wt;
     if (ini == 3) s[4] += wt * psg;
     if (d == 0 || (d == -2 && p.cti)) s[6] += fabs(wt);
     double e_num = en * wt, e_den = ed * wt;
-    if (e_num != 0.0) {
+    if (!PSIT && e_num != 0.0) {
       if (fabs(e_den) < 1e-22) e_den = fabs(e_den);
       s[2] += e_den; s[3] += e_num; s[9] += e_num * e_num; s[10] += e_den * e_den;
       s[11] += e_num * copysign(1.0, e_den); s[12] += fabs(e_den); s[5] += e_num * e_den;
@@ -1121,7 +1149,7 @@ __device__ void finish_all(const FinArgs &f, DevScalars *sc) {
   // the look-back words k_anneal used this step (two arrays, n_ftiles words each) are zero again for the next one
   for (int i = threadIdx.x; i < f.n_ftiles; i += TPB) { f.fstate[i] = 0; f.fstate[f.cap_ftiles + i] = 0; }
   if (threadIdx.x == 0 && f.n_ftiles > 0) *f.fticket = 0;
-  finish_step(f.partials, f.nblocks, f.wabs_part, f.nwabs, f.mode, sc, f.scan_state, f.scan_ticket, f.n_scan_words, f.n_tickets, f.n_children, f.mail, f.expect_nimp);
+  finish_step(f.partials, f.nblocks, f.wabs_part, f.nwabs, f.mode, sc, f.scan_state, f.scan_ticket, f.n_scan_words, f.n_tickets, f.n_children, f.mail, f.expect_nimp, f.partials2, f.nblocks2);
   if (f.mail && threadIdx.x == 0) {
     __threadfence_system();
     f.mail->seq = f.seq;
@@ -1133,7 +1161,8 @@ __device__ void finish_all(const FinArgs &f, DevScalars *sc) {
 // (fixed strided order + fixed tree: reproducible run to run), publishes the step's sums,
 // advances the REPLAY stream and re-zeroes the look-back scan states for the next step
 __device__ void finish_step(const double *__restrict__ partials, int nblocks, const double *__restrict__ wabs_part, int nwabs,
-                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words, int n_tickets, long long n_children, HostMail *mail, long long expect_nimp) {
+                            int mode, DevScalars *sc, u64 *__restrict__ scan_state, u32 *__restrict__ scan_ticket, int n_scan_words, int n_tickets, long long n_children, HostMail *mail, long long expect_nimp,
+                            const double *__restrict__ partials2, int nblocks2) {
   __shared__ double red2[TPB / 64][NSTAT + 2];
   __shared__ double tot[NSTAT + 2];
   for (int i = threadIdx.x; i < n_scan_words; i += TPB) scan_state[i] = 0;
@@ -1151,6 +1180,10 @@ __device__ void finish_step(const double *__restrict__ partials, int nblocks, co
   for (int b = threadIdx.x; b < nblocks; b += TPB) {
 #pragma unroll
     for (int k = 0; k < NSTAT; k++) acc[k] += partials[(long long)b * NSTAT + k];
+  }
+  for (int b = threadIdx.x; b < nblocks2; b += TPB) {
+#pragma unroll
+    for (int k = 0; k < NSTAT; k++) acc[k] += partials2[(long long)b * NSTAT + k];
   }
 #pragma unroll 4
   for (int b = threadIdx.x; b < nwabs; b += TPB) { acc[NSTAT] += wabs_part[2 * b]; acc[NSTAT + 1] += wabs_part[2 * b + 1]; }

@@ -17,6 +17,7 @@ module sqmc_gpu_mod
   public :: sqmc_gpu_det_owner, sqmc_gpu_shard_config, sqmc_gpu_shard_begin, sqmc_gpu_shard_pack, sqmc_gpu_shard_finish
   public :: sqmc_gpu_annihilate, sqmc_gpu_build_spmv_plan, sqmc_gpu_hci_connections_slice
   public :: sqmc_gpu_comm_unique_id, sqmc_gpu_comm_init, sqmc_gpu_comm_size, sqmc_gpu_set_owner_hash, sqmc_gpu_tail_stats, sqmc_gpu_slowest_steps, sqmc_gpu_set_chained_runs, sqmc_gpu_hci_pt2, sqmc_gpu_hci_set_active_space, sqmc_gpu_set_heatbath_tables, sqmc_gpu_propose_heatbath_batch, sqmc_heatbath_tables, sqmc_gpu_shard_step, sqmc_gpu_shard_run
+  public :: sqmc_gpu_set_hf_to_psit
   public :: sqmc_gpu_check
 
   integer(c_int), parameter, public :: SQMC_RNG_REPLAY = 0, SQMC_RNG_COUNTER = 1
@@ -194,6 +195,11 @@ module sqmc_gpu_mod
     integer(c_int) function sqmc_gpu_set_ct_table(ctx, n, up, dn, e_num, e_den) bind(C, name='sqmc_gpu_set_ct_table')
       import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n; integer(c_int64_t), intent(in) :: up(*), dn(*)
       real(c_double), intent(in) :: e_num(*), e_den(*)
+    end function
+    ! hf_to_psit = .true. (do_walk.f90:378): psit_ct_index = my_locations_of_psit (1849-1886), cdet_psi_t in label order (1258), diag_elems (1091-1116)
+    integer(c_int) function sqmc_gpu_set_hf_to_psit(ctx, n_psit, psit_ct_index, cdet_psi_t, diag_elems, sum_order) bind(C, name='sqmc_gpu_set_hf_to_psit')
+      import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n_psit; integer(c_int64_t), intent(in) :: psit_ct_index(*)
+      real(c_double), intent(in) :: cdet_psi_t(*), diag_elems(*); integer(c_int32_t), value :: sum_order
     end function
     integer(c_int) function sqmc_gpu_upload_walkers(ctx, n, up, dn, wt, imp_distance, initiator, perm_sign, matrix_elements, e_num, e_den) &
         bind(C, name='sqmc_gpu_upload_walkers')

@@ -230,12 +230,12 @@ class ChemHost:
         hi = g.hamiltonian_chem_batch([mu], [md], [mu], [md])[0]
         return float(lo), float(hi)
 
-    def setup_walk(self, g, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1):
+    def setup_walk(self, g, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1, rediagonalize=False):
         """Psi_T, C(T), deterministic space for a walk of this molecule on context g"""
         if not hasattr(self, "hb"):
             self.hb_tables(g)
         g.set_hb_tables(*self.hb)
-        return setup_walk(self, g, n_truncate_trial_wf, size_deterministic, tau_multiplier)
+        return setup_walk(self, g, n_truncate_trial_wf, size_deterministic, tau_multiplier, rediagonalize)
 
     def hb_tables(self, g):
         """dtm_hb: for every electron-pair class (p,q) the (r,s,|H|) list, |H| descending.
@@ -398,8 +398,10 @@ class WalkSetup:
     pass
 
 
-def setup_walk(host, g, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1):
-    """Psi_T, C(T) and the deterministic space from one connect-diagonalise-truncate pass."""
+def setup_walk(host, g, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1, rediagonalize=False):
+    """Psi_T, C(T) and the deterministic space from one connect-diagonalise-truncate pass.
+    rediagonalize: the trial wave function is the lowest eigenvector of H among its own determinants, as generate_space_iterate
+    leaves it (semistoch.f90:575, 706-712) -- what hf_to_psit needs; without it the truncated vector is only renormalised."""
     s = WalkSetup()
     tiny = 1e-300
     # the first-order space of the HF determinant by symmetry alone (zero matrix elements included:
@@ -414,6 +416,12 @@ def setup_walk(host, g, n_truncate_trial_wf=100, size_deterministic=1000, tau_mu
     n_t, n_i = _truncate_at_csf(c_s, n_truncate_trial_wf), _truncate_at_csf(c_s, size_deterministic)
     s.psi_up, s.psi_dn = up_s[:n_t].copy(), dn_s[:n_t].copy()
     s.psi_c = c_s[:n_t] / np.sqrt(np.dot(c_s[:n_t], c_s[:n_t]))
+    if rediagonalize:
+        ol = sort_dets(s.psi_up, s.psi_dn)
+        s.psi_up, s.psi_dn = s.psi_up[ol], s.psi_dn[ol]
+        wr, Xr, _ = lowest_state(g, s.psi_up, s.psi_dn, v0=s.psi_c[ol].reshape(-1, 1))
+        cr = Xr[:, 0]
+        s.psi_c, s.e_psi_t = (-cr if cr[np.argmax(np.abs(cr))] < 0 else cr), float(wr[0])
     o = sort_dets(up_s[:n_i], dn_s[:n_i])
     s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
     lo, hi = host.diag_lowest_highest(g)
@@ -452,6 +460,54 @@ def initial_walkers(s, w_abs_gen_begin, r_initiator=1.0, initiator_power=0):
     ini[(ini == 2) & (aw <= thr) & (d > 0)] = 1
     keep = ~((out["wt"] == 0) & (out["imp_distance"] >= 1))
     return {k: v[keep] for k, v in out.items()}
+
+
+def _slots_in(au, ad, bu, bd):
+    """positions of the determinants (au, ad) in the list (bu, bd); -1 where absent"""
+    where = {k: i for i, k in enumerate(zip(bu.tolist(), bd.tolist()))}
+    return np.array([where.get(k, -1) for k in zip(au.tolist(), ad.tolist())], np.int64)
+
+
+def psit_tables(g, s):
+    """The tables of the step variant hf_to_psit = .true. from a walk set-up whose Psi_T is an eigenvector among its own determinants:
+    Psi_T in label order with its places in the C(T) list (do_walk.f90:1258, 1849-1886), diag_elems (1091-1116), and the
+    deterministic-space matrix as generate_sparse_ham_*_upper_triangular builds it with hf_to_psit (chemistry.f90:7885-7897,
+    7926-7933): no first row and column, the (1,1) element stored as 0.  Returns (psit_ct_index 1-based, cdet, diag_elems, counts,
+    indices, values); raises where the reference's assumptions do not hold."""
+    ol = sort_dets(s.psi_up, s.psi_dn)
+    loc_psit = _slots_in(s.psi_up[ol], s.psi_dn[ol], s.ct_up, s.ct_dn)
+    loc_imp = _slots_in(s.imp_up, s.imp_dn, s.ct_up, s.ct_dn)
+    if (loc_imp < 0).any():
+        raise ValueError("hf_to_psit: the deterministic space is not contained in C(T)")
+    if loc_psit[0] != 0 or loc_imp[0] != 0:
+        raise ValueError("hf_to_psit: C(T), Psi_T and the deterministic space do not begin with the same determinant")
+    outside = np.ones(len(s.ct_up), bool)
+    outside[loc_imp] = False
+    diag = np.zeros(len(s.ct_up))
+    diag[outside] = g.hamiltonian_batch(s.ct_up[outside], s.ct_dn[outside], s.ct_up[outside], s.ct_dn[outside])
+    # rows: diagonal first, then the columns below it (1-based).  Row 1 shrinks to its diagonal, set to 0; every other row loses column 1.
+    counts, idx, val = np.asarray(s.prj_counts, np.int64), np.asarray(s.prj_indices, np.int64), np.asarray(s.prj_values, float)
+    row = np.repeat(np.arange(len(counts)), counts)
+    keep = ((row == 0) & (idx == 1)) | ((row != 0) & (idx != 1))
+    val = np.where((row == 0) & (idx == 1), 0.0, val)
+    new_counts = np.bincount(row[keep], minlength=len(counts)).astype(np.int64)
+    return loc_psit + 1, np.asarray(s.psi_c, float)[ol], diag, new_counts, idx[keep], val[keep], ~outside
+
+
+def initial_walkers_psit(s, cdet, in_imp, w_abs_gen_begin):
+    """do_walk.f90:1245-1373 with hf_to_psit: the list is C(T); only its first determinant -- the first state -- carries weight
+    (w_abs_gen_begin, rescaled as at 1332-1334); imp_distance 0 inside the deterministic space, -2 elsewhere; initiator 2, or 3 on the
+    first state when |c_1| is the largest coefficient (1276-1292)."""
+    n = len(s.ct_up)
+    ac = np.abs(cdet)
+    wt = np.zeros(n)
+    wt[0] = w_abs_gen_begin / min(w_abs_gen_begin * ac.max() / ac.sum(), 1.0)
+    ini, psign = np.full(n, 2, np.int8), np.zeros(n, np.int8)
+    if abs(ac[0] - ac.max()) < 1e-3:
+        ini[0], psign[0] = 3, (1 if cdet[0] > 0 else -1)
+        wt[0] = wt[0] if wt[0] * psign[0] >= 1.0 else float(psign[0])
+    return dict(up=s.ct_up.copy(), dn=s.ct_dn.copy(), wt=wt, initiator=ini, imp_distance=np.where(in_imp, 0, -2).astype(np.int8),
+                perm_sign=psign, matrix_elements=np.full(n, 1e51), e_num=np.full(n, 1e51), e_den=np.full(n, 1e51))
 
 
 class PopControl:
@@ -524,15 +580,29 @@ class GpuWalk:
     """A C2-style semistochastic walk resident on one GPU."""
 
     def __init__(self, host, w_target, w_begin=None, mwalk=None, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1,
-                 e_trial=None, seed=(1346, 5634, 6635, 4361), rng_mode=RNG_COUNTER, min_wt=0.5):
+                 e_trial=None, seed=(1346, 5634, 6635, 4361), rng_mode=RNG_COUNTER, min_wt=0.5, hf_to_psit=False, sum_order=1):
         self.host = host
         w_begin = w_begin if w_begin is not None else w_target
         mwalk = mwalk or int(max(4 * (w_target / min_wt + size_deterministic), 200000))
         self.g = host.gpu(rng_mode=rng_mode, seed=seed, mwalk=mwalk)
-        self.setup = s = host.setup_walk(self.g, n_truncate_trial_wf, size_deterministic, tau_multiplier)
-        self.g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
-        self.g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
-        wk = initial_walkers(s, w_begin)
+        if hf_to_psit:
+            self.setup = s = host.setup_walk(self.g, n_truncate_trial_wf, size_deterministic, tau_multiplier, rediagonalize=True)
+            ix, cdet, diag, pc_, pi_, pv_, in_imp = psit_tables(self.g, s)
+            need = int(3 * (w_target / min_wt + len(s.ct_up)))          # do_walk.f90:653-655
+            if mwalk < need:
+                self.g.close()
+                self.g = host.gpu(rng_mode=rng_mode, seed=seed, mwalk=need)
+                if hasattr(host, "hb"):
+                    self.g.set_hb_tables(*host.hb)
+            self.g.set_projector(pc_, pi_, pv_)
+            self.g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
+            self.g.set_hf_to_psit(ix, cdet, diag, sum_order)
+            wk = initial_walkers_psit(s, cdet, in_imp, w_begin)
+        else:
+            self.setup = s = host.setup_walk(self.g, n_truncate_trial_wf, size_deterministic, tau_multiplier)
+            self.g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
+            self.g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
+            wk = initial_walkers(s, w_begin)
         self.g.upload_walkers(wk)
         self.pc = PopControl(s.tau, e_trial if e_trial is not None else s.e_trial0, w_target)
         self.w_abs = float(np.abs(wk["wt"]).sum())
