@@ -53,6 +53,8 @@ def main():
                     "strong: --target is the global population, split over the ranks by determinant ownership")
     ap.add_argument("--hubbard-lattice", default="4x4", help="l_x x l_y (periodic), e.g. 4x4 (configs[0]) or 6x4")
     ap.add_argument("--heg-rs", type=float, default=1.0)
+    ap.add_argument("--hf-to-psit", action="store_true", help="auxiliary: the step variant hf_to_psit = .true. (first basis state = Psi_T, all of C(T) resident; "
+                    "SURVEY section 8 row f4) on one GPU, c2 or heg; no CPU baseline leg")
     ap.add_argument("--heg-cutoff", type=float, default=2.3, help="plane-wave cutoff radius (2.3 -> 57 orbitals; the GPU path holds at most 64)")
     args = ap.parse_args()
 
@@ -61,6 +63,10 @@ def main():
         # nothing that has initialised HIP is ever forked or re-executed) and forwards rank 0's JSON line
         sys.exit(launch_ranks(args.gpus))
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if os.environ.get("SQMC_BENCH_TEST_ONE_RANK_DIES"):     # tests/test_bench_launcher.py: rank 1 dies, rank 0 sits (as in a collective)
+        if rank == 1:
+            sys.exit(3)
+        time.sleep(600)
     if args.gpus != world and rank == 0:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size counts\n" % (args.gpus, world))
     # stdout carries the one JSON line and nothing else: libraries that greet on fd 1 (RCCL prints its version banner there
@@ -151,6 +157,11 @@ def main():
         if args.system == "hubbard":
             kw = dict(w_begin=min(args.target, 1e4), n_truncate_trial_wf=20, size_deterministic=500, tau_multiplier=0.5)
         if args.mwalk: kw["mwalk"] = args.mwalk
+        if args.hf_to_psit:
+            kw["hf_to_psit"] = True
+            kw.setdefault("w_begin", min(args.target, 1e4))
+            if args.system == "heg": kw["n_truncate_trial_wf"] = 20
+            workload += ", hf_to_psit"
         walk = H.GpuWalk(hst, args.target, seed=H.rank_seed((1346, 5634, 6635, 4361), rank), **kw)
         if multi:
             parallelism = "replicas x%d (sharded path unavailable)" % world
@@ -226,7 +237,7 @@ def main():
             dom, dom_ms, dom_bytes = "k_spawn", spawn_ms, 26.0 * s_avg + 34.0 * n_avg
         ach = dom_bytes / (dom_ms * 1e-3) / 1e9
         step_bytes = 68.0 * n_avg + 84.0 * s_avg
-        default_cfg = (args.system == "c2" and args.target == 1e5 and world == 1)
+        default_cfg = (args.system == "c2" and args.target == 1e5 and world == 1 and not args.hf_to_psit)
         tr = load_traffic() if default_cfg else None
 
         def traffic_of(kern):
@@ -264,7 +275,7 @@ def main():
                                         "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
                          "stage_ms_per_step": stage_ms},
         }
-        if not args.no_cpu_baseline and world == 1 and args.system == "c2":
+        if not args.no_cpu_baseline and world == 1 and args.system == "c2" and not args.hf_to_psit:
             cpu = cpu_leg(walk, hst, n_avg)
             line["cpu_baseline"] = cpu["one_core"]
             line["cpu_baseline_all_cores"] = cpu["all_cores"]
@@ -293,11 +304,35 @@ def launch_ranks(n):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # A rank that dies after the rendezvous (out of memory, a HIP error) leaves its peers inside a collective: every child is polled,
+    # the first non-zero exit takes the others down (terminate, then kill), and the whole run has a deadline (SQMC_BENCH_TIMEOUT_S).
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("SQMC_BENCH_TIMEOUT_S", "3000"))
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad_now = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad_now or time.time() > deadline:
+            failed = bad_now or [(-1, "timeout")]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.time() + 10.0
+            while time.time() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10.0)
+    out = b"".join(c for c in chunks if c)
     sys.stdout.write(out.decode())
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    bad = failed or [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
         sys.stderr.write("bench.py: ranks failed (rank, exit code): %r\n" % bad)
         return 1

@@ -384,6 +384,24 @@ def lowest_state(g, up, dn, k=1, v0=None):
     return w, X, (counts, idx, val)
 
 
+def rediagonalize_in_own_space(g, up, dn, guess):
+    """Lowest eigenpair of H among the determinants (up, dn) (label order): the 'Finally, rediagonalize' of generate_space_iterate
+    (semistoch.f90:575, 706-712).  A trial wave function has tens to thousands of determinants: LAPACK on the dense matrix below
+    4000 (real_symmetric_diagonalize is what the reference itself uses for its small cases, semistoch.f90:1037-1043), the GPU
+    Davidson from `guess` above."""
+    n = len(up)
+    if n > 4000:
+        w, X, _ = lowest_state(g, up, dn, v0=np.asarray(guess, float).reshape(-1, 1))
+        return float(w[0]), X[:, 0]
+    counts, idx, val = g.build_sparse_ham(up, dn)
+    A = np.zeros((n, n))
+    r = np.repeat(np.arange(n), counts)
+    A[r, idx - 1] = val
+    A[idx - 1, r] = val
+    w, X = np.linalg.eigh(A)
+    return float(w[0]), X[:, 0]
+
+
 def _truncate_at_csf(c_sorted, n_keep, eps=1e-10):
     prev = 0.0
     for i, v in enumerate(c_sorted):
@@ -416,12 +434,11 @@ def setup_walk(host, g, n_truncate_trial_wf=100, size_deterministic=1000, tau_mu
     n_t, n_i = _truncate_at_csf(c_s, n_truncate_trial_wf), _truncate_at_csf(c_s, size_deterministic)
     s.psi_up, s.psi_dn = up_s[:n_t].copy(), dn_s[:n_t].copy()
     s.psi_c = c_s[:n_t] / np.sqrt(np.dot(c_s[:n_t], c_s[:n_t]))
-    if rediagonalize:
+    if rediagonalize and n_t > 1:
         ol = sort_dets(s.psi_up, s.psi_dn)
         s.psi_up, s.psi_dn = s.psi_up[ol], s.psi_dn[ol]
-        wr, Xr, _ = lowest_state(g, s.psi_up, s.psi_dn, v0=s.psi_c[ol].reshape(-1, 1))
-        cr = Xr[:, 0]
-        s.psi_c, s.e_psi_t = (-cr if cr[np.argmax(np.abs(cr))] < 0 else cr), float(wr[0])
+        e_t, cr = rediagonalize_in_own_space(g, s.psi_up, s.psi_dn, s.psi_c[ol])
+        s.psi_c, s.e_psi_t = (-cr if cr[np.argmax(np.abs(cr))] < 0 else cr), e_t
     o = sort_dets(up_s[:n_i], dn_s[:n_i])
     s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
     lo, hi = host.diag_lowest_highest(g)
@@ -960,7 +977,7 @@ class HegHost:
         keys = sorted(out)
         return np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint64)
 
-    def setup_walk(self, g, n_truncate_trial_wf=1, size_deterministic=500, tau_multiplier=0.1):
+    def setup_walk(self, g, n_truncate_trial_wf=1, size_deterministic=500, tau_multiplier=0.1, rediagonalize=False):
         s = WalkSetup()
         up, dn = self.connected(self.hf_up, self.hf_dn)
         w, X, _ = lowest_state(g, up, dn)
@@ -972,6 +989,11 @@ class HegHost:
         n_t, n_i = _truncate_at_csf(c_s, n_truncate_trial_wf), _truncate_at_csf(c_s, size_deterministic)
         s.psi_up, s.psi_dn = up_s[:n_t].copy(), dn_s[:n_t].copy()
         s.psi_c = c_s[:n_t] / np.sqrt(np.dot(c_s[:n_t], c_s[:n_t]))
+        if rediagonalize and n_t > 1:          # semistoch.f90:575, 706-712 (see setup_walk)
+            ol = sort_dets(s.psi_up, s.psi_dn)
+            s.psi_up, s.psi_dn = s.psi_up[ol], s.psi_dn[ol]
+            e_t, cr = rediagonalize_in_own_space(g, s.psi_up, s.psi_dn, s.psi_c[ol])
+            s.psi_c, s.e_psi_t = (-cr if cr[np.argmax(np.abs(cr))] < 0 else cr), e_t
         o = sort_dets(up_s[:n_i], dn_s[:n_i])
         s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
         n = self.norb

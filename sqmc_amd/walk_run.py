@@ -82,8 +82,8 @@ def parse_walk_deck(text):
         raise SystemExit("sqmc_amd.walk_run: proposal_method %r is not on the GPU path (uniform2: off_diagonal_move_chem / _heg / _hubbard)" % d["proposal_method"])
     if d["importance_sampling"] != 0:
         raise SystemExit("sqmc_amd.walk_run: importance_sampling must be 0")
-    if d["hf_to_psit"]:
-        raise SystemExit("sqmc_amd.walk_run: hf_to_psit = t (the transformed projector) is not on the GPU path")
+    if d["hf_to_psit"] and d["hamiltonian_type"] == "hubbard2":
+        raise SystemExit("sqmc_amd.walk_run: hf_to_psit = t needs the first determinant of Psi_T to be the first determinant of C(T) (chem, heg)")
     if d["use_exponential_projector"]:
         raise SystemExit("sqmc_amd.walk_run: use_exponential_projector = t is not on the GPU path (linear projector)")
     if d["hamiltonian_type"] == "chem" and d["trial_wf_iters"] > 1:
@@ -212,9 +212,12 @@ def run_walk(deck, fcidump="FCIDUMP", out=sys.stdout, walkalize=None, max_equil_
     p("\nsemistochastic run" if semi else "\nnot semistochastic run")
     target = d["w_abs_gen_target"]
     mwalk = int(max(d["mwalk"], 4 * (target / d["min_wt"] + d["size_deterministic"])))      # do_walk.f90:665, 856
+    psit = bool(d["hf_to_psit"]) and semi
+    p(" Replacing HF state with trial wave function" if psit else " NOT replacing HF state with trial wave function")      # do_walk.f90:383-387
     g = hst.gpu(rng_mode=H.RNG_COUNTER, seed=tuple(d["irand_seed"][1]), mwalk=mwalk)
     t0 = time.perf_counter()
-    s = hst.setup_walk(g, **skw)
+    # the trial wave function is rediagonalised among its own determinants, as generate_space_iterate leaves it (semistoch.f90:575, 706-712)
+    s = hst.setup_walk(g, rediagonalize=True, **skw) if d["hamiltonian_type"] != "hubbard2" else hst.setup_walk(g, **skw)
     if d["tau"] != 0:                                         # an explicit tau overrides tau_multiplier (do_walk.f90:1396-1412)
         s.prj_values = s.prj_values * (d["tau"] / s.tau); s.tau = d["tau"]
     n_core = d.get("n_core_orb", 0)
@@ -238,10 +241,24 @@ def run_walk(deck, fcidump="FCIDUMP", out=sys.stdout, walkalize=None, max_equil_
         H.write_dtm_elems(dtm_elems_out, s.imp_up, s.imp_dn, s.prj_counts, s.prj_indices, s.prj_values / (-s.tau), s.e_var, n_core)
     p("ndet_psi_t, ndet_psi_t_connected, n_imp=%8d%10d%8d" % (len(s.psi_up), len(s.ct_up), len(s.imp_up)))
     p("tau=%12.8f  variational energy of the set-up space=%16.8f" % (s.tau, s.e_var))
-    if semi:
-        g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
-    g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
-    wk = H.initial_walkers(s, d["w_abs_gen_begin"], r_initiator=d["r_initiator"], initiator_power=d["initiator_power"])
+    if psit:
+        # hf_to_psit: the matrix loses its first row and column, all of C(T) becomes resident, MWALK follows do_walk.f90:653-655
+        ix, cdet, diag, pcnt, pidx, pval, in_imp = H.psit_tables(g, s)
+        need = int(max(d["mwalk"], 3 * (target / d["min_wt"] + len(s.ct_up))))
+        if need > mwalk:
+            g.close()
+            mwalk = need
+            g = hst.gpu(rng_mode=H.RNG_COUNTER, seed=tuple(d["irand_seed"][1]), mwalk=mwalk)
+        p("Setting MWALK=3*(w_abs_gen_target/min_wt+ndet_psi_t_connected)/ncores=%10d" % mwalk)
+        g.set_projector(pcnt, pidx, pval)
+        g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
+        g.set_hf_to_psit(ix, cdet, diag)
+        wk = H.initial_walkers_psit(s, cdet, in_imp, d["w_abs_gen_begin"])
+    else:
+        if semi:
+            g.set_projector(s.prj_counts, s.prj_indices, s.prj_values)
+        g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
+        wk = H.initial_walkers(s, d["w_abs_gen_begin"], r_initiator=d["r_initiator"], initiator_power=d["initiator_power"])
     if not semi:
         wk["imp_distance"] = np.where(wk["imp_distance"] == 0, 1, wk["imp_distance"]).astype(np.int8)
         keep = ~((wk["wt"] == 0) & (wk["initiator"] < 3))

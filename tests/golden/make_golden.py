@@ -20,6 +20,9 @@
                          of the golden outputs next to them (o_det_ref, o_st_ref) are transcribed into
                          the tests with their line numbers.
 
+  psit_c2_8steps.json    eight steps of the hf_to_psit step variant on the same molecule from the CPU
+                         oracle, both RNG disciplines (README_hf_to_psit.md: what that restatement is and is not pinned by).
+
 Data files are copied byte for byte (cp); nothing here is reference source code.
 """
 import ctypes as C
@@ -69,7 +72,37 @@ def walk_fixture():
     json.dump(gold, open(os.path.join(HERE, "walk_c2_5steps.json"), "w"))
 
 
+def psit_fixture():
+    fcidump = os.path.join(HERE, "C2_r1.24253_FCIDUMP")
+    s = O.ChemSystem(fcidump, 8, 4, "d2h", time_sym=False, hf_mode=0)
+    ws = O.setup_walk(s, 100, 1000, 0.1, coeffs="pt1")           # no eigensolver: bit-reproducible inputs (the variant runs with any Psi_T)
+    q = O.psit_setup(s, ws)
+    gold = {"w_abs_gen_begin": 50, "seed": [1346, 5634, 6635, 4361], "w_target": 3000, "modes": {}}
+    for mode in (0, 1):
+        wk = O.initial_walkers_psit(ws, q, gold["w_abs_gen_begin"])
+        ow = O.OracleWalk(s, ws, wk, 400000, gold["seed"], rng_mode=mode, psit=q)
+        pc = O.PopControl(ws.tau, ws.e_trial0, gold["w_target"])
+        w_abs = float(np.abs(wk["wt"]).sum())
+        steps = []
+        for _ in range(8):
+            r = pc.pre_step(w_abs)
+            if r != 1.0: ow.scale_projector(r)
+            st, out = ow.step(pc.params())
+            assert st == 0
+            steps.append([float(x).hex() for x in out])
+            r = pc.post_step(out)
+            if r != 1.0: ow.scale_projector(r)
+            w_abs = out[1]
+        w = ow.walkers()
+        gold["modes"][str(mode)] = {"steps": steps, "rng_after": ow.rng_state(), "n_outside_ct": ow.n_outside_ct(),
+                                    "det_checksum": int(np.bitwise_xor.reduce(w["up"] * np.uint64(0x9E3779B97F4A7C15) + w["dn"])),
+                                    "wt_checksum": float(np.sum(w["wt"] * np.arange(1, len(w["wt"]) + 1) % 7.0)).hex()}
+        ow.close()
+    json.dump(gold, open(os.path.join(HERE, "psit_c2_8steps.json"), "w"))
+
+
 if __name__ == "__main__":
+    psit_fixture()
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libsqmc_ref.so")):
         rannyu_fixture()
     walk_fixture()

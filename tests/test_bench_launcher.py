@@ -20,3 +20,14 @@ def test_launcher_reports_failed_ranks_without_gpu():
     assert r.returncode != 0
     assert "ranks failed" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_launcher_takes_the_other_ranks_down_when_one_dies():
+    """a rank that dies after the start leaves its peers waiting in a collective: the launcher ends them and reports, promptly"""
+    import time
+    env = dict(os.environ, SQMC_BENCH_TEST_ONE_RANK_DIES="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and time.time() - t0 < 60
+    assert "ranks failed" in r.stderr and "(1, 3)" in r.stderr
