@@ -26,93 +26,86 @@
 // All HBM/latency bound; n_ct = 7.7e4 for C2 cc-pVDZ with a 100-determinant Psi_T: every kernel here is a few microseconds.
 
 // (struct PsitArgs: sqmc_gpu.hip, in front of the context that keeps one)
-#define PSIT_L1 2048          // level-1 sums one wavefront keeps in LDS: sums of up to 64 * PSIT_L1 terms
+#define PSIT_MAXTERMS (64ll * 64 * 64)      // three tree levels
 #define PSIT_FB 120           // blocks of k_psit_finish (grid-stride)
 
-// Sum of n terms by ONE wavefront through the fixed tree (or left to right by lane 0 if seq); every lane returns it.
-// term(i) must be callable by any lane for 0 <= i < n; s_a: PSIT_L1 + 64 doubles of LDS owned by the wavefront.
+// Two tree levels over the 4096 terms [base, base + 4096) of n by ONE wavefront: the 64 terms of chunk c are added left to right
+// (level 1), then the chunk sums left to right (level 2).  The terms are evaluated by all lanes at once -- 16 rows of 64 in flight
+// per round trip -- and parked in LDS (s_t: 64 x 65 doubles, one padded row per chunk) where lane c adds its row; every lane returns
+// the level-2 sum.  term(i) must be callable by any lane for 0 <= i < n.
 template <class F>
-__device__ __forceinline__ double wave_tree_sum(F term, long long n, double *s_a, int seq) {
+__device__ __forceinline__ double wave_sum_4096(F term, long long base, long long n, double (*s_t)[65]) {
   const int lane = threadIdx.x & 63;
-  double tot = 0.0;
+  const long long left = n - base;                       // > 0
+  const int nterm = (int)(left < 4096 ? left : 4096), nrow = (nterm + 63) / 64;
+  for (int r0 = 0; r0 < nrow; r0 += 16) {
+    double t[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) { const int i = 64 * (r0 + q) + lane; t[q] = (r0 + q < nrow && i < nterm) ? term(base + i) : 0.0; }
+#pragma unroll
+    for (int q = 0; q < 16; q++) if (r0 + q < nrow) s_t[r0 + q][lane] = t[q];
+  }
+  __builtin_amdgcn_wave_barrier();
+  double s = 0.0;
+  if (lane < nrow) {
+    const int cnt = nterm - 64 * lane < 64 ? nterm - 64 * lane : 64;
+    s = s_t[lane][0];
+    for (int k = 1; k < cnt; k++) s = s + s_t[lane][k];
+  }
+  __builtin_amdgcn_wave_barrier();                       // the rows are free again for the caller's next block
+  // level 2: every lane the nrow chunk sums in order (handed over through the shuffle network)
+  double tot = __shfl(s, 0, 64);
+  for (int k = 1; k < nrow; k++) { const double v = __shfl(s, k, 64); tot = tot + v; }
+  return tot;
+}
+// Sum of n terms by ONE wavefront through the fixed 64-ary tree (or left to right by lane 0 if seq); every lane returns it.
+// s_t: 64 x 65 doubles of LDS owned by the wavefront; n <= 64^3 (three levels; checked by the host).
+template <class F>
+__device__ __forceinline__ double wave_tree_sum(F term, long long n, double (*s_t)[65], int seq) {
+  const int lane = threadIdx.x & 63;
   if (n <= 0) return 0.0;
   if (seq) {
+    double tot = 0.0;
     if (lane == 0) { tot = term(0); for (long long i = 1; i < n; i++) tot = tot + term(i); }
     return __shfl(tot, 0, 64);
   }
-  double *s_b = s_a + PSIT_L1;
-  const long long n1 = (n + 63) / 64;
-  if (n1 == 1) {            // a single chunk
-    if (lane == 0) { tot = term(0); for (long long i = 1; i < n; i++) tot = tot + term(i); }
-    return __shfl(tot, 0, 64);
+  const long long nblk4096 = (n + 4095) / 4096;
+  double tot = 0.0;                                       // level 3: the block sums in order
+  for (long long b = 0; b < nblk4096; b++) {
+    const double v = wave_sum_4096(term, b * 4096, n, s_t);
+    tot = b == 0 ? v : tot + v;
   }
-  for (long long c = lane; c < n1; c += 64) {
-    const long long b = 64 * c, e = (b + 64 < n) ? b + 64 : n;
-    double s = term(b);
-    for (long long i = b + 1; i < e; i++) s = s + term(i);
-    s_a[c] = s;
-  }
-  __builtin_amdgcn_wave_barrier();
-  const int n2 = (int)((n1 + 63) / 64);
-  if (n2 == 1) {
-    if (lane == 0) { tot = s_a[0]; for (int i = 1; i < (int)n1; i++) tot = tot + s_a[i]; }
-    return __shfl(tot, 0, 64);
-  }
-  if (lane < n2) {
-    const int b = 64 * lane, e = (b + 64 < (int)n1) ? b + 64 : (int)n1;
-    double s = s_a[b];
-    for (int i = b + 1; i < e; i++) s = s + s_a[i];
-    s_b[lane] = s;
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) { tot = s_b[0]; for (int i = 1; i < n2; i++) tot = tot + s_b[i]; }
-  return __shfl(tot, 0, 64);
+  return tot;
 }
 
 // term i of the first row over C(T), more_tools.f90:3657-3660: E_num(1)/E_den(1) w_1, then E_num(i) w_i
 __device__ __forceinline__ double psit_ct_term(const PsitArgs &a, const double *__restrict__ wt, long long i) {
   return i == 0 ? a.cnum[0] / a.cden[0] * wt[0] : a.cnum[i] * wt[i];
 }
-// One wavefront per 4096 slots of C(T): deltaw of the slots (first column + extra diagonal) and two tree levels of the first row's sum.
+// deltaw of the C(T) slots (first column + extra diagonal of the transformed projector), elementwise
+__global__ void __launch_bounds__(TPB) k_psit_ct_col(PsitArgs a, const double *__restrict__ wt) {
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= a.n_ct || i == 0) return;
+  double d = 0.0 + a.cnum[i] * wt[0]; d = d + a.diag[i] * wt[i];
+  a.dw_ct[i] = d;
+}
+// One wavefront per 4096 slots of C(T): two tree levels of the first row's sum.
 __global__ void __launch_bounds__(64) k_psit_ct_terms(PsitArgs a, const double *__restrict__ wt) {
   __shared__ double s_t[64][65];
-  __shared__ double s_1[64];
-  const int lane = threadIdx.x;
-  const long long base = (long long)blockIdx.x * 4096;
-  const double w0 = wt[0];
-  for (int r = 0; r < 64; r++) {
-    const long long i = base + 64 * r + lane;
-    double t = 0.0;
-    if (i < a.n_ct) {
-      const double wi = wt[i], num = a.cnum[i];
-      t = (i == 0) ? num / a.cden[0] * wi : num * wi;
-      if (i > 0) { double d = 0.0 + num * w0; d = d + a.diag[i] * wi; a.dw_ct[i] = d; }
-    }
-    s_t[r][lane] = t;
-  }
-  __builtin_amdgcn_wave_barrier();
   if (a.seq) return;                                   // the row's sum is made left to right by k_psit_rows_fin
-  const long long left = a.n_ct - base;                // terms of this tile
-  const int nrow = (int)((left < 4096 ? left : 4096) + 63) / 64;
-  double s = 0.0;
-  if (lane < nrow) {
-    const long long cnt = left - 64 * lane < 64 ? left - 64 * lane : 64;
-    s = s_t[lane][0];
-    for (int k = 1; k < (int)cnt; k++) s = s + s_t[lane][k];
-  }
-  s_1[lane] = s;
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) { double tot = s_1[0]; for (int k = 1; k < nrow; k++) tot = tot + s_1[k]; a.p2[blockIdx.x] = tot; }
+  const double tot = wave_sum_4096([&](long long i) { return psit_ct_term(a, wt, i); }, (long long)blockIdx.x * 4096, a.n_ct, s_t);
+  if (threadIdx.x == 0) a.p2[blockIdx.x] = tot;
 }
-// One block: wave 0 finishes the first row over C(T); wave 1 makes the first row over the Psi_T locations; all threads its first column.
+// One block: wave 0 finishes the first row over C(T) (level 3 over the blocks' sums); wave 1 makes the first row over the Psi_T
+// locations; all threads its first column.
 __global__ void __launch_bounds__(TPB) k_psit_rows_fin(PsitArgs a, const double *__restrict__ wt, double tau, double e_trial) {
-  __shared__ double s_scr[2][PSIT_L1 + 64];
+  __shared__ double s_scr[2][64][65];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const double one_plus = 1.0 + tau * e_trial;
   if (wv == 0) {
-    double tot;
+    double tot = 0.0;
     if (a.seq) tot = wave_tree_sum([&](long long i) { return psit_ct_term(a, wt, i); }, a.n_ct, s_scr[0], 1);
-    else { const double *p2 = a.p2; tot = wave_tree_sum([&](long long i) { return p2[i]; }, (a.n_ct + 4095) / 4096, s_scr[0], 0); }
+    else if (lane == 0) { const long long nb = (a.n_ct + 4095) / 4096; tot = a.p2[0]; for (long long b = 1; b < nb; b++) tot = tot + a.p2[b]; }
     if (lane == 0) a.dw_ct[0] = 0.0 + tot;
   } else if (wv == 1) {
     double tot = 0.0;
@@ -141,7 +134,7 @@ __global__ void __launch_bounds__(TPB) k_psit_imp_rows(PrjPre pp) {
 
 // T^-1 and its transpose on the Psi_T locations after the merge, do_walk.f90:2394-2442 (one block)
 __global__ void __launch_bounds__(TPB) k_psit_tinv(PsitArgs a, double *__restrict__ wt) {
-  __shared__ double s_scr[PSIT_L1 + 64];
+  __shared__ double s_scr[64][65];
   __shared__ double s_w1;
   if (threadIdx.x < 64) {
     double tmp = 0.0;

@@ -534,7 +534,7 @@ int sqmc_gpu_set_hf_to_psit(sqmc_gpu_ctx *c, int64_t n_psit, const int64_t *psit
   if (!c->d_ct_up || c->n_ct < 1) return fail(SQMC_ERR_BAD_ARG, "set the C(T) table first");
   if (!c->d_prj_ptr || c->n_imp < 1) return fail(SQMC_ERR_BAD_ARG, "set the deterministic-space matrix first");
   if (sum_order != 0 && sum_order != 1) return fail(SQMC_ERR_BAD_ARG, "sum_order must be 0 (left to right) or 1 (64-ary tree)");
-  if (n_psit - 1 > 64ll * PSIT_L1 || (c->n_ct + 4095) / 4096 > 64ll * PSIT_L1) return fail(SQMC_ERR_UNSUPPORTED, "trial wave function or C(T) too long for the tree sums");
+  if (n_psit - 1 > PSIT_MAXTERMS || c->n_ct > PSIT_MAXTERMS) return fail(SQMC_ERR_UNSUPPORTED, "trial wave function or C(T) longer than 64^3 determinants: the tree sums have three levels");
   if (c->n_ct >= (1ll << 31)) return fail(SQMC_ERR_UNSUPPORTED, "C(T) too long");
   psit_off(c);
   const long long n_ct = c->n_ct;
@@ -918,6 +918,7 @@ static int launch_side_kernels(sqmc_gpu_ctx *c, const StepP &p, long long n0, bo
     PrjPre pp; memset(&pp, 0, sizeof(pp));
     pp.n_imp = (int)c->n_imp; pp.ptr = c->d_prj_ptr; pp.col = c->d_prj_col; pp.val = c->d_prj_val; pp.x = c->d_prj_x; pp.y = a.dw_imp;
     hipLaunchKernelGGL(k_psit_imp_rows, dim3(nblk(c->n_imp, TPB / 64)), dim3(TPB), 0, st3, pp);
+    hipLaunchKernelGGL(k_psit_ct_col, dim3(nblk(a.n_ct)), dim3(TPB), 0, st3, a, (const double *)c->w.wt);
     hipLaunchKernelGGL(k_psit_ct_terms, dim3((unsigned)((a.n_ct + 4095) / 4096)), dim3(64), 0, st3, a, (const double *)c->w.wt);
     hipLaunchKernelGGL(k_psit_rows_fin, dim3(1), dim3(TPB), 0, st3, a, (const double *)c->w.wt, p.tau, p.e_trial);
     hipLaunchKernelGGL(k_psit_apply, dim3(nblk(a.n_ct)), dim3(TPB), 0, st3, a, c->w.wt, p.tau, p.e_trial);
