@@ -164,19 +164,20 @@ static inline int device_excl_scan_u64(const u64 *in, u64 *out, long long n, u64
 #define RS_TILE 1024                        // keys per 256-thread block (4 waves x 4 rounds of 64)
 #endif
 
-// histogram: hist[digit * ntiles + tile]; one 256-thread block (4 waves) per tile of 1024 keys
-template <int BITS>
+// histogram: hist[digit * ntiles + tile]; one 256-thread block (4 waves) per tile of 256 * ROUNDS keys (1024; 4096 for long lists: a
+// quarter of the tiles, so that the per-tile histogram matrix of a 10-bit digit is no larger than an 8-bit digit's over small tiles)
+template <int BITS, int ROUNDS>
 __global__ void __launch_bounds__(256) rs_hist_kernel(const u64 *__restrict__ keys, u32 *__restrict__ hist, long long n, int ntiles, int shift) {
-  constexpr int RS_RADIX = 1 << BITS;
+  constexpr int RS_RADIX = 1 << BITS, TILE = 256 * ROUNDS;
   __shared__ u32 cnt[RS_RADIX];
   for (int d = threadIdx.x; d < RS_RADIX; d += 256) cnt[d] = 0;
   __syncthreads();
-  const long long base = (long long)blockIdx.x * RS_TILE;
-  u64 kreg[RS_TILE / 256];
+  const long long base = (long long)blockIdx.x * TILE;
+  u64 kreg[ROUNDS];
 #pragma unroll
-  for (int r = 0; r < RS_TILE / 256; r++) { long long i = base + r * 256 + threadIdx.x; kreg[r] = (i < n) ? keys[i] : ~0ull; }
+  for (int r = 0; r < ROUNDS; r++) { long long i = base + r * 256 + threadIdx.x; kreg[r] = (i < n) ? keys[i] : ~0ull; }
 #pragma unroll
-  for (int r = 0; r < RS_TILE / 256; r++) { long long i = base + r * 256 + threadIdx.x; if (i < n) atomicAdd(&cnt[(kreg[r] >> shift) & (RS_RADIX - 1)], 1u); }
+  for (int r = 0; r < ROUNDS; r++) { long long i = base + r * 256 + threadIdx.x; if (i < n) atomicAdd(&cnt[(kreg[r] >> shift) & (RS_RADIX - 1)], 1u); }
   __syncthreads();
   for (int d = threadIdx.x; d < RS_RADIX; d += 256) hist[(long long)d * ntiles + blockIdx.x] = cnt[d];
 }
@@ -204,18 +205,18 @@ __global__ void __launch_bounds__(SCAN_BLOCK) rs_scan_kernel(u32 *__restrict__ h
 // in 4 rounds of 64.  Rank among equal digits inside a round = popc(match & lanemask_lt) from
 // BITS ballots; per-wave digit counters live in LDS (private to the wave, in-order LDS queue),
 // then the four waves' counters are prefix-added once.  Only 4 sequential rounds per wave.
-template <int BITS, bool VALS>
+template <int BITS, bool VALS, int ROUNDS>
 __global__ void __launch_bounds__(256) rs_scatter_kernel(const u64 *__restrict__ kin, const u32 *__restrict__ vin,
                                                          u64 *__restrict__ kout, u32 *__restrict__ vout,
                                                          const u32 *__restrict__ hist, const u32 *__restrict__ rowtot,
                                                          long long n, int ntiles, int shift) {
-  constexpr int RS_RADIX = 1 << BITS, PER = RS_RADIX / 256, ROUNDS = RS_TILE / 256;
+  constexpr int RS_RADIX = 1 << BITS, PER = RS_RADIX / 256, TILE = 256 * ROUNDS;
   __shared__ u32 off[RS_RADIX];            // global base of each digit for this tile
   __shared__ u32 wcnt[4][RS_RADIX];        // per-wave digit counts -> per-wave bases
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // the tile's keys are requested first: their latency hides behind the digit-base prologue, which has its own
   // chain of dependent loads (row totals -> block scan -> this tile's row prefixes)
-  const long long base = (long long)blockIdx.x * RS_TILE + wv * (64 * ROUNDS);
+  const long long base = (long long)blockIdx.x * TILE + wv * (64 * ROUNDS);
   u64 kreg[ROUNDS]; u32 vreg[ROUNDS], rnk[ROUNDS];
 #pragma unroll
   for (int r = 0; r < ROUNDS; r++) { long long i = base + r * 64 + lane; kreg[r] = (i < n) ? kin[i] : 0; vreg[r] = (VALS && i < n) ? vin[i] : 0; }
@@ -268,12 +269,13 @@ struct SortWork { u64 *k_alt; u32 *v_alt; u32 *hist; u32 *rowtot; long long cap;
 
 // Sorts keys[0..n) (with values) on bits [0, nbits); result ends up in the returned buffers
 // (either the inputs or the alternates).  Stable.
-template <int BITS>
-static inline void radix_pass(u64 *ka, u32 *va, u64 *kb, u32 *vb, long long n, int ntiles, int shift, SortWork &w, hipStream_t st) {
-  hipLaunchKernelGGL(rs_hist_kernel<BITS>, dim3(ntiles), dim3(256), 0, st, ka, w.hist, n, ntiles, shift);
+template <int BITS, int ROUNDS>
+static inline void radix_pass(u64 *ka, u32 *va, u64 *kb, u32 *vb, long long n, int shift, SortWork &w, hipStream_t st) {
+  const int ntiles = (int)((n + 256 * ROUNDS - 1) / (256 * ROUNDS));
+  hipLaunchKernelGGL((rs_hist_kernel<BITS, ROUNDS>), dim3(ntiles), dim3(256), 0, st, ka, w.hist, n, ntiles, shift);
   hipLaunchKernelGGL(rs_scan_kernel, dim3(1 << BITS), dim3(SCAN_BLOCK), 0, st, w.hist, w.rowtot, ntiles);
-  if (va) hipLaunchKernelGGL((rs_scatter_kernel<BITS, true>), dim3(ntiles), dim3(256), 0, st, ka, va, kb, vb, w.hist, w.rowtot, n, ntiles, shift);
-  else hipLaunchKernelGGL((rs_scatter_kernel<BITS, false>), dim3(ntiles), dim3(256), 0, st, ka, va, kb, vb, w.hist, w.rowtot, n, ntiles, shift);
+  if (va) hipLaunchKernelGGL((rs_scatter_kernel<BITS, true, ROUNDS>), dim3(ntiles), dim3(256), 0, st, ka, va, kb, vb, w.hist, w.rowtot, n, ntiles, shift);
+  else hipLaunchKernelGGL((rs_scatter_kernel<BITS, false, ROUNDS>), dim3(ntiles), dim3(256), 0, st, ka, va, kb, vb, w.hist, w.rowtot, n, ntiles, shift);
 }
 // digit width: the fewest passes of at most 10 bits, then the narrowest digit that still
 // covers the key in that many passes (28-bit C2 keys: 3 passes of 10 bits).  vals may be null
@@ -284,13 +286,16 @@ static inline void radix_pass(u64 *ka, u32 *va, u64 *kb, u32 *vb, long long n, i
 // element goes through the pass as well instead of returning untouched with the totals of some earlier sort there.
 static inline void device_radix_sort(u64 *&keys, u32 *&vals, long long n, int nbits, SortWork &w, hipStream_t st, int shift0 = 0, bool counts_wanted = false) {
   if (n <= 0 || (n == 1 && !counts_wanted)) return;
-  int ntiles = (int)((n + RS_TILE - 1) / RS_TILE);
   u64 *ka = keys, *kb = w.k_alt; u32 *va = vals, *vb = vals ? w.v_alt : nullptr;
   // Small inputs are launch bound: the fewest passes (10-bit digits).  Large ones are bound by the
   // per-tile histogram matrix, whose column accesses cost a whole memory sector per 4-byte count
   // and which grows with 2^bits: 8-bit digits there.
   static const int maxbits_env = getenv("SQMC_SORT_MAXBITS") ? atoi(getenv("SQMC_SORT_MAXBITS")) : 0;
-  const int maxbits = (n >= RS_LARGE_N) ? 8 : (maxbits_env ? maxbits_env : 10);
+  // long lists: tiles of 4096 keys (a quarter of the rows in the histogram matrix), so the digits can stay 10 bits wide there too:
+  // 28-bit keys in three passes instead of four (SQMC_SORT_BIG_TILE=0: the 8-bit digits over 1024-key tiles of before)
+  static const bool big_tile_env = !(getenv("SQMC_SORT_BIG_TILE") && getenv("SQMC_SORT_BIG_TILE")[0] == '0');
+  const bool big = n >= RS_LARGE_N && big_tile_env;
+  const int maxbits = maxbits_env ? maxbits_env : ((n >= RS_LARGE_N && !big) ? 8 : 10);
   const int npass = (nbits + maxbits - 1) / maxbits;
   // digit widths as even as the templates allow (8, 9 or 10 bits), the wide ones first: 28 bits in three passes
   // are 10 + 9 + 9, not 10 + 10 + 10 -- every kernel of a pass is a little cheaper with half the bins
@@ -299,9 +304,15 @@ static inline void device_radix_sort(u64 *&keys, u32 *&vals, long long n, int nb
     int bits = (left + (npass - pss) - 1) / (npass - pss); if (bits < 8) bits = 8;
     left -= bits; if (left < 0) left = 0;
     const int used = bits;
-    if (bits == 8) radix_pass<8>(ka, va, kb, vb, n, ntiles, shift, w, st);
-    else if (bits == 9) radix_pass<9>(ka, va, kb, vb, n, ntiles, shift, w, st);
-    else radix_pass<10>(ka, va, kb, vb, n, ntiles, shift, w, st);
+    if (big) {
+      if (bits == 8) radix_pass<8, 16>(ka, va, kb, vb, n, shift, w, st);
+      else if (bits == 9) radix_pass<9, 16>(ka, va, kb, vb, n, shift, w, st);
+      else radix_pass<10, 16>(ka, va, kb, vb, n, shift, w, st);
+    } else {
+      if (bits == 8) radix_pass<8, 4>(ka, va, kb, vb, n, shift, w, st);
+      else if (bits == 9) radix_pass<9, 4>(ka, va, kb, vb, n, shift, w, st);
+      else radix_pass<10, 4>(ka, va, kb, vb, n, shift, w, st);
+    }
     shift += used;
     u64 *tk = ka; ka = kb; kb = tk; u32 *tv = va; va = vb; vb = tv;
   }

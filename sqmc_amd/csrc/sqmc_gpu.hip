@@ -208,7 +208,8 @@ struct sqmc_gpu_ctx {
   bool tail_fills_hii;        // the tail that enqueues the next head is a bucket tail: it computes the H_ii of the determinants it creates itself
   bool fork_valid;            // e_fork was recorded behind the last tail (a head behind a bucket tail forks nothing and skips it)
   bool head_hii, head_hii_joined;     // the pipelined head fills the missing H_ii of this step's walkers (joined: inside k_spawn itself, nothing to wait for)
-  bool head_offsets_done;     // the bucket tail of the step before wrote this step's child offsets and total (no scan launch in the head)
+  bool head_offsets_done;     // the tail of the step before wrote this step's child offsets and total (no scan launch in the head)
+  bool head_offsets_bucket;   // ... and it was a bucket tail (its head's k_spawn carries the final sums in a spare block; behind a radix tail they are a launch of their own)
   double last_wabs;           // sum |w| after the last step (bounds the next step's child count)
   BucketArgs head_ba; long long last_nall;      // partition already done by the head's k_spawn (B > 0), and the length of the last sorted list (sizes the next one)
   int bk_holdoff;             // steps for which the bucket tail stays off (after a bucket overflowed or came close)
@@ -797,7 +798,14 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
     // the bucket tail of the step before wrote keys, child weights, child OFFSETS and their total: nothing to scan.  That
     // step's final sums ride on k_spawn as one extra block.
     c->head_offsets_done = false;
-    spawn_fin = fa;
+    if (c->head_offsets_bucket) spawn_fin = fa;
+    else if (fa.on) {
+      // long lists: k_spawn keeps the registers and LDS of its plain form, and the one block that adds up thousands of tile partials
+      // (20 us at 10^6 walkers, 80 at 10^7) runs BESIDE it on the side stream, as it ran beside the scan; the next tail joins that
+      // stream before its annihilation kernel needs the look-back words this block re-zeroes
+      if (c->st2 != st) { HIPCHK(hipEventRecord(c->e_cnt, st)); HIPCHK(hipStreamWaitEvent(c->st2, c->e_cnt, 0)); }
+      hipLaunchKernelGGL(k_finish, dim3(1), dim3(TPB), 0, c->st2, fa, c->d_sc);
+    }
   } else if (gate_done) {
     // k_anneal of the step before wrote keys, child counts and child weights; the final sums of that step ride on the
     // scan as one extra block.  The scan works on look-back set scan_flip while that block re-zeroes the other set
@@ -882,7 +890,7 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
 static void drop_head(sqmc_gpu_ctx *c) {
   if (!c->head_ready) return;
   c->head_ready = false;
-  hipStreamSynchronize(c->st);
+  hipStreamSynchronize(c->st); hipStreamSynchronize(c->st2);
   hipMemset(c->d_scan_state, 0, 3 * c->cap_tiles * 8); hipMemset(c->d_scan_ticket, 0, 3 * 4);
   c->scan_used[0] = c->scan_used[1] = 0;
 }
@@ -1042,6 +1050,9 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       static const bool no_off = getenv("SQMC_BUCKET_NO_OFFSETS") != nullptr;
       static const bool no_shard_off = getenv("SQMC_SHARD_NO_OFFSETS") != nullptr;
       if (bucket && (use_mail || !no_shard_off) && !no_off && c->n_imp < (1ll << 18) && c->last_wabs > 0 && c->last_wabs < 4.0e6) go.child_off = c->d_child_off;     // 24 bits of the look-back word hold the children
+      // the radix tail of an unsharded pipelined step carries the child offsets too, in a look-back of their own (walk_kernels.h)
+      static const bool no_roff = getenv("SQMC_RADIX_NO_OFFSETS") != nullptr;
+      if (!bucket && use_mail && !c->d_grow && mode == SQMC_RNG_COUNTER && !no_roff) go.child_off = c->d_child_off;
     }
 #define ANNEAL_ARGS c->w, c->m, skey, perm, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, n0, nall, p,  \
                     c->invalid_key, c->pack, mode, seed, step, c->d_sc, c->d_fstate, c->d_fstate + c->cap_ftiles, c->d_fticket, go
@@ -1060,10 +1071,11 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       else hipLaunchKernelGGL(k_anneal_bucket, dim3(nb), dim3(BK_AT), 0, st, BUCKET_ARGS);
 #undef BUCKET_ARGS
       c->bk_steps++;
-      c->head_offsets_done = (go.child_off != nullptr);
+      c->head_offsets_done = (go.child_off != nullptr); c->head_offsets_bucket = true;
       c->scount_B = ba.B; c->scount_buf = ba.kb ? c->head_kb_use : -1; c->scount_pos = c->pos_flip;
     } else if (c->psit_on) { c->scount_B = 0; if (items <= 2) ANNEAL_LAUNCH_(2, 1); else ANNEAL_LAUNCH_(3, 1); }      // hf_to_psit: everything outside C(T); the C(T) segment is finished below
-    else { c->scount_B = 0; if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 3) ANNEAL_LAUNCH(3); else ANNEAL_LAUNCH(4); }
+    else { c->scount_B = 0; if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 3) ANNEAL_LAUNCH(3); else ANNEAL_LAUNCH(4);
+           c->head_offsets_done = (go.child_off != nullptr); c->head_offsets_bucket = false; }
 #undef ANNEAL_LAUNCH_
 #undef ANNEAL_LAUNCH
 #undef ANNEAL_ARGS

@@ -1043,6 +1043,22 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
       if (!drop) { f2[k] = 1ull; if (r[k].d == 0) f2[k] |= (1ull << 32); }
     }
   }
+  // ---- pipelined steps of long lists (go.child_off): the next step's child counts are known as soon as the weights are final, so their
+  //      running sum travels through a look-back of its own -- the words of the REPLAY rank, idle in the COUNTER discipline -- beside
+  //      the positions': the next head needs no scan launch (26 us at 10^6 walkers, 140 at 10^7)
+  const bool choff = go.on && go.child_off != nullptr;
+  u32 ncv[ITEMS], cpre[ITEMS]; u64 ccarry = 0;
+  if (choff) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      u64 nc = 0; double wc;
+      if (f2[k] & 1ull) gate_children(r[k].wt * p.rfi, go.cutoff, seed, go.step_next, key[k], nc, wc);
+      ncv[k] = (u32)nc;
+      const u64 x = wave_incl_scan_u64(nc, lane);
+      cpre[k] = (u32)(x + ccarry - nc); ccarry += __shfl(x, 63, 64);
+    }
+    if (lane == 0) s_wsum[0][wv] = ccarry;
+  }
   // ---- final position (lo) and rank among the deterministic-space walkers (hi)
   carry = 0;
 #pragma unroll
@@ -1050,14 +1066,23 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
   if (lane == 0) s_wsum[1][wv] = carry;
   __syncthreads();
   ex = 0; tot = 0;
+  u64 cex = 0, ctot = 0;
 #pragma unroll
   for (int q = 0; q < TPB / 64; q++) { if (q < wv) ex += s_wsum[1][q]; tot += s_wsum[1][q]; }
+  if (choff) {
+#pragma unroll
+    for (int q = 0; q < TPB / 64; q++) { if (q < wv) cex += s_wsum[0][q]; ctot += s_wsum[0][q]; }
+  }
   if (threadIdx.x < 64) {
     const u64 e = lookback_exclusive(state2, tile, tot, threadIdx.x);
     if (threadIdx.x == 0) { s_ex[1] = e; if (last_tile) { sc->tot2 = e + tot; sc->nwalk = (e + tot) & 0xFFFFFFFFull; } }
+  } else if (choff && threadIdx.x < 128) {        // the second wavefront, at the same time
+    const u64 e = lookback_exclusive(state1, tile, ctot, threadIdx.x - 64);
+    if (threadIdx.x == 64) { s_ex[0] = e; if (last_tile) sc->n_children = e + ctot; }
   }
   __syncthreads();
   ex += s_ex[1];
+  if (choff) cex += s_ex[0];
   APROF(4);
   // ---- compaction, reweighting (2487), estimator pieces (2573-2684, more_tools.f90:4041-4098)
   double s[NSTAT];
@@ -1079,7 +1104,11 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
     o.up[q0] = r[k].up; o.dn[q0] = r[k].dn; o.wt[q0] = wt; o.flg[q0] = r[k].flg;
     o.me[q0] = me; o.en[q0] = en; o.ed[q0] = ed;
-    if (go.on) {
+    if (choff) {        // the child weight follows from the weight and the count (gate_children: w / n above the cutoff, +-cutoff for the one child below it)
+      const u32 nc = ncv[k];
+      go.keys[q0] = (key[k] << 32) | (u64)q0; go.child_off[q0] = cex + (u64)cpre[k];
+      go.wchild[q0] = nc == 0 ? 0.0 : (fabs(wt) < go.cutoff ? copysign(go.cutoff, wt) : wt / (double)nc);
+    } else if (go.on) {
       u64 nc; double wc;
       gate_children(wt, go.cutoff, seed, go.step_next, key[k], nc, wc);
       go.keys[q0] = (key[k] << 32) | (u64)q0; go.nchild[q0] = nc; go.wchild[q0] = wc;
