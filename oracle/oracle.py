@@ -563,43 +563,39 @@ def setup_walk(sysm, n_truncate_trial_wf=100, size_deterministic=1000, tau_multi
     return s
 
 
-def initial_walkers(s, w_abs_gen_begin, r_initiator=1.0, initiator_power=0):
-    """do_walk.f90:1245-1366 (hf_to_psit = false): deterministic-space dets with weight 0 plus
-    Psi_T dets with weight w_begin*c/sum|c|, duplicates combined (equal dets simply add here,
-    the det-space copy comes first and carries imp_distance 0).  Returns sorted SoA + signs."""
-    n_imp, n_t = len(s.imp_up), len(s.psi_up)
-    cmax, csum = np.max(np.abs(s.psi_c)), np.sum(np.abs(s.psi_c))
-    recs = {}
-    for a, b in zip(s.imp_up.tolist(), s.imp_dn.tolist()):
-        recs[(a, b)] = [0.0, 2, 0, 0]
-    scale = min(w_abs_gen_begin * cmax / csum, 1.0)
-    for a, b, c in zip(s.psi_up.tolist(), s.psi_dn.tolist(), s.psi_c.tolist()):
-        wt = (w_abs_gen_begin * c / csum) / scale
-        perm = abs(abs(c) - cmax) < 1e-3
-        r = recs.get((a, b))
-        if r is None:
-            recs[(a, b)] = [wt, 3 if perm else 2, 0 if perm else 1, int(np.sign(c)) if perm else 0]
-        else:
-            r[0] += wt
-            if perm:
-                r[1], r[3] = 3, int(np.sign(c))
-    keys = sorted(recs)
-    n = len(keys)
-    out = dict(
-        up=np.array([k[0] for k in keys], np.uint64), dn=np.array([k[1] for k in keys], np.uint64),
-        wt=np.array([recs[k][0] for k in keys]), initiator=np.array([recs[k][1] for k in keys], np.int8),
-        imp_distance=np.array([recs[k][2] for k in keys], np.int8), perm_sign=np.array([recs[k][3] for k in keys], np.int8),
-        matrix_elements=np.full(n, 1e51), e_num=np.full(n, 1e51), e_den=np.full(n, 1e51))
-    # check_initiator pass of the merge at do_walk.f90:1366 for non-permanent dets outside the core
-    for i in range(n):
-        d, ini, aw = int(out["imp_distance"][i]), int(out["initiator"][i]), abs(out["wt"][i])
-        thr = r_initiator * (max(0, d) ** initiator_power if not (d <= 0 and initiator_power == 0) else 1)
-        if ini == 2 and aw <= thr and d > 0:
-            out["initiator"][i] = 1
-    keep = ~((out["wt"] == 0) & (out["imp_distance"] >= 1))
-    for k in out:
-        out[k] = out[k][keep]
+def _initial_population(s, w_abs_gen_begin, r_initiator, initiator_power, psit=None):
+    """orc_initial_population (oracle/sqmc_oracle_ctl.c): do_walk.f90:1245-1373 as the text runs -- deterministic-space determinants, then
+    Psi_T (or all of C(T) with hf_to_psit), sort, merge_original_with_spawned2 -- instead of a Python reading of its result"""
+    L = lib()
+    L.orc_initial_population.restype = C.c_int64
+    L.orc_initial_population.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                         C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+    o = sort_dets(s.psi_up, s.psi_dn)                      # Psi_T in label order (do_walk.f90:1258)
+    pu, pd, pc_ = np.ascontiguousarray(s.psi_up[o]), np.ascontiguousarray(s.psi_dn[o]), np.ascontiguousarray(np.asarray(s.psi_c, float)[o])
+    iu, idn = np.ascontiguousarray(s.imp_up), np.ascontiguousarray(s.imp_dn)
+    cu, cd = np.ascontiguousarray(s.ct_up), np.ascontiguousarray(s.ct_dn)
+    cap = len(iu) + len(pu) + (len(cu) if psit is not None else 0) + 16
+    h = L.orc_walk_new(cap)
+    w = Walk.from_address(h)
+    p = StepParams(tau=s.tau, e_trial=0.0, reweight_factor_inv=1.0, r_initiator=r_initiator, min_wt=0.5, always_spawn_cutoff_wt=0.5, initiator_power=initiator_power,
+                   initiator_min_distance=0, c_t_initiator=0, semistochastic=1, reached_w_abs_gen=0)
+    n = L.orc_initial_population(h, len(iu), _p(iu), _p(idn), len(pu), _p(pu), _p(pd), _p(pc_), float(w_abs_gen_begin), C.byref(p),
+                                 1 if psit is not None else 0, len(cu), _p(cu), _p(cd))
+    g = lambda ptr: np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+    out = dict(up=g(w.up), dn=g(w.dn), wt=g(w.wt), initiator=g(w.initiator), imp_distance=g(w.imp_distance), matrix_elements=g(w.matrix_elements),
+               e_num=g(w.e_num_walker), e_den=g(w.e_den_walker))
+    signs = np.ctypeslib.as_array(w.sign_perm, shape=(max(w.n_perm, 1),))[:w.n_perm].copy()
+    ps = np.zeros(n, np.int8)
+    ps[out["initiator"] == 3] = signs                      # sorted order on both sides (do_walk.f90:2593-2594)
+    out["perm_sign"] = ps
+    L.orc_walk_free(h)
     return out
+
+
+def initial_walkers(s, w_abs_gen_begin, r_initiator=1.0, initiator_power=0):
+    """do_walk.f90:1245-1366 (hf_to_psit = false): deterministic-space dets with weight 0 plus Psi_T dets with weight w_begin*c/sum|c|,
+    sorted and merged by merge_original_with_spawned2.  Returns sorted SoA + signs."""
+    return _initial_population(s, w_abs_gen_begin, r_initiator, initiator_power)
 
 
 class OracleWalk:
@@ -755,81 +751,65 @@ def psit_setup(sysm, s):
 
 
 def initial_walkers_psit(s, q, w_abs_gen_begin):
-    """do_walk.f90:1245-1329 with hf_to_psit: the deterministic-space determinants (weight 0) and ALL of C(T), where only the first
-    one carries weight; merged (the deterministic-space copy comes first and keeps imp_distance 0, the permanent-initiator flag of
-    the first C(T) determinant survives the merge), then every initiator flag but 3 is set to 2 (1367-1373).  With the
+    """do_walk.f90:1245-1373 with hf_to_psit: the deterministic-space determinants (weight 0) and ALL of C(T), where only the first
+    one carries weight; sorted and merged (the deterministic-space copy comes first and keeps imp_distance 0, the permanent-initiator
+    flag of the first C(T) determinant survives the merge), then every initiator flag but 3 is set to 2 (1367-1373).  With the
     deterministic space inside C(T) the list is C(T) itself."""
-    n = len(s.ct_up)
-    cmax, csum = np.max(np.abs(q.cdet)), np.sum(np.abs(q.cdet))
-    wt = np.zeros(n)
-    wt[0] = w_abs_gen_begin / min(w_abs_gen_begin * cmax / csum, 1.0)
-    perm = abs(abs(q.cdet[0]) - cmax) < 1e-3
-    ini = np.full(n, 2, np.int8)
-    psign = np.zeros(n, np.int8)
-    if perm:
-        ini[0], psign[0] = 3, int(np.sign(q.cdet[0]))
-        if wt[0] * psign[0] < 1.0:          # check_initiator inside the merge at 1366
-            wt[0] = psign[0]
-    return dict(up=s.ct_up.copy(), dn=s.ct_dn.copy(), wt=wt, initiator=ini, imp_distance=np.where(q.in_imp, 0, -2).astype(np.int8),
-                perm_sign=psign, matrix_elements=np.full(n, 1e51), e_num=np.full(n, 1e51), e_den=np.full(n, 1e51))
+    out = _initial_population(s, w_abs_gen_begin, 1.0, 0, psit=q)
+    assert np.array_equal(out["up"], s.ct_up) and np.array_equal(out["dn"], s.ct_dn)
+    return out
+
+
+class _PopCtl(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("tau_sav", "tau", "tau_prev", "e_trial", "e_est", "w_target", "w_abs_gen", "r_init_sav", "r_init", "irp", "pop_exp",
+                                          "rfi", "rfi_max", "e_num_cum", "e_den_cum")] + [("istep", C.c_int64), ("n_equil", C.c_int64), ("reached", C.c_int), ("pad", C.c_int)]
 
 
 class PopControl:
-    """Scalar logic around the step, do_walk.f90:2171-2184 (tau ramp) and 2880-2923
-    (e_est, e_trial, reweight factor); equilibration = first n_equil_steps steps."""
+    """The scalar logic around the step -- tau ramp do_walk.f90:2171-2184, e_est / e_trial / reweight factor 2880-2923; equilibration =
+    the first n_equil_steps steps -- held and advanced by the oracle's C code (oracle/sqmc_oracle_ctl.c: orc_popctl_*), not by a Python
+    copy of the product's host logic.  The attributes read and write the C structure."""
 
     def __init__(self, tau, e_trial, w_target, r_initiator=1.0, initiator_rescale_power=1.0, pop_exp=10.0,
                  rfi_max_multiplier=1.0, n_equil_steps=10**9):
-        self.tau_sav, self.tau, self.tau_prev = tau, tau, tau
-        self.e_trial, self.e_est = e_trial, e_trial
-        self.w_target, self.r_init_sav, self.r_init, self.irp = w_target, r_initiator, r_initiator, initiator_rescale_power
-        self.pop_exp = pop_exp
-        self.rfi, self.rfi_max = 1.0, 1.0 + rfi_max_multiplier * tau
-        self.reached = 0
-        self.n_equil, self.istep = n_equil_steps, 0
-        self.e_num_cum = self.e_den_cum = 0.0
-        self.w_abs_gen = None
+        L = lib()
+        L.orc_popctl_init.argtypes = [C.c_void_p] + [C.c_double] * 7 + [C.c_int64]
+        L.orc_popctl_pre_step.restype = C.c_double
+        L.orc_popctl_pre_step.argtypes = [C.c_void_p, C.c_double]
+        L.orc_popctl_post_step.restype = C.c_double
+        L.orc_popctl_post_step.argtypes = [C.c_void_p, C.c_void_p]
+        object.__setattr__(self, "_L", L)
+        object.__setattr__(self, "_c", _PopCtl())
+        L.orc_popctl_init(C.byref(self._c), float(tau), float(e_trial), float(w_target), float(r_initiator), float(initiator_rescale_power), float(pop_exp),
+                          float(rfi_max_multiplier), int(min(n_equil_steps, 2**62)))
+
+    _names = {f[0] for f in _PopCtl._fields_}
+
+    def __getattr__(self, k):
+        if k in PopControl._names:
+            return getattr(self._c, k)
+        raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        if k in PopControl._names:
+            setattr(self._c, k, v)
+        else:
+            object.__setattr__(self, k, v)
 
     def pre_step(self, w_abs_gen):
         """returns tau_ratio to apply to the projector before the step (or 1.0)"""
-        ratio = 1.0
-        if self.reached == 0:
-            f = 1.0 + np.log(self.w_target / w_abs_gen)
-            self.tau = self.tau_sav * f
-            ratio = self.tau / self.tau_prev
-            self.r_init = self.r_init_sav * f ** self.irp
-        return ratio
+        return float(self._L.orc_popctl_pre_step(C.byref(self._c), float(w_abs_gen)))
 
     def post_step(self, out):
         """returns tau_ratio to apply to the projector after the step (or 1.0)"""
-        self.istep += 1
-        w_abs_gen, e_den_gen, e_num_gen = out[1], out[2], out[3]
-        self.e_num_cum += e_num_gen * np.sign(e_den_gen) if e_den_gen != 0 else 0.0
-        self.e_den_cum += abs(e_den_gen)
-        if self.e_den_cum != 0:
-            self.e_est = self.e_num_cum / self.e_den_cum
-        pw = min(1.0, self.tau * self.pop_exp)
-        if self.istep <= self.n_equil:
-            d = self.e_est - self.e_trial
-            self.e_trial = self.e_trial + np.sign(d) * min(abs(d), 1.0)
-            self.rfi = min(2.0, max(0.5, (self.w_target / w_abs_gen) ** pw))
-        else:
-            self.rfi = min(2.0, max(0.5, (1.0 / (1.0 + self.tau * (self.e_trial - self.e_est))) * (self.w_target / w_abs_gen) ** pw))
-        self.rfi = min(self.rfi, self.rfi_max)
-        ratio = 1.0
-        if self.reached == 0 and w_abs_gen >= self.w_target:
-            self.reached = 2
-            ratio = self.tau_sav / self.tau
-            self.tau = self.tau_sav
-            self.r_init = self.r_init_sav
-        self.tau_prev = self.tau
-        self.w_abs_gen = w_abs_gen
-        return ratio
+        o = np.ascontiguousarray(out, np.float64)
+        return float(self._L.orc_popctl_post_step(C.byref(self._c), _p(o)))
 
     def params(self, min_wt=0.5, cutoff=0.5, initiator_power=0, semistochastic=1):
-        return dict(tau=self.tau, e_trial=self.e_trial, reweight_factor_inv=self.rfi, r_initiator=self.r_init, min_wt=min_wt,
+        c = self._c
+        return dict(tau=c.tau, e_trial=c.e_trial, reweight_factor_inv=c.rfi, r_initiator=c.r_init, min_wt=min_wt,
                     always_spawn_cutoff_wt=cutoff, initiator_power=initiator_power, initiator_min_distance=0, c_t_initiator=0,
-                    semistochastic=semistochastic, reached_w_abs_gen=self.reached)
+                    semistochastic=semistochastic, reached_w_abs_gen=c.reached)
 
 
 # ------------------------------------------------------------------------------ HEG

@@ -1591,3 +1591,6 @@ int64_t orc_build_sparse_ham_hubbard(const orc_hub *h, int64_t n, const det_t *u
 
 /* ==================================================================== hf_to_psit step variant */
 #include "sqmc_oracle_psit.c"
+
+/* ==================================================================== the driver around the step */
+#include "sqmc_oracle_ctl.c"

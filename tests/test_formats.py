@@ -81,8 +81,7 @@ def test_walk_deck_grammar_and_estimators():
     assert d["irand_seed"][1] == [1346, 5634, 6635, 4361] and d["n_truncate_trial_wf"] == [100] and len(d["orbital_symmetries"]) == 26
     with pytest.raises(SystemExit, match="proposal_method"):
         parse_walk_deck(text.replace("uniform2 0", "fast_heatbath 0"))
-    with pytest.raises(SystemExit, match="hf_to_psit"):
-        parse_walk_deck(text.replace("f f 0.5 ", "t f 0.5 "))
+    assert parse_walk_deck(text.replace("f f 0.5 ", "t f 0.5 "))["hf_to_psit"]            # the transformed projector is on the GPU path (tests/test_gpu_psit.py)
     with pytest.raises(SystemExit, match="run_type"):
         parse_walk_deck(text.replace("none  ", "vmc   "))
     rs = np.random.RandomState(7)
