@@ -215,7 +215,6 @@ struct sqmc_gpu_ctx {
   int bk_holdoff;             // steps for which the bucket tail stays off (after a bucket overflowed or came close)
   long long bk_steps, bk_retries;
   // hf_to_psit (psit_kernels.h)
-  bool ext_warm;               // an event-carrying launch has been made on this context (sqmc_gpu_set_timing)
   long long dbg_n0, dbg_nall;          // sizes of the last step's list in front of the merge (sqmc_gpu_debug_premerge)
   bool psit_on; int base_key_bits; PsitArgs psit; int *d_ps_loc, *d_ps_of, *d_ps_impof; double *d_ps_c, *d_ps_diag, *d_ps_dwct, *d_ps_dwps, *d_ps_dwimp, *d_ps_p2, *d_ps_part;
 };
@@ -225,7 +224,6 @@ static void psit_off(sqmc_gpu_ctx *c);
 static int shard_head_project(sqmc_gpu_ctx *c, bool with_sums, bool empty, const FinArgs *fin = nullptr);      // abi_shard.inc
 
 
-__global__ void k_nop() {}
 #include "walk_kernels.h"
 #include "psit_kernels.h"
 #define SPAWN_LAUNCH(HB_, FUSE_, ...) do { if (HB_) hipLaunchKernelGGL((k_spawn<1, 1>), __VA_ARGS__); else if (FUSE_) hipLaunchKernelGGL((k_spawn<0, 1>), __VA_ARGS__); else hipLaunchKernelGGL((k_spawn<0, 0>), __VA_ARGS__); } while (0)
@@ -677,14 +675,6 @@ int sqmc_gpu_set_timing(sqmc_gpu_ctx *c, int on) {
   hipStreamSynchronize(c->st); hipStreamSynchronize(c->st2); hipStreamSynchronize(c->st3); c->timers_pending = false;
   c->timing = on; c->tsteps = 0; c->nt = 0;
   for (int i = 0; i < NTIMERS; i++) c->tsum[i] = 0.0;
-  if (on && !c->ext_warm) {
-    // The first hipExtLaunchKernel that carries start/stop events costs the HOST 60-80 ms inside that one call (the runtime switches
-    // the queue to profiled dispatches; profiles/r03_stall_trace.txt: 68.4 ms inside hipExtLaunchKernel, no kernel running).  It used to
-    // land in whichever step was the first timed one; an empty launch pays it here.
-    hipExtLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, c->st, c->ev0[0], c->ev1[0], 0);
-    hipStreamSynchronize(c->st);
-    c->ext_warm = true;
-  }
   return SQMC_OK;
 }
 int sqmc_gpu_get_timing(sqmc_gpu_ctx *c, int32_t *n, const char **names, float *ms) {
