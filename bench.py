@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--heg-rs", type=float, default=1.0)
     ap.add_argument("--hf-to-psit", action="store_true", help="auxiliary: the step variant hf_to_psit = .true. (first basis state = Psi_T, all of C(T) resident; "
                     "SURVEY section 8 row f4) on one GPU, c2 or heg; no CPU baseline leg")
+    ap.add_argument("--proposal", default="uniform", choices=["uniform", "heatbath"], help="auxiliary: heatbath = proposal_method fast_heatbath (off_diagonal_move_chem_efficient_heatbath, "
+                    "two walker slots per child) on the shipped C2 integrals with 10 electrons -- the synthetic system the reference's own check accepts; one GPU, no CPU baseline leg")
     ap.add_argument("--heg-cutoff", type=float, default=2.3, help="plane-wave cutoff radius (2.3 -> 57 orbitals; the GPU path holds at most 64)")
     args = ap.parse_args()
 
@@ -104,6 +106,9 @@ def main():
         lx, ly = (int(v) for v in args.hubbard_lattice.lower().split("x"))
         hst = H.HubbardHost(lx, ly, True, lx * ly // 2, lx * ly // 2, 1.0, 4.0)
         workload = "%dx%d Hubbard U/t=4 half filling (periodic), real space (hubbard2), semistochastic walk" % (lx, ly)
+    elif args.proposal == "heatbath":
+        hst = H.ChemHost(FCIDUMP, 10, 5, "d2h")
+        workload = "C2 cc-pVDZ integrals with 10 electrons (10e,26o, D2h; synthetic) semistochastic walk, fast_heatbath proposal"
     else:
         hst = H.ChemHost(FCIDUMP, 8, 4, "d2h")
         workload = "C2 cc-pVDZ r=1.24253 (8e,26o, D2h) semistochastic walk, uniform2 proposal"
@@ -157,6 +162,9 @@ def main():
         if args.system == "hubbard":
             kw = dict(w_begin=min(args.target, 1e4), n_truncate_trial_wf=20, size_deterministic=500, tau_multiplier=0.5)
         if args.mwalk: kw["mwalk"] = args.mwalk
+        if args.proposal == "heatbath":
+            kw["proposal"] = "heatbath"
+            kw.setdefault("mwalk", int(4 * (args.target / 0.5 + 1000) * 1.5))       # two walker slots per child
         if args.hf_to_psit:
             kw["hf_to_psit"] = True
             kw.setdefault("w_begin", min(args.target, 1e4))
@@ -237,7 +245,7 @@ def main():
             dom, dom_ms, dom_bytes = "k_spawn", spawn_ms, 26.0 * s_avg + 34.0 * n_avg
         ach = dom_bytes / (dom_ms * 1e-3) / 1e9
         step_bytes = 68.0 * n_avg + 84.0 * s_avg
-        default_cfg = (args.system == "c2" and args.target == 1e5 and world == 1 and not args.hf_to_psit)
+        default_cfg = (args.system == "c2" and args.target == 1e5 and world == 1 and not args.hf_to_psit and args.proposal == "uniform")
         tr = load_traffic() if default_cfg else None
 
         def traffic_of(kern):
@@ -275,7 +283,7 @@ def main():
                                         "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
                          "stage_ms_per_step": stage_ms},
         }
-        if not args.no_cpu_baseline and world == 1 and args.system == "c2" and not args.hf_to_psit:
+        if not args.no_cpu_baseline and world == 1 and args.system == "c2" and not args.hf_to_psit and args.proposal == "uniform":
             cpu = cpu_leg(walk, hst, n_avg)
             line["cpu_baseline"] = cpu["one_core"]
             line["cpu_baseline_all_cores"] = cpu["all_cores"]

@@ -133,6 +133,14 @@ typedef struct {
   const double *Htot_opposite;                             /* (norb, norb, norb) */
 } sqmc_heatbath_tables;
 int sqmc_gpu_set_heatbath_tables(sqmc_gpu_ctx *ctx, const sqmc_heatbath_tables *t);
+/* replaces: setup_efficient_heatbath for run_type /= hci (chemistry.f90:1002-1225) with setup_alias (more_tools.f90:5603-5722) and
+ * check_heatbath_unbiased (9330-9375): the library builds the tables itself -- |H_ijkl| of all orbital quadruples on the device, the
+ * partial sums, normalisations and alias tables in the reference's loop order and precisions -- and installs them as
+ * sqmc_gpu_set_heatbath_tables would.  *is_heatbath_unbiased = (max(nup, ndn) > number of orbitals of unique symmetry); when it is 0
+ * the reference stops ("Heatbath may be biased for this system!", 1219) and nothing is installed.  sqmc_gpu_get_heatbath_tables hands
+ * out the library's host copies (the reference's layout; valid until the next setup call or sqmc_gpu_finalize). */
+int sqmc_gpu_setup_efficient_heatbath(sqmc_gpu_ctx *ctx, int32_t *is_heatbath_unbiased);
+int sqmc_gpu_get_heatbath_tables(sqmc_gpu_ctx *ctx, sqmc_heatbath_tables *t, int32_t *n_orb_uniq_sym);
 /* n proposals of off_diagonal_move_chem_efficient_heatbath, each from its own rannyu state seeds[4 i .. 4 i + 3] (test door, like
  * sqmc_gpu_propose_batch): det_j and weight_j = -tau H_ij / p of the two slots of proposal i at [2 i] and [2 i + 1] (weight 0: no move). */
 int sqmc_gpu_propose_heatbath_batch(sqmc_gpu_ctx *ctx, int64_t n, double tau, const uint64_t *up, const uint64_t *dn, const int32_t *seeds,
@@ -287,7 +295,7 @@ int sqmc_gpu_tail_stats(sqmc_gpu_ctx *ctx, int64_t *bucket_steps, int64_t *bucke
  * of the first step of the NEXT call behind its own tail, as every other step of the call does for its successor, so the GPU keeps
  * working while the host does its block bookkeeping (the first step of a call costs 0.135 instead of 0.075 ms otherwise).  The
  * head is forgotten, at the cost of one stream synchronisation, if anything but a step with the same tau / cutoff / mode comes
- * next (walkers uploaded or downloaded, projector rescaled, RNG reset, chaining switched off, finalize).  The same holds for a host that
+ * next (walkers uploaded or downloaded, projector rescaled, tables of either heat-bath kind set, hf_to_psit set, RNG reset, chaining switched off, finalize).  The same holds for a host that
  * calls sqmc_gpu_step itself, step by step (its own work between steps, as in the reference's loop): with chaining on, every step past the
  * target population enqueues its successor's head.  Single-GPU steps only. */
 int sqmc_gpu_set_chained_runs(sqmc_gpu_ctx *ctx, int32_t on);

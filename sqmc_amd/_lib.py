@@ -12,7 +12,7 @@ RNG_REPLAY, RNG_COUNTER = 0, 1
 _LIB = None
 
 EXPORTS = [
-    "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_init_heg", "sqmc_gpu_init_hubbard", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_heatbath_tables", "sqmc_gpu_propose_heatbath_batch", "sqmc_gpu_set_projector",
+    "sqmc_gpu_set_device", "sqmc_gpu_init_chem", "sqmc_gpu_init_heg", "sqmc_gpu_init_hubbard", "sqmc_gpu_finalize", "sqmc_gpu_last_error", "sqmc_gpu_set_hb_tables", "sqmc_gpu_set_heatbath_tables", "sqmc_gpu_setup_efficient_heatbath", "sqmc_gpu_get_heatbath_tables", "sqmc_gpu_propose_heatbath_batch", "sqmc_gpu_set_projector",
     "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_set_hf_to_psit", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
     "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_annihilate", "sqmc_gpu_det_owner", "sqmc_gpu_set_owner_hash", "sqmc_gpu_shard_config",
     "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init", "sqmc_gpu_comm_size",
@@ -409,6 +409,35 @@ class GpuChem:
         put("htot_same", tabs["htot_same"], np.float64); put("htot_opp", tabs["htot_opp"], np.float64)
         self.L.sqmc_gpu_set_heatbath_tables.argtypes = [C.c_void_p, C.c_void_p]
         _chk(self.L.sqmc_gpu_set_heatbath_tables(self.h, C.byref(t)))
+
+    def setup_efficient_heatbath(self):
+        """setup_efficient_heatbath + check_heatbath_unbiased done by the library (proposal_method fast_heatbath from here on if the
+        check passes).  Returns is_heatbath_unbiased."""
+        ok = C.c_int32()
+        self.L.sqmc_gpu_setup_efficient_heatbath.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(self.L.sqmc_gpu_setup_efficient_heatbath(self.h, C.byref(ok)))
+        return bool(ok.value)
+
+    def heatbath_tables(self):
+        """the tables the library built (copies, the reference's layout as in sqmc_heatbath_tables) and the number of orbitals of unique symmetry"""
+        t, nu = HeatbathTables(), C.c_int32()
+        self.L.sqmc_gpu_get_heatbath_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(self.L.sqmc_gpu_get_heatbath_tables(self.h, C.byref(t), C.byref(nu)))
+        n = t.norb
+        npairs = (n * (n - 1)) // 2 + n
+
+        def take(ptr, count, dt):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(dt)), shape=(count,)).copy()
+        out = dict(norb=n, size_same=t.size_same, size_opp=t.size_opp, n_orb_uniq_sym=nu.value,
+                   one=take(t.one, n, C.c_double), two=take(t.two, 4 * n * n, C.c_double),
+                   three_same=take(t.three_same, n ** 3, C.c_double), three_opp=take(t.three_opp, n ** 3, C.c_double),
+                   j3_same=take(t.j3_same, n ** 3, C.c_int32), j3_opp=take(t.j3_opp, n ** 3, C.c_int32),
+                   q3_same=take(t.q3_same, n ** 3, C.c_double), q3_opp=take(t.q3_opp, n ** 3, C.c_double),
+                   four_same=take(t.four_same, t.size_same, C.c_float), four_opp=take(t.four_opp, t.size_opp, C.c_float),
+                   j4_same=take(t.j4_same, t.size_same, C.c_int32), j4_opp=take(t.j4_opp, t.size_opp, C.c_int32),
+                   q4_same=take(t.q4_same, t.size_same, C.c_float), q4_opp=take(t.q4_opp, t.size_opp, C.c_float),
+                   htot_same=take(t.htot_same, npairs * n, C.c_double), htot_opp=take(t.htot_opp, n ** 3, C.c_double))
+        return out
 
     def propose_heatbath_batch(self, tau, up, dn, seeds):
         u, d = _u64(up), _u64(dn)

@@ -147,6 +147,7 @@ struct PsitArgs {
   int seq;
 };
 
+struct HbHost;            // heatbath_setup.inc: host copies of the efficient heat-bath tables the library built itself
 struct sqmc_gpu_ctx {
   hipStream_t st;
   ChemTab htab; ChemTab *d_tab; double *d_ints; ChemDev dev;
@@ -215,6 +216,7 @@ struct sqmc_gpu_ctx {
   int bk_holdoff;             // steps for which the bucket tail stays off (after a bucket overflowed or came close)
   long long bk_steps, bk_retries;
   // hf_to_psit (psit_kernels.h)
+  HbHost *hb_host;
   long long dbg_n0, dbg_nall;          // sizes of the last step's list in front of the merge (sqmc_gpu_debug_premerge)
   bool psit_on; int base_key_bits; PsitArgs psit; int *d_ps_loc, *d_ps_of, *d_ps_impof; double *d_ps_c, *d_ps_diag, *d_ps_dwct, *d_ps_dwps, *d_ps_dwimp, *d_ps_p2, *d_ps_part;
 };
@@ -421,9 +423,11 @@ int sqmc_gpu_init_hubbard(const sqmc_hubbard_cfg *cfg, sqmc_gpu_ctx **out) {
 }
 
 static void comm_release(sqmc_gpu_ctx *c);
+static void hb_host_release(sqmc_gpu_ctx *c);
 int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   abandon_head(c);
   if (!c) return SQMC_OK;
+  hb_host_release(c);
   hipStreamSynchronize(c->st);
   if (c->mwalk > 0) {
     free_walk(c->w); free_walk(c->m);
@@ -452,6 +456,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
 
 int sqmc_gpu_set_hb_tables(sqmc_gpu_ctx *c, int64_t n_hb, const int32_t *r, const int32_t *s, const double *a, int32_t n_pq,
                            const int64_t *pq_ind, const int32_t *pq_count, double max_double) {
+  abandon_head(c);
   if (!c) return fail(SQMC_ERR_BAD_ARG, "null ctx");
   HIPCHK(hipMalloc(&c->d_hb_r, (n_hb + 1) * 4)); HIPCHK(hipMalloc(&c->d_hb_s, (n_hb + 1) * 4)); HIPCHK(hipMalloc(&c->d_hb_absH, (n_hb + 1) * 8));
   HIPCHK(hipMalloc(&c->d_pq_ind, (n_pq + 1) * 8)); HIPCHK(hipMalloc(&c->d_pq_count, (n_pq + 1) * 4));
@@ -1468,5 +1473,6 @@ int sqmc_gpu_debug_premerge(sqmc_gpu_ctx *c, int64_t cap, int64_t *n0, int64_t *
 
 #include "abi_shard.inc"
 #include "abi_doors.inc"
+#include "heatbath_setup.inc"
 
 }  // extern "C"

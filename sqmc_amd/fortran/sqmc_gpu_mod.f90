@@ -17,7 +17,7 @@ module sqmc_gpu_mod
   public :: sqmc_gpu_det_owner, sqmc_gpu_shard_config, sqmc_gpu_shard_begin, sqmc_gpu_shard_pack, sqmc_gpu_shard_finish
   public :: sqmc_gpu_annihilate, sqmc_gpu_build_spmv_plan, sqmc_gpu_hci_connections_slice
   public :: sqmc_gpu_comm_unique_id, sqmc_gpu_comm_init, sqmc_gpu_comm_size, sqmc_gpu_set_owner_hash, sqmc_gpu_tail_stats, sqmc_gpu_slowest_steps, sqmc_gpu_set_chained_runs, sqmc_gpu_hci_pt2, sqmc_gpu_hci_set_active_space, sqmc_gpu_set_heatbath_tables, sqmc_gpu_propose_heatbath_batch, sqmc_heatbath_tables, sqmc_gpu_shard_step, sqmc_gpu_shard_run
-  public :: sqmc_gpu_set_hf_to_psit
+  public :: sqmc_gpu_set_hf_to_psit, sqmc_gpu_setup_efficient_heatbath, sqmc_gpu_get_heatbath_tables
   public :: sqmc_gpu_check
 
   integer(c_int), parameter, public :: SQMC_RNG_REPLAY = 0, SQMC_RNG_COUNTER = 1
@@ -124,6 +124,13 @@ module sqmc_gpu_mod
     end function
     integer(c_int) function sqmc_gpu_set_heatbath_tables(ctx, t) bind(C, name='sqmc_gpu_set_heatbath_tables')
       import; type(c_ptr), value :: ctx; type(sqmc_heatbath_tables), intent(in) :: t
+    end function
+    ! setup_efficient_heatbath (chemistry.f90:1002-1225) + check_heatbath_unbiased (9330-9375) done by the library; the tables it built
+    integer(c_int) function sqmc_gpu_setup_efficient_heatbath(ctx, is_heatbath_unbiased) bind(C, name='sqmc_gpu_setup_efficient_heatbath')
+      import; type(c_ptr), value :: ctx; integer(c_int32_t), intent(out) :: is_heatbath_unbiased
+    end function
+    integer(c_int) function sqmc_gpu_get_heatbath_tables(ctx, t, n_orb_uniq_sym) bind(C, name='sqmc_gpu_get_heatbath_tables')
+      import; type(c_ptr), value :: ctx; type(sqmc_heatbath_tables), intent(out) :: t; integer(c_int32_t), intent(out) :: n_orb_uniq_sym
     end function
     integer(c_int) function sqmc_gpu_propose_heatbath_batch(ctx, n, tau, up, dn, seeds, det_j_up, det_j_dn, weight_j, seeds_after) &
         bind(C, name='sqmc_gpu_propose_heatbath_batch')

@@ -597,11 +597,15 @@ class GpuWalk:
     """A C2-style semistochastic walk resident on one GPU."""
 
     def __init__(self, host, w_target, w_begin=None, mwalk=None, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1,
-                 e_trial=None, seed=(1346, 5634, 6635, 4361), rng_mode=RNG_COUNTER, min_wt=0.5, hf_to_psit=False, sum_order=1):
+                 e_trial=None, seed=(1346, 5634, 6635, 4361), rng_mode=RNG_COUNTER, min_wt=0.5, hf_to_psit=False, sum_order=1, proposal="uniform"):
         self.host = host
         w_begin = w_begin if w_begin is not None else w_target
         mwalk = mwalk or int(max(4 * (w_target / min_wt + size_deterministic), 200000))
         self.g = host.gpu(rng_mode=rng_mode, seed=seed, mwalk=mwalk)
+        if proposal == "heatbath":          # proposal_method fast_heatbath: the library builds the tables and refuses what the reference refuses
+            if not self.g.setup_efficient_heatbath():
+                self.g.close()
+                raise ValueError("Heatbath may be biased for this system!")
         if hf_to_psit:
             self.setup = s = host.setup_walk(self.g, n_truncate_trial_wf, size_deterministic, tau_multiplier, rediagonalize=True)
             ix, cdet, diag, pc_, pi_, pv_, in_imp = psit_tables(self.g, s)

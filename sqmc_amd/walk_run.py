@@ -78,8 +78,10 @@ def parse_walk_deck(text):
         a = _numbers(nxt(), 2); d.update(nup=int(a[0]), ndn=int(a[1]))
     else:
         raise SystemExit("sqmc_amd.walk_run: hamiltonian_type %r has no GPU operator (chem, heg, hubbard2)" % d["hamiltonian_type"])
-    if d["proposal_method"] not in ("uniform2", "uniform"):
-        raise SystemExit("sqmc_amd.walk_run: proposal_method %r is not on the GPU path (uniform2: off_diagonal_move_chem / _heg / _hubbard)" % d["proposal_method"])
+    if d["proposal_method"] not in ("uniform2", "uniform") and not (d["proposal_method"] == "fast_heatbath" and d["hamiltonian_type"] == "chem"):
+        raise SystemExit("sqmc_amd.walk_run: proposal_method %r is not on the GPU path (uniform2: off_diagonal_move_chem / _heg / _hubbard; fast_heatbath: chem)" % d["proposal_method"])
+    if d["proposal_method"] == "fast_heatbath" and d["hf_to_psit"]:
+        raise SystemExit("sqmc_amd.walk_run: proposal_method fast_heatbath with hf_to_psit = t is not built")
     if d["importance_sampling"] != 0:
         raise SystemExit("sqmc_amd.walk_run: importance_sampling must be 0")
     if d["hf_to_psit"] and d["hamiltonian_type"] == "hubbard2":
@@ -239,6 +241,16 @@ def run_walk(deck, fcidump="FCIDUMP", out=sys.stdout, walkalize=None, max_equil_
     if dtm_elems_out and semi:
         p(" Dumping the deterministic matrix elements into file " + dtm_elems_out)
         H.write_dtm_elems(dtm_elems_out, s.imp_up, s.imp_dn, s.prj_counts, s.prj_indices, s.prj_values / (-s.tau), s.e_var, n_core)
+    if d["proposal_method"] == "fast_heatbath":
+        # setup_efficient_heatbath + check_heatbath_unbiased (chemistry.f90:1002-1225, 9330-9375), done by the library
+        p(" Checking whether there is any potential bias for using heatbath on this system...")
+        if not g.setup_efficient_heatbath():
+            p(" Check failed! Heatbath is (potentially) biased for this system. Aborting run...")
+            g.close()
+            raise SystemExit("Heatbath may be biased for this system!")
+        p(" Check passed! Heatbath is unbiased for this system!")
+        mwalk_hb = int(max(d["mwalk"], 3.5 * (target / d["min_wt"] + d["size_deterministic"])))      # do_walk.f90:668-669
+        p("1Setting MWALK=3.5*(w_abs_gen_target/min_wt+n_imp)=%10d" % mwalk_hb)
     p("ndet_psi_t, ndet_psi_t_connected, n_imp=%8d%10d%8d" % (len(s.psi_up), len(s.ct_up), len(s.imp_up)))
     p("tau=%12.8f  variational energy of the set-up space=%16.8f" % (s.tau, s.e_var))
     if psit:

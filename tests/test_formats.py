@@ -79,8 +79,9 @@ def test_walk_deck_grammar_and_estimators():
     assert (d["w_abs_gen_begin"], d["w_abs_gen_target"], d["mwalk"]) == (100, 10000, 0)
     assert d["proposal_method"] == "uniform2" and d["semistochastic"] and d["size_deterministic"] == 1000
     assert d["irand_seed"][1] == [1346, 5634, 6635, 4361] and d["n_truncate_trial_wf"] == [100] and len(d["orbital_symmetries"]) == 26
+    assert parse_walk_deck(text.replace("uniform2 0", "fast_heatbath 0"))["proposal_method"] == "fast_heatbath"      # the library builds its tables (test_library_builds_the_heatbath_tables_itself)
     with pytest.raises(SystemExit, match="proposal_method"):
-        parse_walk_deck(text.replace("uniform2 0", "fast_heatbath 0"))
+        parse_walk_deck(text.replace("uniform2 0", "heat_bath 0"))
     assert parse_walk_deck(text.replace("f f 0.5 ", "t f 0.5 "))["hf_to_psit"]            # the transformed projector is on the GPU path (tests/test_gpu_psit.py)
     with pytest.raises(SystemExit, match="run_type"):
         parse_walk_deck(text.replace("none  ", "vmc   "))

@@ -1813,3 +1813,50 @@ def test_heatbath_walk_trajectory_bit_exact(oracle, c2_10e):
     for k in ("up", "dn", "imp_distance", "initiator"):
         assert np.array_equal(wg[k], wc[k]), k
     assert np.array_equal(wg["wt"], wc["wt"]) and len(wg["up"]) > 3000
+
+
+def test_library_builds_the_heatbath_tables_itself(oracle, c2_walk, c2_10e):
+    """sqmc_gpu_setup_efficient_heatbath (setup_efficient_heatbath chemistry.f90:1002-1225, setup_alias more_tools.f90:5603-5722,
+    check_heatbath_unbiased 9330-9375 on the product side): every table equals the oracle's, entry for entry -- the partial sums in
+    double, the four-index tables and their alias tables in single precision --, the 8-electron system the reference refuses is
+    refused, and a walk driven by the library's own tables is the walk driven by the oracle's."""
+    sysm = c2_10e
+    hb = oracle.HeatBath(sysm)
+    ref = hb.fortran_arrays()
+    g = gpu_ctx_from_oracle(sysm, rng_mode=1, seed=SEED, mwalk=300000)
+    assert g.setup_efficient_heatbath() is True and hb.unbiased
+    mine = g.heatbath_tables()
+    assert mine["n_orb_uniq_sym"] == hb.s.n_orb_uniq_sym and mine["size_same"] == ref["size_same"] and mine["size_opp"] == ref["size_opp"]
+    for k in ("one", "two", "three_same", "three_opp", "q3_same", "q3_opp", "htot_same", "htot_opp", "four_same", "four_opp", "q4_same", "q4_opp"):
+        a, b = np.asarray(mine[k]), np.asarray(ref[k]).reshape(-1)
+        assert a.shape == b.shape and np.array_equal(a, b), (k, np.max(np.abs(a.astype(float) - b.astype(float))))
+    for k in ("j3_same", "j3_opp", "j4_same", "j4_opp"):
+        assert np.array_equal(np.asarray(mine[k]), np.asarray(ref[k]).reshape(-1)), k
+    assert np.count_nonzero(mine["four_same"]) > 10000 and np.count_nonzero(mine["q4_opp"]) > 10000
+    # a walk on the library's tables against the oracle's walk on its own
+    su = oracle.setup_walk(sysm, 100, 1000, 0.1)
+    g.set_projector(su.prj_counts, su.prj_indices, su.prj_values)
+    g.set_ct_table(su.ct_up, su.ct_dn, su.ct_num, su.ct_den)
+    wk = oracle.initial_walkers(su, 50)
+    g.upload_walkers(wk)
+    ow = oracle.OracleWalk(sysm, su, wk, 300000, SEED, rng_mode=1, heatbath=hb)
+    pc = oracle.PopControl(su.tau, su.e_trial0, 4000)
+    w_abs = float(np.abs(wk["wt"]).sum())
+    for it in range(40):
+        r = pc.pre_step(w_abs)
+        if r != 1.0:
+            ow.scale_projector(r); g.scale_projector(r)
+        st, oc = ow.step(pc.params())
+        og = g.step(pc.params())
+        assert st == 0 and og[5] == oc[5] and og[15] == oc[15] and _sums_close(og, oc), (it, og, oc)
+        r = pc.post_step(oc)
+        if r != 1.0:
+            ow.scale_projector(r); g.scale_projector(r)
+        w_abs = oc[1]
+    wg, wc = g.download_walkers(), ow.walkers()
+    assert np.array_equal(wg["up"], wc["up"]) and np.array_equal(wg["dn"], wc["dn"]) and np.array_equal(wg["wt"], wc["wt"])
+    g.close(); ow.close(); hb.close()
+    # C2 with 8 electrons: 4 orbitals of unique symmetry are not fewer than max(nup, ndn) = 4 -- "Heatbath may be biased for this system!"
+    g8 = gpu_ctx_from_oracle(c2_walk)
+    assert g8.setup_efficient_heatbath() is False
+    g8.close()
