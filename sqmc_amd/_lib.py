@@ -7,7 +7,17 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libsqmc_gpu.so")
+def _lib_path():
+    """the library's file: builds with extra flags (SQMC_EXTRA_CFLAGS: the instrumented builds of tools/*_prof.py) get a name of their own, so
+    that they can neither overwrite the product's library nor be mistaken for it by the staleness check"""
+    extra = os.environ.get("SQMC_EXTRA_CFLAGS", "").split()
+    if not extra:
+        return os.path.join(_HERE, "libsqmc_gpu.so")
+    import hashlib
+    return os.path.join(_HERE, "libsqmc_gpu_%s.so" % hashlib.sha1(" ".join(extra).encode()).hexdigest()[:10])
+
+
+LIB_PATH = _lib_path()
 RNG_REPLAY, RNG_COUNTER = 0, 1
 _LIB = None
 

@@ -1099,7 +1099,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     device_excl_scan_u64(c->d_flags, c->d_pos, nall, &c->d_sc->tot1, sw[1], st);
     TEND(merge, st);
     TBEG(round, st);
-    static const bool serial_join = getenv("SQMC_SERIAL_JOIN") != nullptr;
+    const bool serial_join = getenv("SQMC_SERIAL_JOIN") != nullptr;      // read per call: the one-lane k_join (REPLAY's kernel) on a COUNTER walk, for tests
     if (mode == SQMC_RNG_COUNTER && !serial_join) {
       // the arrays of the rounding pass behind it are idle: the chunks' candidates (|w|, draw key | index) and their counts go there
       const unsigned nchunks = (unsigned)((nall + JP_TILE - 1) / JP_TILE);

@@ -699,7 +699,8 @@ __global__ void __launch_bounds__(TPB) k_round(WalkArr m, const u64 *__restrict_
 // exceeds min_wt; positive walkers first, then negative ones.  Which walkers end a chain depends on
 // the running sum, so the chain is followed by ONE lane; the 256 threads of the block only stream
 // the merged list through LDS in 1024-walker tiles (coalesced) ahead of it.  Draws: REPLAY = the
-// rannyu stream in join order, COUNTER = stream keyed by the merged index of the later walker.
+// rannyu stream in join order, COUNTER = stream keyed by the later walker's rank among the merged walkers (the low word of pos),
+// the key k_join_par uses too.
 #define JOIN_TILE 1024
 __global__ void __launch_bounds__(TPB) k_join(WalkArr m, const u64 *__restrict__ flags, const u64 *__restrict__ pos, long long n_all, StepP p,
                                               int mode, u64 seed, u64 step, DevScalars *sc) {

@@ -1279,14 +1279,21 @@ def test_plain_annihilate_door_with_chains_longer_than_a_tile(oracle, c2_walk, c
     n = L.orc_join_walker2(ow.h, n, C.byref(p))
     ow.w.nwalk = n
     ref = ow.walkers(); ow.close()
-    g = gpu_ctx_from_oracle(c2_walk, rng_mode=1, seed=SEED, mwalk=50000)
-    g.set_ct_table(c2_setup.ct_up, c2_setup.ct_dn, c2_setup.ct_num, c2_setup.ct_den)
-    g.upload_walkers(main)
-    out = g.annihilate(prm, dict(up=up, dn=dn, wt=wt, imp_distance=impd, initiator=init))
-    got = g.download_walkers(); g.close()
-    assert len(got["up"]) == n == int(out[5])
-    for k in ("up", "dn", "wt", "imp_distance", "initiator"):
-        assert np.array_equal(got[k], ref[k]), k
+    import os
+    for serial in (False, True):            # SQMC_SERIAL_JOIN: the one-lane k_join walks the same chains with the same draws
+        if serial:
+            os.environ["SQMC_SERIAL_JOIN"] = "1"
+        try:
+            g = gpu_ctx_from_oracle(c2_walk, rng_mode=1, seed=SEED, mwalk=50000)
+            g.set_ct_table(c2_setup.ct_up, c2_setup.ct_dn, c2_setup.ct_num, c2_setup.ct_den)
+            g.upload_walkers(main)
+            out = g.annihilate(prm, dict(up=up, dn=dn, wt=wt, imp_distance=impd, initiator=init))
+            got = g.download_walkers(); g.close()
+        finally:
+            os.environ.pop("SQMC_SERIAL_JOIN", None)
+        assert len(got["up"]) == n == int(out[5])
+        for k in ("up", "dn", "wt", "imp_distance", "initiator"):
+            assert np.array_equal(got[k], ref[k]), (serial, k)
     assert n_merged > 8000 and n < n_merged - 5000                  # thousands of joins happened
     assert (ref["wt"] > 0.5).sum() >= 1 and int(pos_.sum()) > 2 * 2048     # positive chains closed above min_wt; their members fill more than two tiles
 

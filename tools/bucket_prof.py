@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the time of k_anneal_bucket goes: rebuilds the library with -DBUCKET_PROF on the GPU box, runs the bench
 configuration for a few hundred steps and prints, per phase, the mean / max over the buckets of the last step (wall clock,
-100 MHz ticks -> us).  Restores the normal build afterwards."""
+100 MHz ticks -> us).  The instrumented build is a file of its own (sqmc_amd/_lib.py: the flags are part of its name); the product's library is not touched."""
 import ctypes as C
 import os
 import sys
@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 os.environ["SQMC_EXTRA_CFLAGS"] = "-DBUCKET_PROF"
 import torch  # noqa: F401
 import sqmc_amd
-sqmc_amd.build_library(force=True)
+sqmc_amd.build_library()
 from sqmc_amd import host as H
 
 target = float(sys.argv[1]) if len(sys.argv) > 1 else 1e5
@@ -60,5 +60,3 @@ print("first buckets (id: R + S): " + ", ".join("%d: %d + %d" % (ids[i], a[i, 13
 d = (a[:, 10] - a[:, 0]) / 100.0
 print("bucket life: mean %.1f max %.1f us; end skew mean %.1f" % (d.mean(), d.max(), (a[:, 10].max() - a[:, 10]).mean() / 100.0))
 w.close()
-os.environ.pop("SQMC_EXTRA_CFLAGS")
-sqmc_amd.build_library(force=True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the time of k_spawn goes at the bench size: rebuilds the library with -DSPAWN_PROF on the GPU box, runs the bench
 configuration and prints, per phase, the mean / max over the spawning blocks of the last step (wall clock, 100 MHz ticks).
-Restores the normal build afterwards."""
+The instrumented build is a file of its own (sqmc_amd/_lib.py: the flags are part of its name); the product's library is not touched."""
 import ctypes as C
 import os
 import sys
@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 os.environ["SQMC_EXTRA_CFLAGS"] = "-DSPAWN_PROF"
 import torch  # noqa: F401
 import sqmc_amd
-sqmc_amd.build_library(force=True)
+sqmc_amd.build_library()
 from sqmc_amd import host as H
 
 target = float(sys.argv[1]) if len(sys.argv) > 1 else 1e5
@@ -39,5 +39,3 @@ for k in range(1, 6):
 d = (a[:, 5] - a[:, 0]) / 100.0
 print("block life: mean %.1f max %.1f us" % (d.mean(), d.max()))
 w.close()
-os.environ.pop("SQMC_EXTRA_CFLAGS")
-sqmc_amd.build_library(force=True)
