@@ -5,7 +5,8 @@
 // ============================================================================ SpMV
 // Symmetric matrix kept as FULL CSR (int32 columns) so that every row is owned by one
 // wavefront and no atomics are needed: 12 B per stored entry + 8 B gathered x.
-struct sqmc_spmv_plan { long long n, nnz_full; int *d_ptr, *d_col; double *d_val, *d_x, *d_y; hipStream_t st; };
+struct sqmc_spmv_plan { long long n, nnz_full; int *d_ptr, *d_col; double *d_val, *d_x, *d_y; hipStream_t st;
+                        int *u_ptr, *u_col; double *u_val; };      // u_*: the stored triangle as it came (only with SQMC_SPMV_UPPER_ATOMIC: the layout measured against the full CSR)
 // ---- full CSR of the symmetric matrix on the device, from the upper-triangular storage that
 // k_build_ham leaves in HBM (row i: diagonal first, then columns j < i ascending).  Row j of the
 // full matrix = its stored part followed by the entries (i, j), i > j, in increasing i: the order
@@ -60,6 +61,27 @@ __global__ void __launch_bounds__(64 * SPMV_ROWS_PER_BLOCK) k_spmv_wave(const in
   for (int k = b + lane; k < e; k += 64) s += val[k] * x[col[k]];
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   if (lane == 0) y[row] = s;
+}
+
+// The other layout SURVEY section 7 asks to be measured: the stored triangle only (12 B per stored entry instead of 24), the transposed
+// half applied with native fp64 atomics, y zeroed in front.  Sums in an order that changes from run to run -- HCI's selection thresholds
+// would see different eigenvector bits --, and 1.8 10^7 scattered atomics cost far more than the bytes they save:
+// kept only as the measured alternative, behind SQMC_SPMV_UPPER_ATOMIC=1.
+__global__ void __launch_bounds__(64 * SPMV_ROWS_PER_BLOCK) k_spmv_upper_atomic(const int *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val,
+                                                                                const double *__restrict__ x, double *__restrict__ y, long long n) {
+  const long long row = (long long)blockIdx.x * SPMV_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const int b = ptr[row], e = ptr[row + 1];
+  const double xr = x[row];
+  double s = 0.0;
+  for (int k = b + lane; k < e; k += 64) {
+    const int m = col[k]; const double a = val[k];
+    s += a * x[m];
+    if (m != (int)row) unsafeAtomicAdd(&y[m], a * xr);
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) unsafeAtomicAdd(&y[row], s);
 }
 
 static void expand_full_csr(long long n, const int64_t *rc, const int64_t *idx, const double *val,
