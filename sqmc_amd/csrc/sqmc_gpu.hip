@@ -843,7 +843,9 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
   static const bool no_early = getenv("SQMC_NO_EARLY_HII") != nullptr;
   // Behind a bucket tail there is nothing to fill: that kernel computes the H_ii of the determinants it creates, and the step
   // runs on one stream (no fork, no join: every cross-stream wait costs 5-12 us on the critical path at 10^5 walkers).
-  const bool early = dev_n && !c->d_grow && !no_early && !tail_fills;
+  // (long lists: k_spawn and the sort are longer than both passes of k_diag together, and the early pass only takes resources from
+  //  k_spawn -- 0.449 -> 0.444 ms at 10^6 walkers, 3.15 -> 3.10 ms at 10^7 without it)
+  const bool early = dev_n && !c->d_grow && !no_early && !tail_fills && c->last_nall < (1ll << 20);
   if (early) {
     HIPCHK(hipStreamWaitEvent(c->st2, c->e_fork, 0));
     hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, c->st2, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc, 1);
