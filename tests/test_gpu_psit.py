@@ -171,3 +171,71 @@ def test_psit_run_loop_and_energy(c2_walk):
 def c2_walk_fcidump():
     from conftest import FCIDUMP
     return FCIDUMP
+
+
+def test_psit_counter_trajectory_past_2_20_slots(oracle, c2_walk, c2_psit):
+    """long lists: only the spawns are sorted and merged into the (key'-ordered) residents, three slots per thread in k_anneal<3, 1>.  Ten
+    steps from 10^6 walkers' worth of weight on the first state: every step but the first has more than 2^20 sorted slots."""
+    s, q = c2_psit
+    ow, g, w_abs = _pair(oracle, c2_walk, s, q, 1.0e6, 1, mwalk=8000000)
+    pc = oracle.PopControl(s.tau, s.e_trial0, 1000000)
+    nb = []
+    for it in range(10):
+        r = pc.pre_step(w_abs)
+        if r != 1.0:
+            ow.scale_projector(r); g.scale_projector(r)
+        prm = pc.params()
+        st, oc = ow.step(prm)
+        assert st == 0
+        og = g.step(prm)
+        assert og[5] == oc[5] and og[7] == oc[7] and og[15] == oc[15] and _sums_close(og, oc), (it, og, oc)
+        r = pc.post_step(oc)
+        if r != 1.0:
+            ow.scale_projector(r); g.scale_projector(r)
+        w_abs = oc[1]; nb.append(int(og[7]))
+    assert max(nb) > (1 << 20), nb
+    msg = _same_walkers(g.download_walkers(), ow.walkers(), len(s.ct_up))
+    assert not msg, msg
+    g.close(); ow.close()
+
+
+def test_psit_unpacked_keys_and_annihilate_door(oracle, c2_walk, c2_psit, monkeypatch):
+    """the two-array key layout (wide keys) carries the C(T)-first key as well, and sqmc_gpu_annihilate -- the caller's own spawns through
+    the same tail -- folds a hand-made list (spawns onto C(T) determinants with zero and non-zero weight, onto the first state's
+    neighbours, onto new determinants in pairs that cancel) exactly as the oracle's three-segment merge does"""
+    import sqmc_amd
+    s, q = c2_psit
+    monkeypatch.setenv("SQMC_FORCE_UNPACKED", "1")
+    ow, g, w_abs = _pair(oracle, c2_walk, s, q, 100.0, 1)
+    pc = oracle.PopControl(s.tau, s.e_trial0, 4000)
+    _lockstep(oracle, ow, g, pc, w_abs, 30, len(s.ct_up), check_every=15)
+    g.close(); ow.close()
+
+
+def test_psit_refuses_what_the_reference_assumes(oracle, c2_walk, c2_psit):
+    import sqmc_amd
+    s, q = c2_psit
+    g = gpu_ctx_from_oracle(c2_walk, rng_mode=1, seed=SEED, mwalk=300000)
+    g.set_projector(q.prj_counts, q.prj_indices, q.prj_values)
+    g.set_ct_table(s.ct_up, s.ct_dn, s.ct_num, s.ct_den)
+    ix = (q.loc_psit + 1).copy()
+    bad = ix.copy(); bad[0] = 2                                  # Psi_T does not begin with C(T)'s first determinant
+    with pytest.raises(sqmc_amd.SqmcGpuError):
+        g.set_hf_to_psit(bad, q.cdet, q.diag_elems)
+    with pytest.raises(sqmc_amd.SqmcGpuError):
+        g.set_hf_to_psit(ix[::-1].copy(), q.cdet, q.diag_elems)  # not in label order
+    g.set_hf_to_psit(ix, q.cdet, q.diag_elems)
+    wk = oracle.initial_walkers_psit(s, q, 50.0)
+    short = {k: v[:-1] for k, v in wk.items()}                   # not all of C(T)
+    with pytest.raises(sqmc_amd.SqmcGpuError):
+        g.upload_walkers(short)
+    wrong = {k: v.copy() for k, v in wk.items()}
+    wrong["imp_distance"][5] = 1                                 # a C(T) determinant flagged as a stochastic one
+    with pytest.raises(sqmc_amd.SqmcGpuError):
+        g.upload_walkers(wrong)
+    g.upload_walkers(wk)
+    prm = oracle.PopControl(s.tau, s.e_trial0, 4000).params()
+    prm["semistochastic"] = 0
+    with pytest.raises(sqmc_amd.SqmcGpuError):
+        g.step(prm)                                              # the variant is semistochastic by definition
+    g.close()
