@@ -115,7 +115,7 @@ const char *sqmc_gpu_last_error(void);
  * After this call sqmc_gpu_step spawns with off_diagonal_move_chem_efficient_heatbath (5086-5347) instead of
  * off_diagonal_move_chem: every child may add TWO walkers (a single excitation larger than all its doubles together comes
  * back with a double, do_walk.f90:3604-3611 -> add_walker 7584-7697), so a step needs room for 2 x children spawned walkers.
- * COUNTER discipline only.  Systems for which check_heatbath_unbiased (9330-9375) fails are the caller's to refuse, as the
+ * Both RNG disciplines (REPLAY: one lane runs every proposal to follow the stream).  Systems for which check_heatbath_unbiased (9330-9375) fails are the caller's to refuse, as the
  * reference does (1215-1223).  tests/golden/README_heatbath.md records what parity is defined against. */
 typedef struct {
   int32_t norb, reserved;

@@ -1234,7 +1234,6 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   if (c->mwalk <= 0 || c->nwalk <= 0) return fail(SQMC_ERR_NO_WALKERS, "my_nwalk=0");
   if (c->d_grow) return fail(SQMC_ERR_BAD_ARG, "context is configured for sharded steps: use sqmc_gpu_shard_begin/pack/finish");
   if (sp->semistochastic && (c->n_imp <= 0 || !c->d_prj_ptr)) return fail(SQMC_ERR_BAD_ARG, "semistochastic step without projector");
-  if (c->dev.hb.on && c->rng_mode == SQMC_RNG_REPLAY) return fail(SQMC_ERR_UNSUPPORTED, "the efficient heat-bath proposal runs in the COUNTER discipline only");
   if (!c->d_ct_up) return fail(SQMC_ERR_BAD_ARG, "C(T) table not set");
   hipStream_t st = c->st;
   StepP p; p.tau = sp->tau; p.e_trial = sp->e_trial; p.rfi = sp->reweight_factor_inv; p.r_init = sp->r_initiator; p.min_wt = sp->min_wt;
@@ -1280,7 +1279,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
     // ---- gate / child offsets (the gate kernel also clears the step's device scalars)
     if (t_gate_scan >= 0) hipEventRecord(c->ev0[t_gate_scan], st);
     hipLaunchKernelGGL(k_replay_prepass, dim3(1), dim3(64), 0, st, c->d_tab, c->w.up, c->w.dn, c->w.wt, c->d_nchild, c->d_wchild, c->d_child_off,
-                       c->d_child_state, n0, M - n0, p, c->d_sc);
+                       c->d_child_state, n0, (M - n0) / (c->dev.hb.on ? 2 : 1), p, c->d_sc, c->dev);
     if (t_gate_scan >= 0) hipEventRecord(c->ev1[t_gate_scan], st);
     HIPCHK(hipEventRecord(c->e_fork, st)); c->fork_valid = true;
     cseq = ++c->cnt_seq;

@@ -73,10 +73,12 @@ __global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict
 
 // REPLAY discipline: one lane walks the walkers in order, consuming the single rannyu
 // stream exactly as the reference does, and records where every child starts in it.
+// (proposal_method fast_heatbath: the same walk with propose_heatbath -- how many draws a proposal takes depends on the tables and on the
+//  matrix elements it computes, so the lane runs the whole proposal, not just its control flow)
 __global__ void __launch_bounds__(64) k_replay_prepass(const ChemTab *__restrict__ gtab, const u64 *__restrict__ up, const u64 *__restrict__ dn,
                                                        const double *__restrict__ wt, u64 *__restrict__ nchild, double *__restrict__ wchild,
                                                        u64 *__restrict__ child_off, u64 *__restrict__ child_state, long long n,
-                                                       long long cap_children, StepP p, DevScalars *sc) {
+                                                       long long cap_children, StepP p, DevScalars *sc, ChemDev dev) {
   __shared__ ChemTab t;
   stage_tab(&t, gtab, tab_words_used(gtab->c2_stride));
   if (threadIdx.x != 0) return;
@@ -97,8 +99,8 @@ __global__ void __launch_bounds__(64) k_replay_prepass(const ChemTab *__restrict
     u64 iu = up[i], id = dn[i];
     for (long long k = 0; k < nc; k++) {
       if ((long long)c < cap_children) child_state[c] = g.x;
-      u64 ju, jd; double pr;
-      propose_any(t, g, iu, id, ju, jd, pr);
+      if (dev.hb.on) { u64 ju2[2], jd2[2]; double wj2[2]; propose_heatbath(t, dev.integrals, dev.hb, g, p.tau, iu, id, ju2, jd2, wj2); }
+      else { u64 ju, jd; double pr; propose_any(t, g, iu, id, ju, jd, pr); }
       c++;
     }
   }

@@ -1867,3 +1867,39 @@ def test_library_builds_the_heatbath_tables_itself(oracle, c2_walk, c2_10e):
     g8 = gpu_ctx_from_oracle(c2_walk)
     assert g8.setup_efficient_heatbath() is False
     g8.close()
+
+
+def test_heatbath_walk_replay_discipline(oracle, c2_10e):
+    """fast_heatbath in the REPLAY discipline: one lane walks the reference's single rannyu stream through every proposal (alias draws,
+    the second excitation of a single-and-double return) and the parallel k_spawn<1, .> resumes from the recorded states: walkers,
+    weights and the stream's state equal the oracle's after every block of steps."""
+    sysm = c2_10e
+    hb = oracle.HeatBath(sysm)
+    su = oracle.setup_walk(sysm, 100, 1000, 0.1)
+    g = gpu_ctx_from_oracle(sysm, rng_mode=0, seed=SEED, mwalk=300000)
+    g.set_heatbath_tables(hb.fortran_arrays())
+    g.set_projector(su.prj_counts, su.prj_indices, su.prj_values)
+    g.set_ct_table(su.ct_up, su.ct_dn, su.ct_num, su.ct_den)
+    wk = oracle.initial_walkers(su, 50)
+    g.upload_walkers(wk)
+    ow = oracle.OracleWalk(sysm, su, wk, 300000, SEED, rng_mode=0, heatbath=hb)
+    pc = oracle.PopControl(su.tau, su.e_trial0, 2500)
+    w_abs = float(np.abs(wk["wt"]).sum())
+    for it in range(40):
+        r = pc.pre_step(w_abs)
+        if r != 1.0:
+            ow.scale_projector(r); g.scale_projector(r)
+        st, oc = ow.step(pc.params())
+        og = g.step(pc.params())
+        assert st == 0 and og[5] == oc[5] and og[7] == oc[7] and og[15] == oc[15] and _sums_close(og, oc), (it, og, oc)
+        r = pc.post_step(oc)
+        if r != 1.0:
+            ow.scale_projector(r); g.scale_projector(r)
+        w_abs = oc[1]
+        if it % 10 == 9:
+            assert g.rng_state() == ow.rng_state(), it
+    wg, wc = g.download_walkers(), ow.walkers()
+    g.close(); ow.close(); hb.close()
+    for k in ("up", "dn", "imp_distance", "initiator", "wt"):
+        assert np.array_equal(wg[k], wc[k]), k
+    assert len(wg["up"]) > 1200
