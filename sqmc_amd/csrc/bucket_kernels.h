@@ -148,7 +148,7 @@ __device__ __forceinline__ double bk_wave_sum_lane63(double v) {
 #define BK_PER_R ((BK_CAP_R + BK_AT - 1) / BK_AT)
 #define BK_PER_T ((BK_CAP_T + BK_AT - 1) / BK_AT)
 
-__global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, const u64 *__restrict__ rkeys, int *__restrict__ loc_imp,
+__global__ void __launch_bounds__(BK_AT, BK_PER_CU * (BK_AT / 64) / 4) k_anneal_bucket(WalkArr w, WalkArr o, const u64 *__restrict__ rkeys, int *__restrict__ loc_imp,
                                                          const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 hmask,
                                                          const double *__restrict__ cnum, const double *__restrict__ cden,
                                                          double *__restrict__ partials, double *__restrict__ wabs_part, long long n0, long long nch, StepP p,
@@ -159,10 +159,14 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
   __shared__ double s_w[BK_CAP_T]; __shared__ u32 s_f[BK_CAP_T];   // weight / flags by SOURCE: residents [0, R), sorted spawns [R, R + S); later the merged walker of a run, at its head
   __shared__ u32 m2s[BK_CAP_T];                           // merged order -> source (| BK_STOP at the first slot of a run)
   __shared__ __align__(16) unsigned short rnk[BK_CAP_T];               // sort: rank inside its digit; later: keep code of a merged slot
-  __shared__ __align__(16) u32 scratch[(BK_AT / 64) * 1024];   // rows of the gather (offset u16 + base u32), then the digit counters of the sort, then child counts [0, T) + the Slater-Condon tables [4096, ...)
+  // rows of the gather (offset u16 + base u32), then the digit counters of the sort, then child counts [0, T) + the Slater-Condon tables [BK_SCR_TAB, ...)
+  constexpr int BK_SCR_TAB = (BK_CAP_T + 3) & ~3;
+  constexpr int BK_SCR_ROWS = (BK_CAP_ROWS / 2 + 4) + BK_CAP_ROWS + 1, BK_SCR_CNT = (BK_AT / 64) * 1024 * (int)sizeof(bk_cnt_t) / 4, BK_SCR_TABEND = BK_SCR_TAB + ((int)sizeof(ChemTab) + 3) / 4;
+  constexpr int BK_SCR_WORDS = ((BK_SCR_ROWS > BK_SCR_CNT ? (BK_SCR_ROWS > BK_SCR_TABEND ? BK_SCR_ROWS : BK_SCR_TABEND) : (BK_SCR_CNT > BK_SCR_TABEND ? BK_SCR_CNT : BK_SCR_TABEND)) + 3) & ~3;
+  __shared__ __align__(16) u32 scratch[BK_SCR_WORDS];
   __shared__ unsigned short s_hq[BK_CAP_T]; __shared__ int s_hqn;      // kept walkers of this bucket that have no H_ii yet (position inside the bucket's output)
-  static_assert(sizeof(ChemTab) <= ((BK_AT / 64) * 1024 - 4096) * 4 && BK_CAP_T <= 4096, "the tables share the idle sort counters with the child counts");
-  ChemTab *s_tab = (ChemTab *)(scratch + 4096);
+  static_assert(BK_CAP_T <= 4096 && (sizeof(bk_cnt_t) == 4 || BK_CAP_S <= 65535), "ranks inside a bucket are 12 bits; the counters hold a bucket's spawns");
+  ChemTab *s_tab = (ChemTab *)(scratch + BK_SCR_TAB);
   u64 *s_hdet = (u64 *)rnk;                               // (up, dn) of the first BK_HQ_DETS queued determinants: the keep codes are idle once the ranks exist
   __shared__ u32 s_tile; __shared__ u32 s_kmin, s_kmax;
   __shared__ double s_red[BK_AT / 64][NSTAT + 2];
@@ -186,7 +190,8 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
 #pragma unroll
   for (int q = 0; q < BK_PER_R; q++) { const int i = tid + q * BK_AT; rk_reg[q] = (fits && i < R) ? (u32)(rkeys[r_lo + i] >> 32) : 0u; }
   int S = 0;
-  if (fits) {
+  const bool rows_ok = nsb <= BK_CAP_ROWS;             // (the host checks this before it launches)
+  if (rows_ok) {                                       // also for a bucket that will give up: the host learns the next boundaries from every bucket's count
     const int C = (nsb + BK_AT - 1) / BK_AT;
     unsigned short lo_[BK_PER_ROWS], hi_[BK_PER_ROWS];
 #pragma unroll
@@ -206,12 +211,16 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     }
     if (tid == 0) seg_base[nsb] = (u32)tot;
     S = (int)tot;
-    fits = S <= BK_CAP_S && R + S <= BK_CAP_T && !ba.force_retry;
+    fits = fits && S <= BK_CAP_S && R + S <= BK_CAP_T && !ba.force_retry;
   }
   const int T = R + S;
   if (!fits) {
     // nothing was written that the radix path would miss; the look-back must still see this bucket
     if (tid == 0) atomicExch((int *)&sc->retry, 1);
+    if (tid == 0 && ba.scount && rows_ok) { ba.scount[b] = (u32)S; if (b == 0) ba.scount[B] = (u32)n0; }
+#ifdef BUCKET_PROF
+    if (tid == 0) printf("bucket %d of %d does not fit: rows %d, R %d, S %d (r_lo %lld)\n", b, B, nsb, R, S, r_lo);
+#endif
     if (tid < 64) lookback_exclusive(ba.state, (u32)b, 0ull, tid);
     return;
   }
@@ -250,10 +259,10 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
   static_assert((BK_CAP_S + 1026) * 2 <= BK_CAP_T * 4, "gap tables fit the merged-order array");
   if (gap_sort) {
     unsigned short *gp = s_hq;                            // gap by creation order (the H_ii queue is idle until the compaction)
-    u32(*wcnt)[1024] = (u32(*)[1024])scratch;
+    bk_cnt_t(*wcnt)[1024] = (bk_cnt_t(*)[1024])scratch;
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int chunk = ((S + BK_AT - 1) / BK_AT) * 64;
-    for (int d = tid; d < (BK_AT / 64) * 1024; d += BK_AT) scratch[d] = 0;
+    for (int d = tid; d < BK_SCR_CNT; d += BK_AT) scratch[d] = 0;
     for (int j = tid; j < S; j += BK_AT) {
       const u32 k = (u32)(sa[j] >> 32);
       int lo = 0, hi = R;
@@ -273,7 +282,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
         u32 prev = 0;
         if (valid) prev = wcnt[wv][dig];
         __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) wcnt[wv][dig] = prev + cnt;
+        if (valid && rank == 0) wcnt[wv][dig] = (bk_cnt_t)(prev + cnt);
         __builtin_amdgcn_wave_barrier();
         if (valid) rnk[idx] = (unsigned short)(prev + rank);
       }
@@ -288,7 +297,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
       for (int q = 0; q < 2; q++) {
         const int d = tid * 2 + q; u32 a2 = ex;
         if (d <= R) gst[d] = (unsigned short)ex;
-        for (int v = 0; v < BK_AT / 64; v++) { const u32 cn = wcnt[v][d]; wcnt[v][d] = a2; a2 += cn; }
+        for (int v = 0; v < BK_AT / 64; v++) { const u32 cn = wcnt[v][d]; wcnt[v][d] = (bk_cnt_t)a2; a2 += cn; }
         ex += t2[q];
       }
       if (tid == 0) gst[R + 1] = (unsigned short)S;
@@ -315,11 +324,11 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     int nbits = 0; while (nbits < 32 && (span >> nbits)) nbits++;
     const int npass = (nbits + 9) / 10, dbits = npass ? (nbits + npass - 1) / npass : 0;
     const int chunk = ((S + BK_AT - 1) / BK_AT) * 64;             // consecutive elements one wave ranks, in rounds of 64
-    u32(*wcnt)[1024] = (u32(*)[1024])scratch;
+    bk_cnt_t(*wcnt)[1024] = (bk_cnt_t(*)[1024])scratch;
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int ps = 0, shift = 0; ps < npass && S > 1; ps++, shift += dbits) {
       const u32 mask = (1u << dbits) - 1u;
-      for (int d = tid; d < (BK_AT / 64) * 1024; d += BK_AT) scratch[d] = 0;
+      for (int d = tid; d < BK_SCR_CNT; d += BK_AT) scratch[d] = 0;
       __syncthreads();
       const int beg = wv * chunk, end = (beg + chunk < S) ? beg + chunk : S;
       for (int base = beg; base < end; base += 64) {
@@ -331,7 +340,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
         u32 prev = 0;
         if (valid) prev = wcnt[wv][dig];
         __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) wcnt[wv][dig] = prev + cnt;
+        if (valid && rank == 0) wcnt[wv][dig] = (bk_cnt_t)(prev + cnt);
         __builtin_amdgcn_wave_barrier();
         if (valid) rnk[idx] = (unsigned short)(prev + rank);
       }
@@ -342,7 +351,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
         for (int q = 0; q < 2; q++) { const int d = tid * 2 + q; u32 s2 = 0; for (int v = 0; v < BK_AT / 64; v++) s2 += wcnt[v][d]; t2[q] = s2; sum += s2; }
         u64 tt; u32 ex = (u32)bk_block_excl_scan(sum, &tt);
 #pragma unroll
-        for (int q = 0; q < 2; q++) { const int d = tid * 2 + q; u32 a = ex; for (int v = 0; v < BK_AT / 64; v++) { const u32 cn = wcnt[v][d]; wcnt[v][d] = a; a += cn; } ex += t2[q]; }
+        for (int q = 0; q < 2; q++) { const int d = tid * 2 + q; u32 a = ex; for (int v = 0; v < BK_AT / 64; v++) { const u32 cn = wcnt[v][d]; wcnt[v][d] = (bk_cnt_t)a; a += cn; } ex += t2[q]; }
       }
       __syncthreads();
       for (int idx = tid; idx < S; idx += BK_AT) {
@@ -703,7 +712,7 @@ __global__ void __launch_bounds__(BK_AT) k_anneal_bucket(WalkArr w, WalkArr o, c
     // few determinants (a bucket creates 13 on average at the bench size, 28 at most): more lanes each -- the phase is the latency
     // of one lane's decode + fetch + sum chain, and a lane with 2 tasks is through sooner than one with 5
     if (nq == n_def) { }
-    else if (hg == 8 && nq - n_def <= BK_AT / 32) BK_HII_PASSES(32)
+    else if ((hg == 8 || hg == 16) && nq - n_def <= BK_AT / 32 && bk_hii_terms(*s_tab) <= BK_HG_TERMS(32)) BK_HII_PASSES(32)
     else if (hg == 8 && nq - n_def <= BK_AT / 16) BK_HII_PASSES(16)
     else if (hg == 8) BK_HII_PASSES(8)
     else if (hg == 16) BK_HII_PASSES(16)

@@ -6,13 +6,32 @@
 #define BK_T 256
 #define BK_PART_STRIDE(B) (((B) + 63) & ~63)             // counters per wave of a partitioning block (ws below)
 #define BK_PART_LDS(B) ((1 + BK_T / 64) * BK_PART_STRIDE(B) * 4)     // dynamic LDS of a kernel that partitions its block's children: splitters + per-wave counters, sized by the buckets there are
-#define BK_CAP_S 2560                 // spawns of one bucket
-#define BK_CAP_R 1536                 // residents of one bucket
-#define BK_CAP_T 3584                 // both
+// Two sizes of bucket.  Default: one block of k_anneal_bucket per CU with the whole LDS.  -DBK_HALF=1: a bucket is half a CU's LDS and two
+// blocks share a CU.  Measured in round 3: a bucket's chain is as long at 575 slots as at 1150 (it is barriers and
+// dependent round trips, not elements), so twice as many buckets took as long each -- 42 us for the launch against 40 -- while the
+// fullest bucket moved from 1.25x to 2.2x the mean and the partition rows doubled.  Kept as a switch for other machines.
+#ifndef BK_HALF
+#define BK_HALF 0
+#endif
+#if BK_HALF
+#define BK_CAP_S 1024                 // spawns of one bucket
+#define BK_CAP_R 768                  // residents of one bucket
+#define BK_CAP_T 1536                 // both
+#define BK_TARGET 575                 // slots per bucket the host aims at (B = nall / BK_TARGET, at most two blocks per CU while that holds)
+#define BK_PER_CU 2
+typedef unsigned short bk_cnt_t;      // digit counters of the in-LDS sort (a bucket's spawns fit 16 bits)
+#else
+#define BK_CAP_S 2560
+#define BK_CAP_R 1536
+#define BK_CAP_T 3584
+#define BK_TARGET 1150                // one block per CU
+#define BK_PER_CU 1
+typedef u32 bk_cnt_t;
+#endif
+#define BK_RESIDENTS_MAX (BK_HALF ? BK_CAP_R * 80 / 100 : 1000)     // boundaries that would put more residents into a bucket are not used
 #define BK_HQ_DEFER 64                // deferred H_ii positions per bucket (13 on average at the bench size; the rest is done in the tail)
 #define BK_CAP_ROWS 2560              // partition blocks (256 children each)
 #define BK_MAXB 1024
-#define BK_TARGET 1150                // slots per bucket the host aims at (B = nall / BK_TARGET, at most one block per CU while that holds)
 #define BK_STOP 0x80000000u           // in the merged-order array (source index: residents [0, R), sorted spawns [R, R + S)): this slot starts a run
 
 // What the bucket tail does itself instead of the side-stream kernels when `on`: death/clone of every resident outside the
@@ -46,7 +65,7 @@ struct BucketArgs {
   const u32 *pos_prev;                 // where kb_prev lay in the list scount was taken from (the pos of that step)
   const u32 *hint; u32 *hint_out;      // about where kb lies in today's list (found when it was made) / the same for kb_out
 };
-#define BK_REBAL_MAXB 256
+#define BK_REBAL_MAXB (256 * BK_PER_CU)
 #define BK_REBAL_SPAWN_COST 1.2        // a spawn against a resident in a bucket's cost.  Its time to publish fits 7.1 + 0.0101 S + 0.0059 R us over the
                                        // buckets of a step, i.e. 1.7; the smaller weight keeps the residents of spawn-poor ranges below the gap sort's 1023
 __device__ __forceinline__ long long bk_bound(const BucketArgs &ba, int b, long long n0) {
@@ -135,7 +154,7 @@ __device__ __forceinline__ void bk_rebalance_block(const BucketArgs &ba, const u
   __syncthreads();
   for (int j = tid; j < B; j += BK_T) {
     const u32 r = s_pn[j + 1] - s_pn[j];
-    if (r > 1000u || ((j == 0 || j == B - 1) && r == 0u)) s_bad = 1;
+    if (r > (u32)BK_RESIDENTS_MAX || ((j == 0 || j == B - 1) && r == 0u)) s_bad = 1;
   }
   __syncthreads();
   const bool bad = s_bad != 0;

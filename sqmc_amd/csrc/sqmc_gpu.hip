@@ -771,8 +771,9 @@ static int choose_boundaries(sqmc_gpu_ctx *c, long long B, long long n_known, Bu
 static inline long long bucket_count(long long nall) {
   static const long long bk_target = getenv("SQMC_BUCKET_TARGET") ? atoll(getenv("SQMC_BUCKET_TARGET")) : BK_TARGET;
   long long B = (nall + bk_target - 1) / bk_target;
-  // one block per CU (its LDS is the bucket): up to 256 blocks run at once; a few blocks more would wait for a whole second round
-  if (B > 256 && nall <= 256 * (long long)(bk_target + bk_target / 4)) B = 256;
+  // BK_PER_CU blocks per CU (their LDS is the bucket): up to 256 BK_PER_CU blocks run at once; a few blocks more would wait for a whole second round
+  const long long conc = 256 * BK_PER_CU;
+  if (B > conc && nall <= conc * (long long)(bk_target + bk_target / 4)) B = conc;
   return B < 1 ? 1 : (B > BK_MAXB ? BK_MAXB : B);
 }
 static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0, bool dev_n, hipEvent_t g0, hipEvent_t g1, hipEvent_t s0, hipEvent_t s1, u64 *cseq,
@@ -1198,8 +1199,23 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed); std::swap(c->w.irk, c->m.irk);
       if (fuse_gate) std::swap(c->d_keys, c->d_keys_alt);
       c->pipeline_next = false; c->bk_retries++; c->head_offsets_done = false; c->shard_y_ok = false; c->shard_x_ready = false;
-      c->kb_B[0] = c->kb_B[1] = c->kb_B[2] = 0; c->scount_B = 0; c->kb_next = c->scount_buf = -1;      // boundaries are learnt anew
-      { static const int hold = getenv("SQMC_BUCKET_HOLDOFF") ? atoi(getenv("SQMC_BUCKET_HOLDOFF")) : 8; c->bk_holdoff = hold; }
+      // The boundaries are learnt anew -- from this attempt: every bucket left its count of spawns, also the ones that gave up (with
+      // equal-residents boundaries the spawn-rich key ranges hold 4x the mean), and the list they were counted in is the input again.
+      static const bool no_learn = getenv("SQMC_BUCKET_NO_RETRY_LEARN") != nullptr;
+      const int B_failed = c->scount_B, set_failed = c->scount_buf;
+      bool learnt = false;
+      if (!no_learn && !c->d_grow && c->comm == nullptr && B_failed > 0 && B_failed <= BK_REBAL_MAXB && n0 >= 16ll * B_failed && !ba.force_retry) {
+        BucketArgs rb; memset(&rb, 0, sizeof(rb));
+        int out = 0; while (out == set_failed) out++;
+        rb.B = B_failed; rb.scount = c->d_bscount;
+        rb.kb_prev = set_failed >= 0 ? c->d_bkb + set_failed * (BK_MAXB + 1) : (const u32 *)nullptr;
+        rb.pos_prev = set_failed >= 0 ? c->d_bpos + c->scount_pos * (BK_MAXB + 1) : (const u32 *)nullptr;
+        rb.kb_out = c->d_bkb + out * (BK_MAXB + 1); rb.hint_out = c->d_bhint + out * (BK_MAXB + 1);
+        hipLaunchKernelGGL(k_bucket_boundaries, dim3(1), dim3(BK_T), 0, st, (const u64 *)c->d_keys, n0, rb);
+        c->kb_B[0] = c->kb_B[1] = c->kb_B[2] = 0; c->kb_B[out] = B_failed; c->kb_next = out; learnt = true;
+      } else { c->kb_B[0] = c->kb_B[1] = c->kb_B[2] = 0; c->kb_next = -1; }
+      c->scount_B = 0; c->scount_buf = -1;
+      { static const int hold = getenv("SQMC_BUCKET_HOLDOFF") ? atoi(getenv("SQMC_BUCKET_HOLDOFF")) : 8; c->bk_holdoff = (learnt && set_failed < 0) ? 1 : hold; }
       return SQMC_INTERNAL_RETRY;
     }
     if (c->h_sc->bk_fill > 850) c->bk_holdoff = 4;         // thin head-room: radix tail for a few steps
