@@ -175,6 +175,7 @@ def main():
             parallelism = "replicas x%d (sharded path unavailable)" % world
     sharded = isinstance(walk, H.ShardedWalk)
     slowest = None
+    shard_split = None
 
     if sharded and not walk.in_library:
         for _ in range(args.equil + args.warmup):
@@ -207,10 +208,13 @@ def main():
         if chain: walk.g.set_chained_runs(True)
         walk.run(args.warmup, keep_stats=False)
         fence()
+        if sharded: walk.g.shard_time_split(reset=True)
         t0 = time.perf_counter()
         stats, totals = walk.run(args.steps, keep_stats=True)
         fence()
         dt = time.perf_counter() - t0
+        # N > 1: where rank 0's host spent the timed steps (head / exchange / tail, and how much of that waiting for the GPU's mail)
+        shard_split = {k: round(v, 2) for k, v in walk.g.shard_time_split()[0].items()} if sharded else None
         nwalk_sum, spawn_sum = float(totals[5]) / (world if sharded else 1), float(totals[15])      # sharded: nwalk is the global count
         e_num, e_den = float((stats[:, 3] * np.sign(stats[:, 2])).sum()), float(np.abs(stats[:, 2]).sum())
         slowest = walk.g.slowest_steps()                   # wall clock of the slowest timed steps: host jitter, reruns
@@ -273,7 +277,8 @@ def main():
                        "projected_energy_Ha": e_num / e_den, "rng": "counter", "parallelism": parallelism,
                        "rccl_ranks": rccl_ranks, "devices": min(world, ndev),
                        "short_list_tail": dict(zip(("bucket_steps", "rerun_through_radix_tail"), tail)),
-                       "slowest_steps_us": slowest, "chained_runs": bool(not sharded and not os.environ.get('SQMC_BENCH_NO_CHAIN'))},
+                       "slowest_steps_us": slowest, "chained_runs": bool(not sharded and not os.environ.get('SQMC_BENCH_NO_CHAIN')),
+                       "sharded_step_host_split_us_rank0": shard_split},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic_of(dom)[0], "traffic_detail": traffic_of(dom)[1], "ms_per_launch": dom_ms,
                          "algorithmic_bytes_per_launch": dom_bytes,

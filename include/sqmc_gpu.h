@@ -285,6 +285,13 @@ int sqmc_gpu_comm_init(sqmc_gpu_ctx *ctx, const uint8_t id[SQMC_COMM_ID_BYTES]);
 int sqmc_gpu_comm_size(sqmc_gpu_ctx *ctx, int32_t *nranks);
 int sqmc_gpu_shard_step(sqmc_gpu_ctx *ctx, const sqmc_step_params *p, double out_stats[16]);
 int sqmc_gpu_shard_run(sqmc_gpu_ctx *ctx, sqmc_popctl *pc, int64_t nsteps, double *stats /* nsteps*16 or NULL */, double totals[16]);
+/* diagnostics: where the HOST spent the wall clock of the sqmc_gpu_shard_step calls since the last reset, in microseconds summed over
+ * *steps completed steps: us[0] head (gate, spawn and death/clone enqueued or taken over from the pipelined head, until the child count is
+ * known), us[1] exchange (projection all-reduce, bucketing by owner, pack, all-gather of the send counts until the host has read them,
+ * grouped send/receive enqueued), us[2] tail (unpack, sort and annihilation enqueued, until the all-reduced sums are read; the next
+ * step's head is enqueued in here), us[3] the part of all three spent waiting for a word the GPU writes.  What a scaling run needs to
+ * explain itself: kernel time hides inside the waits, link latency inside us[1] and us[2]. */
+int sqmc_gpu_shard_time_split(sqmc_gpu_ctx *ctx, double us[4], int64_t *steps, int32_t reset);
 
 /* RNG state of the REPLAY stream (savern / setrn, rannyu.f90:11-21,77-87) */
 /* How many steps took the short-list tail (block-local partition + one annihilation kernel per key range, no global sort) and

@@ -26,7 +26,7 @@ EXPORTS = [
     "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_set_hf_to_psit", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
     "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_annihilate", "sqmc_gpu_det_owner", "sqmc_gpu_set_owner_hash", "sqmc_gpu_shard_config",
     "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init", "sqmc_gpu_comm_size",
-    "sqmc_gpu_shard_step", "sqmc_gpu_shard_run", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_tail_stats", "sqmc_gpu_slowest_steps", "sqmc_gpu_set_chained_runs", "sqmc_gpu_spmv_prepare",
+    "sqmc_gpu_shard_step", "sqmc_gpu_shard_run", "sqmc_gpu_shard_time_split", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_tail_stats", "sqmc_gpu_slowest_steps", "sqmc_gpu_set_chained_runs", "sqmc_gpu_spmv_prepare",
     "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_build_spmv_plan", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
     "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_hci_connections_slice", "sqmc_gpu_hci_pt2", "sqmc_gpu_hci_set_active_space", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
 ]
@@ -318,6 +318,14 @@ class GpuChem:
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         self.L.sqmc_gpu_comm_init.argtypes = [C.c_void_p, C.c_void_p]
         _chk(self.L.sqmc_gpu_comm_init(self.h, buf))
+
+    def shard_time_split(self, reset=False):
+        """host wall clock of the in-library sharded steps since the last reset: ({head, exchange, tail, waiting_for_gpu} in us per step, steps)"""
+        us, n = (C.c_double * 4)(), C.c_int64()
+        self.L.sqmc_gpu_shard_time_split.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        _chk(self.L.sqmc_gpu_shard_time_split(self.h, us, C.byref(n), 1 if reset else 0))
+        k = max(n.value, 1)
+        return {"head_us": us[0] / k, "exchange_us": us[1] / k, "tail_us": us[2] / k, "of_which_waiting_for_the_gpu_us": us[3] / k}, n.value
 
     def tail_stats(self):
         """(steps that took the short-list bucket tail, how many of them were re-run through the radix tail)"""

@@ -51,6 +51,8 @@ __global__ void __launch_bounds__(TPB) k_csr_fill_transposed(const u64 *__restri
 }
 
 #define SPMV_ROWS_PER_BLOCK 4
+// PROBE (measurement only, tools/bench_hci.py): every lane gathers from the same 512 bytes of x -- what the product would cost if the gather were free
+template <int PROBE>
 __global__ void __launch_bounds__(64 * SPMV_ROWS_PER_BLOCK) k_spmv_wave(const int *__restrict__ ptr, const int *__restrict__ col, const double *__restrict__ val,
                                                                         const double *__restrict__ x, double *__restrict__ y, long long n) {
   const long long row = (long long)blockIdx.x * SPMV_ROWS_PER_BLOCK + (threadIdx.x >> 6);
@@ -58,7 +60,7 @@ __global__ void __launch_bounds__(64 * SPMV_ROWS_PER_BLOCK) k_spmv_wave(const in
   if (row >= n) return;
   const int b = ptr[row], e = ptr[row + 1];
   double s = 0.0;
-  for (int k = b + lane; k < e; k += 64) s += val[k] * x[col[k]];
+  for (int k = b + lane; k < e; k += 64) s += val[k] * x[PROBE ? (col[k] & 63) : col[k]];
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   if (lane == 0) y[row] = s;
 }

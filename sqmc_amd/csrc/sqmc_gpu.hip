@@ -215,6 +215,7 @@ struct sqmc_gpu_ctx {
   BucketArgs head_ba; long long last_nall;      // partition already done by the head's k_spawn (B > 0), and the length of the last sorted list (sizes the next one)
   int bk_holdoff;             // steps for which the bucket tail stays off (after a bucket overflowed or came close)
   long long bk_steps, bk_retries;
+  double sh_us[4]; long long sh_steps;      // host wall clock of the in-library sharded steps: head, exchange, tail, of which waiting for the GPU's mail (sqmc_gpu_shard_time_split)
   // hf_to_psit (psit_kernels.h)
   HbHost *hb_host;
   long long dbg_n0, dbg_nall;          // sizes of the last step's list in front of the merge (sqmc_gpu_debug_premerge)
@@ -703,7 +704,15 @@ static int comm_allreduce_stats(sqmc_gpu_ctx *c);
 // A stream that neither drains nor delivers within SQMC_MAIL_TIMEOUT_S seconds (default 300; a step takes milliseconds) is
 // reported as hipErrorLaunchTimeOut instead of spinning for ever: a peer rank that never enters its collective must not
 // turn into a silent hang of the whole job.
+static inline double now_us() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e6 * (double)t.tv_sec + 1e-3 * (double)t.tv_nsec; }
+static double *g_mail_wait_us = nullptr;      // sqmc_gpu_shard_step: where the time spent in here is added up (sqmc_gpu_shard_time_split)
+static int wait_mail_(volatile u64 *flag, u64 expect, hipStream_t st);
 static int wait_mail(volatile u64 *flag, u64 expect, hipStream_t st) {
+  if (!g_mail_wait_us) return wait_mail_(flag, expect, st);
+  const double t0 = now_us(); const int r = wait_mail_(flag, expect, st); *g_mail_wait_us += now_us() - t0;
+  return r;
+}
+static int wait_mail_(volatile u64 *flag, u64 expect, hipStream_t st) {
   static const double limit_s = getenv("SQMC_MAIL_TIMEOUT_S") ? atof(getenv("SQMC_MAIL_TIMEOUT_S")) : 300.0;
   struct timespec t0; bool timed = false;
   for (unsigned long it = 1;; it++) {

@@ -41,6 +41,15 @@ for _ in range(reps):
     L.sqmc_gpu_spmv_apply(plan.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), 1)
 torch.cuda.synchronize(); t4 = time.perf_counter()
 ms = (t4 - t3) / reps * 1e3
+os.environ["SQMC_SPMV_PROBE_NO_GATHER"] = "1"          # what the product would cost if the gather of x were free (wrong sums: timing only)
+yp = torch.empty_like(x)
+for _ in range(3):
+    L.sqmc_gpu_spmv_apply(plan.h, C.c_void_p(x.data_ptr()), C.c_void_p(yp.data_ptr()), 1)
+tp = time.perf_counter()
+for _ in range(reps):
+    L.sqmc_gpu_spmv_apply(plan.h, C.c_void_p(x.data_ptr()), C.c_void_p(yp.data_ptr()), 1)
+ms_probe = (time.perf_counter() - tp) / reps * 1e3
+os.environ.pop("SQMC_SPMV_PROBE_NO_GATHER")
 # the other layout (stored triangle + fp64 atomics for the transposed half), measured on the same matrix
 os.environ["SQMC_SPMV_UPPER_ATOMIC"] = "1"
 plan2 = sqmc_amd.SpmvPlan(counts, idx, val)
@@ -56,6 +65,6 @@ err_atomic = float((y2 - y).abs().max() / y.abs().max())
 plan2.close()
 alg = 20.0 * nnz + 20.0 * n            # 20 B per stored nonzero + 20 B per row
 print(json.dumps({"hci_variational_s": t2 - t1, "setup_s": t1 - t0, "ndets_history": hist, "e_var": float(e[0]), "eps_var": args.eps_var, "pt2_eps": args.eps_pt, "pt2_slices": args.pt_slices, "pt2_delta_e": de_pt, "pt2_connected_dets": n_conn, "pt2_s": t2b - t2, "e_total": float(e[0]) + de_pt,
-                  "build_sparse_ham_s": tb - ta, "n": n, "nnz_upper": nnz, "spmv_ms": ms, "spmv_upper_atomic_ms": ms_atomic, "spmv_upper_atomic_rel_dev": err_atomic,
+                  "build_sparse_ham_s": tb - ta, "n": n, "nnz_upper": nnz, "spmv_ms": ms, "spmv_ms_if_the_gather_were_free": ms_probe, "spmv_upper_atomic_ms": ms_atomic, "spmv_upper_atomic_rel_dev": err_atomic,
                   "spmv_algorithmic_GBs": alg / (ms * 1e-3) / 1e9, "spmv_frac_of_8TBs": alg / (ms * 1e-3) / 1e9 / 8000.0,
                   "spmv_moved_GBs_full_csr": (12.0 * nnz_full + 8.0 * nnz_full + 20.0 * n) / (ms * 1e-3) / 1e9}))
