@@ -321,6 +321,13 @@ int sqmc_gpu_spmv_prepare(int64_t n, const int64_t *row_counts, const int64_t *i
                           const double *values, sqmc_spmv_plan **plan);
 int sqmc_gpu_spmv_apply(sqmc_spmv_plan *plan, const double *x, double *y, int on_device);
 int sqmc_gpu_spmv_free(sqmc_spmv_plan *plan);
+/* The lowest n_states eigenpairs of the plan's matrix by the diagonally preconditioned Davidson of davidson_sparse
+ * (more_tools.f90:2018-2244; davidson_sparse_single :3056-3230), every vector resident on the device.  diag[n]: the diagonal (the
+ * preconditioner, as sqmc_gpu_build_spmv_plan returns it); v0: n x n_states start vectors, column-major (initial_vector), or NULL for
+ * unit vectors on the first rows (more_tools.f90:3113-3114: the HF determinant when it is listed first); tol: the reference's
+ * epsilon = 1e-10 on the eigenvalues.  Out: evals[n_states], evecs[n x n_states] column-major (largest component of the small
+ * problem's eigenvector positive), *n_matvec (may be NULL) the products it took. */
+int sqmc_gpu_davidson(sqmc_spmv_plan *plan, const double *diag, int32_t n_states, const double *v0, double tol, double *evals, double *evecs, int32_t *n_matvec);
 /* generate_sparse_ham_chem_upper_triangular (chemistry.f90:7639-8010) and the plan of the Davidson
  * matvec in one call, with the matrix never leaving the GPU: for a determinant list sorted by
  * (up,dn) the Hamiltonian is built and expanded to the full symmetric CSR on the device; diag[n]

@@ -458,14 +458,12 @@ def hci_variational(sysm, eps_var, eps_sched=(), n_states=1, max_iters=50, log=N
 # (semistoch.f90:27-133); initial population as do_walk.f90:1245-1366.
 # ------------------------------------------------------------------------------------
 def _truncate_at_csf(c_sorted, n_keep, eps=1e-10):
-    """semistoch.f90:331-345: cut where |c| changes, never inside a group of equal |c|."""
-    prev = 0.0
-    for i, v in enumerate(c_sorted):
-        if abs(abs(prev) - abs(v)) > eps:
-            prev = v
-            if i + 1 > n_keep:
-                return i
-    return len(c_sorted)
+    """semistoch.f90:331-345 (orc_truncate_at_csf, sqmc_oracle_setup.c)"""
+    L = lib()
+    L.orc_truncate_at_csf.restype = C.c_int64
+    L.orc_truncate_at_csf.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_double]
+    a = np.ascontiguousarray(c_sorted, np.float64)
+    return int(L.orc_truncate_at_csf(_p(a), len(a), int(n_keep), float(eps)))
 
 
 class WalkSetup:
@@ -493,13 +491,57 @@ def _reps(cu, cd):
     return np.array([k[0] for k in keys], np.uint64), np.array([k[1] for k in keys], np.uint64)
 
 
+def _take(ptr, n, dtype):
+    """copy n items out of a malloc'ed C array and free it"""
+    ct = {np.uint64: C.c_uint64, np.float64: C.c_double}[dtype]
+    out = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(max(n, 1),))[:n].copy() if n else np.zeros(0, dtype)
+    lib().orc_free(ptr)
+    return out
+
+
+def _cut_and_connect(kind, sysm, up, dn, c, e0, n_truncate_trial_wf, size_deterministic, tau, rediagonalize, eigenvector=True):
+    """What every system's set-up does once it holds a wave function (up, dn, c) on a sorted determinant list: Psi_T and the
+    deterministic space by |c| (cut at CSF boundaries), optional rediagonalisation of Psi_T in its own space (semistoch.f90:575,
+    706-712), the projector -tau H on the deterministic space (do_walk.f90:954-962) and the local-energy pieces of C(T)
+    (orc_psi_t_connected).  kind: 0 chem, 1 heg, 2 hubbard2."""
+    import math
+    s = WalkSetup()
+    if eigenvector and c[np.argmax(np.abs(c))] < 0:          # an eigenvector's overall sign is the solver's: largest component positive
+        c = -c
+    by = np.argsort(-np.abs(c), kind="stable")
+    up_s, dn_s, c_s = up[by], dn[by], c[by]
+    n_t, n_i = _truncate_at_csf(c_s, n_truncate_trial_wf), _truncate_at_csf(c_s, size_deterministic)
+    norm = 1.0 / math.sqrt(math.fsum(float(x) * float(x) for x in c_s[:n_t]))
+    s.psi_up, s.psi_dn, s.psi_c = up_s[:n_t].copy(), dn_s[:n_t].copy(), c_s[:n_t] * norm
+    if rediagonalize:
+        o = sort_dets(s.psi_up, s.psi_dn)
+        s.psi_up, s.psi_dn = s.psi_up[o], s.psi_dn[o]
+        counts, idx, val = sysm.build_sparse_ham(s.psi_up, s.psi_dn)
+        wr, vr = _lowest_in_space(counts, idx, val, s.psi_c[o])
+        cr = vr[:, 0]
+        s.psi_c, s.e_psi_t = (-cr if cr[np.argmax(np.abs(cr))] < 0 else cr), float(wr[0])
+    o = sort_dets(up_s[:n_i], dn_s[:n_i])
+    s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
+    s.tau, s.e_var = tau, float(e0)
+    pc, pi, pv = sysm.build_sparse_ham(s.imp_up, s.imp_dn)
+    s.prj_counts, s.prj_indices, s.prj_values = pc, pi, -s.tau * pv
+    L = lib()
+    L.orc_psi_t_connected.restype = C.c_int64
+    L.orc_psi_t_connected.argtypes = [C.c_int, C.c_void_p, C.c_int64] + [C.c_void_p] * 7
+    pu, pd, pn, pe = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    psi_up, psi_dn, psi_c = (np.ascontiguousarray(s.psi_up, np.uint64), np.ascontiguousarray(s.psi_dn, np.uint64), np.ascontiguousarray(s.psi_c, np.float64))
+    handle = sysm.h
+    n_ct = int(L.orc_psi_t_connected(kind, handle, len(psi_c), _p(psi_up), _p(psi_dn), _p(psi_c), C.byref(pu), C.byref(pd), C.byref(pn), C.byref(pe)))
+    s.ct_up, s.ct_dn, s.ct_num, s.ct_den = _take(pu, n_ct, np.uint64), _take(pd, n_ct, np.uint64), _take(pn, n_ct, np.float64), _take(pe, n_ct, np.float64)
+    s.e_trial0 = float(math.fsum(a * b for a, b in zip(s.ct_num, s.ct_den)) / math.fsum(b * b for b in s.ct_den))
+    return s
+
+
 def setup_walk(sysm, n_truncate_trial_wf=100, size_deterministic=1000, tau_multiplier=0.1, coeffs="eig", rediagonalize=False):
     """Returns Psi_T, C(T), deterministic space + projector (-tau*H), tau.
     coeffs="eig": lowest eigenvector of H in {HF + connections} (the reference's scheme);
     coeffs="pt1": first-order perturbation coefficients H_i0/(H_00-H_ii), which involve no
     eigensolver/BLAS and are therefore bit-reproducible on any machine (golden fixtures)."""
-    import math
-    s = WalkSetup()
     ts = bool(sysm.s.time_sym)
     cu, cd, el = sysm.connected(sysm.hf_up, sysm.hf_dn, with_elems=(coeffs == "pt1"))
     if ts:      # time-reversal symmetry: work with the representatives up <= dn (chemistry.f90:7346-7386)
@@ -511,56 +553,13 @@ def setup_walk(sysm, n_truncate_trial_wf=100, size_deterministic=1000, tau_multi
         h00 = sysm.ham(sysm.hf_up, sysm.hf_dn, sysm.hf_up, sysm.hf_dn)
         c = np.array([1.0 if (int(a), int(b)) == (sysm.hf_up, sysm.hf_dn) else h / (h00 - sysm.ham(int(a), int(b), int(a), int(b)))
                       for a, b, h in zip(up, dn, el[order])])
-        w = np.array([h00])
+        e0 = h00
     else:
         counts, idx, val = sysm.build_sparse_ham(up, dn)
         w, v = davidson_sparse(counts, idx, val, 1)          # starts on the first (= HF) determinant, more_tools.f90:3113-3114
-        c = v[:, 0]
-        if c[np.argmax(np.abs(c))] < 0:
-            c = -c
-    by = np.argsort(-np.abs(c), kind="stable")
-    up_s, dn_s, c_s = up[by], dn[by], c[by]
-    n_t = _truncate_at_csf(c_s, n_truncate_trial_wf)
-    n_i = _truncate_at_csf(c_s, size_deterministic)
-    norm = 1.0 / math.sqrt(math.fsum(float(x) * float(x) for x in c_s[:n_t]))
-    s.psi_up, s.psi_dn, s.psi_c = up_s[:n_t].copy(), dn_s[:n_t].copy(), c_s[:n_t] * norm
-    if rediagonalize:
-        # "Finally, rediagonalize" (semistoch.f90:575, 706-712): the trial wave function is the lowest eigenvector of H among its own
-        # determinants, in label order -- what the hf_to_psit projector assumes ((H Psi_T)_i = E c_i on every determinant of Psi_T)
-        o = sort_dets(s.psi_up, s.psi_dn)
-        s.psi_up, s.psi_dn = s.psi_up[o], s.psi_dn[o]
-        counts, idx, val = sysm.build_sparse_ham(s.psi_up, s.psi_dn)
-        wr, vr = _lowest_in_space(counts, idx, val, s.psi_c[o])
-        cr = vr[:, 0]
-        if cr[np.argmax(np.abs(cr))] < 0:
-            cr = -cr
-        s.psi_c, s.e_psi_t = cr, float(wr[0])
-    o = sort_dets(up_s[:n_i], dn_s[:n_i])
-    s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
+        c, e0 = v[:, 0], w[0]
     lo, hi = sysm.diag_lowest_highest()
-    s.tau = tau_multiplier / (hi - lo)
-    s.e_var = float(w[0])
-    # projector: -tau * H on the deterministic space (do_walk.f90:954-962)
-    pc, pi, pv = sysm.build_sparse_ham(s.imp_up, s.imp_dn)
-    s.prj_counts, s.prj_indices, s.prj_values = pc, pi, -s.tau * pv
-    # C(T)
-    acc = {}
-    psi_index = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(s.psi_up, s.psi_dn))}
-    for j in range(n_t):
-        pu, pd = int(s.psi_up[j]), int(s.psi_dn[j])
-        xu, xd, el = sysm.connected(pu, pd, with_elems=not ts, cap=40000)
-        if ts:
-            xu, xd = _reps(xu, xd)
-            el = np.array([sysm.ham(int(a), int(b), pu, pd) for a, b in zip(xu, xd)])
-        for a, b, h in zip(xu.tolist(), xd.tolist(), el.tolist()):
-            acc[(a, b)] = acc.get((a, b), 0.0) + h * s.psi_c[j]
-    keys = sorted(acc)
-    s.ct_up = np.array([k[0] for k in keys], np.uint64)
-    s.ct_dn = np.array([k[1] for k in keys], np.uint64)
-    s.ct_num = np.array([acc[k] for k in keys])
-    s.ct_den = np.array([s.psi_c[psi_index[k]] if k in psi_index else 0.0 for k in keys])
-    s.e_trial0 = float(math.fsum(a * b for a, b in zip(s.ct_num, s.ct_den)) / math.fsum(b * b for b in s.ct_den))
-    return s
+    return _cut_and_connect(0, sysm, up, dn, c, e0, n_truncate_trial_wf, size_deterministic, tau_multiplier / (hi - lo), rediagonalize, eigenvector=(coeffs != "pt1"))
 
 
 def _initial_population(s, w_abs_gen_begin, r_initiator, initiator_power, psit=None):
@@ -892,50 +891,13 @@ def setup_walk_heg(hsys, size_deterministic=500, tau_multiplier=0.1, n_truncate_
     """HEG walk set-up: Psi_T = the largest-|c| determinants of the ground state in {HF + its
     double excitations} (n_truncate_trial_wf = 1: HF alone, the usual choice for a closed shell),
     deterministic space = the size_deterministic largest, C(T) = connections of Psi_T."""
-    import math
-    s = WalkSetup()
     cu, cd, _ = hsys.connected(hsys.hf_up, hsys.hf_dn, with_elems=False)
     order = sort_dets(cu, cd)
     up, dn = cu[order], cd[order]
     counts, idx, val = hsys.build_sparse_ham(up, dn)
     w, v = davidson_sparse(counts, idx, val, 1)
-    c = v[:, 0]
-    if c[np.argmax(np.abs(c))] < 0:
-        c = -c
-    by = np.argsort(-np.abs(c), kind="stable")
-    up_s, dn_s, c_s = up[by], dn[by], c[by]
-    n_t, n_i = _truncate_at_csf(c_s, n_truncate_trial_wf), _truncate_at_csf(c_s, size_deterministic)
-    norm = 1.0 / math.sqrt(math.fsum(float(x) * float(x) for x in c_s[:n_t]))
-    s.psi_up, s.psi_dn, s.psi_c = up_s[:n_t].copy(), dn_s[:n_t].copy(), c_s[:n_t] * norm
-    if rediagonalize:
-        # "Finally, rediagonalize" (semistoch.f90:575, 706-712): the trial wave function is the lowest eigenvector of H among its own
-        # determinants, in label order -- what the hf_to_psit projector assumes ((H Psi_T)_i = E c_i on every determinant of Psi_T)
-        o = sort_dets(s.psi_up, s.psi_dn)
-        s.psi_up, s.psi_dn = s.psi_up[o], s.psi_dn[o]
-        counts, idx, val = hsys.build_sparse_ham(s.psi_up, s.psi_dn)
-        wr, vr = _lowest_in_space(counts, idx, val, s.psi_c[o])
-        cr = vr[:, 0]
-        if cr[np.argmax(np.abs(cr))] < 0:
-            cr = -cr
-        s.psi_c, s.e_psi_t = cr, float(wr[0])
-    o = sort_dets(up_s[:n_i], dn_s[:n_i])
-    s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
     lo, hi = hsys.diag_lowest_highest()
-    s.tau, s.e_var = tau_multiplier / (hi - lo), float(w[0])
-    pc, pi, pv = hsys.build_sparse_ham(s.imp_up, s.imp_dn)
-    s.prj_counts, s.prj_indices, s.prj_values = pc, pi, -s.tau * pv
-    acc = {}
-    psi_index = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(s.psi_up, s.psi_dn))}
-    for j in range(n_t):
-        xu, xd, el = hsys.connected(int(s.psi_up[j]), int(s.psi_dn[j]), with_elems=True, cap=100000)
-        for a, b, h in zip(xu.tolist(), xd.tolist(), el.tolist()):
-            acc[(a, b)] = acc.get((a, b), 0.0) + h * s.psi_c[j]
-    keys = sorted(acc)
-    s.ct_up = np.array([k[0] for k in keys], np.uint64); s.ct_dn = np.array([k[1] for k in keys], np.uint64)
-    s.ct_num = np.array([acc[k] for k in keys])
-    s.ct_den = np.array([s.psi_c[psi_index[k]] if k in psi_index else 0.0 for k in keys])
-    s.e_trial0 = float(math.fsum(a * b for a, b in zip(s.ct_num, s.ct_den)) / math.fsum(b * b for b in s.ct_den))
-    return s
+    return _cut_and_connect(1, hsys, up, dn, v[:, 0], w[0], n_truncate_trial_wf, size_deterministic, tau_multiplier / (hi - lo), rediagonalize)
 
 
 class Hub(C.Structure):
@@ -1036,36 +998,10 @@ def setup_walk_hubbard(hsys, size_deterministic=500, tau_multiplier=0.5, n_trunc
     last branch, hubbard.f90:4514-4527): ground state of H in {start det + n_levels hops};
     Psi_T = its n_truncate_trial_wf largest determinants, deterministic space = the
     size_deterministic largest, C(T) = the connections of Psi_T with sum_j H_ij c_j."""
-    import math
-    s = WalkSetup()
     up, dn = hsys.first_order_space(n_levels)
     counts, idx, val = hsys.build_sparse_ham(up, dn)
     w, v = davidson_sparse(counts, idx, val, 1)
-    c = v[:, 0]
-    if c[np.argmax(np.abs(c))] < 0:
-        c = -c
-    by = np.argsort(-np.abs(c), kind="stable")
-    up_s, dn_s, c_s = up[by], dn[by], c[by]
-    n_t, n_i = _truncate_at_csf(c_s, n_truncate_trial_wf), _truncate_at_csf(c_s, size_deterministic)
-    norm = 1.0 / math.sqrt(math.fsum(float(x) * float(x) for x in c_s[:n_t]))
-    s.psi_up, s.psi_dn, s.psi_c = up_s[:n_t].copy(), dn_s[:n_t].copy(), c_s[:n_t] * norm
-    o = sort_dets(up_s[:n_i], dn_s[:n_i])
-    s.imp_up, s.imp_dn = up_s[:n_i][o].copy(), dn_s[:n_i][o].copy()
-    s.tau, s.e_var = tau_multiplier / hsys.spectral_range_bound(), float(w[0])
-    pc, pi, pv = hsys.build_sparse_ham(s.imp_up, s.imp_dn)
-    s.prj_counts, s.prj_indices, s.prj_values = pc, pi, -s.tau * pv
-    acc = {}
-    psi_index = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(s.psi_up, s.psi_dn))}
-    for j in range(n_t):
-        xu, xd, el = hsys.connected(int(s.psi_up[j]), int(s.psi_dn[j]), with_elems=True)
-        for a, b, h in zip(xu.tolist(), xd.tolist(), el.tolist()):
-            acc[(a, b)] = acc.get((a, b), 0.0) + h * s.psi_c[j]
-    keys = sorted(acc)
-    s.ct_up = np.array([k[0] for k in keys], np.uint64); s.ct_dn = np.array([k[1] for k in keys], np.uint64)
-    s.ct_num = np.array([acc[k] for k in keys])
-    s.ct_den = np.array([s.psi_c[psi_index[k]] if k in psi_index else 0.0 for k in keys])
-    s.e_trial0 = float(math.fsum(a * b for a, b in zip(s.ct_num, s.ct_den)) / math.fsum(b * b for b in s.ct_den))
-    return s
+    return _cut_and_connect(2, hsys, up, dn, v[:, 0], w[0], n_truncate_trial_wf, size_deterministic, tau_multiplier / hsys.spectral_range_bound(), False)
 
 
 def hci_pt2(sysm, up, dn, coeffs, e_var, eps_pt):

@@ -1594,3 +1594,6 @@ int64_t orc_build_sparse_ham_hubbard(const orc_hub *h, int64_t n, const det_t *u
 
 /* ==================================================================== the driver around the step */
 #include "sqmc_oracle_ctl.c"
+
+/* ==================================================================== the set-up in front of the walk */
+#include "sqmc_oracle_setup.c"

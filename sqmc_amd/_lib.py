@@ -26,7 +26,7 @@ EXPORTS = [
     "sqmc_gpu_scale_projector", "sqmc_gpu_set_ct_table", "sqmc_gpu_set_hf_to_psit", "sqmc_gpu_upload_walkers", "sqmc_gpu_num_walkers",
     "sqmc_gpu_download_walkers", "sqmc_gpu_step", "sqmc_gpu_run", "sqmc_gpu_annihilate", "sqmc_gpu_det_owner", "sqmc_gpu_set_owner_hash", "sqmc_gpu_shard_config",
     "sqmc_gpu_shard_begin", "sqmc_gpu_shard_pack", "sqmc_gpu_shard_finish", "sqmc_gpu_comm_unique_id", "sqmc_gpu_comm_init", "sqmc_gpu_comm_size",
-    "sqmc_gpu_shard_step", "sqmc_gpu_shard_run", "sqmc_gpu_shard_time_split", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_tail_stats", "sqmc_gpu_slowest_steps", "sqmc_gpu_set_chained_runs", "sqmc_gpu_spmv_prepare",
+    "sqmc_gpu_shard_step", "sqmc_gpu_shard_run", "sqmc_gpu_shard_time_split", "sqmc_gpu_get_rng", "sqmc_gpu_set_rng", "sqmc_gpu_tail_stats", "sqmc_gpu_slowest_steps", "sqmc_gpu_set_chained_runs", "sqmc_gpu_spmv_prepare", "sqmc_gpu_davidson",
     "sqmc_gpu_spmv_apply", "sqmc_gpu_spmv_free", "sqmc_gpu_build_spmv_plan", "sqmc_gpu_spmv_sym_upper", "sqmc_gpu_hamiltonian_batch",
     "sqmc_gpu_propose_batch", "sqmc_gpu_hamiltonian_chem_batch", "sqmc_gpu_build_sparse_ham", "sqmc_gpu_hci_connections", "sqmc_gpu_hci_connections_slice", "sqmc_gpu_hci_pt2", "sqmc_gpu_hci_set_active_space", "sqmc_gpu_free", "sqmc_gpu_set_timing", "sqmc_gpu_get_timing",
 ]
@@ -543,6 +543,15 @@ class SpmvPlan:
         x = _f64(x); y = np.zeros(self.n)
         _chk(self.L.sqmc_gpu_spmv_apply(self.h, _p(x), _p(y), 0))
         return y
+
+    def davidson(self, diag, k=1, v0=None, tol=1e-10):
+        """sqmc_gpu_davidson: lowest k eigenpairs, basis and products resident on the device.  Returns (eigenvalues[k], vectors[n, k], matvecs)"""
+        d = _f64(diag)
+        ev = np.zeros(k); X = np.zeros((k, self.n)); nm = C.c_int32()
+        s = None if v0 is None else np.ascontiguousarray(np.asarray(v0, float).reshape(self.n, -1)[:, :k].T)       # column-major n x k
+        self.L.sqmc_gpu_davidson.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(self.L.sqmc_gpu_davidson(self.h, _p(d), int(k), None if s is None else _p(s), float(tol), _p(ev), _p(X), C.byref(nm)))
+        return ev, np.ascontiguousarray(X.T), nm.value
 
     def close(self):
         if self.h:

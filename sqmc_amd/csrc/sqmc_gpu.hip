@@ -1499,6 +1499,7 @@ int sqmc_gpu_debug_premerge(sqmc_gpu_ctx *c, int64_t cap, int64_t *n0, int64_t *
 
 #include "abi_shard.inc"
 #include "abi_doors.inc"
+#include "davidson.inc"
 #include "heatbath_setup.inc"
 
 }  // extern "C"

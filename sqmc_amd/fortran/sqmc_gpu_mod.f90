@@ -16,7 +16,7 @@ module sqmc_gpu_mod
   public :: sqmc_gpu_hci_connections, sqmc_gpu_free, sqmc_gpu_set_timing, sqmc_gpu_get_timing
   public :: sqmc_gpu_det_owner, sqmc_gpu_shard_config, sqmc_gpu_shard_begin, sqmc_gpu_shard_pack, sqmc_gpu_shard_finish
   public :: sqmc_gpu_annihilate, sqmc_gpu_build_spmv_plan, sqmc_gpu_hci_connections_slice
-  public :: sqmc_gpu_comm_unique_id, sqmc_gpu_comm_init, sqmc_gpu_comm_size, sqmc_gpu_set_owner_hash, sqmc_gpu_tail_stats, sqmc_gpu_slowest_steps, sqmc_gpu_set_chained_runs, sqmc_gpu_hci_pt2, sqmc_gpu_hci_set_active_space, sqmc_gpu_set_heatbath_tables, sqmc_gpu_propose_heatbath_batch, sqmc_heatbath_tables, sqmc_gpu_shard_step, sqmc_gpu_shard_run, sqmc_gpu_shard_time_split
+  public :: sqmc_gpu_comm_unique_id, sqmc_gpu_comm_init, sqmc_gpu_comm_size, sqmc_gpu_set_owner_hash, sqmc_gpu_tail_stats, sqmc_gpu_slowest_steps, sqmc_gpu_set_chained_runs, sqmc_gpu_hci_pt2, sqmc_gpu_hci_set_active_space, sqmc_gpu_set_heatbath_tables, sqmc_gpu_propose_heatbath_batch, sqmc_heatbath_tables, sqmc_gpu_shard_step, sqmc_gpu_shard_run, sqmc_gpu_shard_time_split, sqmc_gpu_davidson
   public :: sqmc_gpu_set_hf_to_psit, sqmc_gpu_setup_efficient_heatbath, sqmc_gpu_get_heatbath_tables
   public :: sqmc_gpu_check
 
@@ -103,6 +103,10 @@ module sqmc_gpu_mod
     end function
     integer(c_int) function sqmc_gpu_set_owner_hash(ctx, mode) bind(C, name='sqmc_gpu_set_owner_hash')
       import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: mode
+    end function
+    integer(c_int) function sqmc_gpu_davidson(plan, diag, n_states, v0, tol, evals, evecs, n_matvec) bind(C, name='sqmc_gpu_davidson')
+      import; type(c_ptr), value :: plan; real(c_double), intent(in) :: diag(*); integer(c_int32_t), value :: n_states
+      type(c_ptr), value :: v0; real(c_double), value :: tol; real(c_double), intent(out) :: evals(*), evecs(*); integer(c_int32_t), intent(out) :: n_matvec
     end function
     integer(c_int) function sqmc_gpu_shard_time_split(ctx, us, steps, reset) bind(C, name='sqmc_gpu_shard_time_split')
       import; type(c_ptr), value :: ctx; real(c_double), intent(out) :: us(4); integer(c_int64_t), intent(out) :: steps; integer(c_int32_t), value :: reset

@@ -281,76 +281,10 @@ class ChemHost:
 
 # ----------------------------------------------------------------------------- Davidson
 def davidson_lowest(plan, diag, k=1, v0=None, tol=1e-10):
-    """Lowest k eigenpairs with the GPU matvec, following the reference's own iteration so that
-    the SAME state is tracked (davidson_sparse, more_tools.f90:2018-2244; one-state twin
-    davidson_sparse_single :3056-3230).  Start: v0 (Gram-Schmidt in order) or unit vectors on the
-    first k rows; per sweep one correction vector per state, (H w - e w)/(e - H_ii) with -1 where
-    the denominator vanishes, orthogonalised against the whole basis; the small Krylov matrix is
-    diagonalised on the host after every k additions; stop when the eigenvalues move by less than
-    tol (epsilon = 1e-10, more_tools.f90:73) or the summed squared correction norms fall below
-    1e-12; the 50-vectors-per-state basis is recycled from the current best vectors.  A start in
-    one symmetry sector stays there: a generic "lowest eigenvalue" solver would not."""
-    n = len(diag)
-    if n == 1:
-        return np.array([diag[0]]), np.ones((1, 1))
-    iterations = min(n, 50)
-    v = np.zeros((n, k * iterations)); Hv = np.zeros_like(v)
-    if v0 is not None:
-        iv = np.asarray(v0, float).reshape(n, -1)
-        for i in range(k):
-            v[:, i] = iv[:, i] / np.sqrt(np.dot(iv[:, i], iv[:, i]))
-            if i > 0:
-                for j in range(i):
-                    v[:, i] -= np.dot(v[:, i], v[:, j]) * v[:, j]
-                v[:, i] /= np.sqrt(np.dot(v[:, i], v[:, i]))
-    else:
-        for i in range(k):
-            v[i, i] = 1.0
-    hk = np.zeros((k * iterations, k * iterations))
-    low = np.zeros(k)
-
-    def seed_block():
-        for i in range(k):
-            low[i] = np.dot(v[:, i], Hv[:, i]); hk[i, i] = low[i]
-            for j in range(i + 1, k):
-                hk[i, j] = hk[j, i] = np.dot(v[:, i], Hv[:, j])
-    for i in range(k):
-        Hv[:, i] = plan.apply(v[:, i])
-    seed_block()
-    w, Hw = v[:, :k].copy(), Hv[:, :k].copy()
-    res, low_prev, converged = np.ones(k), np.full(k, np.inf), False
-    niter = min(n, k * iterations)
-    it = k
-    while it < niter * 10:
-        it += 1
-        itc = (it - 1) % niter + 1
-        if it > niter and itc == 1:
-            v[:, :k], Hv[:, :k] = w, Hw
-            seed_block()
-            continue
-        i = (itc - 1) % k
-        den = low[i] - diag
-        small = np.abs(den) < 1e-8
-        t = (Hw[:, i] - low[i] * w[:, i]) / np.where(small, 1.0, den)
-        t[small] = -1.0
-        res[i] = np.dot(t, t)
-        if res.sum() < 1.0e-12:
-            converged = True
-        for j in range(itc - 1):
-            t -= np.dot(t, v[:, j]) * v[:, j]
-        t /= np.sqrt(np.dot(t, t))
-        v[:, itc - 1] = t
-        Hv[:, itc - 1] = plan.apply(t)
-        for j in range(itc):
-            hk[j, itc - 1] = hk[itc - 1, j] = np.dot(v[:, j], Hv[:, itc - 1])
-        if itc % k == 0:
-            ev, y = np.linalg.eigh(hk[:itc, :itc])
-            low = ev[:k].copy()
-            w, Hw = v[:, :itc] @ y[:, :k], Hv[:, :itc] @ y[:, :k]
-            if np.max(np.abs(low - low_prev)) < tol or converged:
-                break
-            low_prev = low.copy()
-    return low, w
+    """Lowest k eigenpairs of the plan's matrix: sqmc_gpu_davidson (csrc/davidson.inc), the reference's own iteration
+    (davidson_sparse, more_tools.f90:2018-2244) with basis, products and correction vectors resident on the device."""
+    w, X, _ = plan.davidson(diag, k=k, v0=v0, tol=tol)
+    return w, X
 
 
 def sort_dets(up, dn):

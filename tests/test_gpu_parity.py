@@ -113,6 +113,67 @@ def test_spmv_matches_oracle(oracle, c2_setup):
     plan.close()
 
 
+def test_device_davidson_matches_oracle_and_lapack(oracle, c2_setup):
+    """sqmc_gpu_davidson (basis resident on the device) against the oracle's restatement of davidson_sparse and against LAPACK on the
+    dense matrix: the deterministic-space Hamiltonian of C2 (1000 determinants; the projector is -tau H), one and two states, with
+    and without start vectors; and a matrix with a degenerate lowest pair where the start vector decides which state is tracked."""
+    import sqmc_amd
+    s = c2_setup
+    counts, idx = s.prj_counts, s.prj_indices
+    val = s.prj_values / (-s.tau)
+    n = len(counts)
+    starts = np.concatenate(([0], np.cumsum(counts)))[:-1]
+    diag = val[starts]
+    A = np.zeros((n, n)); r = np.repeat(np.arange(n), counts)
+    A[r, idx - 1] = val; A[idx - 1, r] = val
+    wl, Xl = np.linalg.eigh(A)
+    plan = sqmc_amd.SpmvPlan(counts, idx, val)
+    try:
+        for k in (1, 2):
+            ev, X, nmv = plan.davidson(diag, k=k)
+            wo, Xo = oracle.davidson_sparse(counts, idx, val, k)
+            assert np.allclose(ev, wo[:k], rtol=0, atol=1e-9) and 0 < nmv < 400
+            # the unit start vectors live in the totally symmetric sector: the states found are the lowest ones LAPACK finds there
+            for q in range(k):
+                j = int(np.argmin(np.abs(wl - ev[q])))
+                assert abs(wl[j] - ev[q]) < 1e-8
+                assert min(np.abs(X[:, q] - Xl[:, j]).max(), np.abs(X[:, q] + Xl[:, j]).max()) < 1e-4
+                assert min(np.abs(X[:, q] - Xo[:, q]).max(), np.abs(X[:, q] + Xo[:, q]).max()) < 1e-4
+                assert abs(np.dot(X[:, q], X[:, q]) - 1.0) < 1e-12
+                assert np.abs(plan.apply(X[:, q]) - ev[q] * X[:, q]).max() < 1e-4
+        # a start vector: same state, fewer products
+        ev1, X1, n1 = plan.davidson(diag, k=1)
+        guess = X1[:, 0] + 1e-3 * np.random.default_rng(1).standard_normal(n)
+        ev2, X2, n2 = plan.davidson(diag, k=1, v0=guess.reshape(-1, 1))
+        assert abs(ev2[0] - ev1[0]) < 1e-9 and n2 < n1
+    finally:
+        plan.close()
+    # run-to-run identical bits (fixed reduction trees)
+    plan = sqmc_amd.SpmvPlan(counts, idx, val)
+    a = plan.davidson(diag, k=2); b = plan.davidson(diag, k=2)
+    plan.close()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    # two decoupled blocks (the second one the first shifted up by 0.5): a start inside a block stays there -- from the second block
+    # the iteration finds THAT block's lowest state, not the matrix's
+    rng = np.random.default_rng(7)
+    m = 40
+    B = rng.standard_normal((m, m)); B = B + B.T + np.diag(np.arange(m) * 3.0)
+    Z = np.zeros((m, m)); D = np.block([[B, Z], [Z, B + 0.5 * np.eye(m)]])
+    c2, i2, v2 = [], [], []
+    for i in range(2 * m):
+        cols = [i] + [j for j in range(i) if D[i, j] != 0.0]
+        c2.append(len(cols)); i2 += [j + 1 for j in cols]; v2 += [D[i, j] for j in cols]
+    plan = sqmc_amd.SpmvPlan(np.array(c2), np.array(i2), np.array(v2))
+    try:
+        for half in (0, 1):
+            v0 = np.zeros((2 * m, 1)); v0[half * m, 0] = 1.0
+            ev, X, _ = plan.davidson(np.diag(D).copy(), k=1, v0=v0)
+            assert abs(ev[0] - (np.linalg.eigvalsh(B)[0] + 0.5 * half)) < 1e-9
+            assert np.abs(X[(1 - half) * m:(2 - half) * m, 0]).max() == 0.0      # never leaves its block
+    finally:
+        plan.close()
+
+
 @pytest.mark.parametrize("which,eps", [("hci", 2e-4), ("hci", 5e-3), ("walk", 1e-3)])
 def test_hci_connections_match_oracle(oracle, c2_walk, c2_hci, which, eps):
     sysm = c2_walk if which == "walk" else c2_hci
