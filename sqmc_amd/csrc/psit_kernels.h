@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(TPB) k_psit_tinv(PsitArgs a, double *__restric
 }
 
 // check_initiator over C(T) (nothing is discarded), the reweighting, and everything the step sums over the C(T) slots
-__global__ void __launch_bounds__(TPB) k_psit_finish(PsitArgs a, double *__restrict__ wt, u32 *__restrict__ flg, StepP p, double *__restrict__ partials2) {
+// (pipelined steps, go.on: also the next step's gate of the C(T) slots -- k_anneal<., 1> wrote the keys and the gate of everything outside)
+__global__ void __launch_bounds__(TPB) k_psit_finish(PsitArgs a, double *__restrict__ wt, u32 *__restrict__ flg, StepP p, double *__restrict__ partials2, GateOut go, u64 seed) {
   double s[NSTAT];
 #pragma unroll
   for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
@@ -169,6 +170,12 @@ __global__ void __launch_bounds__(TPB) k_psit_finish(PsitArgs a, double *__restr
     }
     w = w * p.rfi;                                      // 2487
     wt[i] = w; flg[i] = pack_flg(d, ini, ps);
+    if (go.on) {
+      u64 nc; double wc;
+      gate_children(w, go.cutoff, seed, go.step_next, go.keys[i] >> 32, nc, wc);
+      if (i == 0) { nc = 0; wc = 0.0; }                 // all moves of the first state are deterministic (do_walk.f90:3574)
+      go.nchild[i] = nc; go.wchild[i] = wc;
+    }
     s[0] += w; s[1] += fabs(w); s[8] += w * w;          // 2590-2598
     if (ini == 3) s[4] += w * ps;
     if (d == 0 || (d == -2 && p.cti)) s[6] += fabs(w);

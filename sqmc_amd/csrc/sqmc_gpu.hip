@@ -1059,7 +1059,8 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     nb = n_ft = bucket ? ba.B : (int)((nall + (long long)TPB * items - 1) / ((long long)TPB * items));
     // pipelined steps: the kernel also does the next step's gate (keys, child counts, child weights) as it places a walker
     static const bool no_fuse = getenv("SQMC_NO_GATE_FUSION") != nullptr;
-    fuse_gate = c->pipeline_next && c->pack && !no_fuse && !c->psit_on;
+    static const bool no_psit_fuse = getenv("SQMC_PSIT_NO_GATE_FUSION") != nullptr;
+    fuse_gate = c->pipeline_next && c->pack && !no_fuse && !(c->psit_on && no_psit_fuse);
     GateOut go; memset(&go, 0, sizeof(go));
     if (fuse_gate) {
       go.on = 1; go.keys = (skey == c->d_keys) ? c->d_keys_alt : c->d_keys;      // never the buffer the kernel reads its sorted words from
@@ -1069,7 +1070,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       if (bucket && (use_mail || !no_shard_off) && !no_off && c->n_imp < (1ll << 18) && c->last_wabs > 0 && c->last_wabs < 4.0e6) go.child_off = c->d_child_off;     // 24 bits of the look-back word hold the children
       // the radix tail of an unsharded pipelined step carries the child offsets too, in a look-back of their own (walk_kernels.h)
       static const bool no_roff = getenv("SQMC_RADIX_NO_OFFSETS") != nullptr;
-      if (!bucket && use_mail && !c->d_grow && mode == SQMC_RNG_COUNTER && !no_roff) go.child_off = c->d_child_off;
+      if (!bucket && use_mail && !c->d_grow && mode == SQMC_RNG_COUNTER && !no_roff && !c->psit_on) go.child_off = c->d_child_off;      // (hf_to_psit: the C(T) segment's counts come from a later kernel: the head scans)
     }
 #define ANNEAL_ARGS c->w, c->m, skey, perm, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, n0, nall, p,  \
                     c->invalid_key, c->pack, mode, seed, step, c->d_sc, c->d_fstate, c->d_fstate + c->cap_ftiles, c->d_fticket, go
@@ -1102,7 +1103,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     if (c->psit_on) {          // do_walk.f90:2394-2462, 2487, 2590-2598, 2701-2722 on the C(T) segment of the NEW list
       TBEG(psit_fin, st);
       hipLaunchKernelGGL(k_psit_tinv, dim3(1), dim3(TPB), 0, st, c->psit, c->w.wt);
-      hipLaunchKernelGGL(k_psit_finish, dim3(PSIT_FB), dim3(TPB), 0, st, c->psit, c->w.wt, c->w.flg, p, c->d_ps_part);
+      hipLaunchKernelGGL(k_psit_finish, dim3(PSIT_FB), dim3(TPB), 0, st, c->psit, c->w.wt, c->w.flg, p, c->d_ps_part, go, seed);
       TEND(psit_fin, st);
     }
   } else {
@@ -1275,7 +1276,8 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   // a host that calls step by step (the reference's own loop does work between steps) and has promised to come back with the
   // same tau and cutoff (sqmc_gpu_set_chained_runs): this step enqueues the next one's head, as the steps of sqmc_gpu_run do
   if (!c->in_run) c->pipeline_next = c->chained_runs && sp->reached_w_abs_gen == 2 && mode != SQMC_RNG_REPLAY && !getenv("SQMC_NO_PIPELINE");
-  if (c->psit_on) c->pipeline_next = false;          // hf_to_psit: the tail's last kernels need E_T-independent sums only, but its head is not pipelined yet
+  { static const bool psit_no_pipe = getenv("SQMC_PSIT_NO_PIPELINE") != nullptr;      // hf_to_psit: the head (gate, scan, spawn) behind the tail like any other step's; the gate stays a kernel of its own
+    if (c->psit_on && psit_no_pipe) c->pipeline_next = false; }
   collect_timers(c);
   c->nt = 0;
   hipStream_t st2 = c->st2;

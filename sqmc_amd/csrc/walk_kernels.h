@@ -1112,9 +1112,12 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
       go.keys[q0] = (key[k] << 32) | (u64)q0; go.child_off[q0] = cex + (u64)cpre[k];
       go.wchild[q0] = nc == 0 ? 0.0 : (fabs(wt) < go.cutoff ? copysign(go.cutoff, wt) : wt / (double)nc);
     } else if (go.on) {
-      u64 nc; double wc;
-      gate_children(wt, go.cutoff, seed, go.step_next, key[k], nc, wc);
-      go.keys[q0] = (key[k] << 32) | (u64)q0; go.nchild[q0] = nc; go.wchild[q0] = wc;
+      go.keys[q0] = (key[k] << 32) | (u64)q0;
+      if (!ct_head) {          // hf_to_psit: the weights of the C(T) segment are not final yet -- k_psit_finish writes their gate; the draw is keyed by the determinant, not by where it sorts
+        u64 nc; double wc;
+        gate_children(wt, go.cutoff, seed, go.step_next, PSIT ? key[k] - p.koff : key[k], nc, wc);
+        go.nchild[q0] = nc; go.wchild[q0] = wc;
+      }
     }
     if (d == 0 && p.semi && (long long)(ex2 >> 32) < p.nimp_cap) loc_imp[ex2 >> 32] = (int)q0;
     if (ct_head) continue;

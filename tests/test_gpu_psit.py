@@ -136,6 +136,23 @@ def test_psit_heg_trajectory_bit_exact(oracle, heg14):
     g.close(); ow.close()
 
 
+@pytest.mark.parametrize("fuse", [True, False])
+def test_psit_pipelined_steps_bit_exact(oracle, c2_walk, c2_psit, monkeypatch, fuse):
+    """past the target population a chained host's step enqueues the next step's head behind its own tail (sqmc_gpu_set_chained_runs);
+    with hf_to_psit the gate of the next step is written by k_anneal<., 1> (everything outside C(T)) and k_psit_finish (the C(T)
+    segment, whose weights are final only there), or by k_gate in the head (SQMC_PSIT_NO_GATE_FUSION).  Same trajectory as the oracle's
+    unpipelined steps, bit for bit, through 120 steps of which 100 are pipelined."""
+    if not fuse:
+        monkeypatch.setenv("SQMC_PSIT_NO_GATE_FUSION", "1")
+    s, q = c2_psit
+    ow, g, w_abs = _pair(oracle, c2_walk, s, q, 100.0, 1)
+    g.set_chained_runs(True)
+    pc = oracle.PopControl(s.tau, s.e_trial0, 3000)
+    _lockstep(oracle, ow, g, pc, w_abs, 120, len(s.ct_up), check_every=20)
+    assert pc.reached == 2
+    g.close(); ow.close()
+
+
 def test_psit_run_loop_and_energy(c2_walk):
     """sqmc_gpu_run with hf_to_psit (population control inside the library) from the product's own set-up: the projected energy of the
     transformed walk agrees with the untransformed walk's and with this geometry's HCI+PT2 total (-75.72854 Ha, pinned to the
