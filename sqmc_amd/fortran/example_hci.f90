@@ -1,9 +1,8 @@
 !> A Fortran host for the variational stage of HCI on the GPU path (INTEGRATION.md, patch sketch 3):
 !> what perform_hci does per iteration (hci.f90:359-520) with the three heavy pieces behind
 !> sqmc_gpu_mod -- sqmc_gpu_hci_connections for find_doubly_excited + dedup (hci.f90:905-931),
-!> sqmc_gpu_build_spmv_plan for generate_sparse_ham_chem_upper_triangular, sqmc_gpu_spmv_apply for
-!> the matvec inside the Davidson iteration -- and the host logic (list bookkeeping, the small
-!> Krylov problem) written here.  Tables come from a deck written by sqmc_amd.host.dump_hci_deck.
+!> sqmc_gpu_build_spmv_plan for generate_sparse_ham_chem_upper_triangular, sqmc_gpu_davidson for
+!> davidson_sparse (more_tools.f90:2018-2244) -- and the host logic (the list bookkeeping of get_next_det_list) written here.  Tables come from a deck written by sqmc_amd.host.dump_hci_deck.
 !>   usage: example_hci <deck> [eps_pt]      with eps_pt: the Epstein-Nesbet correction of state 1 (second_order_pt,
 !>   hci.f90:1100-1182) in one call, sqmc_gpu_hci_pt2, on the basis the deck's context works in
 module hci_host_tools
@@ -60,47 +59,6 @@ contains
       endif
     enddo
   end function
-
-  !> all eigenpairs of a small symmetric matrix by cyclic Jacobi rotations, eigenvalues ascending
-  subroutine jacobi_eig(m, a, w, v)
-    integer, intent(in) :: m
-    real(c_double), intent(inout) :: a(m, m)
-    real(c_double), intent(out) :: w(m), v(m, m)
-    integer :: sweep, p, q, i, k
-    real(c_double) :: off, theta, t, c, s, apq, tmp, x(m)
-    v = 0; do i = 1, m; v(i, i) = 1; enddo
-    do sweep = 1, 100
-      off = 0
-      do p = 1, m - 1; do q = p + 1, m; off = off + a(p, q)**2; enddo; enddo
-      if (off < 1.d-30) exit
-      do p = 1, m - 1
-        do q = p + 1, m
-          apq = a(p, q)
-          if (abs(apq) < 1.d-300) cycle
-          theta = (a(q, q) - a(p, p)) / (2 * apq)
-          t = sign(1.d0, theta) / (abs(theta) + sqrt(theta*theta + 1)); c = 1 / sqrt(t*t + 1); s = t * c
-          do k = 1, m
-            tmp = a(k, p); a(k, p) = c*tmp - s*a(k, q); a(k, q) = s*tmp + c*a(k, q)
-          enddo
-          do k = 1, m
-            tmp = a(p, k); a(p, k) = c*tmp - s*a(q, k); a(q, k) = s*tmp + c*a(q, k)
-          enddo
-          do k = 1, m
-            tmp = v(k, p); v(k, p) = c*tmp - s*v(k, q); v(k, q) = s*tmp + c*v(k, q)
-          enddo
-        enddo
-      enddo
-    enddo
-    do i = 1, m; w(i) = a(i, i); enddo
-    do i = 1, m - 1                                  ! selection sort, ascending
-      k = i
-      do p = i + 1, m; if (w(p) < w(k)) k = p; enddo
-      if (k /= i) then
-        tmp = w(i); w(i) = w(k); w(k) = tmp
-        x = v(:, i); v(:, i) = v(:, k); v(:, k) = x
-      endif
-    enddo
-  end subroutine
 end module
 
 program example_hci
@@ -109,7 +67,7 @@ program example_hci
   use hci_host_tools
   implicit none
   character(len=512) :: deck
-  integer :: u, it, ns, nsched, i, j, k, itc, niter, iters, ist
+  integer :: u, it, ns, nsched, i
   integer(c_int64_t) :: hdr(18), n, n_old, n_new, n_conn, nnz, q
   real(c_double) :: max_double, eps, tol, eps_pt, delta_e
   character(len=64) :: arg2
@@ -118,12 +76,13 @@ program example_hci
   integer(c_int64_t), allocatable :: pq_ind(:)
   real(c_double), allocatable, target :: ints(:), hb_a(:)
   integer(c_int64_t), allocatable :: up(:), dn(:), tu(:), td(:), order(:), us(:), ds(:)
-  real(c_double), allocatable :: wts(:,:), coeffs(:), energy(:), old_energy(:), diag(:), start(:,:)
-  real(c_double), allocatable :: v(:,:), hv(:,:), w(:,:), hw(:,:), hk(:,:), hwork(:,:), ev(:), y(:,:), low(:), low_prev(:), res(:), t(:), den(:)
+  real(c_double), allocatable :: wts(:,:), coeffs(:), energy(:), old_energy(:), diag(:)
+  real(c_double), allocatable, target :: start(:,:)
+  real(c_double), allocatable :: w(:,:), low(:)
+  integer(c_int32_t) :: n_mv
   integer(c_int64_t), pointer :: p_up(:), p_dn(:)
   type(c_ptr) :: gpu, plan, c_up, c_dn, c_num, c_den
   type(sqmc_chem_cfg) :: cfg
-  logical :: converged
 
   if (command_argument_count() < 1) stop 'usage: example_hci <deck> [eps_pt]'
   call get_command_argument(1, deck)
@@ -204,67 +163,17 @@ program example_hci
         if (order(q) <= n_old) start(q, :) = wts(order(q), :)
       enddo
     endif
-    ! ---- Davidson with diagonal preconditioner, the reference's scheme (more_tools.f90:2018-2244):
-    !      one correction vector per state and sweep, Krylov matrix diagonalised after every ns additions
-    iters = min(int(n), 50); niter = min(int(n), ns * iters)
-    allocate(v(n, ns*iters), hv(n, ns*iters), w(n, ns), hw(n, ns), hk(ns*iters, ns*iters), low(ns), low_prev(ns), res(ns), t(n), den(n))
-    v = 0; hv = 0; hk = 0
-    do i = 1, ns
-      v(:, i) = start(:, i) / sqrt(dot_product(start(:, i), start(:, i)))
-      do j = 1, i - 1
-        v(:, i) = v(:, i) - dot_product(v(:, i), v(:, j)) * v(:, j)
-      enddo
-      if (i > 1) v(:, i) = v(:, i) / sqrt(dot_product(v(:, i), v(:, i)))
-      call sqmc_gpu_check(sqmc_gpu_spmv_apply(plan, v(:, i), hv(:, i), 0_c_int), 'spmv_apply')
-    enddo
-    call seed_block()
-    w = v(:, 1:ns); hw = hv(:, 1:ns)
-    res = 1; low_prev = huge(1.d0); converged = .false.
-    ist = ns
-    do while (ist < niter * 10)
-      ist = ist + 1
-      itc = mod(ist - 1, niter) + 1
-      if (ist > niter .and. itc == 1) then
-        v(:, 1:ns) = w; hv(:, 1:ns) = hw
-        call seed_block()
-        cycle
-      endif
-      i = mod(itc - 1, ns) + 1
-      den = low(i) - diag
-      where (abs(den) < 1.d-8)
-        t = -1
-      elsewhere
-        t = (hw(:, i) - low(i) * w(:, i)) / den
-      end where
-      res(i) = dot_product(t, t)
-      if (sum(res) < 1.d-12) converged = .true.
-      do j = 1, itc - 1
-        t = t - dot_product(t, v(:, j)) * v(:, j)
-      enddo
-      t = t / sqrt(dot_product(t, t))
-      v(:, itc) = t
-      call sqmc_gpu_check(sqmc_gpu_spmv_apply(plan, v(:, itc), hv(:, itc), 0_c_int), 'spmv_apply')
-      do j = 1, itc
-        hk(j, itc) = dot_product(v(:, j), hv(:, itc)); hk(itc, j) = hk(j, itc)
-      enddo
-      if (mod(itc, ns) == 0) then
-        allocate(hwork(itc, itc), ev(itc), y(itc, itc))
-        hwork = hk(1:itc, 1:itc)
-        call jacobi_eig(itc, hwork, ev, y)
-        low = ev(1:ns)
-        w = matmul(v(:, 1:itc), y(:, 1:ns)); hw = matmul(hv(:, 1:itc), y(:, 1:ns))
-        deallocate(hwork, ev, y)
-        if (maxval(abs(low - low_prev)) < tol .or. converged) exit
-        low_prev = low
-      endif
-    enddo
+    ! ---- davidson_sparse (more_tools.f90:2018-2244) in one call: basis, products and corrections stay on the device; start = the last
+    !      iteration's vectors on the old determinants (initial_vector), unit vectors on the first rows in iteration 1
+    allocate(w(n, ns), low(ns))
+    call sqmc_gpu_check(sqmc_gpu_davidson(plan, diag, int(ns, c_int32_t), c_loc(start), tol, low, w, n_mv), 'davidson')
     call sqmc_gpu_check(sqmc_gpu_spmv_free(plan), 'spmv_free')
     deallocate(wts); allocate(wts(n, ns))
     do q = 1, n
       wts(order(q), :) = w(q, :)
     enddo
     energy = low
-    deallocate(v, hv, w, hw, hk, low, low_prev, res, t, den, order, us, ds, diag, start)
+    deallocate(w, low, order, us, ds, diag, start)
     write(6, '(''Iteration'',i4,'' eps1='',es7.1e1,'' ndets='',i9,'' nnz='',i11,'' energy='',10f16.9)') it, eps, n, nnz, energy
     if (maxval(abs(energy - old_energy)) < 1.d-5 .and. it >= nsched) exit
     old_energy = energy
@@ -278,14 +187,4 @@ program example_hci
   endif
   call sqmc_gpu_check(sqmc_gpu_finalize(gpu), 'finalize')
 
-contains
-  subroutine seed_block()
-    integer :: a, b
-    do a = 1, ns
-      low(a) = dot_product(v(:, a), hv(:, a)); hk(a, a) = low(a)
-      do b = a + 1, ns
-        hk(a, b) = dot_product(v(:, a), hv(:, b)); hk(b, a) = hk(a, b)
-      enddo
-    enddo
-  end subroutine
 end program
