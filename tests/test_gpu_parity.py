@@ -1847,9 +1847,11 @@ def test_heatbath_proposals_bit_exact(oracle, c2_10e, time_sym):
     assert moves > n // 3 and two > 20
 
 
-def test_heatbath_walk_trajectory_bit_exact(oracle, c2_10e):
+@pytest.mark.parametrize("chained", [False, True])
+def test_heatbath_walk_trajectory_bit_exact(oracle, c2_10e, chained):
     """A semistochastic walk with proposal_method fast_heatbath (two walker slots per child, do_walk.f90:3604-3611 ->
-    add_walker 7584-7697) in the COUNTER discipline: 120 steps, walkers, weights and flags equal the oracle's."""
+    add_walker 7584-7697) in the COUNTER discipline: 120 steps, walkers, weights and flags equal the oracle's.  chained: past the
+    target population every step enqueues its successor's head (gate fused into the annihilation kernel, k_spawn<1, .> behind it)."""
     sysm = c2_10e
     hb = oracle.HeatBath(sysm)
     su = oracle.setup_walk(sysm, 100, 1000, 0.1)
@@ -1859,11 +1861,12 @@ def test_heatbath_walk_trajectory_bit_exact(oracle, c2_10e):
     g.set_ct_table(su.ct_up, su.ct_dn, su.ct_num, su.ct_den)
     wk = oracle.initial_walkers(su, 50)
     g.upload_walkers(wk)
+    if chained: g.set_chained_runs(True)
     ow = oracle.OracleWalk(sysm, su, wk, 400000, SEED, rng_mode=1, heatbath=hb)
-    pc = oracle.PopControl(su.tau, su.e_trial0, 8000)
+    pc = oracle.PopControl(su.tau, su.e_trial0, 600 if chained else 8000)
     w_abs = float(np.abs(wk["wt"]).sum())
     try:
-        for it in range(120):
+        for it in range(200 if chained else 120):
             r = pc.pre_step(w_abs)
             if r != 1.0:
                 ow.scale_projector(r); g.scale_projector(r)
@@ -1880,7 +1883,8 @@ def test_heatbath_walk_trajectory_bit_exact(oracle, c2_10e):
         g.close(); ow.close(); hb.close()
     for k in ("up", "dn", "imp_distance", "initiator"):
         assert np.array_equal(wg[k], wc[k]), k
-    assert np.array_equal(wg["wt"], wc["wt"]) and len(wg["up"]) > 3000
+    assert np.array_equal(wg["wt"], wc["wt"]) and len(wg["up"]) > (300 if chained else 3000)
+    assert not chained or pc.reached == 2
 
 
 def test_library_builds_the_heatbath_tables_itself(oracle, c2_walk, c2_10e):

@@ -153,6 +153,18 @@ def test_psit_pipelined_steps_bit_exact(oracle, c2_walk, c2_psit, monkeypatch, f
     g.close(); ow.close()
 
 
+def test_psit_heg_pipelined_steps_bit_exact(oracle, heg14):
+    """the same for the electron gas: chained steps past the target population against the oracle's unpipelined ones"""
+    s = oracle.setup_walk_heg(heg14, 200, 0.1, n_truncate_trial_wf=20, rediagonalize=True)
+    q = oracle.psit_setup(heg14, s)
+    ow, g, w_abs = _pair(oracle, heg14, s, q, 100.0, 1, heg=True)
+    g.set_chained_runs(True)
+    pc = oracle.PopControl(s.tau, s.e_trial0, 250)
+    _lockstep(oracle, ow, g, pc, w_abs, 160, len(s.ct_up), check_every=20)
+    assert pc.reached == 2
+    g.close(); ow.close()
+
+
 def test_psit_run_loop_and_energy(c2_walk):
     """sqmc_gpu_run with hf_to_psit (population control inside the library) from the product's own set-up: the projected energy of the
     transformed walk agrees with the untransformed walk's and with this geometry's HCI+PT2 total (-75.72854 Ha, pinned to the
