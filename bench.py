@@ -26,7 +26,7 @@ FCIDUMP = os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # HBM bytes per launch of the two kernels: read from the PMC summary the profiling script wrote (tools/profile_bench.sh ->
 # profiles/*_traffic.json, with the commit it was taken at); never typed in here
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_bench_1e5_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_bench_1e5_traffic.json")
 
 
 def load_traffic():
