@@ -14,7 +14,7 @@
 //   k_psit_rows_fin         ... the first row's sum; the Psi_T locations with (1 + tau E_T) c (2286; more_tools.f90:3663-3667)
 //   k_psit_apply            w_i <- w_i - tau dw_i + tau E_T w_i on C(T), + the Psi_T row, + the deterministic-space product (2313-2323)
 //   k_anneal<ITEMS, 1>      merge_my_original_with_spawned3 + reduce_my_walker for everything outside C(T)
-//   k_psit_tinv             T^-1 and its transpose on the Psi_T locations (2394-2442)
+//   (k_psit_finish)         T^-1 and its transpose on the Psi_T locations (2394-2442), in front of the finish of every slot
 //   k_psit_finish           check_initiator over C(T) without discarding (2444-2462), reweighting (2487), the sums over C(T) and the
 //                           energy estimator, a plain loop over the C(T) slots (2701-2722)
 //
@@ -133,33 +133,28 @@ __global__ void __launch_bounds__(TPB) k_psit_imp_rows(PrjPre pp) {
 }
 
 // T^-1 and its transpose on the Psi_T locations after the merge, do_walk.f90:2394-2442 (one block)
-__global__ void __launch_bounds__(TPB) k_psit_tinv(PsitArgs a, double *__restrict__ wt) {
+// check_initiator over C(T) (nothing is discarded), the reweighting, and everything the step sums over the C(T) slots
+// (pipelined steps, go.on: also the next step's gate of the C(T) slots -- k_anneal<., 1> wrote the keys and the gate of everything outside)
+__global__ void __launch_bounds__(TPB) k_psit_finish(PsitArgs a, double *__restrict__ wt, u32 *__restrict__ flg, StepP p, double *__restrict__ partials2, GateOut go, u64 seed) {
+  // T^-1 and its transpose on the Psi_T locations (2394-2442): w_1 = ((w_1 - sum_{k>1} c_k w_k) / c_1) / c_1, then w_k -= c_k w_1.  Every
+  // block forms the sum itself, in the one order, from the copy k_anneal<., 1> left of those weights (go.ps_raw): the slots themselves
+  // are being overwritten by other blocks.  One kernel less on the step's critical path.
   __shared__ double s_scr[64][65];
   __shared__ double s_w1;
   if (threadIdx.x < 64) {
     double tmp = 0.0;
-    if (a.n_psit > 1) tmp = 0.0 + wave_tree_sum([&](long long i) { return a.cdet[i + 1] * wt[a.loc_psit[i + 1]]; }, a.n_psit - 1, s_scr, a.seq);
-    if (threadIdx.x == 0) {
-      const int l0 = a.loc_psit[0];
-      double w1 = wt[l0];
-      w1 = w1 - tmp; w1 = w1 / a.cdet[0]; w1 = w1 / a.cdet[0];
-      wt[l0] = w1; s_w1 = w1;
-    }
+    if (a.n_psit > 1) tmp = 0.0 + wave_tree_sum([&](long long i) { return a.cdet[i + 1] * go.ps_raw[i + 1]; }, a.n_psit - 1, s_scr, a.seq);
+    if (threadIdx.x == 0) { double w1 = go.ps_raw[0]; w1 = w1 - tmp; w1 = w1 / a.cdet[0]; w1 = w1 / a.cdet[0]; s_w1 = w1; }
   }
   __syncthreads();
   const double w1 = s_w1;
-  for (long long k = 1 + threadIdx.x; k < a.n_psit; k += TPB) { const int l = a.loc_psit[k]; wt[l] = wt[l] - a.cdet[k] * w1; }
-}
-
-// check_initiator over C(T) (nothing is discarded), the reweighting, and everything the step sums over the C(T) slots
-// (pipelined steps, go.on: also the next step's gate of the C(T) slots -- k_anneal<., 1> wrote the keys and the gate of everything outside)
-__global__ void __launch_bounds__(TPB) k_psit_finish(PsitArgs a, double *__restrict__ wt, u32 *__restrict__ flg, StepP p, double *__restrict__ partials2, GateOut go, u64 seed) {
   double s[NSTAT];
 #pragma unroll
   for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
   const double r0 = a.cnum[0] / a.cden[0];
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < a.n_ct; i += (long long)gridDim.x * TPB) {
     double w = wt[i]; const u32 f = flg[i];
+    { const int kp = a.psit_of[i]; if (kp == 0) w = w1; else if (kp > 0) w = w - a.cdet[kp] * w1; }
     int d = flg_impd(f), ini = flg_init(f); const int ps = flg_psign(f);
     if (!p.cti || i < a.n_perm) {                       // 2447-2461: with c_t_initiator only the first n_permanent_initiator slots are visited
       const int dd = d - p.imind > 0 ? d - p.imind : 0;

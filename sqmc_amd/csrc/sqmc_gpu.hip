@@ -219,7 +219,7 @@ struct sqmc_gpu_ctx {
   // hf_to_psit (psit_kernels.h)
   HbHost *hb_host;
   long long dbg_n0, dbg_nall;          // sizes of the last step's list in front of the merge (sqmc_gpu_debug_premerge)
-  bool psit_on; int base_key_bits; PsitArgs psit; int *d_ps_loc, *d_ps_of, *d_ps_impof; double *d_ps_c, *d_ps_diag, *d_ps_dwct, *d_ps_dwps, *d_ps_dwimp, *d_ps_p2, *d_ps_part;
+  bool psit_on; int base_key_bits; PsitArgs psit; int *d_ps_loc, *d_ps_of, *d_ps_impof; double *d_ps_c, *d_ps_diag, *d_ps_dwct, *d_ps_dwps, *d_ps_dwimp, *d_ps_p2, *d_ps_part, *d_ps_raw;
 };
 // a head enqueued for a step that is not going to be the next thing that happens (chained runs): forget it
 static void abandon_head(sqmc_gpu_ctx *c);
@@ -443,7 +443,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x); hipFree(c->d_prj_xs[0]); hipFree(c->d_prj_xs[1]); hipFree(c->d_prj_y);
   hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den); hipFree(c->d_ct_hkey); hipFree(c->d_ct_hidx);
   hipFree(c->d_ps_loc); hipFree(c->d_ps_of); hipFree(c->d_ps_impof); hipFree(c->d_ps_c); hipFree(c->d_ps_diag); hipFree(c->d_ps_dwct); hipFree(c->d_ps_dwps);
-  hipFree(c->d_ps_dwimp); hipFree(c->d_ps_p2); hipFree(c->d_ps_part);
+  hipFree(c->d_ps_dwimp); hipFree(c->d_ps_p2); hipFree(c->d_ps_part); hipFree(c->d_ps_raw);
   hipFree(c->d_sc); hipHostFree(c->h_sc); if (c->h_mail) hipHostFree((void *)c->h_mail);
   for (int i = 0; i < NTIMERS; i++) { hipEventDestroy(c->ev0[i]); hipEventDestroy(c->ev1[i]); }
   hipEventDestroy(c->e_fork); hipEventDestroy(c->e_join); hipEventDestroy(c->e_cnt);
@@ -561,7 +561,8 @@ int sqmc_gpu_set_hf_to_psit(sqmc_gpu_ctx *c, int64_t n_psit, const int64_t *psit
   if (c->base_key_bits + 1 > 62) return fail(SQMC_ERR_UNSUPPORTED, "determinant space too large for the hf_to_psit sort key");
   int *d_loc, *d_of, *d_impof; double *d_c, *d_diag, *d_dwct, *d_dwps, *d_dwimp, *d_p2, *d_part;
   hipFree(c->d_ps_loc); hipFree(c->d_ps_of); hipFree(c->d_ps_impof); hipFree(c->d_ps_c); hipFree(c->d_ps_diag); hipFree(c->d_ps_dwct); hipFree(c->d_ps_dwps);
-  hipFree(c->d_ps_dwimp); hipFree(c->d_ps_p2); hipFree(c->d_ps_part);
+  hipFree(c->d_ps_dwimp); hipFree(c->d_ps_p2); hipFree(c->d_ps_part); hipFree(c->d_ps_raw); c->d_ps_raw = nullptr;
+  HIPCHK(hipMalloc(&c->d_ps_raw, n_psit * 8));
   HIPCHK(hipMalloc(&d_loc, n_psit * 4)); HIPCHK(hipMalloc(&d_of, n_ct * 4)); HIPCHK(hipMalloc(&d_impof, n_ct * 4));
   HIPCHK(hipMalloc(&d_c, n_psit * 8)); HIPCHK(hipMalloc(&d_diag, n_ct * 8)); HIPCHK(hipMalloc(&d_dwct, n_ct * 8)); HIPCHK(hipMalloc(&d_dwps, n_psit * 8));
   HIPCHK(hipMalloc(&d_dwimp, (c->n_imp + 1) * 8)); HIPCHK(hipMalloc(&d_p2, ((n_ct + 4095) / 4096 + 1) * 8)); HIPCHK(hipMalloc(&d_part, (size_t)PSIT_FB * NSTAT * 8));
@@ -1062,6 +1063,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     static const bool no_psit_fuse = getenv("SQMC_PSIT_NO_GATE_FUSION") != nullptr;
     fuse_gate = c->pipeline_next && c->pack && !no_fuse && !(c->psit_on && no_psit_fuse);
     GateOut go; memset(&go, 0, sizeof(go));
+    if (c->psit_on) { go.ps_of = c->d_ps_of; go.ps_raw = c->d_ps_raw; }
     if (fuse_gate) {
       go.on = 1; go.keys = (skey == c->d_keys) ? c->d_keys_alt : c->d_keys;      // never the buffer the kernel reads its sorted words from
       go.nchild = c->d_nchild; go.wchild = c->d_wchild; go.cutoff = p.cutoff; go.step_next = step + 1;
@@ -1102,7 +1104,6 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed); std::swap(c->w.irk, c->m.irk);
     if (c->psit_on) {          // do_walk.f90:2394-2462, 2487, 2590-2598, 2701-2722 on the C(T) segment of the NEW list
       TBEG(psit_fin, st);
-      hipLaunchKernelGGL(k_psit_tinv, dim3(1), dim3(TPB), 0, st, c->psit, c->w.wt);
       hipLaunchKernelGGL(k_psit_finish, dim3(PSIT_FB), dim3(TPB), 0, st, c->psit, c->w.wt, c->w.flg, p, c->d_ps_part, go, seed);
       TEND(psit_fin, st);
     }

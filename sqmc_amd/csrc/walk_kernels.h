@@ -52,7 +52,10 @@ __device__ __forceinline__ void gate_children(double w, double cutoff, u64 seed,
 // What k_gate would compute for the NEXT step, written by k_anneal as it places a walker (pipelined steps: the
 // parameters of the gate do not change any more, and the walker's key is at hand): one kernel less on the critical path.
 struct GateOut { u64 *keys; u64 *nchild; double *wchild; double cutoff; u64 step_next; int on;
-                 u64 *child_off; };      // child_off != null (bucket tail only): the kernel also writes the next step's child offsets and total -- no scan launch
+                 u64 *child_off;
+                 // hf_to_psit (set whether or not the gate is fused): slot of C(T) -> index in Psi_T or -1, and where k_anneal<., 1> leaves the
+                 // merged weights of the Psi_T determinants -- k_psit_finish sums them for T^-1 while other blocks already overwrite the slots
+                 const int *ps_of; double *ps_raw; };      // child_off != null (bucket tail only): the kernel also writes the next step's child offsets and total -- no scan launch
 // gate + child count.
 __global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, const double *__restrict__ wt,
                                               u64 *__restrict__ nchild, double *__restrict__ wchild, u64 *__restrict__ keys, u32 *__restrict__ vals,
@@ -1107,6 +1110,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
     o.up[q0] = r[k].up; o.dn[q0] = r[k].dn; o.wt[q0] = wt; o.flg[q0] = r[k].flg;
     o.me[q0] = me; o.en[q0] = en; o.ed[q0] = ed;
+    if (PSIT && ct_head) { const int kp = go.ps_of[q0]; if (kp >= 0) go.ps_raw[kp] = wt; }
     if (choff) {        // the child weight follows from the weight and the count (gate_children: w / n above the cutoff, +-cutoff for the one child below it)
       const u32 nc = ncv[k];
       go.keys[q0] = (key[k] << 32) | (u64)q0; go.child_off[q0] = cex + (u64)cpre[k];
