@@ -287,12 +287,24 @@ def davidson_lowest(plan, diag, k=1, v0=None, tol=1e-10):
     return w, X
 
 
+def _key64(up, dn):
+    """(up, dn) as one 64-bit sort key when both strings fit 32 bits (up to 32 orbitals), else None"""
+    up, dn = np.asarray(up, np.uint64), np.asarray(dn, np.uint64)
+    if len(up) and (int(up.max()) >> 32 or int(dn.max()) >> 32):
+        return None
+    return (up << np.uint64(32)) | dn
+
+
 def sort_dets(up, dn):
-    return np.lexsort((dn, up))
+    k = _key64(up, dn)
+    return np.lexsort((dn, up)) if k is None else np.argsort(k, kind="stable")
 
 
 def _dets_in(au, ad, bu, bd):
     """mask over the determinants (au, ad): which of them occur in the list (bu, bd); repeats allowed on both sides"""
+    ka, kb = _key64(au, ad), _key64(bu, bd)
+    if ka is not None and kb is not None:
+        return np.isin(ka, kb)
     n = len(au)
     u = np.concatenate((au, bu)); d = np.concatenate((ad, bd))
     o = np.lexsort((d, u))
