@@ -254,6 +254,10 @@ def _inlib_worker(port, outdir):
     a = np.array([w.step().copy() for _ in range(NSTEPS // 2)])        # sqmc_gpu_shard_step
     b, _ = w.run(NSTEPS - NSTEPS // 2)                                 # sqmc_gpu_shard_run
     wk = w.g.download_walkers()
+    split, nsplit = w.g.shard_time_split(reset=True)          # sqmc_gpu_shard_time_split: every step of both loops went through it
+    assert nsplit == NSTEPS and all(v >= 0.0 for v in split.values()) and split["head_us"] + split["exchange_us"] + split["tail_us"] > 1.0
+    assert split["of_which_waiting_for_the_gpu_us"] <= split["head_us"] + split["exchange_us"] + split["tail_us"] + 1e-9
+    assert w.g.shard_time_split()[1] == 0
     np.savez(os.path.join(outdir, "inlib.npz"), outs=np.concatenate([a, b]), **wk)
     w.close()
 
