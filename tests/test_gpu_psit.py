@@ -165,6 +165,34 @@ def test_psit_heg_pipelined_steps_bit_exact(oracle, heg14):
     g.close(); ow.close()
 
 
+def test_psit_run_loop_equals_single_steps_at_the_bench_size(c2_walk):
+    """BASELINE configs[1]'s population (w_abs_gen_target 10^5; 76,900 resident C(T) determinants + the survivors outside) with
+    hf_to_psit: sqmc_gpu_run -- population control in the library, pipelined steps past the target -- leaves the same walkers, bit
+    for bit, as single unpipelined sqmc_gpu_step calls driven by the host's PopControl; and the layout's invariants hold there."""
+    from sqmc_amd import host as H
+    h = H.ChemHost(c2_walk_fcidump(), 8, 4, "d2h")
+    res = []
+    for mode in ("run", "step"):
+        gw = H.GpuWalk(h, 1e5, w_begin=1e4, hf_to_psit=True, seed=(1346, 5634, 6635, 4361))
+        if mode == "run":
+            gw.run(260, keep_stats=False)
+        else:
+            for _ in range(260):
+                gw.step()
+        res.append(gw.g.download_walkers())
+        reached, n_ct, setup = gw.pc.reached, len(gw.setup.ct_up), gw.setup
+        gw.close()
+        assert reached == 2
+    a, b = res
+    for k in ("up", "dn", "wt", "imp_distance", "initiator"):
+        assert np.array_equal(a[k], b[k]), k
+    assert len(a["up"]) > n_ct + 40000
+    assert np.array_equal(a["up"][:n_ct], setup.ct_up) and np.array_equal(a["dn"][:n_ct], setup.ct_dn)
+    u, d = a["up"][n_ct:], a["dn"][n_ct:]
+    assert np.all((u[1:] > u[:-1]) | ((u[1:] == u[:-1]) & (d[1:] > d[:-1]))) and a["imp_distance"][n_ct:].min() >= 1
+    assert np.all(np.abs(a["wt"][n_ct:]) > 0)
+
+
 def test_psit_run_loop_and_energy(c2_walk):
     """sqmc_gpu_run with hf_to_psit (population control inside the library) from the product's own set-up: the projected energy of the
     transformed walk agrees with the untransformed walk's and with this geometry's HCI+PT2 total (-75.72854 Ha, pinned to the
