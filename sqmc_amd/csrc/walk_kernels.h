@@ -134,9 +134,23 @@ __device__ __forceinline__ void diag_block(const ChemTab &t, const ChemDev &dev,
   if (need) q[base + __popcll(bal & ((1ull << lane) - 1ull))] = threadIdx.x;
   __syncthreads();
   if (qn) {
-    for (int k = threadIdx.x; k < qn; k += TPB) {
-      const long long j = blk * TPB + q[k];
-      me[j] = hq[q[k]] = h_any(t, dev.integrals, up[j], dn[j], up[j], dn[j]);
+    if (bk_hii_group_lanes(t)) {
+      // chemistry without time-reversal symmetry: 16 lanes per determinant fetch all of h_diag's ~50 integrals in one round trip and one
+      // lane per sum adds them in the reference's order (hii_group.h: the same bits as the serial sum, without its ~13 dependent round trips)
+      __shared__ double s_hg[(TPB / 16) * BK_HG_TERMS(16)];
+      const int G = (int)threadIdx.x / 16, g = (int)threadIdx.x % 16;
+      for (int k0 = 0; k0 < qn; k0 += TPB / 16) {
+        const int k = k0 + G; const bool valid = k < qn;
+        const long long j = valid ? blk * TPB + q[k] : 0;
+        const u64 u = valid ? up[j] : 0ull, d = valid ? dn[j] : 0ull;
+        const double v = bk_hii_group<16>(t, dev.integrals, u, d, valid, s_hg + G * BK_HG_TERMS(16), g);
+        if (valid && g == 0) { me[j] = v; hq[q[k]] = v; }
+      }
+    } else {
+      for (int k = threadIdx.x; k < qn; k += TPB) {
+        const long long j = blk * TPB + q[k];
+        me[j] = hq[q[k]] = h_any(t, dev.integrals, up[j], dn[j], up[j], dn[j]);
+      }
     }
     __syncthreads();
     if (need) hii = hq[threadIdx.x];
