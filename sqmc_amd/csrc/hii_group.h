@@ -93,3 +93,40 @@ __device__ __forceinline__ double bk_hii_group(const ChemTab &t, const double *_
   __syncthreads();
   return e1 + (ex + di) + t.nuclear;
 }
+
+// ---- the same for the electron gas (hamiltonian_heg's diagonal, heg.f90:845-1011 as restated in h_heg): 14 kinetic terms and 42 pair
+// terms 4 pi / |k_a - k_b|^2 for 7 + 7 electrons, each a chain of subtractions, a sum of squares and an fp64 divide -- one lane on its
+// own works ~2,000 dependent instructions per determinant.  Here the terms are spread over the HG lanes of a group, parked in LDS in the
+// reference's order, and two lanes add them up in that order: the same value bit for bit.
+__device__ __forceinline__ int heg_hii_terms(const ChemTab &t) { return (t.nup + t.ndn) + t.nup * (t.nup - 1) / 2 + t.ndn * (t.ndn - 1) / 2; }
+__device__ __forceinline__ bool heg_hii_group_ok(const ChemTab &t) { return t.sys_type == 1 && heg_hii_terms(t) <= BK_HG_TERMS(16); }
+template <int HG>
+__device__ __forceinline__ double heg_hii_group(const ChemTab &t, u64 up, u64 dn, bool valid, double *sg, int g) {
+  const int nup = t.nup, ndn = t.ndn, nuu = nup * (nup - 1) / 2, ndd = ndn * (ndn - 1) / 2;
+  const int L_kin = nup + ndn, L_pot = nuu + ndd, ntask = valid ? L_kin + L_pot : 0;
+  for (int k = g; k < ntask; k += HG) {
+    double v;
+    if (k < L_kin) {
+      const int o = (k < nup) ? bk_nth_orb(up, k) : bk_nth_orb(dn, k - nup);
+      v = heg_sumsq(t, t.kvec[o + 1]) * 0.5;
+    } else {
+      int r = k - L_kin; u64 det = up; int n = nup;
+      if (r >= nuu) { r -= nuu; det = dn; n = ndn; }
+      int a = 0;
+      while (r >= n - 1 - a) { r -= n - 1 - a; a++; }            // pair (a, a + 1 + r) in the order of the reference's double loop
+      v = heg_inv_k2(t, bk_nth_orb(det, a) + 1, bk_nth_orb(det, a + 1 + r) + 1);
+    }
+    sg[k] = v;
+  }
+  __syncthreads();
+  double acc = 0.0;
+  if (valid && g < 2) {
+    const int o = g ? L_kin : 0, L = g ? L_pot : L_kin;
+    for (int q = 0; q < L; q++) acc = acc + sg[o + q];
+  }
+  const double me = __shfl(acc, 0, HG), pot = __shfl(acc, 1, HG);
+  __syncthreads();
+  const double Lc = t.length_cell;
+  return me - pot / (Lc * Lc * Lc);
+}
+

@@ -134,16 +134,25 @@ __device__ __forceinline__ void diag_block(const ChemTab &t, const ChemDev &dev,
   if (need) q[base + __popcll(bal & ((1ull << lane) - 1ull))] = threadIdx.x;
   __syncthreads();
   if (qn) {
+    __shared__ double s_hg[(TPB / 16) * BK_HG_TERMS(16)];      // the groups' terms (chemistry or electron gas)
     if (bk_hii_group_lanes(t)) {
       // chemistry without time-reversal symmetry: 16 lanes per determinant fetch all of h_diag's ~50 integrals in one round trip and one
       // lane per sum adds them in the reference's order (hii_group.h: the same bits as the serial sum, without its ~13 dependent round trips)
-      __shared__ double s_hg[(TPB / 16) * BK_HG_TERMS(16)];
       const int G = (int)threadIdx.x / 16, g = (int)threadIdx.x % 16;
       for (int k0 = 0; k0 < qn; k0 += TPB / 16) {
         const int k = k0 + G; const bool valid = k < qn;
         const long long j = valid ? blk * TPB + q[k] : 0;
         const u64 u = valid ? up[j] : 0ull, d = valid ? dn[j] : 0ull;
         const double v = bk_hii_group<16>(t, dev.integrals, u, d, valid, s_hg + G * BK_HG_TERMS(16), g);
+        if (valid && g == 0) { me[j] = v; hq[q[k]] = v; }
+      }
+    } else if (heg_hii_group_ok(t)) {          // electron gas: the pair terms of a determinant spread over 16 lanes (hii_group.h)
+      const int G = (int)threadIdx.x / 16, g = (int)threadIdx.x % 16;
+      for (int k0 = 0; k0 < qn; k0 += TPB / 16) {
+        const int k = k0 + G; const bool valid = k < qn;
+        const long long j = valid ? blk * TPB + q[k] : 0;
+        const u64 u = valid ? up[j] : 0ull, d = valid ? dn[j] : 0ull;
+        const double v = heg_hii_group<16>(t, u, d, valid, s_hg + G * BK_HG_TERMS(16), g);
         if (valid && g == 0) { me[j] = v; hq[q[k]] = v; }
       }
     } else {
