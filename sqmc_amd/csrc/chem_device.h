@@ -38,7 +38,8 @@ struct ChemTab {
   };
   signed char krel[SQ_MAXORB + 1][3];  // the same in units of 2 pi / L (k_vectors_rel): exact momentum bookkeeping
   int heg_nmax;                        // max |krel component|
-  int c2_stride, c2_pad;               // combine_2 is stored packed: c2[i*c2_stride + j], 1-based
+  int c2_stride, c2_pad;               // combine_2 is stored packed: c2[i*c2_stride + j], 1-based.  heg: c2_pad = 1 when the bytes of c2 hold the
+                                       // plane-wave lookup (krel + heg_nmax, base 2 heg_nmax + 1) -> orbital, 0 = no such plane wave (heg_lut)
   unsigned short c2[(SQ_MAXORB + 2) * (SQ_MAXORB + 2)];   // only the first c2_stride^2 entries are used/staged
 };
 
@@ -566,9 +567,9 @@ __device__ inline int propose_heg(const ChemTab &t, Rng &g, u64 iu, u64 id, u64 
   do { e2 = rng_int(g, nelec); } while (e1 == e2);
   const int spin = ((e1 > nup) ? -1 : 1) + ((e2 > nup) ? -1 : 1);
   double from[3] = {0.0, 0.0, 0.0}, to1[3] = {0.0, 0.0, 0.0};
-  int ie = 0;
-  for (u64 d = iu; d; d &= d - 1) { const int i = ctz64(d) + 1; ie++; if (ie == e1 || ie == e2) { for (int j = 0; j < nd; j++) from[j] = from[j] + t.kvec[i][j]; ju &= ~bit64(i - 1); } }
-  for (u64 d = id; d; d &= d - 1) { const int i = ctz64(d) + 1; ie++; if (ie == e1 || ie == e2) { for (int j = 0; j < nd; j++) from[j] = from[j] + t.kvec[i][j]; jd &= ~bit64(i - 1); } }
+  int ie = 0, kf[3] = {0, 0, 0}, i_first = 0;
+  for (u64 d = iu; d; d &= d - 1) { const int i = ctz64(d) + 1; ie++; if (ie == e1 || ie == e2) { for (int j = 0; j < nd; j++) from[j] = from[j] + t.kvec[i][j]; for (int j = 0; j < 3; j++) kf[j] += t.krel[i][j]; ju &= ~bit64(i - 1); } }
+  for (u64 d = id; d; d &= d - 1) { const int i = ctz64(d) + 1; ie++; if (ie == e1 || ie == e2) { for (int j = 0; j < nd; j++) from[j] = from[j] + t.kvec[i][j]; for (int j = 0; j < 3; j++) kf[j] += t.krel[i][j]; jd &= ~bit64(i - 1); } }
   bool first_up, second_up; int to1n; float denom;
   if (spin == 2) { to1n = rng_int(g, norb - nup); first_up = true; second_up = true; denom = (float)(nelec * (nelec - 1) * (norb - nup)); }
   else if (spin == -2) { to1n = rng_int(g, norb - ndn); first_up = false; second_up = false; denom = (float)(nelec * (nelec - 1) * (norb - ndn)); }
@@ -578,10 +579,28 @@ __device__ inline int propose_heg(const ChemTab &t, Rng &g, u64 iu, u64 id, u64 
   }
   {
     const int i = kth_set(t.orb_mask & ~(first_up ? iu : id), to1n);
+    i_first = i;
     for (int j = 0; j < nd; j++) to1[j] = to1[j] + t.kvec[i][j];
     if (first_up) ju |= bit64(i - 1); else jd |= bit64(i - 1);
   }
-  for (u64 fr = t.orb_mask & ~(second_up ? (iu | ju) : (id | jd)); fr; fr &= fr - 1) {
+  const u64 free2 = t.orb_mask & ~(second_up ? (iu | ju) : (id | jd));
+  if (t.c2_pad) {
+    // The reference scans the free orbitals upwards for the first one whose plane wave closes the momentum balance to 1e-15 (1451-1467).
+    // Plane waves are integer multiples of 2 pi / L: at most ONE orbital can -- the one whose integer vector is the balance -- and any
+    // other misses by at least 2 pi / L.  Look that one up, then put it to the reference's own floating-point test: the same decision.
+    const int nm = t.heg_nmax, W = 2 * nm + 1;
+    int idx = 0; bool inside = true;
+    for (int j = 0; j < 3; j++) { const int kj = kf[j] - t.krel[i_first][j]; inside = inside && kj >= -nm && kj <= nm; idx = idx * W + (kj + nm); }
+    const int i = inside ? (int)reinterpret_cast<const unsigned char *>(t.c2)[idx] : 0;
+    if (i == 0 || !((free2 >> (i - 1)) & 1ull)) return 0;
+    int ok = 0;
+    for (int j = 0; j < nd; j++) if (fabs(from[j] - (to1[j] + t.kvec[i][j])) < 1.0e-15) ok++;
+    if (ok != nd) return 0;
+    if (second_up) ju |= bit64(i - 1); else jd |= bit64(i - 1);
+    prob = (double)(4.0f / denom);
+    return 2;
+  }
+  for (u64 fr = free2; fr; fr &= fr - 1) {
     const int i = ctz64(fr) + 1;
     int ok = 0;
     for (int j = 0; j < nd; j++) if (fabs(from[j] - (to1[j] + t.kvec[i][j])) < 1.0e-15) ok++;

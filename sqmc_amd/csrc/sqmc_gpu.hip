@@ -387,6 +387,16 @@ int sqmc_gpu_init_heg(const sqmc_heg_cfg *cfg, sqmc_gpu_ctx **out) {
     t.krel[i][j] = (signed char)kr;
     if (llabs(kr) > t.heg_nmax) t.heg_nmax = (int)llabs(kr);
   }
+  // plane-wave lookup for the proposal's momentum balance (propose_heg): integer vector -> orbital, in the bytes combine_2 has no use for here
+  t.c2_pad = 0;
+  { const int W = 2 * t.heg_nmax + 1;
+    if ((size_t)W * W * W <= sizeof(t.c2) && !getenv("SQMC_HEG_NO_LUT")) {
+      unsigned char *lut = reinterpret_cast<unsigned char *>(t.c2);
+      memset(lut, 0, (size_t)W * W * W);
+      for (int i = 1; i <= cfg->norb; i++) lut[((t.krel[i][0] + t.heg_nmax) * W + (t.krel[i][1] + t.heg_nmax)) * W + (t.krel[i][2] + t.heg_nmax)] = (unsigned char)i;
+      int stride = 1; while ((size_t)stride * stride * sizeof(unsigned short) < (size_t)W * W * W) stride++;
+      t.c2_stride = stride; t.c2_pad = 1;          // (c2_stride only sizes the staging of the table here)
+    } }
   return init_common(c, cfg->norb, cfg->nup, cfg->ndn, cfg->rng_mode, cfg->irand_seed, cfg->mwalk, out);
 }
 
