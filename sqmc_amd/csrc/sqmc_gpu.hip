@@ -178,7 +178,8 @@ struct sqmc_gpu_ctx {
   // timing
   int timing; hipEvent_t ev0[NTIMERS], ev1[NTIMERS]; const char *tname[NTIMERS]; int nt; float tms[NTIMERS];
   double tsum[NTIMERS]; long long tsteps;         // accumulated over the steps since sqmc_gpu_set_timing
-  hipStream_t st2; hipEvent_t e_fork, e_join, e_cnt;    // second stream: death/clone beside spawn + sort
+  hipStream_t st2; hipEvent_t e_fork, e_join, e_cnt, e_spawned;    // second stream: death/clone beside spawn + sort (long lists: behind k_spawn, beside the sort)
+  bool spawned_valid;
   hipStream_t st3; hipEvent_t e_join3;                   // third stream: the deterministic projection (it touches the deterministic-space walkers only, death/clone all the others)
   // pipelined head (sqmc_gpu_run, COUNTER discipline, target population reached): gate + scan + spawn of step n+1 are
   // enqueued right behind k_finish of step n, before the host has read step n's sums
@@ -321,7 +322,7 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
   if (getenv("SQMC_ONE_STREAM")) { c->st2 = c->st; c->st3 = c->st; }      // experiment: no side streams (their fork/join costs event latencies)
   else { HIPCHK(hipStreamCreate(&c->st2)); HIPCHK(hipStreamCreate(&c->st3)); }
   HIPCHK(hipEventCreateWithFlags(&c->e_join3, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&c->e_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->e_join, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->e_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->e_join, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->e_spawned, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->e_cnt, hipEventDisableTiming));
   for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->hev[i]));
   *out = c;
@@ -456,7 +457,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   hipFree(c->d_ps_dwimp); hipFree(c->d_ps_p2); hipFree(c->d_ps_part); hipFree(c->d_ps_raw);
   hipFree(c->d_sc); hipHostFree(c->h_sc); if (c->h_mail) hipHostFree((void *)c->h_mail);
   for (int i = 0; i < NTIMERS; i++) { hipEventDestroy(c->ev0[i]); hipEventDestroy(c->ev1[i]); }
-  hipEventDestroy(c->e_fork); hipEventDestroy(c->e_join); hipEventDestroy(c->e_cnt);
+  hipEventDestroy(c->e_fork); hipEventDestroy(c->e_join); hipEventDestroy(c->e_cnt); hipEventDestroy(c->e_spawned);
   for (int i = 0; i < 4; i++) hipEventDestroy(c->hev[i]);
   hipEventDestroy(c->e_join3); if (c->st3 != c->st) hipStreamDestroy(c->st3);
   if (c->st2 != c->st) hipStreamDestroy(c->st2);
@@ -911,6 +912,7 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
       SPAWN_LAUNCH(c->dev.hb.on, spawn_fuse, dim3(nblk(nfree) + (spawn_fin.on ? 1 : 0) + hq_blk + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0)), dim3(TPB), spawn_lds, st, c->dev, c->w, c->d_child_off, c->d_wchild, c->d_child_state, c->d_keys, c->d_vals,
                          n0, M, p, c->rng_mode, c->seed64, step, c->invalid_key, (const DevScalars *)c->d_sc, c->d_mail, *cseq, c->pack, dev_n ? 1 : 0, oo, hb, spawn_fin, pp, (spawn_fin.on ? 1 : 0) + hq_blk + (pp.n_imp > 0 ? nblk(pp.n_imp, TPB / 64) : 0) + ((hb.kb || hb.kb_out) ? 1 : 0));
   } else if (s0) { hipEventRecord(s0, st); hipEventRecord(s1, st); }
+  HIPCHK(hipEventRecord(c->e_spawned, st)); c->spawned_valid = true;
   HIPCHK(hipGetLastError());
   return SQMC_OK;
 }
@@ -936,7 +938,12 @@ static void abandon_head(sqmc_gpu_ctx *c) {
 static int launch_side_kernels(sqmc_gpu_ctx *c, const StepP &p, long long n0, bool serial) {
   if (!serial && !c->fork_valid) { HIPCHK(hipEventRecord(c->e_fork, c->st)); c->fork_valid = true; }      // the head forked nothing: the side streams start behind what is enqueued so far
   hipStream_t st2 = serial ? c->st : c->st2;
-  if (!serial) HIPCHK(hipStreamWaitEvent(st2, c->e_fork, 0));
+  // long lists: death/clone starts behind k_spawn and runs beside the sort, whose kernels leave most of the chip idle -- beside k_spawn it
+  // took its wave slots (k_spawn alone: 80 us at 10^6 walkers, 93 with death/clone beside it)
+  static const bool diag_late_env = !(getenv("SQMC_DIAG_BESIDE_SPAWN") != nullptr);
+  const bool diag_late = diag_late_env && !serial && c->spawned_valid && c->last_nall >= (1ll << 20);
+  if (!serial) HIPCHK(hipStreamWaitEvent(st2, diag_late ? c->e_spawned : c->e_fork, 0));
+  c->spawned_valid = false;
   TBEG(diag, st2);
   hipLaunchKernelGGL(k_diag, dim3(nblk(n0)), dim3(TPB), 0, st2, c->dev, c->w.up, c->w.dn, c->w.wt, c->w.flg, c->w.me, n0, p, c->d_sc, 0);
   TEND(diag, st2);
