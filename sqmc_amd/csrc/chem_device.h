@@ -567,9 +567,20 @@ __device__ inline int propose_heg(const ChemTab &t, Rng &g, u64 iu, u64 id, u64 
   do { e2 = rng_int(g, nelec); } while (e1 == e2);
   const int spin = ((e1 > nup) ? -1 : 1) + ((e2 > nup) ? -1 : 1);
   double from[3] = {0.0, 0.0, 0.0}, to1[3] = {0.0, 0.0, 0.0};
-  int ie = 0, kf[3] = {0, 0, 0}, i_first = 0;
-  for (u64 d = iu; d; d &= d - 1) { const int i = ctz64(d) + 1; ie++; if (ie == e1 || ie == e2) { for (int j = 0; j < nd; j++) from[j] = from[j] + t.kvec[i][j]; for (int j = 0; j < 3; j++) kf[j] += t.krel[i][j]; ju &= ~bit64(i - 1); } }
-  for (u64 d = id; d; d &= d - 1) { const int i = ctz64(d) + 1; ie++; if (ie == e1 || ie == e2) { for (int j = 0; j < nd; j++) from[j] = from[j] + t.kvec[i][j]; for (int j = 0; j < 3; j++) kf[j] += t.krel[i][j]; jd &= ~bit64(i - 1); } }
+  int kf[3] = {0, 0, 0}, i_first = 0;
+  // the two electrons in the order the reference's loop over the occupied orbitals meets them (up ascending, then dn ascending):
+  // electron e of that order is the e-th set bit of iu, or the (e - nup)-th of id
+  {
+    const int ea = e1 < e2 ? e1 : e2, eb = e1 < e2 ? e2 : e1;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int e = q ? eb : ea; const bool isup = e <= nup;
+      const int i = kth_set_wide(isup ? iu : id, isup ? e : e - nup);
+      for (int j = 0; j < nd; j++) from[j] = from[j] + t.kvec[i][j];
+      for (int j = 0; j < 3; j++) kf[j] += t.krel[i][j];
+      if (isup) ju &= ~bit64(i - 1); else jd &= ~bit64(i - 1);
+    }
+  }
   bool first_up, second_up; int to1n; float denom;
   if (spin == 2) { to1n = rng_int(g, norb - nup); first_up = true; second_up = true; denom = (float)(nelec * (nelec - 1) * (norb - nup)); }
   else if (spin == -2) { to1n = rng_int(g, norb - ndn); first_up = false; second_up = false; denom = (float)(nelec * (nelec - 1) * (norb - ndn)); }
@@ -578,7 +589,7 @@ __device__ inline int propose_heg(const ChemTab &t, Rng &g, u64 iu, u64 id, u64 
     if (to1n <= norb - nup) { first_up = true; second_up = false; } else { to1n -= (norb - nup); first_up = false; second_up = true; }
   }
   {
-    const int i = kth_set(t.orb_mask & ~(first_up ? iu : id), to1n);
+    const int i = kth_set_wide(t.orb_mask & ~(first_up ? iu : id), to1n);      // (up to 50 free orbitals: no data-dependent loop)
     i_first = i;
     for (int j = 0; j < nd; j++) to1[j] = to1[j] + t.kvec[i][j];
     if (first_up) ju |= bit64(i - 1); else jd |= bit64(i - 1);
