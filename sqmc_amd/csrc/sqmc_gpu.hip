@@ -147,6 +147,9 @@ struct PsitArgs {
   int seq;
 };
 
+// staging buffer of the two-kernel annihilation of long lists (walk_kernels.h, k_anneal<., 0, 1>): the kept walkers of every tile, compacted
+// inside the tile, and the tiles' counts (kept | deterministic-space << 32; children)
+struct AnnealStage { u64 *up, *dn, *key; double *wt, *me, *en, *ed; u32 *flg, *nc, *lch, *ldet; u64 *cnt_a, *cnt_b; };
 struct HbHost;            // heatbath_setup.inc: host copies of the efficient heat-bath tables the library built itself
 struct sqmc_gpu_ctx {
   hipStream_t st;
@@ -216,6 +219,7 @@ struct sqmc_gpu_ctx {
   BucketArgs head_ba; long long last_nall;      // partition already done by the head's k_spawn (B > 0), and the length of the last sorted list (sizes the next one)
   int bk_holdoff;             // steps for which the bucket tail stays off (after a bucket overflowed or came close)
   long long bk_steps, bk_retries;
+  AnnealStage stage; void *stage_mem; long long stage_cap;      // long lists: staging buffer of the two-kernel annihilation (k_anneal<., 0, 1> + k_anneal_place), allocated at first use
   double sh_us[4]; long long sh_steps;      // host wall clock of the in-library sharded steps: head, exchange, tail, of which waiting for the GPU's mail (sqmc_gpu_shard_time_split)
   // hf_to_psit (psit_kernels.h)
   HbHost *hb_host;
@@ -454,7 +458,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x); hipFree(c->d_prj_xs[0]); hipFree(c->d_prj_xs[1]); hipFree(c->d_prj_y);
   hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den); hipFree(c->d_ct_hkey); hipFree(c->d_ct_hidx);
   hipFree(c->d_ps_loc); hipFree(c->d_ps_of); hipFree(c->d_ps_impof); hipFree(c->d_ps_c); hipFree(c->d_ps_diag); hipFree(c->d_ps_dwct); hipFree(c->d_ps_dwps);
-  hipFree(c->d_ps_dwimp); hipFree(c->d_ps_p2); hipFree(c->d_ps_part); hipFree(c->d_ps_raw);
+  hipFree(c->d_ps_dwimp); hipFree(c->d_ps_p2); hipFree(c->d_ps_part); hipFree(c->d_ps_raw); hipFree(c->stage_mem);
   hipFree(c->d_sc); hipHostFree(c->h_sc); if (c->h_mail) hipHostFree((void *)c->h_mail);
   for (int i = 0; i < NTIMERS; i++) { hipEventDestroy(c->ev0[i]); hipEventDestroy(c->ev1[i]); }
   hipEventDestroy(c->e_fork); hipEventDestroy(c->e_join); hipEventDestroy(c->e_cnt); hipEventDestroy(c->e_spawned);
@@ -977,6 +981,26 @@ static int launch_side_kernels(sqmc_gpu_ctx *c, const StepP &p, long long n0, bo
   HIPCHK(hipGetLastError());
   return SQMC_OK;
 }
+// the two-kernel annihilation of long lists: pipelined COUNTER steps of one GPU whose tail carries the child offsets; allocates the
+// staging buffer (72 bytes per walker slot) the first time
+static bool anneal_split_ok(sqmc_gpu_ctx *c, const StepP &p, int mode, long long nall, int items, bool child_off, bool use_mail) {
+  static const int env = getenv("SQMC_ANNEAL_SPLIT") ? atoi(getenv("SQMC_ANNEAL_SPLIT")) : 1;
+  if (!env || !p.semi || c->psit_on || mode != SQMC_RNG_COUNTER || !child_off || !use_mail || c->d_grow || nall < (1ll << 20) || items < 3 || !c->pack) return false;
+  const long long M = c->mwalk;
+  if (!c->stage_mem || c->stage_cap < M) {
+    hipFree(c->stage_mem); c->stage_mem = nullptr; c->stage_cap = 0;
+    const long long nt = M / (TPB * 3) + 2;
+    const size_t bytes = (size_t)M * (7 * 8 + 4 * 4) + (size_t)nt * 16 + 256;
+    if (hipMalloc(&c->stage_mem, bytes) != hipSuccess) { (void)hipGetLastError(); c->stage_mem = nullptr; return false; }
+    char *b = (char *)c->stage_mem; AnnealStage &g = c->stage;
+    g.up = (u64 *)b; b += M * 8; g.dn = (u64 *)b; b += M * 8; g.key = (u64 *)b; b += M * 8;
+    g.wt = (double *)b; b += M * 8; g.me = (double *)b; b += M * 8; g.en = (double *)b; b += M * 8; g.ed = (double *)b; b += M * 8;
+    g.flg = (u32 *)b; b += M * 4; g.nc = (u32 *)b; b += M * 4; g.lch = (u32 *)b; b += M * 4; g.ldet = (u32 *)b; b += M * 4;
+    g.cnt_a = (u64 *)b; b += nt * 8; g.cnt_b = (u64 *)b;
+    c->stage_cap = M;
+  }
+  return true;
+}
 #define SQMC_INTERNAL_RETRY 1000      // step_tail_impl: the bucket tail gave up, nothing of it counts; run the radix tail
 static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long long nall, bool join_side_stream, double out[16], bool allow_bucket) {
   StepP p = p_in;
@@ -1093,8 +1117,8 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     }
 #define ANNEAL_ARGS c->w, c->m, skey, perm, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, n0, nall, p,  \
                     c->invalid_key, c->pack, mode, seed, step, c->d_sc, c->d_fstate, c->d_fstate + c->cap_ftiles, c->d_fticket, go
-#define ANNEAL_LAUNCH_(I, P) do { if (t_anneal >= 0) hipExtLaunchKernelGGL((k_anneal<I, P>), dim3(nb), dim3(TPB), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, ANNEAL_ARGS); \
-                                  else hipLaunchKernelGGL((k_anneal<I, P>), dim3(nb), dim3(TPB), 0, st, ANNEAL_ARGS); } while (0)
+#define ANNEAL_LAUNCH_(I, P) do { if (t_anneal >= 0) hipExtLaunchKernelGGL((k_anneal<I, P, 0>), dim3(nb), dim3(TPB), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, ANNEAL_ARGS, AnnealStage{}); \
+                                  else hipLaunchKernelGGL((k_anneal<I, P, 0>), dim3(nb), dim3(TPB), 0, st, ANNEAL_ARGS, AnnealStage{}); } while (0)
 #define ANNEAL_LAUNCH(I) ANNEAL_LAUNCH_(I, 0)
     if (bucket) {
       FusedSide fs; memset(&fs, 0, sizeof(fs));
@@ -1111,6 +1135,20 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       c->head_offsets_done = (go.child_off != nullptr); c->head_offsets_bucket = true;
       c->scount_B = ba.B; c->scount_buf = ba.kb ? c->head_kb_use : -1; c->scount_pos = c->pos_flip;
     } else if (c->psit_on) { c->scount_B = 0; if (items <= 2) ANNEAL_LAUNCH_(2, 1); else ANNEAL_LAUNCH_(3, 1); }      // hf_to_psit: everything outside C(T); the C(T) segment is finished below
+    else if (anneal_split_ok(c, p, mode, nall, items, go.child_off != nullptr, use_mail)) {
+      // long lists: fold + round + a compaction inside every tile, a scan of the tiles' counts, then every tile to its place: no tile waits
+      // for the slowest tile in front of it (18.7 of a tile's 44 us at 10^6 walkers, tools/anneal_prof.py)
+      c->scount_B = 0;
+      const AnnealStage sg = c->stage;
+      if (t_anneal >= 0) hipEventRecord(c->ev0[t_anneal], st);
+      if (items == 3) hipLaunchKernelGGL((k_anneal<3, 0, 1>), dim3(nb), dim3(TPB), 0, st, ANNEAL_ARGS, sg);
+      else hipLaunchKernelGGL((k_anneal<4, 0, 1>), dim3(nb), dim3(TPB), 0, st, ANNEAL_ARGS, sg);
+      hipLaunchKernelGGL(k_anneal_split_scan, dim3(1), dim3(TPB), 0, st, sg.cnt_a, sg.cnt_b, nb, c->d_sc);
+      if (items == 3) hipLaunchKernelGGL(k_anneal_place<3>, dim3(nb), dim3(TPB), 0, st, sg, c->m, c->d_loc_imp, (const u64 *)c->d_ct_hkey, (const u32 *)c->d_ct_hidx, c->ct_mask, (const double *)c->d_ct_num, (const double *)c->d_ct_den, c->d_partials, p, nb, go, (const DevScalars *)c->d_sc);
+      else hipLaunchKernelGGL(k_anneal_place<4>, dim3(nb), dim3(TPB), 0, st, sg, c->m, c->d_loc_imp, (const u64 *)c->d_ct_hkey, (const u32 *)c->d_ct_hidx, c->ct_mask, (const double *)c->d_ct_num, (const double *)c->d_ct_den, c->d_partials, p, nb, go, (const DevScalars *)c->d_sc);
+      if (t_anneal >= 0) hipEventRecord(c->ev1[t_anneal], st);
+      c->head_offsets_done = true; c->head_offsets_bucket = false;
+    }
     else { c->scount_B = 0; if (items == 1) ANNEAL_LAUNCH(1); else if (items == 2) ANNEAL_LAUNCH(2); else if (items == 3) ANNEAL_LAUNCH(3); else ANNEAL_LAUNCH(4);
            c->head_offsets_done = (go.child_off != nullptr); c->head_offsets_bucket = false; }
 #undef ANNEAL_LAUNCH_

@@ -990,17 +990,21 @@ extern "C" int sqmc_gpu_debug_aprof(unsigned long long *out) { return (int)hipMe
 // PSIT: the hf_to_psit step (fold_slot<1>).  The C(T) segment comes out where it was (its determinants sort first and none is dropped) with
 // the merged weights and flags only: T^-1, the initiator test, the reweighting and every sum over C(T) -- the whole energy estimator,
 // do_walk.f90:2701-2722 -- are k_psit_tinv / k_psit_finish's; the walkers outside C(T) are finished here, without an estimator lookup.
-template <int ITEMS, int PSIT>
+// SPLIT (long lists, COUNTER discipline, pipelined): no tile waits for the tiles in front.  The kernel stops behind the rounding: the kept
+// walkers of a tile go, compacted inside the tile, to a staging buffer with their counts (k_anneal_split_scan adds the counts up,
+// k_anneal_place moves every tile to its place and does what needs the place: the estimator sums, the next gate, the row table).
+// (struct AnnealStage: sqmc_gpu.hip, in front of the context that keeps one)
+template <int ITEMS, int PSIT, int SPLIT>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) k_anneal(WalkArr w, WalkArr o, const u64 *__restrict__ skey, const u32 *__restrict__ perm, int *__restrict__ loc_imp,
                                                 const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 hmask,
                                                 const double *__restrict__ cnum, const double *__restrict__ cden,
                                                 double *__restrict__ partials, double *__restrict__ wabs_part, long long n0, long long n_all, StepP p,
                                                 u64 invalid_key, int pack, int mode, u64 seed, u64 step, DevScalars *sc,
-                                                u64 *__restrict__ state1, u64 *__restrict__ state2, u32 *__restrict__ ticket, GateOut go) {
+                                                u64 *__restrict__ state1, u64 *__restrict__ state2, u32 *__restrict__ ticket, GateOut go, AnnealStage sg) {
   constexpr int TILE = TPB * ITEMS;
   __shared__ u32 s_tile; __shared__ u64 s_ex[2]; __shared__ u64 s_wsum[2][TPB / 64];
   __shared__ double s_w[TILE]; __shared__ u32 s_f[TILE];          // weight and flags of every slot of the tile
-  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  if (threadIdx.x == 0) s_tile = SPLIT ? (u32)blockIdx.x : atomicAdd(ticket, 1u);
   __syncthreads();
   const u32 tile = s_tile;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1102,6 +1106,23 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
     for (int q = 0; q < TPB / 64; q++) { if (q < wv) cex += s_wsum[0][q]; ctot += s_wsum[0][q]; }
   }
+  if (SPLIT) {
+    // the tile's own counts, and its kept walkers at their places inside the tile: nothing here depends on another tile
+    if (threadIdx.x == 0) { sg.cnt_a[tile] = tot; sg.cnt_b[tile] = ctot; }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      if (!(f2[k] & 1ull)) continue;
+      const u64 ex2 = ex + inc[k] - f2[k];
+      const long long q = (long long)tile * TILE + (long long)(ex2 & 0xFFFFFFFFull);
+      double me = r[k].me, en = r[k].en, ed = r[k].ed;
+      if (PARK) { const int qq = wv * (64 * ITEMS) + k * 64 + lane; me = s_park[0][qq]; en = s_park[PARK ? 1 : 0][qq]; ed = s_park[PARK ? 2 : 0][qq]; }
+      sg.up[q] = r[k].up; sg.dn[q] = r[k].dn; sg.key[q] = key[k]; sg.wt[q] = r[k].wt * p.rfi; sg.flg[q] = r[k].flg;
+      sg.me[q] = me; sg.en[q] = en; sg.ed[q] = ed;
+      sg.nc[q] = ncv[k]; sg.lch[q] = (u32)(cex + (u64)cpre[k]); sg.ldet[q] = (u32)(ex2 >> 32);
+    }
+    APROF(4); APROF(5);
+    return;
+  }
   if (threadIdx.x < 64) {
     const u64 e = lookback_exclusive(state2, tile, tot, threadIdx.x);
     if (threadIdx.x == 0) { s_ex[1] = e; if (last_tile) { sc->tot2 = e + tot; sc->nwalk = (e + tot) & 0xFFFFFFFFull; } }
@@ -1172,6 +1193,69 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     partials[(long long)tile * NSTAT + threadIdx.x] = v;
   }
   APROF(5);
+}
+// exclusive sums of the tiles' counts (one block: a few thousand to a few ten thousand tiles); the totals are the step's
+__global__ void __launch_bounds__(TPB) k_anneal_split_scan(u64 *__restrict__ cnt_a, u64 *__restrict__ cnt_b, int ntiles, DevScalars *sc) {
+  __shared__ u64 s_a[TPB], s_b[TPB];
+  const int C = (ntiles + TPB - 1) / TPB, beg = threadIdx.x * C, end = (beg + C < ntiles) ? beg + C : ntiles;
+  u64 a = 0, b = 0;
+  for (int t = beg; t < end; t++) { a += cnt_a[t]; b += cnt_b[t]; }
+  s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
+  __syncthreads();
+  u64 ea = 0, eb = 0;
+  for (int q = 0; q < (int)threadIdx.x; q++) { ea += s_a[q]; eb += s_b[q]; }
+  for (int t = beg; t < end; t++) { const u64 ca = cnt_a[t], cb = cnt_b[t]; cnt_a[t] = ea; cnt_b[t] = eb; ea += ca; eb += cb; }
+  if (threadIdx.x == TPB - 1) { sc->tot2 = ea; sc->nwalk = ea & 0xFFFFFFFFull; sc->n_children = eb; }
+}
+// every tile's kept walkers from the staging buffer to their places in the new list, with everything that needed the place
+// (the second half of k_anneal: reweighted weights are staged already; estimator pieces, row table, next gate and child offsets)
+template <int ITEMS>
+__global__ void __launch_bounds__(TPB) k_anneal_place(AnnealStage sg, WalkArr o, int *__restrict__ loc_imp, const u64 *__restrict__ hkey, const u32 *__restrict__ hidx, u64 hmask,
+                                                      const double *__restrict__ cnum, const double *__restrict__ cden, double *__restrict__ partials, StepP p, int ntiles, GateOut go,
+                                                      const DevScalars *__restrict__ sc) {
+  constexpr int TILE = TPB * ITEMS;
+  const int tile = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const u64 base_a = sg.cnt_a[tile], base_b = sg.cnt_b[tile];
+  const u64 end_a = (tile + 1 < ntiles) ? sg.cnt_a[tile + 1] : (u64)sc->tot2;      // (the scan left exclusive sums; the total is the step's walker count)
+  double s[NSTAT];
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
+  const long long pos0 = (long long)(base_a & 0xFFFFFFFFull), det0 = (long long)(base_a >> 32);
+  const u32 cnt = (u32)((end_a & 0xFFFFFFFFull) - (base_a & 0xFFFFFFFFull));
+  for (u32 j = threadIdx.x; j < cnt; j += TPB) {
+    const long long q = (long long)tile * TILE + j, q0 = pos0 + j;
+    const u64 up = sg.up[q], dn = sg.dn[q], key = sg.key[q]; const double wt = sg.wt[q]; const u32 fl = sg.flg[q];
+    double me = sg.me[q], en = sg.en[q], ed = sg.ed[q]; const u32 nc = sg.nc[q];
+    const int d = flg_impd(fl), ini = flg_init(fl), psg = flg_psign(fl);
+    if (en > 1e50) { const long long h = ct_lookup(hkey, hidx, hmask, key); if (h < 0) { en = 0.0; ed = 0.0; } else { en = cnum[h]; ed = cden[h]; } }
+    o.up[q0] = up; o.dn[q0] = dn; o.wt[q0] = wt; o.flg[q0] = fl; o.me[q0] = me; o.en[q0] = en; o.ed[q0] = ed;
+    go.keys[q0] = (key << 32) | (u64)q0; go.child_off[q0] = base_b + (u64)sg.lch[q];
+    go.wchild[q0] = nc == 0 ? 0.0 : (fabs(wt) < go.cutoff ? copysign(go.cutoff, wt) : wt / (double)nc);
+    const long long qd = det0 + (long long)sg.ldet[q];
+    if (d == 0 && p.semi && qd < p.nimp_cap) loc_imp[qd] = (int)q0;
+    s[0] += wt; s[1] += fabs(wt); s[8] += wt * wt;
+    if (ini == 3) s[4] += wt * psg;
+    if (d == 0 || (d == -2 && p.cti)) s[6] += fabs(wt);
+    double e_num = en * wt, e_den = ed * wt;
+    if (e_num != 0.0) {
+      if (fabs(e_den) < 1e-22) e_den = fabs(e_den);
+      s[2] += e_den; s[3] += e_num; s[9] += e_num * e_num; s[10] += e_den * e_den;
+      s[11] += e_num * copysign(1.0, e_den); s[12] += fabs(e_den); s[5] += e_num * e_den;
+    }
+  }
+  __shared__ double red[TPB / 64][NSTAT];
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) {
+    double v = s[k];
+    for (int q = 32; q > 0; q >>= 1) v += __shfl_down(v, q, 64);
+    if (lane == 0) red[wv][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NSTAT) {
+    double v = 0.0;
+    for (int q = 0; q < TPB / 64; q++) v += red[q][threadIdx.x];
+    partials[(long long)tile * NSTAT + threadIdx.x] = v;
+  }
 }
 // posts the (all-reduced) scalars of a sharded step to the host mailbox
 __device__ __forceinline__ void post_reduced(DevScalars *sc, HostMail *mail, u64 seq, const double *red_at = nullptr) {
