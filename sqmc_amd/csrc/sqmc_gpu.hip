@@ -985,7 +985,7 @@ static int launch_side_kernels(sqmc_gpu_ctx *c, const StepP &p, long long n0, bo
 // staging buffer (72 bytes per walker slot) the first time
 static bool anneal_split_ok(sqmc_gpu_ctx *c, const StepP &p, int mode, long long nall, int items, bool child_off, bool use_mail) {
   static const int env = getenv("SQMC_ANNEAL_SPLIT") ? atoi(getenv("SQMC_ANNEAL_SPLIT")) : 1;
-  if (!env || !p.semi || c->psit_on || mode != SQMC_RNG_COUNTER || !child_off || !use_mail || c->d_grow || nall < (1ll << 20) || items < 3 || !c->pack) return false;
+  if (!env || !p.semi || c->psit_on || mode != SQMC_RNG_COUNTER || !child_off || !use_mail || c->d_grow || nall < (1ll << 20) || items < 3) return false;
   const long long M = c->mwalk;
   if (!c->stage_mem || c->stage_cap < M) {
     hipFree(c->stage_mem); c->stage_mem = nullptr; c->stage_cap = 0;
@@ -1102,11 +1102,13 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     // pipelined steps: the kernel also does the next step's gate (keys, child counts, child weights) as it places a walker
     static const bool no_fuse = getenv("SQMC_NO_GATE_FUSION") != nullptr;
     static const bool no_psit_fuse = getenv("SQMC_PSIT_NO_GATE_FUSION") != nullptr;
-    fuse_gate = c->pipeline_next && c->pack && !no_fuse && !(c->psit_on && no_psit_fuse);
+    static const bool no_wide_fuse = getenv("SQMC_NO_WIDE_KEY_GATE_FUSION") != nullptr;      // keys wider than 32 bits (the electron gas): fused as well, the slot index in its own array
+    fuse_gate = c->pipeline_next && (c->pack || (!c->psit_on && !no_wide_fuse && !bucket)) && !no_fuse && !(c->psit_on && no_psit_fuse);
     GateOut go; memset(&go, 0, sizeof(go));
     if (c->psit_on) { go.ps_of = c->d_ps_of; go.ps_raw = c->d_ps_raw; }
     if (fuse_gate) {
       go.on = 1; go.keys = (skey == c->d_keys) ? c->d_keys_alt : c->d_keys;      // never the buffer the kernel reads its sorted words from
+      go.vals = (skey == c->d_keys) ? c->d_vals_alt : c->d_vals; go.pack = c->pack;
       go.nchild = c->d_nchild; go.wchild = c->d_wchild; go.cutoff = p.cutoff; go.step_next = step + 1;
       static const bool no_off = getenv("SQMC_BUCKET_NO_OFFSETS") != nullptr;
       static const bool no_shard_off = getenv("SQMC_SHARD_NO_OFFSETS") != nullptr;
@@ -1154,7 +1156,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
 #undef ANNEAL_LAUNCH_
 #undef ANNEAL_LAUNCH
 #undef ANNEAL_ARGS
-    if (fuse_gate && go.keys == c->d_keys_alt) std::swap(c->d_keys, c->d_keys_alt);      // the next step's spawn kernel appends its keys behind the walkers'
+    if (fuse_gate && go.keys == c->d_keys_alt) { std::swap(c->d_keys, c->d_keys_alt); if (!c->pack) std::swap(c->d_vals, c->d_vals_alt); }      // the next step's spawn kernel appends its keys behind the walkers'
     std::swap(c->w.up, c->m.up); std::swap(c->w.dn, c->m.dn); std::swap(c->w.wt, c->m.wt); std::swap(c->w.flg, c->m.flg);
     std::swap(c->w.me, c->m.me); std::swap(c->w.en, c->m.en); std::swap(c->w.ed, c->m.ed); std::swap(c->w.irk, c->m.irk);
     if (c->psit_on) {          // do_walk.f90:2394-2462, 2487, 2590-2598, 2701-2722 on the C(T) segment of the NEW list

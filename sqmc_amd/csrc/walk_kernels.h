@@ -53,6 +53,7 @@ __device__ __forceinline__ void gate_children(double w, double cutoff, u64 seed,
 // parameters of the gate do not change any more, and the walker's key is at hand): one kernel less on the critical path.
 struct GateOut { u64 *keys; u64 *nchild; double *wchild; double cutoff; u64 step_next; int on;
                  u64 *child_off;
+                 u32 *vals; int pack;       // keys wider than 32 bits: the slot index travels in vals (put_key)
                  // hf_to_psit (set whether or not the gate is fused): slot of C(T) -> index in Psi_T or -1, and where k_anneal<., 1> leaves the
                  // merged weights of the Psi_T determinants -- k_psit_finish sums them for T^-1 while other blocks already overwrite the slots
                  const int *ps_of; double *ps_raw; };      // child_off != null (bucket tail only): the kernel also writes the next step's child offsets and total -- no scan launch
@@ -1157,10 +1158,10 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (PSIT && ct_head) { const int kp = go.ps_of[q0]; if (kp >= 0) go.ps_raw[kp] = wt; }
     if (choff) {        // the child weight follows from the weight and the count (gate_children: w / n above the cutoff, +-cutoff for the one child below it)
       const u32 nc = ncv[k];
-      go.keys[q0] = (key[k] << 32) | (u64)q0; go.child_off[q0] = cex + (u64)cpre[k];
+      put_key(go.keys, go.vals, q0, key[k], go.pack); go.child_off[q0] = cex + (u64)cpre[k];
       go.wchild[q0] = nc == 0 ? 0.0 : (fabs(wt) < go.cutoff ? copysign(go.cutoff, wt) : wt / (double)nc);
     } else if (go.on) {
-      go.keys[q0] = (key[k] << 32) | (u64)q0;
+      put_key(go.keys, go.vals, q0, key[k], go.pack);
       if (!ct_head) {          // hf_to_psit: the weights of the C(T) segment are not final yet -- k_psit_finish writes their gate; the draw is keyed by the determinant, not by where it sorts
         u64 nc; double wc;
         gate_children(wt, go.cutoff, seed, go.step_next, PSIT ? key[k] - p.koff : key[k], nc, wc);
@@ -1229,7 +1230,7 @@ __global__ void __launch_bounds__(TPB) k_anneal_place(AnnealStage sg, WalkArr o,
     const int d = flg_impd(fl), ini = flg_init(fl), psg = flg_psign(fl);
     if (en > 1e50) { const long long h = ct_lookup(hkey, hidx, hmask, key); if (h < 0) { en = 0.0; ed = 0.0; } else { en = cnum[h]; ed = cden[h]; } }
     o.up[q0] = up; o.dn[q0] = dn; o.wt[q0] = wt; o.flg[q0] = fl; o.me[q0] = me; o.en[q0] = en; o.ed[q0] = ed;
-    go.keys[q0] = (key << 32) | (u64)q0; go.child_off[q0] = base_b + (u64)sg.lch[q];
+    put_key(go.keys, go.vals, q0, key, go.pack); go.child_off[q0] = base_b + (u64)sg.lch[q];
     go.wchild[q0] = nc == 0 ? 0.0 : (fabs(wt) < go.cutoff ? copysign(go.cutoff, wt) : wt / (double)nc);
     const long long qd = det0 + (long long)sg.ldet[q];
     if (d == 0 && p.semi && qd < p.nimp_cap) loc_imp[qd] = (int)q0;

@@ -241,12 +241,13 @@ def test_hci_connections_active_space_masks(oracle, c2_walk, c2_hci, which):
         assert abs(got[0][k] - (got[1].get(k, 0.0) + got[2].get(k, 0.0))) < 1e-12
 
 
-def _run_pair(oracle, sysm, setup, rng_mode, nsteps, w_begin, w_target, mwalk=400000, n_equil=10**9, e_trial=-75.72):
+def _run_pair(oracle, sysm, setup, rng_mode, nsteps, w_begin, w_target, mwalk=400000, n_equil=10**9, e_trial=-75.72, chained=False):
     g = gpu_ctx_from_oracle(sysm, rng_mode=rng_mode, seed=SEED, mwalk=mwalk)
     g.set_projector(setup.prj_counts, setup.prj_indices, setup.prj_values)
     g.set_ct_table(setup.ct_up, setup.ct_dn, setup.ct_num, setup.ct_den)
     wk = oracle.initial_walkers(setup, w_begin)
     g.upload_walkers(wk)
+    if chained: g.set_chained_runs(True)
     ow = oracle.OracleWalk(sysm, setup, wk, mwalk, SEED, rng_mode=rng_mode)
     pc = oracle.PopControl(setup.tau, e_trial, w_target, n_equil_steps=n_equil)
     w_abs = np.abs(wk["wt"]).sum()
@@ -323,16 +324,20 @@ def test_walk_counter_trajectory_bit_exact_at_bench_size(oracle, c2_walk, c2_set
     assert _cached_hii_agree(wg, wc)
 
 
-def test_walk_counter_trajectory_bit_exact_past_2_20_slots(oracle, c2_walk, c2_setup):
+@pytest.mark.parametrize("chained", [False, True])
+def test_walk_counter_trajectory_bit_exact_past_2_20_slots(oracle, c2_walk, c2_setup, chained):
     """The variants long lists switch to -- 8-bit radix passes over the spawns only and a merge with the walkers, which are in
     order already; 3 slots per thread in the annihilation kernel; the large scan tiles -- start at 2^20 sorted slots.  Twelve
-    steps from 10^6 walkers' worth of weight put every step but the first there: bit for bit against the oracle."""
-    wg, wc, _, _, og, oc = _run_pair(oracle, c2_walk, c2_setup, 1, 12, 1000000, 1000000, mwalk=8000000)
+    steps from 10^6 walkers' worth of weight put every step but the first there: bit for bit against the oracle.  chained: the steps past
+    the target population are pipelined, and their annihilation is the two-kernel form (k_anneal<3, 0, 1>, k_anneal_split_scan,
+    k_anneal_place: no look-back, the next gate and child offsets written as the walkers are placed)."""
+    wg, wc, _, _, og, oc = _run_pair(oracle, c2_walk, c2_setup, 1, 12, 1000000, 1000000, mwalk=8000000, chained=chained)
     assert int(og[7]) > (1 << 20)
     for k in ("up", "dn", "imp_distance", "initiator"):
         assert np.array_equal(wg[k], wc[k]), k
     assert np.array_equal(wg["wt"], wc["wt"])
-    assert np.array_equal(wg["matrix_elements"], wc["matrix_elements"])
+    if chained: assert _cached_hii_agree(wg, wc)
+    else: assert np.array_equal(wg["matrix_elements"], wc["matrix_elements"])
 
 
 @pytest.mark.parametrize("w_target,nsteps", [(200000, 120), (800000, 140)])
