@@ -1197,16 +1197,21 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
 }
 // exclusive sums of the tiles' counts (one block: a few thousand to a few ten thousand tiles); the totals are the step's
 __global__ void __launch_bounds__(TPB) k_anneal_split_scan(u64 *__restrict__ cnt_a, u64 *__restrict__ cnt_b, int ntiles, DevScalars *sc) {
-  __shared__ u64 s_a[TPB], s_b[TPB];
-  const int C = (ntiles + TPB - 1) / TPB, beg = threadIdx.x * C, end = (beg + C < ntiles) ? beg + C : ntiles;
-  u64 a = 0, b = 0;
-  for (int t = beg; t < end; t++) { a += cnt_a[t]; b += cnt_b[t]; }
-  s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
-  __syncthreads();
-  u64 ea = 0, eb = 0;
-  for (int q = 0; q < (int)threadIdx.x; q++) { ea += s_a[q]; eb += s_b[q]; }
-  for (int t = beg; t < end; t++) { const u64 ca = cnt_a[t], cb = cnt_b[t]; cnt_a[t] = ea; cnt_b[t] = eb; ea += ca; eb += cb; }
-  if (threadIdx.x == TPB - 1) { sc->tot2 = ea; sc->nwalk = ea & 0xFFFFFFFFull; sc->n_children = eb; }
+  // rounds of 4 TPB tiles: a thread takes four consecutive counts (their loads in flight together), the block scans the threads' sums
+  u64 carry_a = 0, carry_b = 0;
+  for (int base = 0; base < ntiles; base += 4 * TPB) {
+    const int i0 = base + (int)threadIdx.x * 4;
+    u64 va[4], vb[4], sa = 0, sb = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { va[k] = (i0 + k < ntiles) ? cnt_a[i0 + k] : 0ull; vb[k] = (i0 + k < ntiles) ? cnt_b[i0 + k] : 0ull; sa += va[k]; sb += vb[k]; }
+    u64 ta, tb;
+    u64 ea = carry_a + block_excl_scan_u64(sa, &ta);
+    u64 eb = carry_b + block_excl_scan_u64(sb, &tb);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (i0 + k < ntiles) { cnt_a[i0 + k] = ea; cnt_b[i0 + k] = eb; } ea += va[k]; eb += vb[k]; }
+    carry_a += ta; carry_b += tb;
+  }
+  if (threadIdx.x == 0) { sc->tot2 = carry_a; sc->nwalk = carry_a & 0xFFFFFFFFull; sc->n_children = carry_b; }
 }
 // every tile's kept walkers from the staging buffer to their places in the new list, with everything that needed the place
 // (the second half of k_anneal: reweighted weights are staged already; estimator pieces, row table, next gate and child offsets)
