@@ -985,7 +985,9 @@ static int launch_side_kernels(sqmc_gpu_ctx *c, const StepP &p, long long n0, bo
 // staging buffer (72 bytes per walker slot) the first time
 static bool anneal_split_ok(sqmc_gpu_ctx *c, const StepP &p, int mode, long long nall, int items, bool child_off, bool use_mail) {
   static const int env = getenv("SQMC_ANNEAL_SPLIT") ? atoi(getenv("SQMC_ANNEAL_SPLIT")) : 1;
-  if (!env || !p.semi || c->psit_on || mode != SQMC_RNG_COUNTER || !child_off || !use_mail || c->d_grow || nall < (1ll << 20) || items < 3) return false;
+  const char *mn = getenv("SQMC_ANNEAL_SPLIT_MIN");          // tests: the two-kernel form on short lists too (read per step)
+  const long long min_slots = mn ? atoll(mn) : (1ll << 20);
+  if (!env || !p.semi || c->psit_on || mode != SQMC_RNG_COUNTER || !child_off || !use_mail || c->d_grow || nall < min_slots || items < 3) return false;
   const long long M = c->mwalk;
   if (!c->stage_mem || c->stage_cap < M) {
     hipFree(c->stage_mem); c->stage_mem = nullptr; c->stage_cap = 0;
@@ -1097,6 +1099,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     // small lists want many tiles, large ones short look-back chains; 4 slots per thread spill 31 registers at the 4 waves per SIMD
     // the kernel wants (3: 8), which only pays from ~10^7 slots on (measured: 0.449 against 0.458 ms/step at 2.5e6 slots, 3.44 against 3.35 at 1.7e7)
     int items = items_env ? items_env : (nall < (1ll << 20) ? 2 : (nall < (1ll << 23) ? 3 : 4));
+    if (items < 3 && getenv("SQMC_ANNEAL_SPLIT_MIN") && nall >= atoll(getenv("SQMC_ANNEAL_SPLIT_MIN"))) items = 3;      // (tests: the two-kernel form exists for 3 and 4 slots per thread)
     if (c->psit_on) items = items <= 2 ? 2 : 3;          // the two shapes k_anneal<., 1> is instantiated with
     nb = n_ft = bucket ? ba.B : (int)((nall + (long long)TPB * items - 1) / ((long long)TPB * items));
     // pipelined steps: the kernel also does the next step's gate (keys, child counts, child weights) as it places a walker

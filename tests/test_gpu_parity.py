@@ -324,6 +324,59 @@ def test_walk_counter_trajectory_bit_exact_at_bench_size(oracle, c2_walk, c2_set
     assert _cached_hii_agree(wg, wc)
 
 
+@pytest.mark.parametrize("system", ["c2", "c2_wide", "heg", "heatbath"])
+def test_two_kernel_annihilation_on_short_lists(oracle, c2_walk, c2_setup, heg14, c2_10e, monkeypatch, system):
+    """The annihilation of long pipelined lists (k_anneal<3, 0, 1>: fold, round, compaction inside the tile; k_anneal_split_scan;
+    k_anneal_place: estimator sums, row table, next gate and child offsets) forced onto short lists (SQMC_ANNEAL_SPLIT_MIN, radix tail),
+    where the oracle follows every step: C2 (packed 28-bit keys: only while the process has not yet fixed its choice of tail -- run
+    alone; c2_wide forces the two-array key layout, which always takes the radix tail), the electron gas (wide keys: the slot index in its own array, the gate
+    fused as well) and the fast_heatbath proposal (two slots per child, 33-bit keys).  Chained steps; walkers bit for bit."""
+    import sqmc_amd
+    from conftest import gpu_ctx_heg
+    monkeypatch.setenv("SQMC_ANNEAL_SPLIT_MIN", "1")
+    monkeypatch.setenv("SQMC_BUCKET", "0")
+    hb = None
+    if system == "c2_wide": monkeypatch.setenv("SQMC_FORCE_UNPACKED", "1")
+    if system in ("c2", "c2_wide"):
+        sysm, su, g = c2_walk, c2_setup, gpu_ctx_from_oracle(c2_walk, rng_mode=1, seed=SEED, mwalk=400000)
+    elif system == "heg":
+        sysm = heg14; su = oracle.setup_walk_heg(heg14, 300, 0.1)
+        g = gpu_ctx_heg(heg14, rng_mode=sqmc_amd.RNG_COUNTER, seed=SEED, mwalk=400000)
+    else:
+        sysm = c2_10e; hb = oracle.HeatBath(sysm); su = oracle.setup_walk(sysm, 100, 1000, 0.1)
+        g = gpu_ctx_from_oracle(sysm, rng_mode=1, seed=SEED, mwalk=400000)
+        g.set_heatbath_tables(hb.fortran_arrays())
+    g.set_projector(su.prj_counts, su.prj_indices, su.prj_values)
+    g.set_ct_table(su.ct_up, su.ct_dn, su.ct_num, su.ct_den)
+    wk = oracle.initial_walkers(su, 100)
+    g.upload_walkers(wk)
+    g.set_chained_runs(True)
+    ow = oracle.OracleWalk(sysm, su, wk, 400000, SEED, rng_mode=1, heatbath=hb)
+    pc = oracle.PopControl(su.tau, su.e_trial0, {"c2": 1500, "c2_wide": 1500, "heg": 250, "heatbath": 600}[system])
+    w_abs = float(np.abs(wk["wt"]).sum())
+    try:
+        for it in range({"c2": 160, "c2_wide": 160, "heg": 200, "heatbath": 220}[system]):
+            r = pc.pre_step(w_abs)
+            if r != 1.0:
+                ow.scale_projector(r); g.scale_projector(r)
+            st, oc = ow.step(pc.params())
+            og = g.step(pc.params())
+            assert st == 0 and og[5] == oc[5] and og[7] == oc[7] and og[15] == oc[15], (system, it, og, oc)
+            assert _sums_close(og, oc), (system, it)
+            r = pc.post_step(oc)
+            if r != 1.0:
+                ow.scale_projector(r); g.scale_projector(r)
+            w_abs = oc[1]
+        wg, wc = g.download_walkers(), ow.walkers()
+    finally:
+        g.close(); ow.close()
+        if hb is not None: hb.close()
+    assert pc.reached == 2
+    for k in ("up", "dn", "wt", "imp_distance", "initiator"):
+        assert np.array_equal(wg[k], wc[k]), (system, k)
+    assert _cached_hii_agree(wg, wc)
+
+
 @pytest.mark.parametrize("chained", [False, True])
 def test_walk_counter_trajectory_bit_exact_past_2_20_slots(oracle, c2_walk, c2_setup, chained):
     """The variants long lists switch to -- 8-bit radix passes over the spawns only and a merge with the walkers, which are in
