@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(BK_AT, BK_PER_CU * (BK_AT / 64) / 4) k_anneal_
         u64 nc; double wc;
         gate_children(wt, go.cutoff, seed, go.step_next, key_[z], nc, wc);
         go.keys[q0] = (key_[z] << 32) | (u64)q0; go.wchild[q0] = wc;
-        if (go.child_off) go.child_off[q0] = (ex_glob >> 38) + (u64)s_nc[q0b + z * BK_AT]; else go.nchild[q0] = nc;
+        if (go.child_off) { const u64 off = (ex_glob >> 38) + (u64)s_nc[q0b + z * BK_AT]; go.child_off[q0] = off; gate_block_parents(go.bpar, off, nc, q0); } else go.nchild[q0] = nc;
       }
       if (d == 0 && p.semi && qd < p.nimp_cap) { loc_imp[qd] = (int)q0; o.irk[q0] = (u32)qd; if (fs.x_out) fs.x_out[qd] = wt; }
       st[0] += wt; st[1] += fabs(wt); st[8] += wt * wt;

@@ -64,6 +64,9 @@ struct BucketArgs {
   const u32 *kb_prev; u32 *kb_out;     // k_spawn's spare block: the next boundaries from scount and the boundaries it was counted with (null: equal residents)
   const u32 *pos_prev;                 // where kb_prev lay in the list scount was taken from (the pos of that step)
   const u32 *hint; u32 *hint_out;      // about where kb lies in today's list (found when it was made) / the same for kb_out
+  // k_spawn: parent of the first child of every spawning block (written by the kernel that wrote the child offsets; null: the block
+  // searches the offsets itself, three dependent round trips at 10^6 walkers where this is one)
+  const u32 *parent_hint;
 };
 #define BK_REBAL_MAXB (256 * BK_PER_CU)
 #define BK_REBAL_SPAWN_COST 1.2        // a spawn against a resident in a bucket's cost.  Its time to publish fits 7.1 + 0.0101 S + 0.0059 R us over the

@@ -219,6 +219,7 @@ struct sqmc_gpu_ctx {
   BucketArgs head_ba; long long last_nall;      // partition already done by the head's k_spawn (B > 0), and the length of the last sorted list (sizes the next one)
   int bk_holdoff;             // steps for which the bucket tail stays off (after a bucket overflowed or came close)
   long long bk_steps, bk_retries;
+  u32 *d_bpar; bool head_bpar_ok;      // parent of the first child of every block of 256 children, written beside the child offsets; valid for the head that follows
   AnnealStage stage; void *stage_mem; long long stage_cap;      // long lists: staging buffer of the two-kernel annihilation (k_anneal<., 0, 1> + k_anneal_place), allocated at first use
   double sh_us[4]; long long sh_steps;      // host wall clock of the in-library sharded steps: head, exchange, tail, of which waiting for the GPU's mail (sqmc_gpu_shard_time_split)
   // hf_to_psit (psit_kernels.h)
@@ -303,6 +304,7 @@ static int init_common(sqmc_gpu_ctx *c, int norb, int nup, int ndn, int rng_mode
     HIPCHK(hipMalloc(&c->d_vals, M * 4)); HIPCHK(hipMalloc(&c->d_vals_alt, M * 4));
     long long ntiles = (M + RS_TILE - 1) / RS_TILE;
     HIPCHK(hipMalloc(&c->d_hist, ntiles * RS_MAX_RADIX * 4)); HIPCHK(hipMalloc(&c->d_rowtot, RS_MAX_RADIX * 4));
+    HIPCHK(hipMalloc(&c->d_bpar, (M / TPB + 4) * 4)); HIPCHK(hipMemset(c->d_bpar, 0, (M / TPB + 4) * 4));
     HIPCHK(hipMalloc(&c->d_flags, M * 8)); HIPCHK(hipMalloc(&c->d_pos, M * 8));
     HIPCHK(hipMalloc(&c->d_flags2, M * 8)); HIPCHK(hipMalloc(&c->d_pos2, M * 8)); HIPCHK(hipMalloc(&c->d_jcnt, (M / 2048 + 2) * 4));
     c->cap_tiles = (M + SCAN_TILE - 1) / SCAN_TILE + 1;
@@ -458,7 +460,7 @@ int sqmc_gpu_finalize(sqmc_gpu_ctx *c) {
   hipFree(c->d_prj_ptr); hipFree(c->d_prj_col); hipFree(c->d_prj_val); hipFree(c->d_loc_imp); hipFree(c->d_prj_x); hipFree(c->d_prj_xs[0]); hipFree(c->d_prj_xs[1]); hipFree(c->d_prj_y);
   hipFree(c->d_ct_up); hipFree(c->d_ct_dn); hipFree(c->d_ct_num); hipFree(c->d_ct_den); hipFree(c->d_ct_hkey); hipFree(c->d_ct_hidx);
   hipFree(c->d_ps_loc); hipFree(c->d_ps_of); hipFree(c->d_ps_impof); hipFree(c->d_ps_c); hipFree(c->d_ps_diag); hipFree(c->d_ps_dwct); hipFree(c->d_ps_dwps);
-  hipFree(c->d_ps_dwimp); hipFree(c->d_ps_p2); hipFree(c->d_ps_part); hipFree(c->d_ps_raw); hipFree(c->stage_mem);
+  hipFree(c->d_ps_dwimp); hipFree(c->d_ps_p2); hipFree(c->d_ps_part); hipFree(c->d_ps_raw); hipFree(c->stage_mem); hipFree(c->d_bpar);
   hipFree(c->d_sc); hipHostFree(c->h_sc); if (c->h_mail) hipHostFree((void *)c->h_mail);
   for (int i = 0; i < NTIMERS; i++) { hipEventDestroy(c->ev0[i]); hipEventDestroy(c->ev1[i]); }
   hipEventDestroy(c->e_fork); hipEventDestroy(c->e_join); hipEventDestroy(c->e_cnt); hipEventDestroy(c->e_spawned);
@@ -899,6 +901,8 @@ static int enqueue_head(sqmc_gpu_ctx *c, const StepP &p, u64 step, long long n0,
     }
     c->head_ba = hb;
   }
+  if (gate_done && c->head_bpar_ok && dev_n) hb.parent_hint = c->d_bpar;      // the tail that enqueues this head wrote the child offsets and, beside them, every block's first parent
+  c->head_bpar_ok = false;
   int hq_blk = 0;
   if (dev_n && tail_fills && c->hii_deferred_B > 0) {      // the tail left the new determinants' H_ii to this kernel: one spare block per bucket's queue
     hb.hq_cnt = c->d_hq_cnt; hb.hq_pos = c->d_hq_pos; hb.hq_B = c->hii_deferred_B; hb.hq_nblk = hq_blk = c->hii_deferred_B;
@@ -1119,7 +1123,10 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       // the radix tail of an unsharded pipelined step carries the child offsets too, in a look-back of their own (walk_kernels.h)
       static const bool no_roff = getenv("SQMC_RADIX_NO_OFFSETS") != nullptr;
       if (!bucket && use_mail && !c->d_grow && mode == SQMC_RNG_COUNTER && !no_roff && !c->psit_on) go.child_off = c->d_child_off;      // (hf_to_psit: the C(T) segment's counts come from a later kernel: the head scans)
+      static const bool no_hint = getenv("SQMC_NO_PARENT_HINT") != nullptr;
+      if (go.child_off && use_mail && !c->d_grow && !no_hint) go.bpar = c->d_bpar;
     }
+    c->head_bpar_ok = go.bpar != nullptr;
 #define ANNEAL_ARGS c->w, c->m, skey, perm, c->d_loc_imp, c->d_ct_hkey, c->d_ct_hidx, c->ct_mask, c->d_ct_num, c->d_ct_den, c->d_partials, c->d_wabs_part, n0, nall, p,  \
                     c->invalid_key, c->pack, mode, seed, step, c->d_sc, c->d_fstate, c->d_fstate + c->cap_ftiles, c->d_fticket, go
 #define ANNEAL_LAUNCH_(I, P) do { if (t_anneal >= 0) hipExtLaunchKernelGGL((k_anneal<I, P, 0>), dim3(nb), dim3(TPB), 0, st, c->ev0[t_anneal], c->ev1[t_anneal], 0, ANNEAL_ARGS, AnnealStage{}); \

@@ -54,9 +54,15 @@ __device__ __forceinline__ void gate_children(double w, double cutoff, u64 seed,
 struct GateOut { u64 *keys; u64 *nchild; double *wchild; double cutoff; u64 step_next; int on;
                  u64 *child_off;
                  u32 *vals; int pack;       // keys wider than 32 bits: the slot index travels in vals (put_key)
+                 u32 *bpar;                 // with child_off: parent of the first child of every block of 256 children (k_spawn's parent_hint)
                  // hf_to_psit (set whether or not the gate is fused): slot of C(T) -> index in Psi_T or -1, and where k_anneal<., 1> leaves the
                  // merged weights of the Psi_T determinants -- k_psit_finish sums them for T^-1 while other blocks already overwrite the slots
                  const int *ps_of; double *ps_raw; };      // child_off != null (bucket tail only): the kernel also writes the next step's child offsets and total -- no scan launch
+// the walker at q0 owns the children [off, off + nc): it is the parent of the first child of every block of 256 children that starts inside
+__device__ __forceinline__ void gate_block_parents(u32 *__restrict__ bpar, u64 off, u64 nc, long long q0) {
+  if (!bpar || nc == 0) return;
+  for (u64 b = (off + 255) >> 8; (b << 8) < off + nc; b++) bpar[b] = (u32)q0;
+}
 // gate + child count.
 __global__ void __launch_bounds__(TPB) k_gate(ChemDev dev, const u64 *__restrict__ up, const u64 *__restrict__ dn, const double *__restrict__ wt,
                                               u64 *__restrict__ nchild, double *__restrict__ wchild, u64 *__restrict__ keys, u32 *__restrict__ vals,
@@ -368,6 +374,10 @@ __global__ void __launch_bounds__(TPB) k_spawn(ChemDev dev, WalkArr w, const u64
   const long long c0 = (long long)bx * TPB;
   long long wlo = 0, whi = n0;                       // invariant: child_off[wlo] <= c0, answer for c0 in [wlo, whi)
   u64 pv = 0;
+  if (ba.parent_hint) {                              // the kernel that wrote the offsets left the parent of this block's first child
+    const long long h = (long long)ba.parent_hint[bx];
+    wlo = (h < n0) ? h : (n0 > 0 ? n0 - 1 : 0); whi = wlo;      // (blocks past the last child read a stale word and return below)
+  }
   if (whi - wlo > SPAWN_WIN) {
     const long long stepw = (whi - wlo + TPB - 1) / TPB, probe = wlo + (long long)threadIdx.x * stepw;
     pv = (probe < whi) ? child_off[probe] : ~0ull;
@@ -1158,7 +1168,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (PSIT && ct_head) { const int kp = go.ps_of[q0]; if (kp >= 0) go.ps_raw[kp] = wt; }
     if (choff) {        // the child weight follows from the weight and the count (gate_children: w / n above the cutoff, +-cutoff for the one child below it)
       const u32 nc = ncv[k];
-      put_key(go.keys, go.vals, q0, key[k], go.pack); go.child_off[q0] = cex + (u64)cpre[k];
+      put_key(go.keys, go.vals, q0, key[k], go.pack); go.child_off[q0] = cex + (u64)cpre[k]; gate_block_parents(go.bpar, cex + (u64)cpre[k], nc, q0);
       go.wchild[q0] = nc == 0 ? 0.0 : (fabs(wt) < go.cutoff ? copysign(go.cutoff, wt) : wt / (double)nc);
     } else if (go.on) {
       put_key(go.keys, go.vals, q0, key[k], go.pack);
@@ -1235,7 +1245,7 @@ __global__ void __launch_bounds__(TPB) k_anneal_place(AnnealStage sg, WalkArr o,
     const int d = flg_impd(fl), ini = flg_init(fl), psg = flg_psign(fl);
     if (en > 1e50) { const long long h = ct_lookup(hkey, hidx, hmask, key); if (h < 0) { en = 0.0; ed = 0.0; } else { en = cnum[h]; ed = cden[h]; } }
     o.up[q0] = up; o.dn[q0] = dn; o.wt[q0] = wt; o.flg[q0] = fl; o.me[q0] = me; o.en[q0] = en; o.ed[q0] = ed;
-    put_key(go.keys, go.vals, q0, key, go.pack); go.child_off[q0] = base_b + (u64)sg.lch[q];
+    put_key(go.keys, go.vals, q0, key, go.pack); go.child_off[q0] = base_b + (u64)sg.lch[q]; gate_block_parents(go.bpar, base_b + (u64)sg.lch[q], nc, q0);
     go.wchild[q0] = nc == 0 ? 0.0 : (fabs(wt) < go.cutoff ? copysign(go.cutoff, wt) : wt / (double)nc);
     const long long qd = det0 + (long long)sg.ldet[q];
     if (d == 0 && p.semi && qd < p.nimp_cap) loc_imp[qd] = (int)q0;

@@ -18,8 +18,8 @@ from sqmc_amd import host as H
 
 target = float(sys.argv[1]) if len(sys.argv) > 1 else 1e5
 hst = H.ChemHost(os.path.join(ROOT, "tests", "golden", "C2_r1.24253_FCIDUMP"), 8, 4, "d2h")
-w = H.GpuWalk(hst, target, seed=(1346, 5634, 6635, 4361))
-w.run(500, keep_stats=False)
+w = H.GpuWalk(hst, target, seed=(1346, 5634, 6635, 4361), w_begin=min(target, 1e4))
+w.run(500 if target <= 2e5 else 1200, keep_stats=False)
 L = sqmc_amd.load_library()
 buf = (C.c_uint64 * (8 * 8192))()
 assert L.sqmc_gpu_debug_prof(buf) == 0
