@@ -200,6 +200,25 @@ __global__ void __launch_bounds__(SCAN_BLOCK) rs_scan_kernel(u32 *__restrict__ h
   }
   if (threadIdx.x == 0) rowtot[blockIdx.x] = (u32)carry;
 }
+// the same for short rows (ntiles <= 64 * RS_ROW_PER_LANE): one WAVE per digit row, a lane takes consecutive entries (their loads in
+// flight together), one shuffle scan of the lanes' sums -- no barrier, a quarter of the blocks
+#define RS_ROW_PER_LANE 16
+__global__ void __launch_bounds__(SCAN_BLOCK) rs_scan_rows_wave(u32 *__restrict__ hist, u32 *__restrict__ rowtot, int ntiles, int nrows) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * (SCAN_BLOCK / 64) + (threadIdx.x >> 6);
+  if (r >= nrows) return;
+  u32 *row = hist + (long long)r * ntiles;
+  const int per = (ntiles + 63) / 64, i0 = lane * per;
+  u32 v[RS_ROW_PER_LANE]; u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < RS_ROW_PER_LANE; k++) { v[k] = (k < per && i0 + k < ntiles) ? row[i0 + k] : 0u; s += v[k]; }
+  u32 inc = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+  u32 ex = inc - s;
+#pragma unroll
+  for (int k = 0; k < RS_ROW_PER_LANE; k++) { if (k < per && i0 + k < ntiles) row[i0 + k] = ex; ex += v[k]; }
+  if (lane == 63) rowtot[r] = inc;
+}
 
 // Stable scatter: a 256-thread block owns a 1024-key tile; wave w owns keys [256w, 256w+256)
 // in 4 rounds of 64.  Rank among equal digits inside a round = popc(match & lanemask_lt) from
@@ -273,7 +292,11 @@ template <int BITS, int ROUNDS>
 static inline void radix_pass(u64 *ka, u32 *va, u64 *kb, u32 *vb, long long n, int shift, SortWork &w, hipStream_t st) {
   const int ntiles = (int)((n + 256 * ROUNDS - 1) / (256 * ROUNDS));
   hipLaunchKernelGGL((rs_hist_kernel<BITS, ROUNDS>), dim3(ntiles), dim3(256), 0, st, ka, w.hist, n, ntiles, shift);
-  hipLaunchKernelGGL(rs_scan_kernel, dim3(1 << BITS), dim3(SCAN_BLOCK), 0, st, w.hist, w.rowtot, ntiles);
+  static const bool rows_by_wave = !(getenv("SQMC_RS_SCAN_BLOCKS") && getenv("SQMC_RS_SCAN_BLOCKS")[0] == '1');
+  if (rows_by_wave && ntiles <= 64 * RS_ROW_PER_LANE)
+    hipLaunchKernelGGL(rs_scan_rows_wave, dim3(((1 << BITS) + SCAN_BLOCK / 64 - 1) / (SCAN_BLOCK / 64)), dim3(SCAN_BLOCK), 0, st, w.hist, w.rowtot, ntiles, 1 << BITS);
+  else
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(1 << BITS), dim3(SCAN_BLOCK), 0, st, w.hist, w.rowtot, ntiles);
   if (va) hipLaunchKernelGGL((rs_scatter_kernel<BITS, true, ROUNDS>), dim3(ntiles), dim3(256), 0, st, ka, va, kb, vb, w.hist, w.rowtot, n, ntiles, shift);
   else hipLaunchKernelGGL((rs_scatter_kernel<BITS, false, ROUNDS>), dim3(ntiles), dim3(256), 0, st, ka, va, kb, vb, w.hist, w.rowtot, n, ntiles, shift);
 }

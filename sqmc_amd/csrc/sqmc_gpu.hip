@@ -149,7 +149,7 @@ struct PsitArgs {
 
 // staging buffer of the two-kernel annihilation of long lists (walk_kernels.h, k_anneal<., 0, 1>): the kept walkers of every tile, compacted
 // inside the tile, and the tiles' counts (kept | deterministic-space << 32; children)
-struct AnnealStage { u64 *up, *dn, *key; double *wt, *me, *en, *ed; u32 *flg, *nc, *lch, *ldet; u64 *cnt_a, *cnt_b; };
+struct AnnealStage { u64 *up, *dn, *key; double *wt, *me, *en, *ed; u32 *flg, *nc, *lch, *ldet; u64 *cnt_a, *cnt_b, *off_a, *off_b; };
 struct HbHost;            // heatbath_setup.inc: host copies of the efficient heat-bath tables the library built itself
 struct sqmc_gpu_ctx {
   hipStream_t st;
@@ -996,13 +996,13 @@ static bool anneal_split_ok(sqmc_gpu_ctx *c, const StepP &p, int mode, long long
   if (!c->stage_mem || c->stage_cap < M) {
     hipFree(c->stage_mem); c->stage_mem = nullptr; c->stage_cap = 0;
     const long long nt = M / (TPB * 3) + 2;
-    const size_t bytes = (size_t)M * (7 * 8 + 4 * 4) + (size_t)nt * 16 + 256;
+    const size_t bytes = (size_t)M * (7 * 8 + 4 * 4) + (size_t)nt * 32 + 256;
     if (hipMalloc(&c->stage_mem, bytes) != hipSuccess) { (void)hipGetLastError(); c->stage_mem = nullptr; return false; }
     char *b = (char *)c->stage_mem; AnnealStage &g = c->stage;
     g.up = (u64 *)b; b += M * 8; g.dn = (u64 *)b; b += M * 8; g.key = (u64 *)b; b += M * 8;
     g.wt = (double *)b; b += M * 8; g.me = (double *)b; b += M * 8; g.en = (double *)b; b += M * 8; g.ed = (double *)b; b += M * 8;
     g.flg = (u32 *)b; b += M * 4; g.nc = (u32 *)b; b += M * 4; g.lch = (u32 *)b; b += M * 4; g.ldet = (u32 *)b; b += M * 4;
-    g.cnt_a = (u64 *)b; b += nt * 8; g.cnt_b = (u64 *)b;
+    g.cnt_a = (u64 *)b; b += nt * 8; g.cnt_b = (u64 *)b; b += nt * 8; g.off_a = (u64 *)b; b += nt * 8; g.off_b = (u64 *)b;
     c->stage_cap = M;
   }
   return true;
@@ -1155,7 +1155,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
       if (t_anneal >= 0) hipEventRecord(c->ev0[t_anneal], st);
       if (items == 3) hipLaunchKernelGGL((k_anneal<3, 0, 1>), dim3(nb), dim3(TPB), 0, st, ANNEAL_ARGS, sg);
       else hipLaunchKernelGGL((k_anneal<4, 0, 1>), dim3(nb), dim3(TPB), 0, st, ANNEAL_ARGS, sg);
-      hipLaunchKernelGGL(k_anneal_split_scan, dim3(1), dim3(TPB), 0, st, sg.cnt_a, sg.cnt_b, nb, c->d_sc);
+      hipLaunchKernelGGL(k_anneal_split_scan, dim3((nb + 4 * TPB - 1) / (4 * TPB)), dim3(TPB), 0, st, (const u64 *)sg.cnt_a, (const u64 *)sg.cnt_b, sg.off_a, sg.off_b, (int)nb, c->d_sc);
       if (items == 3) hipLaunchKernelGGL(k_anneal_place<3>, dim3(nb), dim3(TPB), 0, st, sg, c->m, c->d_loc_imp, (const u64 *)c->d_ct_hkey, (const u32 *)c->d_ct_hidx, c->ct_mask, (const double *)c->d_ct_num, (const double *)c->d_ct_den, c->d_partials, p, nb, go, (const DevScalars *)c->d_sc);
       else hipLaunchKernelGGL(k_anneal_place<4>, dim3(nb), dim3(TPB), 0, st, sg, c->m, c->d_loc_imp, (const u64 *)c->d_ct_hkey, (const u32 *)c->d_ct_hidx, c->ct_mask, (const double *)c->d_ct_num, (const double *)c->d_ct_den, c->d_partials, p, nb, go, (const DevScalars *)c->d_sc);
       if (t_anneal >= 0) hipEventRecord(c->ev1[t_anneal], st);

@@ -1205,23 +1205,35 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
   }
   APROF(5);
 }
-// exclusive sums of the tiles' counts (one block: a few thousand to a few ten thousand tiles); the totals are the step's
-__global__ void __launch_bounds__(TPB) k_anneal_split_scan(u64 *__restrict__ cnt_a, u64 *__restrict__ cnt_b, int ntiles, DevScalars *sc) {
-  // rounds of 4 TPB tiles: a thread takes four consecutive counts (their loads in flight together), the block scans the threads' sums
-  u64 carry_a = 0, carry_b = 0;
-  for (int base = 0; base < ntiles; base += 4 * TPB) {
-    const int i0 = base + (int)threadIdx.x * 4;
-    u64 va[4], vb[4], sa = 0, sb = 0;
+// exclusive sums of the tiles' counts (a few thousand to a few ten thousand tiles), 4 TPB tiles a block: a block first adds up
+// every count in front of its own (coalesced, all blocks at once -- no chain from block to block), then scans its own; the last
+// block's totals are the step's.  Counts in, sums out: separate arrays, the blocks read each other's counts.
+__global__ void __launch_bounds__(TPB) k_anneal_split_scan(const u64 *__restrict__ cnt_a, const u64 *__restrict__ cnt_b, u64 *__restrict__ off_a, u64 *__restrict__ off_b,
+                                                           int ntiles, DevScalars *sc) {
+  const int b0 = (int)blockIdx.x * 4 * TPB;
+  u64 pa = 0, pb = 0;
+  for (int i = (int)threadIdx.x; i < b0; i += 4 * TPB) {      // (b0 is a multiple of 4 TPB)
+    u64 xa[4], xb[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { va[k] = (i0 + k < ntiles) ? cnt_a[i0 + k] : 0ull; vb[k] = (i0 + k < ntiles) ? cnt_b[i0 + k] : 0ull; sa += va[k]; sb += vb[k]; }
-    u64 ta, tb;
-    u64 ea = carry_a + block_excl_scan_u64(sa, &ta);
-    u64 eb = carry_b + block_excl_scan_u64(sb, &tb);
+    for (int k = 0; k < 4; k++) { xa[k] = cnt_a[i + k * TPB]; xb[k] = cnt_b[i + k * TPB]; }
 #pragma unroll
-    for (int k = 0; k < 4; k++) { if (i0 + k < ntiles) { cnt_a[i0 + k] = ea; cnt_b[i0 + k] = eb; } ea += va[k]; eb += vb[k]; }
-    carry_a += ta; carry_b += tb;
+    for (int k = 0; k < 4; k++) { pa += xa[k]; pb += xb[k]; }
   }
-  if (threadIdx.x == 0) { sc->tot2 = carry_a; sc->nwalk = carry_a & 0xFFFFFFFFull; sc->n_children = carry_b; }
+  const int i0 = b0 + (int)threadIdx.x * 4;
+  u64 va[4], vb[4], sa = 0, sb = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { va[k] = (i0 + k < ntiles) ? cnt_a[i0 + k] : 0ull; vb[k] = (i0 + k < ntiles) ? cnt_b[i0 + k] : 0ull; sa += va[k]; sb += vb[k]; }
+  u64 front_a, front_b, own_a, own_b;
+  (void)block_excl_scan_u64(pa, &front_a);
+  (void)block_excl_scan_u64(pb, &front_b);
+  u64 ea = front_a + block_excl_scan_u64(sa, &own_a);
+  u64 eb = front_b + block_excl_scan_u64(sb, &own_b);
+#pragma unroll
+  for (int k = 0; k < 4; k++) { if (i0 + k < ntiles) { off_a[i0 + k] = ea; off_b[i0 + k] = eb; } ea += va[k]; eb += vb[k]; }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    const u64 tot_a = front_a + own_a, tot_b = front_b + own_b;
+    sc->tot2 = tot_a; sc->nwalk = tot_a & 0xFFFFFFFFull; sc->n_children = tot_b;
+  }
 }
 // every tile's kept walkers from the staging buffer to their places in the new list, with everything that needed the place
 // (the second half of k_anneal: reweighted weights are staged already; estimator pieces, row table, next gate and child offsets)
@@ -1231,8 +1243,8 @@ __global__ void __launch_bounds__(TPB) k_anneal_place(AnnealStage sg, WalkArr o,
                                                       const DevScalars *__restrict__ sc) {
   constexpr int TILE = TPB * ITEMS;
   const int tile = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const u64 base_a = sg.cnt_a[tile], base_b = sg.cnt_b[tile];
-  const u64 end_a = (tile + 1 < ntiles) ? sg.cnt_a[tile + 1] : (u64)sc->tot2;      // (the scan left exclusive sums; the total is the step's walker count)
+  const u64 base_a = sg.off_a[tile], base_b = sg.off_b[tile];
+  const u64 end_a = (tile + 1 < ntiles) ? sg.off_a[tile + 1] : (u64)sc->tot2;      // (the scan left exclusive sums; the total is the step's walker count)
   double s[NSTAT];
 #pragma unroll
   for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
