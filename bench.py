@@ -199,7 +199,7 @@ def main():
     else:
         # equilibration + warmup (untimed), then EXACTLY --steps timed steps inside sqmc_gpu_run
         walk.run(args.equil, keep_stats=False)
-        walk.g.set_timing(0 if os.environ.get('SQMC_BENCH_NO_EVENTS') else 1)           # HIP events around the k_spawn / k_anneal launches only (every 8th step), accumulated from here on
+        walk.g.set_timing(0 if os.environ.get('SQMC_BENCH_NO_EVENTS') else 1)           # HIP events around the annihilation kernel's launch only (every 8th step), accumulated from here on
         # A host that walks in blocks calls sqmc_gpu_run once per block; with chained runs the last step of a call enqueues the head
         # of the first step of the next one, as every step does for its successor.  Warm-up and timed region are two such calls: the K
         # timed steps then are K tails and K heads (the last one enqueues -- and the closing fence waits for -- the head of a step
@@ -224,6 +224,8 @@ def main():
         walk.g.set_timing(2)                                # informational stage breakdown from an untimed tail
         walk.run(20, keep_stats=False)
         stage_ms = dict(walk.g.timing())
+    if spawn_ms != spawn_ms:                                # a semistochastic walk times only its annihilation kernel inside the timed region
+        spawn_ms = stage_ms.get("spawn", spawn_ms)
     tot = torch.tensor([nwalk_sum, spawn_sum, dt], dtype=torch.float64, device=comm_dev)
     if multi:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)

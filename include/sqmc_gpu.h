@@ -403,8 +403,9 @@ int sqmc_gpu_hci_pt2(sqmc_gpu_ctx *ctx, int64_t n_var, const uint64_t *var_up, c
                      double eps_pt, int32_t n_slices, double *delta_e, int64_t *n_connections);
 void sqmc_gpu_free(void *p);
 
-/* HIP-event timing on the library's streams.  level 0 off; 1 = only the k_spawn launch
- * (one pair of events per step); 2 = every stage of the step.  get_timing returns the mean
+/* HIP-event timing on the library's streams.  level 0 off; 1 = only the longest kernel on the
+ * critical path, on every 8th step (the annihilation kernel of a semistochastic walk, k_spawn of
+ * a plain one: a timed launch cannot overlap its neighbours); 2 = every stage of every step.  get_timing returns the mean
  * milliseconds per step of each timer over the steps run since set_timing (n <= 32). */
 int sqmc_gpu_set_timing(sqmc_gpu_ctx *ctx, int level);
 int sqmc_gpu_get_timing(sqmc_gpu_ctx *ctx, int32_t *n, const char **names, float *ms);

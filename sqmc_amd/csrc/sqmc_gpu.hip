@@ -711,10 +711,13 @@ int sqmc_gpu_get_timing(sqmc_gpu_ctx *c, int32_t *n, const char **names, float *
 // stage timers: a pair of HIP events on the stream the stage runs on
 #define TBEG(NAME, STREAM) int t_##NAME = -1; do { if ((c->timing >= 2 || (c->timing == 1 && !strcmp(#NAME, "spawn") && c->step_no % 8 == 0)) && c->nt < NTIMERS) { t_##NAME = c->nt++; c->tname[t_##NAME] = #NAME; hipEventRecord(c->ev0[t_##NAME], STREAM); } } while (0)
 #define TEND(NAME, STREAM) do { if (t_##NAME >= 0) hipEventRecord(c->ev1[t_##NAME], STREAM); } while (0)
-// Timing level 1 takes the kernel-exact start/stop events of k_spawn and k_anneal on every SQMC_TIMING_STRIDE-th step only:
+// Timing level 1 takes the kernel-exact start/stop events of k_anneal (plain walks: k_spawn) on every SQMC_TIMING_STRIDE-th step only:
 // each timed launch costs about 5 us of the step it sits in, which a throughput measurement should not pay on every step.
 #define SQMC_TIMING_STRIDE 8
 static inline bool kernel_events_on(const sqmc_gpu_ctx *c, u64 step) { return c->timing >= 2 || (c->timing == 1 && step % SQMC_TIMING_STRIDE == 0); }
+// level 1 of a semistochastic walk times the annihilation kernel only (the longest on the critical path, the one the roofline is
+// quoted on): a timed launch cannot overlap its neighbours, and a second timed kernel on the same step costs the step another 2 us
+static inline bool spawn_events_on(const sqmc_gpu_ctx *c, u64 step, int semi) { return c->timing >= 2 || (!semi && kernel_events_on(c, step)); }
 
 static int comm_allreduce_stats(sqmc_gpu_ctx *c);
 // Spin on a mailbox word the GPU writes into pinned host memory.  Returns 0 when it arrived, -1
@@ -1235,7 +1238,7 @@ static int step_tail_impl(sqmc_gpu_ctx *c, const StepP &p_in, long long n0, long
     // reads this step's sums and does its population control.  nall bounds the new walker count.
     c->pipeline_next = false;
     int rh = enqueue_head(c, p, step + 1, nall, true, c->timing >= 2 ? c->hev[0] : nullptr, c->timing >= 2 ? c->hev[1] : nullptr,
-                          kernel_events_on(c, step + 1) ? c->hev[2] : nullptr, kernel_events_on(c, step + 1) ? c->hev[3] : nullptr, &c->head_cseq, (fin_in_gate || mail_in_gate) ? &fa : nullptr, fuse_gate);
+                          spawn_events_on(c, step + 1, p.semi) ? c->hev[2] : nullptr, spawn_events_on(c, step + 1, p.semi) ? c->hev[3] : nullptr, &c->head_cseq, (fin_in_gate || mail_in_gate) ? &fa : nullptr, fuse_gate);
     if (rh) return rh;
     c->head_ready = true; c->head_p = p;
   }
@@ -1351,7 +1354,7 @@ int sqmc_gpu_step(sqmc_gpu_ctx *c, const sqmc_step_params *sp, double out[16]) {
   hipStream_t st2 = c->st2;
   int t_gate_scan = -1, t_spawn = -1;
   if (c->timing >= 2 && c->nt < NTIMERS) { t_gate_scan = c->nt++; c->tname[t_gate_scan] = "gate_scan"; }
-  if (kernel_events_on(c, step) && c->nt < NTIMERS) { t_spawn = c->nt++; c->tname[t_spawn] = "spawn"; }
+  if (spawn_events_on(c, step, p.semi) && c->nt < NTIMERS) { t_spawn = c->nt++; c->tname[t_spawn] = "spawn"; }
   u64 cseq;
   if (c->head_ready) {                 // chained runs: the caller came back with other parameters than it left with
     const StepP &h0 = c->head_p;
