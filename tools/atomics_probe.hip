@@ -25,6 +25,55 @@ __global__ void __launch_bounds__(256) hist_lds(const u64 *__restrict__ keys, u3
   __syncthreads();
   for (int d = threadIdx.x; d < R; d += 256) hist[(long long)d * ntiles + blockIdx.x] = cnt[d];
 }
+// (a') the same tile by 1024 threads, four keys each: a shorter chain per thread
+template <int BITS>
+__global__ void __launch_bounds__(1024) hist_lds_wide(const u64 *__restrict__ keys, u32 *__restrict__ hist, long long n, int ntiles, int shift) {
+  constexpr int R = 1 << BITS;
+  __shared__ u32 cnt[R];
+  const long long base = (long long)blockIdx.x * 4096;
+  u64 k[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) { const long long i = base + r * 1024 + threadIdx.x; k[r] = i < n ? keys[i] : ~0ull; }
+  for (int d = threadIdx.x; d < R; d += 1024) cnt[d] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; r++) { const long long i = base + r * 1024 + threadIdx.x; if (i < n) atomicAdd(&cnt[(k[r] >> shift) & (R - 1)], 1u); }
+  __syncthreads();
+  for (int d = threadIdx.x; d < R; d += 1024) hist[(long long)d * ntiles + blockIdx.x] = cnt[d];
+}
+// (a'') 256 threads, the loads issued before the counters are cleared
+template <int BITS>
+__global__ void __launch_bounds__(256) hist_lds_early(const u64 *__restrict__ keys, u32 *__restrict__ hist, long long n, int ntiles, int shift) {
+  constexpr int R = 1 << BITS;
+  __shared__ u32 cnt[R];
+  const long long base = (long long)blockIdx.x * 4096;
+  u64 k[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) { const long long i = base + r * 256 + threadIdx.x; k[r] = i < n ? keys[i] : ~0ull; }
+  for (int d = threadIdx.x; d < R; d += 256) cnt[d] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; r++) { const long long i = base + r * 256 + threadIdx.x; if (i < n) atomicAdd(&cnt[(k[r] >> shift) & (R - 1)], 1u); }
+  __syncthreads();
+  for (int d = threadIdx.x; d < R; d += 256) hist[(long long)d * ntiles + blockIdx.x] = cnt[d];
+}
+// (a''') what the strided write costs: the same kernel writing its counters as one row (hist[tile][digit]) -- not a layout the scan
+//        and the scatter can use as they are, a bound
+template <int BITS>
+__global__ void __launch_bounds__(256) hist_lds_row(const u64 *__restrict__ keys, u32 *__restrict__ hist, long long n, int ntiles, int shift) {
+  constexpr int R = 1 << BITS;
+  __shared__ u32 cnt[R];
+  const long long base = (long long)blockIdx.x * 4096;
+  u64 k[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) { const long long i = base + r * 256 + threadIdx.x; k[r] = i < n ? keys[i] : ~0ull; }
+  for (int d = threadIdx.x; d < R; d += 256) cnt[d] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; r++) { const long long i = base + r * 256 + threadIdx.x; if (i < n) atomicAdd(&cnt[(k[r] >> shift) & (R - 1)], 1u); }
+  __syncthreads();
+  for (int d = threadIdx.x; d < R; d += 256) hist[(long long)blockIdx.x * R + d] = cnt[d];
+}
 // (b) the keys are in registers anyway (a scatter pass, k_spawn): one global atomic per key on hist[digit][tile of dst]
 //     dst = a random permutation target, as after a scatter on other bits
 template <int BITS>
@@ -72,6 +121,11 @@ int main() {
     };
     timeit("LDS histogram kernel, 10 bits", [&] { hipLaunchKernelGGL(hist_lds<10>, dim3(ntiles), dim3(256), 0, 0, dk, dh, n, ntiles, 0); });
     timeit("LDS histogram kernel, 9 bits", [&] { hipLaunchKernelGGL(hist_lds<9>, dim3(ntiles), dim3(256), 0, 0, dk, dh, n, ntiles, 10); });
+    timeit("LDS histogram, 1024 threads, 10 bits", [&] { hipLaunchKernelGGL(hist_lds_wide<10>, dim3(ntiles), dim3(1024), 0, 0, dk, dh, n, ntiles, 0); });
+    timeit("LDS histogram, 1024 threads, 9 bits", [&] { hipLaunchKernelGGL(hist_lds_wide<9>, dim3(ntiles), dim3(1024), 0, 0, dk, dh, n, ntiles, 10); });
+    timeit("LDS histogram, loads first, 10 bits", [&] { hipLaunchKernelGGL(hist_lds_early<10>, dim3(ntiles), dim3(256), 0, 0, dk, dh, n, ntiles, 0); });
+    timeit("LDS histogram, loads first, 9 bits", [&] { hipLaunchKernelGGL(hist_lds_early<9>, dim3(ntiles), dim3(256), 0, 0, dk, dh, n, ntiles, 10); });
+    timeit("LDS histogram, loads first, row write, 10 bits", [&] { hipLaunchKernelGGL(hist_lds_row<10>, dim3(ntiles), dim3(256), 0, 0, dk, dh, n, ntiles, 0); });
     timeit("global atomics, tile of a random destination", [&] { hipLaunchKernelGGL(hist_global<9>, dim3(ntiles), dim3(256), 0, 0, dk, dd, dh, n, ntiles, 10); });
     timeit("global atomics, tile of the own position", [&] { hipLaunchKernelGGL(hist_global_own<10>, dim3(ntiles), dim3(256), 0, 0, dk, dh, n, ntiles, 0); });
     CHK(hipFree(dk)); CHK(hipFree(dd)); CHK(hipFree(dh));
