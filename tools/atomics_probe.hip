@@ -74,6 +74,30 @@ __global__ void __launch_bounds__(256) hist_lds_row(const u64 *__restrict__ keys
   __syncthreads();
   for (int d = threadIdx.x; d < R; d += 256) hist[(long long)blockIdx.x * R + d] = cnt[d];
 }
+// (a4) G consecutive tiles per block of 1024 threads, counters of all G in LDS, written G at a time: hist[digit][tile .. tile+G) is one
+//      piece of 4 G bytes instead of G pieces a stride apart -- the layout of the scan and the scatter stays
+template <int BITS, int G>
+__global__ void __launch_bounds__(1024) hist_lds_group(const u64 *__restrict__ keys, u32 *__restrict__ hist, long long n, int ntiles, int shift) {
+  constexpr int R = 1 << BITS;
+  __shared__ u32 cnt[R * G];                                   // [digit][g]
+  const int t0 = blockIdx.x * G;
+  for (int d = threadIdx.x; d < R * G; d += 1024) cnt[d] = 0;
+  __syncthreads();
+  constexpr int B = G < 4 ? G : 4;                             // tiles whose loads are in flight together (4 keys a thread and tile)
+  for (int g0 = 0; g0 < G; g0 += B) {
+    u64 k[B][4];
+#pragma unroll
+    for (int g = 0; g < B; g++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) { const long long i = (long long)(t0 + g0 + g) * 4096 + r * 1024 + threadIdx.x; k[g][r] = i < n ? keys[i] : ~0ull; }
+#pragma unroll
+    for (int g = 0; g < B; g++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) { const long long i = (long long)(t0 + g0 + g) * 4096 + r * 1024 + threadIdx.x; if (i < n) atomicAdd(&cnt[((k[g][r] >> shift) & (R - 1)) * G + g0 + g], 1u); }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < R * G; e += 1024) { const int d = e / G, g = e % G; if (t0 + g < ntiles) hist[(long long)d * ntiles + t0 + g] = cnt[e]; }
+}
 // (b) the keys are in registers anyway (a scatter pass, k_spawn): one global atomic per key on hist[digit][tile of dst]
 //     dst = a random permutation target, as after a scatter on other bits
 template <int BITS>
@@ -126,6 +150,12 @@ int main() {
     timeit("LDS histogram, loads first, 10 bits", [&] { hipLaunchKernelGGL(hist_lds_early<10>, dim3(ntiles), dim3(256), 0, 0, dk, dh, n, ntiles, 0); });
     timeit("LDS histogram, loads first, 9 bits", [&] { hipLaunchKernelGGL(hist_lds_early<9>, dim3(ntiles), dim3(256), 0, 0, dk, dh, n, ntiles, 10); });
     timeit("LDS histogram, loads first, row write, 10 bits", [&] { hipLaunchKernelGGL(hist_lds_row<10>, dim3(ntiles), dim3(256), 0, 0, dk, dh, n, ntiles, 0); });
+    timeit("LDS histogram, 4 tiles a block, 10 bits", [&] { hipLaunchKernelGGL((hist_lds_group<10, 4>), dim3((ntiles + 3) / 4), dim3(1024), 0, 0, dk, dh, n, ntiles, 0); });
+    timeit("LDS histogram, 4 tiles a block, 9 bits", [&] { hipLaunchKernelGGL((hist_lds_group<9, 4>), dim3((ntiles + 3) / 4), dim3(1024), 0, 0, dk, dh, n, ntiles, 10); });
+    timeit("LDS histogram, 2 tiles a block, 10 bits", [&] { hipLaunchKernelGGL((hist_lds_group<10, 2>), dim3((ntiles + 1) / 2), dim3(1024), 0, 0, dk, dh, n, ntiles, 0); });
+    timeit("LDS histogram, 8 tiles a block, 10 bits", [&] { hipLaunchKernelGGL((hist_lds_group<10, 8>), dim3((ntiles + 7) / 8), dim3(1024), 0, 0, dk, dh, n, ntiles, 0); });
+    timeit("LDS histogram, 16 tiles a block, 10 bits", [&] { hipLaunchKernelGGL((hist_lds_group<10, 16>), dim3((ntiles + 15) / 16), dim3(1024), 0, 0, dk, dh, n, ntiles, 0); });
+    timeit("LDS histogram, 16 tiles a block, 9 bits", [&] { hipLaunchKernelGGL((hist_lds_group<9, 16>), dim3((ntiles + 15) / 16), dim3(1024), 0, 0, dk, dh, n, ntiles, 10); });
     timeit("global atomics, tile of a random destination", [&] { hipLaunchKernelGGL(hist_global<9>, dim3(ntiles), dim3(256), 0, 0, dk, dd, dh, n, ntiles, 10); });
     timeit("global atomics, tile of the own position", [&] { hipLaunchKernelGGL(hist_global_own<10>, dim3(ntiles), dim3(256), 0, 0, dk, dh, n, ntiles, 0); });
     CHK(hipFree(dk)); CHK(hipFree(dd)); CHK(hipFree(dh));
