@@ -316,8 +316,8 @@ static inline void device_radix_sort(u64 *&keys, u32 *&vals, long long n, int nb
   static const int maxbits_env = getenv("SQMC_SORT_MAXBITS") ? atoi(getenv("SQMC_SORT_MAXBITS")) : 0;
   // long lists: tiles of 4096 keys (a quarter of the rows in the histogram matrix), so the digits can stay 10 bits wide there too:
   // 28-bit keys in three passes instead of four (SQMC_SORT_BIG_TILE=0: the 8-bit digits over 1024-key tiles of before)
-  static const bool big_tile_env = !(getenv("SQMC_SORT_BIG_TILE") && getenv("SQMC_SORT_BIG_TILE")[0] == '0');
-  const bool big = n >= RS_LARGE_N && big_tile_env;
+  static const int big_tile_env = getenv("SQMC_SORT_BIG_TILE") ? atoi(getenv("SQMC_SORT_BIG_TILE")) : 1;      // (2: the long lists' tiles for every list -- tests)
+  const bool big = big_tile_env == 2 || (n >= RS_LARGE_N && big_tile_env);
   const int maxbits = maxbits_env ? maxbits_env : ((n >= RS_LARGE_N && !big) ? 8 : 10);
   const int npass = (nbits + maxbits - 1) / maxbits;
   // digit widths as even as the templates allow (8, 9 or 10 bits), the wide ones first: 28 bits in three passes

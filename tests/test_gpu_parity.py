@@ -1195,6 +1195,19 @@ def test_spawn_only_sort_and_merge_is_bit_exact():
 
 
 @pytest.mark.gpu
+def test_long_list_sort_tiles_on_short_lists_are_bit_exact():
+    """Lists of 2^20 keys and more sort in tiles of 4096 keys (`rs_hist_kernel<., 16>`, `rs_scatter_kernel<., ., 16>`);
+    SQMC_SORT_BIG_TILE=2 gives every list those tiles (ragged last tile, few tiles): the trajectory and annihilation-door tests
+    must pass unchanged against the oracle."""
+    import subprocess, sys
+    env = dict(os.environ, SQMC_SORT_BIG_TILE="2", SQMC_BUCKET="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "walk_trajectory_bit_exact or annihilate_door"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.gpu
 def test_radix_rows_scanned_by_blocks_is_bit_exact():
     """The per-tile digit histograms of a radix pass are scanned one wave per digit row when a row is short (<= 1,024 tiles, every
     other test) and one block per row beyond; SQMC_RS_SCAN_BLOCKS=1 forces the long-row kernel on the short rows: the trajectory and
